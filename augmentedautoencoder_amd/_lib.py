@@ -1,0 +1,125 @@
+"""ctypes binding of libaae_hip.so (include/aae_hip.h).
+
+The product path has exactly one back end: the hand-written HIP library built
+in-tree by ``__graft_entry__.build()``.  There is no CPU fallback -- if the
+library or a GPU is missing, loading fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+AAE_OK = 0
+AAE_DTYPE_U8 = 0
+AAE_DTYPE_F32 = 1
+AAE_MAX_LAYERS = 8
+AAE_SCAN_AUTO, AAE_SCAN_GEMV, AAE_SCAN_MFMA = 0, 1, 2
+AAE_ABI_VERSION = 1
+
+LIB_NAME = 'libaae_hip.so'
+
+# every symbol include/aae_hip.h declares (tests check the .so exports all of them)
+EXPORTED_SYMBOLS = (
+    'aae_abi_version', 'aae_last_error',
+    'aae_encoder_create', 'aae_encoder_destroy', 'aae_encoder_set_option', 'aae_encoder_workspace_bytes', 'aae_encoder_forward',
+    'aae_encoder_forward_timed', 'aae_encoder_kernel_label', 'aae_encoder_kernel_flops',
+    'aae_encoder_activation_info',
+    'aae_codebook_create', 'aae_codebook_update', 'aae_codebook_destroy', 'aae_codebook_set_scan_mode',
+    'aae_codebook_workspace_bytes', 'aae_codebook_nn', 'aae_codebook_similarity', 'aae_l2_normalize',
+)
+
+
+class EncoderDesc(Structure):
+    _fields_ = [
+        ('in_h', c_int32), ('in_w', c_int32), ('in_c', c_int32),
+        ('num_layers', c_int32),
+        ('num_filters', c_int32 * AAE_MAX_LAYERS),
+        ('strides', c_int32 * AAE_MAX_LAYERS),
+        ('kernel_size', c_int32),
+        ('latent_size', c_int32),
+        ('batch_norm', c_int32),
+        ('bn_eps', c_float),
+    ]
+
+
+def declare(lib):
+    """Attach argtypes/restypes for every entry point of include/aae_hip.h."""
+    lib.aae_abi_version.restype = c_int
+    lib.aae_abi_version.argtypes = []
+    lib.aae_last_error.restype = c_char_p
+    lib.aae_last_error.argtypes = []
+
+    lib.aae_encoder_create.restype = c_int
+    lib.aae_encoder_create.argtypes = [POINTER(EncoderDesc), POINTER(c_void_p), c_int, POINTER(c_void_p)]
+    lib.aae_encoder_destroy.restype = None
+    lib.aae_encoder_destroy.argtypes = [c_void_p]
+    lib.aae_encoder_set_option.restype = c_int
+    lib.aae_encoder_set_option.argtypes = [c_void_p, c_char_p, c_int]
+    lib.aae_encoder_workspace_bytes.restype = c_size_t
+    lib.aae_encoder_workspace_bytes.argtypes = [c_void_p, c_int]
+    lib.aae_encoder_forward.restype = c_int
+    lib.aae_encoder_forward.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.aae_encoder_forward_timed.restype = c_int
+    lib.aae_encoder_forward_timed.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p,
+                                              POINTER(c_float), c_int, POINTER(c_int)]
+    lib.aae_encoder_kernel_label.restype = c_char_p
+    lib.aae_encoder_kernel_label.argtypes = [c_void_p, c_int]
+    lib.aae_encoder_kernel_flops.restype = c_double
+    lib.aae_encoder_kernel_flops.argtypes = [c_void_p, c_int]
+    lib.aae_encoder_activation_info.restype = c_int
+    lib.aae_encoder_activation_info.argtypes = [c_void_p, c_int, c_int, POINTER(c_size_t), POINTER(c_size_t)]
+
+    lib.aae_codebook_create.restype = c_int
+    lib.aae_codebook_create.argtypes = [c_void_p, c_int, c_int, c_int, c_int, POINTER(c_void_p)]
+    lib.aae_codebook_update.restype = c_int
+    lib.aae_codebook_update.argtypes = [c_void_p, c_void_p, c_int, c_void_p]
+    lib.aae_codebook_destroy.restype = None
+    lib.aae_codebook_destroy.argtypes = [c_void_p]
+    lib.aae_codebook_set_scan_mode.restype = c_int
+    lib.aae_codebook_set_scan_mode.argtypes = [c_void_p, c_int]
+    lib.aae_codebook_workspace_bytes.restype = c_size_t
+    lib.aae_codebook_workspace_bytes.argtypes = [c_void_p, c_int, c_int]
+    lib.aae_codebook_nn.restype = c_int
+    lib.aae_codebook_nn.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.aae_codebook_similarity.restype = c_int
+    lib.aae_codebook_similarity.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.aae_l2_normalize.restype = c_int
+    lib.aae_l2_normalize.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p]
+    return lib
+
+
+def library_path():
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+
+
+_LIB = None
+
+
+def load():
+    """Load libaae_hip.so.  torch is imported first so that the library binds to the
+    HIP runtime torch already loaded (one runtime per process: device pointers,
+    streams and events are shared between torch tensors and our kernels)."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    import torch  # noqa: F401  (must precede the dlopen below)
+    path = library_path()
+    if not os.path.exists(path):
+        raise RuntimeError(
+            '%s not built: run `python -c "import __graft_entry__ as g; g.build()"` at the repo root '
+            '(hipcc --offload-arch=gfx950).  There is no CPU fallback.' % path)
+    lib = declare(ctypes.CDLL(path))
+    if lib.aae_abi_version() != AAE_ABI_VERSION:
+        raise RuntimeError('libaae_hip.so ABI version %d != expected %d' % (lib.aae_abi_version(), AAE_ABI_VERSION))
+    _LIB = lib
+    return lib
+
+
+def check(lib, rc, what):
+    if rc != AAE_OK:
+        msg = lib.aae_last_error()
+        msg = msg.decode('utf-8', 'replace') if msg else ''
+        if rc in (-1, -2, -4):
+            raise ValueError('%s failed (%d): %s' % (what, rc, msg))
+        raise RuntimeError('%s failed (%d): %s' % (what, rc, msg))

@@ -1,0 +1,10 @@
+// libaae_hip.so translation unit: gfx950 device code + the C ABI of include/aae_hip.h.
+// Build: hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC aae_hip.hip -o libaae_hip.so
+#include <hip/hip_runtime.h>
+
+#include "device_intrinsics.h"
+
+#define AAE_LAUNCH(kernel, grid, block, smem, stream, ...) \
+    hipLaunchKernelGGL(kernel, (grid), (block), (smem), (stream), __VA_ARGS__)
+
+#include "aae_hip_impl.h"

@@ -1,0 +1,650 @@
+// Host side of libaae_hip.so: handle management, weight packing, launch planning.
+// Compiled by hipcc for gfx950 through aae_hip.hip.  (tests/emu/ compiles the
+// same text against a CPU fiber emulator to unit-test the launch logic; that
+// build is test infrastructure and is never loaded by the package.)
+//
+// The including translation unit provides: the HIP runtime API, the wave
+// primitives of device_intrinsics.h and
+//   AAE_LAUNCH(kernel, grid, block, smem_bytes, stream, args...)
+#pragma once
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/aae_hip.h"
+#include "kernels/tile_f32.h"
+#include "kernels/conv_igemm_f32.h"
+#include "kernels/conv_first_f32.h"
+#include "kernels/conv_direct_generic.h"
+#include "kernels/codebook_scan_f32.h"
+
+namespace aae_host {
+
+static thread_local std::string g_last_error;
+
+static int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    g_last_error = buf;
+    return code;
+}
+
+#define AAE_HIP_TRY(expr)                                                                       \
+    do {                                                                                        \
+        hipError_t e__ = (expr);                                                                \
+        if (e__ != hipSuccess)                                                                  \
+            return aae_host::fail(AAE_ERR_RUNTIME, "%s failed: %s (%s:%d)", #expr,              \
+                                  hipGetErrorString(e__), __FILE__, __LINE__);                  \
+    } while (0)
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
+
+// [TF-semantics] 'SAME': out = ceil(in/s); total = max((out-1)*s + k - in, 0); before = total/2.
+static inline void same_pad(int in, int k, int s, int* out, int* before) {
+    const int o = ceil_div(in, s);
+    int total = (o - 1) * s + k - in;
+    if (total < 0) total = 0;
+    *out = o;
+    *before = total / 2;
+}
+
+enum LayerKind { KIND_FIRST_MFMA = 0, KIND_IGEMM = 1, KIND_GENERIC = 2 };
+
+struct Layer {
+    int H = 0, W = 0, Cin = 0, Ho = 0, Wo = 0, Cout = 0, CoutPad = 0;
+    int KS = 0, S = 0, pt = 0, pl = 0;
+    int relu = 1;
+    LayerKind kind = KIND_GENERIC;
+    float* w_hwio = nullptr;    // device [KS*KS*Cin][Cout]
+    float* wp = nullptr;        // device [K/4][CoutPad][4]      (igemm)
+    float* bias = nullptr;
+    float* bn_scale = nullptr;  // folded inference BN: x*scale + shift
+    float* bn_shift = nullptr;
+    // first-layer staging geometry
+    int rowlen = 0, first_smem = 0;
+    long long K() const { return (long long)KS * KS * Cin; }
+};
+
+struct KernelRecord {
+    std::string label;
+    double flops;
+};
+
+}  // namespace aae_host
+
+struct aae_encoder {
+    aae_encoder_desc desc;
+    std::vector<aae_host::Layer> layers;   // conv layers
+    aae_host::Layer dense;                 // 1x1 "conv" over the flattened activation
+    float* lut = nullptr;                  // device [256] float32(v/255.)
+    std::vector<void*> allocations;
+    std::vector<aae_host::KernelRecord> records;   // of the most recent forward
+    int splitk_min_base_blocks = 384;      // split K only when the un-split grid is smaller than this
+    int splitk_target_blocks = 512;        // ... and then aim for about this many blocks
+};
+
+struct aae_codebook {
+    float* E = nullptr;    // device [N][J]
+    int N = 0, J = 0;
+    int scan_mode = AAE_SCAN_AUTO;
+};
+
+namespace aae_host {
+
+// ------------------------------------------------------------------ helpers
+static int upload(aae_encoder* enc, const float* host, size_t count, float** dev) {
+    void* p = nullptr;
+    AAE_HIP_TRY(hipMalloc(&p, count * sizeof(float)));
+    enc->allocations.push_back(p);
+    AAE_HIP_TRY(hipMemcpy(p, host, count * sizeof(float), hipMemcpyHostToDevice));
+    *dev = static_cast<float*>(p);
+    return AAE_OK;
+}
+
+// HWIO / [F][J] kernel -> [K/4][CoutPad][4]; k = (kh*KS + kw)*Cin + ci is already
+// the row index of the HWIO array flattened to [K][Cout].
+static std::vector<float> pack_weights(const float* w, long long K, int Cout, int CoutPad) {
+    std::vector<float> out((size_t)K * CoutPad, 0.f);
+    for (long long k = 0; k < K; ++k)
+        for (int n = 0; n < Cout; ++n)
+            out[((size_t)(k >> 2) * CoutPad + n) * 4 + (k & 3)] = w[(size_t)k * Cout + n];
+    return out;
+}
+
+static bool first_layer_instantiated(int KS, int C) { return KS == 5 && (C == 3 || C == 1); }
+
+static void plan_first_layer(Layer& L) {
+    L.rowlen = ((L.Wo - 1) * L.S + L.KS) * L.Cin;
+    int max_out_rows = 127 / L.Wo + 2;
+    if (max_out_rows > L.Ho) max_out_rows = L.Ho;
+    const int max_in_rows = (max_out_rows - 1) * L.S + L.KS;
+    L.first_smem = (256 + max_in_rows * L.rowlen) * (int)sizeof(float);
+}
+
+// split-K factor: aim for >= ~512 resident-able blocks without splitting finer than one slab
+static void choose_splits(const aae_encoder* enc, int base_blocks, int slabs, int* splits, int* per_split) {
+    int s = 1;
+    if (base_blocks < enc->splitk_min_base_blocks) {
+        s = ceil_div(enc->splitk_target_blocks, base_blocks);
+        if (s < 1) s = 1;
+        if (s > slabs) s = slabs;
+    }
+    const int per = ceil_div(slabs, s);
+    *per_split = per;
+    *splits = ceil_div(slabs, per);
+}
+
+struct Workspace {
+    std::vector<size_t> act_off;   // per conv layer
+    size_t partial_off = 0, partial_bytes = 0;
+    size_t total = 0;
+};
+
+static Workspace plan_workspace(const aae_encoder* enc, int B) {
+    Workspace ws;
+    size_t off = 0;
+    size_t partial = 0;
+    auto need_partial = [&](const Layer& L, int M) {
+        if (L.kind != KIND_IGEMM) return;
+        int splits, per;
+        choose_splits(enc, ceil_div(M, 128) * (L.CoutPad / 128), (int)(L.K() / 32), &splits, &per);
+        if (splits > 1) {
+            const size_t bytes = (size_t)splits * M * L.Cout * sizeof(float);
+            if (bytes > partial) partial = bytes;
+        }
+    };
+    for (const Layer& L : enc->layers) {
+        ws.act_off.push_back(off);
+        off += align_up((size_t)B * L.Ho * L.Wo * L.Cout * sizeof(float), 256);
+        need_partial(L, B * L.Ho * L.Wo);
+    }
+    need_partial(enc->dense, B);
+    ws.partial_off = off;
+    ws.partial_bytes = partial;
+    off += align_up(partial, 256);
+    ws.total = off;
+    return ws;
+}
+
+// ------------------------------------------------------------ layer launches
+struct Timer {
+    bool on = false;
+    hipStream_t stream = nullptr;
+    std::vector<hipEvent_t> ev;
+    int mark() {
+        if (!on) return AAE_OK;
+        hipEvent_t e;
+        AAE_HIP_TRY(hipEventCreate(&e));
+        ev.push_back(e);
+        AAE_HIP_TRY(hipEventRecord(e, stream));
+        return AAE_OK;
+    }
+};
+
+static int launch_igemm(aae_encoder* enc, const Layer& L, const float* x, int M, float* out, float* partial,
+                        hipStream_t stream, Timer& tm, const char* name) {
+    aae::ConvIgemmArgs a;
+    a.x = x; a.wp = L.wp; a.bias = L.bias; a.bn_scale = L.bn_scale; a.bn_shift = L.bn_shift;
+    a.H = L.H; a.W = L.W; a.Cin = L.Cin; a.Ho = L.Ho; a.Wo = L.Wo; a.Cout = L.Cout; a.CoutPad = L.CoutPad;
+    a.KS = L.KS; a.S = L.S; a.pt = L.pt; a.pl = L.pl; a.M = M; a.relu = L.relu;
+    a.slabs_total = (int)(L.K() / 32);
+    a.num_mt = ceil_div(M, 128);
+    a.num_nt = L.CoutPad / 128;
+    choose_splits(enc, a.num_mt * a.num_nt, a.slabs_total, &a.splits, &a.slabs_per_split);
+    const int nblk = a.num_mt * a.num_nt * a.splits;
+    const double flops = 2.0 * (double)M * (double)L.K() * (double)L.Cout;
+    char label[96];
+    if (a.splits == 1) {
+        a.out = out;
+        AAE_LAUNCH((aae::conv_igemm_f32_kernel<false>), dim3(nblk), dim3(256), aae::kConvIgemmSmem, stream, a);
+        snprintf(label, sizeof(label), "%s:conv_igemm_f32 M=%d N=%d K=%lld", name, M, L.Cout, L.K());
+        enc->records.push_back({label, flops});
+        AAE_HIP_TRY(hipGetLastError());
+        return tm.mark();
+    }
+    a.out = partial;
+    AAE_LAUNCH((aae::conv_igemm_f32_kernel<true>), dim3(nblk), dim3(256), aae::kConvIgemmSmem, stream, a);
+    snprintf(label, sizeof(label), "%s:conv_igemm_f32_splitk%d M=%d N=%d K=%lld", name, a.splits, M, L.Cout, L.K());
+    enc->records.push_back({label, flops});
+    AAE_HIP_TRY(hipGetLastError());
+    if (int rc = tm.mark()) return rc;
+    aae::SplitKReduceArgs r;
+    r.partial = partial; r.bias = L.bias; r.bn_scale = L.bn_scale; r.bn_shift = L.bn_shift; r.out = out;
+    r.MN = (long long)M * L.Cout; r.Cout = L.Cout; r.splits = a.splits; r.relu = L.relu;
+    long long blocks = (r.MN + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    AAE_LAUNCH((aae::splitk_reduce_kernel), dim3((unsigned)blocks), dim3(256), 0, stream, r);
+    snprintf(label, sizeof(label), "%s:splitk_reduce", name);
+    enc->records.push_back({label, 0.0});
+    AAE_HIP_TRY(hipGetLastError());
+    return tm.mark();
+}
+
+template <int KS, int C>
+static void launch_first_t(const aae::ConvFirstArgs& a, bool u8, dim3 grid, int smem, hipStream_t stream) {
+    if (u8) AAE_LAUNCH((aae::conv_first_f32_kernel<KS, C, true>), grid, dim3(256), smem, stream, a);
+    else AAE_LAUNCH((aae::conv_first_f32_kernel<KS, C, false>), grid, dim3(256), smem, stream, a);
+}
+
+static int launch_first(aae_encoder* enc, const Layer& L, const void* x, bool u8, int B, float* out,
+                        hipStream_t stream, Timer& tm) {
+    aae::ConvFirstArgs a;
+    a.x = x; a.lut = enc->lut; a.w = L.w_hwio; a.bias = L.bias; a.bn_scale = L.bn_scale; a.bn_shift = L.bn_shift;
+    a.out = out; a.H = L.H; a.W = L.W; a.Ho = L.Ho; a.Wo = L.Wo; a.Cout = L.Cout;
+    a.S = L.S; a.pt = L.pt; a.pl = L.pl; a.rowlen = L.rowlen; a.relu = L.relu;
+    a.tiles_per_image = ceil_div(L.Ho * L.Wo, 128);
+    a.total_tiles = B * a.tiles_per_image;
+    int tpb = ceil_div(a.total_tiles, 1024);
+    if (tpb < 1) tpb = 1;
+    if (tpb > 8) tpb = 8;
+    a.tiles_per_block = tpb;
+    const dim3 grid(ceil_div(a.total_tiles, tpb), ceil_div(L.Cout, 128));
+    if (L.Cin == 3) launch_first_t<5, 3>(a, u8, grid, L.first_smem, stream);
+    else launch_first_t<5, 1>(a, u8, grid, L.first_smem, stream);
+    char label[96];
+    snprintf(label, sizeof(label), "conv1:conv_first_f32 M=%d N=%d K=%lld", B * L.Ho * L.Wo, L.Cout, L.K());
+    enc->records.push_back({label, 2.0 * (double)B * L.Ho * L.Wo * (double)L.K() * L.Cout});
+    AAE_HIP_TRY(hipGetLastError());
+    return tm.mark();
+}
+
+static int launch_generic(aae_encoder* enc, const Layer& L, const void* x, bool u8, long long B, float* out,
+                          hipStream_t stream, Timer& tm, const char* name) {
+    aae::ConvDirectArgs a;
+    a.x = x; a.lut = enc->lut; a.w = L.w_hwio; a.bias = L.bias; a.bn_scale = L.bn_scale; a.bn_shift = L.bn_shift;
+    a.out = out; a.H = L.H; a.W = L.W; a.Cin = L.Cin; a.Ho = L.Ho; a.Wo = L.Wo; a.Cout = L.Cout;
+    a.KS = L.KS; a.S = L.S; a.pt = L.pt; a.pl = L.pl; a.relu = L.relu;
+    a.total = B * L.Ho * L.Wo * L.Cout;
+    long long blocks = (a.total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (u8) AAE_LAUNCH((aae::conv_direct_generic_kernel<true>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    else AAE_LAUNCH((aae::conv_direct_generic_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
+    char label[96];
+    snprintf(label, sizeof(label), "%s:conv_direct_generic", name);
+    enc->records.push_back({label, 2.0 * (double)B * L.Ho * L.Wo * (double)L.K() * L.Cout});
+    AAE_HIP_TRY(hipGetLastError());
+    return tm.mark();
+}
+
+static int forward_impl(aae_encoder* enc, const void* x, int x_dtype, int B, float* z_out, void* workspace,
+                        size_t ws_bytes, void* stream_v, Timer& tm) {
+    if (!enc || !x || !z_out) return fail(AAE_ERR_INVALID, "aae_encoder_forward: null argument");
+    if (B < 1) return fail(AAE_ERR_INVALID, "aae_encoder_forward: batch %d < 1", B);
+    if (x_dtype != AAE_DTYPE_U8 && x_dtype != AAE_DTYPE_F32)
+        return fail(AAE_ERR_INVALID, "aae_encoder_forward: x_dtype %d (want AAE_DTYPE_U8 or AAE_DTYPE_F32)", x_dtype);
+    const Workspace ws = plan_workspace(enc, B);
+    if (ws_bytes < ws.total) return fail(AAE_ERR_WORKSPACE, "workspace %zu B < required %zu B for batch %d", ws_bytes, ws.total, B);
+    if (!workspace || ((uintptr_t)workspace & 255)) return fail(AAE_ERR_WORKSPACE, "workspace must be non-null and 256-B aligned");
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    unsigned char* base = static_cast<unsigned char*>(workspace);
+    float* partial = reinterpret_cast<float*>(base + ws.partial_off);
+    enc->records.clear();
+    tm.stream = stream;
+    if (int rc = tm.mark()) return rc;
+
+    const void* cur = x;
+    bool cur_u8 = (x_dtype == AAE_DTYPE_U8);
+    for (size_t li = 0; li < enc->layers.size(); ++li) {
+        const Layer& L = enc->layers[li];
+        float* out = reinterpret_cast<float*>(base + ws.act_off[li]);
+        char name[16];
+        snprintf(name, sizeof(name), "conv%zu", li + 1);
+        int rc;
+        if (li == 0 && L.kind == KIND_FIRST_MFMA) rc = launch_first(enc, L, cur, cur_u8, B, out, stream, tm);
+        else if (L.kind == KIND_IGEMM && !cur_u8)
+            rc = launch_igemm(enc, L, static_cast<const float*>(cur), B * L.Ho * L.Wo, out, partial, stream, tm, name);
+        else rc = launch_generic(enc, L, cur, cur_u8, B, out, stream, tm, name);
+        if (rc) return rc;
+        cur = out;
+        cur_u8 = false;
+    }
+    const Layer& D = enc->dense;
+    if (D.kind == KIND_IGEMM) return launch_igemm(enc, D, static_cast<const float*>(cur), B, z_out, partial, stream, tm, "dense");
+    return launch_generic(enc, D, cur, false, B, z_out, stream, tm, "dense");
+}
+
+// --------------------------------------------------------------- codebook side
+struct ScanPlan {
+    int nblk, Bpad, Bstride, Jpad, NT;
+    bool gemv;
+    size_t q_off, qp_off, pval_off, pidx_off, cs_off, total;
+};
+
+static ScanPlan plan_scan(const aae_codebook* cb, int B, int topk) {
+    ScanPlan s;
+    s.nblk = ceil_div(cb->N, 128);
+    s.Jpad = 128;
+    s.gemv = (cb->scan_mode == AAE_SCAN_GEMV) || (cb->scan_mode == AAE_SCAN_AUTO && B <= 4);
+    if (B > 4) s.gemv = false;
+    s.NT = B <= 32 ? 1 : (B <= 64 ? 2 : 4);
+    s.Bpad = (int)align_up((size_t)B, (size_t)(32 * s.NT));
+    s.Bstride = s.Bpad;
+    size_t off = 0;
+    s.q_off = off;    off += align_up((size_t)B * cb->J * sizeof(float), 256);
+    s.qp_off = off;   off += align_up((size_t)(s.Jpad / 4) * s.Bpad * 4 * sizeof(float), 256);
+    s.pval_off = off; off += align_up((size_t)s.nblk * s.Bstride * sizeof(float), 256);
+    s.pidx_off = off; off += align_up((size_t)s.nblk * s.Bstride * sizeof(int), 256);
+    s.cs_off = off;
+    if (topk > 1) off += align_up((size_t)B * cb->N * sizeof(float), 256);
+    s.total = off;
+    return s;
+}
+
+template <int NT>
+static void launch_scan_mfma_t(const aae::ScanArgs& a, bool upright, int nblk, hipStream_t stream) {
+    constexpr int smem = aae::scan_mfma_smem<NT>();
+    if (upright) {
+        (void)hipFuncSetAttribute((const void*)aae::scan_mfma_kernel<NT, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        AAE_LAUNCH((aae::scan_mfma_kernel<NT, true>), dim3(nblk), dim3(256), smem, stream, a);
+    } else {
+        (void)hipFuncSetAttribute((const void*)aae::scan_mfma_kernel<NT, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        AAE_LAUNCH((aae::scan_mfma_kernel<NT, false>), dim3(nblk), dim3(256), smem, stream, a);
+    }
+}
+
+static int run_scan(aae_codebook* cb, const float* z, int B, int col_stride, float* cs_out, const ScanPlan& s,
+                    unsigned char* base, hipStream_t stream) {
+    float* q = reinterpret_cast<float*>(base + s.q_off);
+    float* qp = reinterpret_cast<float*>(base + s.qp_off);
+    aae::L2NormArgs n;
+    n.z = z; n.q = q; n.qp = s.gemv ? nullptr : qp; n.B = B; n.J = cb->J; n.Jpad = s.Jpad; n.Bpad = s.gemv ? B : s.Bpad;
+    AAE_LAUNCH((aae::l2norm_pack_kernel), dim3(ceil_div(n.Bpad, 4)), dim3(256), 0, stream, n);
+    AAE_HIP_TRY(hipGetLastError());
+
+    aae::ScanArgs a;
+    a.E = cb->E; a.q = q; a.qp = qp;
+    a.pval = reinterpret_cast<float*>(base + s.pval_off);
+    a.pidx = reinterpret_cast<int*>(base + s.pidx_off);
+    a.cs = cs_out;
+    a.N = cb->N; a.J = cb->J; a.Jpad = s.Jpad; a.B = B; a.Bpad = s.Bpad; a.Bstride = s.Bstride;
+    a.col_stride = col_stride;
+    const bool upright = col_stride > 1;
+    if (s.gemv) {
+        const int smem = 2 * 4 * 4 * (int)sizeof(float);
+        if (upright) AAE_LAUNCH((aae::scan_gemv_kernel<4, true>), dim3(s.nblk), dim3(256), smem, stream, a);
+        else AAE_LAUNCH((aae::scan_gemv_kernel<4, false>), dim3(s.nblk), dim3(256), smem, stream, a);
+    } else if (s.NT == 1) launch_scan_mfma_t<1>(a, upright, s.nblk, stream);
+    else if (s.NT == 2) launch_scan_mfma_t<2>(a, upright, s.nblk, stream);
+    else launch_scan_mfma_t<4>(a, upright, s.nblk, stream);
+    AAE_HIP_TRY(hipGetLastError());
+    return AAE_OK;
+}
+
+}  // namespace aae_host
+
+// =============================================================== C ABI
+extern "C" {
+
+int aae_abi_version(void) { return AAE_ABI_VERSION; }
+const char* aae_last_error(void) { return aae_host::g_last_error.c_str(); }
+
+int aae_encoder_create(const aae_encoder_desc* d, const void* const* hw, int n_weights, aae_encoder** out) {
+    using namespace aae_host;
+    if (!d || !hw || !out) return fail(AAE_ERR_INVALID, "aae_encoder_create: null argument");
+    if (d->num_layers < 1 || d->num_layers > AAE_MAX_LAYERS)
+        return fail(AAE_ERR_INVALID, "num_layers %d outside [1,%d]", d->num_layers, AAE_MAX_LAYERS);
+    if (d->in_h < 1 || d->in_w < 1 || d->in_c < 1 || d->kernel_size < 1 || d->latent_size < 1)
+        return fail(AAE_ERR_INVALID, "non-positive shape in encoder desc");
+    const int per_layer = d->batch_norm ? 6 : 2;
+    if (n_weights != d->num_layers * per_layer + 2)
+        return fail(AAE_ERR_INVALID, "expected %d weight arrays, got %d", d->num_layers * per_layer + 2, n_weights);
+    for (int i = 0; i < n_weights; ++i)
+        if (!hw[i]) return fail(AAE_ERR_INVALID, "weight array %d is null", i);
+
+    aae_encoder* enc = new aae_encoder();
+    enc->desc = *d;
+    auto bail = [&](int rc) { aae_encoder_destroy(enc); return rc; };
+
+    float lut[256];
+    for (int v = 0; v < 256; ++v) lut[v] = (float)((double)v / 255.0);   // float64 quotient, float32 feed cast
+    if (int rc = upload(enc, lut, 256, &enc->lut)) return bail(rc);
+
+    int H = d->in_h, W = d->in_w, C = d->in_c, wi = 0;
+    const float eps = d->bn_eps > 0.f ? d->bn_eps : 1e-3f;
+    for (int li = 0; li < d->num_layers; ++li) {
+        Layer L;
+        L.H = H; L.W = W; L.Cin = C; L.Cout = d->num_filters[li]; L.KS = d->kernel_size; L.S = d->strides[li];
+        if (L.Cout < 1 || L.S < 1) return bail(fail(AAE_ERR_INVALID, "layer %d: filters %d stride %d", li, L.Cout, L.S));
+        same_pad(H, L.KS, L.S, &L.Ho, &L.pt);
+        same_pad(W, L.KS, L.S, &L.Wo, &L.pl);
+        L.CoutPad = (int)align_up((size_t)L.Cout, 128);
+        const float* k = static_cast<const float*>(hw[wi++]);
+        const float* b = static_cast<const float*>(hw[wi++]);
+        if (int rc = upload(enc, k, (size_t)L.K() * L.Cout, &L.w_hwio)) return bail(rc);
+        if (int rc = upload(enc, b, L.Cout, &L.bias)) return bail(rc);
+        if (d->batch_norm) {
+            const float* g = static_cast<const float*>(hw[wi++]);
+            const float* be = static_cast<const float*>(hw[wi++]);
+            const float* mu = static_cast<const float*>(hw[wi++]);
+            const float* var = static_cast<const float*>(hw[wi++]);
+            std::vector<float> sc(L.Cout), sh(L.Cout);
+            for (int c = 0; c < L.Cout; ++c) {       // tf.nn.batch_normalization: inv = rsqrt(var+eps)*gamma
+                const float inv = (1.0f / sqrtf(var[c] + eps)) * g[c];
+                sc[c] = inv;
+                sh[c] = be[c] - mu[c] * inv;
+            }
+            if (int rc = upload(enc, sc.data(), L.Cout, &L.bn_scale)) return bail(rc);
+            if (int rc = upload(enc, sh.data(), L.Cout, &L.bn_shift)) return bail(rc);
+        }
+        if (li == 0 && first_layer_instantiated(L.KS, L.Cin)) {
+            plan_first_layer(L);
+            L.kind = (L.first_smem <= 160 * 1024) ? KIND_FIRST_MFMA : KIND_GENERIC;
+        }
+        if (L.kind == KIND_GENERIC && L.Cin % 32 == 0) {
+            L.kind = KIND_IGEMM;
+            const std::vector<float> packed = pack_weights(k, L.K(), L.Cout, L.CoutPad);
+            if (int rc = upload(enc, packed.data(), packed.size(), &L.wp)) return bail(rc);
+        }
+        enc->layers.push_back(L);
+        H = L.Ho; W = L.Wo; C = L.Cout;
+    }
+    Layer& D = enc->dense;
+    D.H = D.W = D.Ho = D.Wo = 1; D.KS = 1; D.S = 1; D.pt = D.pl = 0; D.relu = 0;
+    D.Cin = H * W * C;                       // tf.layers.flatten, NHWC row-major
+    D.Cout = d->latent_size;
+    D.CoutPad = (int)align_up((size_t)D.Cout, 128);
+    {
+        const float* k = static_cast<const float*>(hw[wi++]);
+        const float* b = static_cast<const float*>(hw[wi++]);
+        if (int rc = upload(enc, b, D.Cout, &D.bias)) return bail(rc);
+        if (D.Cin % 32 == 0) {
+            D.kind = KIND_IGEMM;
+            const std::vector<float> packed = pack_weights(k, D.K(), D.Cout, D.CoutPad);
+            if (int rc = upload(enc, packed.data(), packed.size(), &D.wp)) return bail(rc);
+        } else {
+            D.kind = KIND_GENERIC;
+            if (int rc = upload(enc, k, (size_t)D.K() * D.Cout, &D.w_hwio)) return bail(rc);
+        }
+    }
+    (void)hipFuncSetAttribute((const void*)aae::conv_igemm_f32_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
+    (void)hipFuncSetAttribute((const void*)aae::conv_igemm_f32_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
+    if (enc->layers[0].kind == KIND_FIRST_MFMA) {
+        const int sm = enc->layers[0].first_smem;
+        (void)hipFuncSetAttribute((const void*)aae::conv_first_f32_kernel<5, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
+        (void)hipFuncSetAttribute((const void*)aae::conv_first_f32_kernel<5, 3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
+        (void)hipFuncSetAttribute((const void*)aae::conv_first_f32_kernel<5, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
+        (void)hipFuncSetAttribute((const void*)aae::conv_first_f32_kernel<5, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
+    }
+    *out = enc;
+    return AAE_OK;
+}
+
+void aae_encoder_destroy(aae_encoder* enc) {
+    if (!enc) return;
+    for (void* p : enc->allocations) (void)hipFree(p);
+    delete enc;
+}
+
+int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
+    using namespace aae_host;
+    if (!enc || !name) return fail(AAE_ERR_INVALID, "aae_encoder_set_option: null argument");
+    if (!strcmp(name, "splitk_min_base_blocks")) enc->splitk_min_base_blocks = value;
+    else if (!strcmp(name, "splitk_target_blocks")) enc->splitk_target_blocks = value;
+    else return fail(AAE_ERR_INVALID, "unknown encoder option '%s'", name);
+    return AAE_OK;
+}
+
+size_t aae_encoder_workspace_bytes(const aae_encoder* enc, int B) {
+    if (!enc || B < 1) return 0;
+    return aae_host::plan_workspace(enc, B).total;
+}
+
+int aae_encoder_forward(aae_encoder* enc, const void* x, int x_dtype, int B, float* z_out, void* workspace,
+                        size_t ws_bytes, void* stream) {
+    aae_host::Timer tm;
+    return aae_host::forward_impl(enc, x, x_dtype, B, z_out, workspace, ws_bytes, stream, tm);
+}
+
+int aae_encoder_forward_timed(aae_encoder* enc, const void* x, int x_dtype, int B, float* z_out, void* workspace,
+                              size_t ws_bytes, void* stream, float* kernel_ms, int max_kernels, int* n_kernels) {
+    using namespace aae_host;
+    if (!kernel_ms || !n_kernels) return fail(AAE_ERR_INVALID, "aae_encoder_forward_timed: null output");
+    Timer tm;
+    tm.on = true;
+    int rc = forward_impl(enc, x, x_dtype, B, z_out, workspace, ws_bytes, stream, tm);
+    if (rc == AAE_OK && !tm.ev.empty()) {
+        hipError_t e = hipEventSynchronize(tm.ev.back());
+        if (e != hipSuccess) rc = fail(AAE_ERR_RUNTIME, "hipEventSynchronize: %s", hipGetErrorString(e));
+    }
+    int n = (int)tm.ev.size() - 1;
+    if (n < 0) n = 0;
+    if (rc == AAE_OK) {
+        for (int i = 0; i < n && i < max_kernels; ++i) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, tm.ev[i], tm.ev[i + 1]);
+            kernel_ms[i] = ms;
+        }
+        *n_kernels = n;
+    }
+    for (hipEvent_t e : tm.ev) (void)hipEventDestroy(e);
+    return rc;
+}
+
+const char* aae_encoder_kernel_label(const aae_encoder* enc, int i) {
+    if (!enc || i < 0 || i >= (int)enc->records.size()) return "";
+    return enc->records[i].label.c_str();
+}
+
+double aae_encoder_kernel_flops(const aae_encoder* enc, int i) {
+    if (!enc || i < 0 || i >= (int)enc->records.size()) return 0.0;
+    return enc->records[i].flops;
+}
+
+int aae_encoder_activation_info(const aae_encoder* enc, int B, int layer, size_t* offset_bytes, size_t* count) {
+    using namespace aae_host;
+    if (!enc || !offset_bytes || !count || B < 1) return fail(AAE_ERR_INVALID, "aae_encoder_activation_info: bad argument");
+    if (layer < 0 || layer >= (int)enc->layers.size()) return fail(AAE_ERR_INVALID, "layer %d out of range", layer);
+    const Workspace ws = plan_workspace(enc, B);
+    const Layer& L = enc->layers[layer];
+    *offset_bytes = ws.act_off[layer];
+    *count = (size_t)B * L.Ho * L.Wo * L.Cout;
+    return AAE_OK;
+}
+
+int aae_codebook_create(const void* E, int N, int J, int dtype, int src_is_device, aae_codebook** out) {
+    using namespace aae_host;
+    if (!E || !out) return fail(AAE_ERR_INVALID, "aae_codebook_create: null argument");
+    if (N < 1 || J < 1) return fail(AAE_ERR_INVALID, "codebook shape [%d,%d]", N, J);
+    if (dtype != AAE_DTYPE_F32) return fail(AAE_ERR_UNSUPPORTED, "codebook dtype %d: only float32 is implemented", dtype);
+    if (J % 4 != 0 || J > 128) return fail(AAE_ERR_UNSUPPORTED, "latent size %d: the scan kernels need J %% 4 == 0 and J <= 128", J);
+    aae_codebook* cb = new aae_codebook();
+    cb->N = N; cb->J = J;
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, (size_t)N * J * sizeof(float));
+    if (e != hipSuccess) { delete cb; return fail(AAE_ERR_RUNTIME, "hipMalloc(codebook): %s", hipGetErrorString(e)); }
+    cb->E = static_cast<float*>(p);
+    e = hipMemcpy(cb->E, E, (size_t)N * J * sizeof(float), src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice);
+    if (e != hipSuccess) { aae_codebook_destroy(cb); return fail(AAE_ERR_RUNTIME, "hipMemcpy(codebook): %s", hipGetErrorString(e)); }
+    *out = cb;
+    return AAE_OK;
+}
+
+int aae_codebook_update(aae_codebook* cb, const void* E, int src_is_device, void* stream) {
+    using namespace aae_host;
+    if (!cb || !E) return fail(AAE_ERR_INVALID, "aae_codebook_update: null argument");
+    AAE_HIP_TRY(hipMemcpyAsync(cb->E, E, (size_t)cb->N * cb->J * sizeof(float),
+                               src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
+    AAE_HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return AAE_OK;
+}
+
+void aae_codebook_destroy(aae_codebook* cb) {
+    if (!cb) return;
+    if (cb->E) (void)hipFree(cb->E);
+    delete cb;
+}
+
+int aae_codebook_set_scan_mode(aae_codebook* cb, int mode) {
+    using namespace aae_host;
+    if (!cb) return fail(AAE_ERR_INVALID, "aae_codebook_set_scan_mode: null handle");
+    if (mode != AAE_SCAN_AUTO && mode != AAE_SCAN_GEMV && mode != AAE_SCAN_MFMA) return fail(AAE_ERR_INVALID, "scan mode %d", mode);
+    cb->scan_mode = mode;
+    return AAE_OK;
+}
+
+size_t aae_codebook_workspace_bytes(const aae_codebook* cb, int B, int topk) {
+    if (!cb || B < 1 || topk < 1) return 0;
+    return aae_host::plan_scan(cb, B, topk).total;
+}
+
+int aae_codebook_nn(aae_codebook* cb, const float* z, int B, int topk, int col_stride, int64_t* idx_out,
+                    float* score_out, void* workspace, size_t ws_bytes, void* stream_v) {
+    using namespace aae_host;
+    if (!cb || !z || !idx_out || !score_out) return fail(AAE_ERR_INVALID, "aae_codebook_nn: null argument");
+    if (B < 1 || topk < 1 || topk > cb->N) return fail(AAE_ERR_INVALID, "aae_codebook_nn: B=%d topk=%d N=%d", B, topk, cb->N);
+    if (col_stride < 1) return fail(AAE_ERR_INVALID, "col_stride %d < 1", col_stride);
+    if (topk > 1 && col_stride != 1) return fail(AAE_ERR_INVALID, "upright (col_stride>1) is defined for topk == 1 only (codebook.py:65-66)");
+    const ScanPlan s = plan_scan(cb, B, topk);
+    if (ws_bytes < s.total) return fail(AAE_ERR_WORKSPACE, "workspace %zu B < required %zu B", ws_bytes, s.total);
+    if (!workspace || ((uintptr_t)workspace & 255)) return fail(AAE_ERR_WORKSPACE, "workspace must be non-null and 256-B aligned");
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    unsigned char* base = static_cast<unsigned char*>(workspace);
+    float* cs = topk > 1 ? reinterpret_cast<float*>(base + s.cs_off) : nullptr;
+    if (int rc = run_scan(cb, z, B, col_stride, cs, s, base, stream)) return rc;
+    if (topk == 1) {
+        aae::ArgmaxReduceArgs r;
+        r.pval = reinterpret_cast<float*>(base + s.pval_off);
+        r.pidx = reinterpret_cast<int*>(base + s.pidx_off);
+        r.idx_out = reinterpret_cast<long long*>(idx_out);
+        r.score_out = score_out; r.nblk = s.nblk; r.B = B; r.Bstride = s.Bstride;
+        AAE_LAUNCH((aae::argmax_reduce_kernel), dim3(B), dim3(64), 0, stream, r);
+    } else {
+        aae::TopKArgs t;
+        t.cs = cs; t.idx_out = reinterpret_cast<long long*>(idx_out); t.score_out = score_out; t.N = cb->N; t.k = topk;
+        AAE_LAUNCH((aae::topk_rows_kernel), dim3(B), dim3(256), 64, stream, t);
+    }
+    AAE_HIP_TRY(hipGetLastError());
+    return AAE_OK;
+}
+
+int aae_codebook_similarity(aae_codebook* cb, const float* z, int B, float* cs_out, void* workspace, size_t ws_bytes,
+                            void* stream_v) {
+    using namespace aae_host;
+    if (!cb || !z || !cs_out) return fail(AAE_ERR_INVALID, "aae_codebook_similarity: null argument");
+    if (B < 1) return fail(AAE_ERR_INVALID, "aae_codebook_similarity: B=%d", B);
+    const ScanPlan s = plan_scan(cb, B, 1);
+    if (ws_bytes < s.total) return fail(AAE_ERR_WORKSPACE, "workspace %zu B < required %zu B", ws_bytes, s.total);
+    if (!workspace || ((uintptr_t)workspace & 255)) return fail(AAE_ERR_WORKSPACE, "workspace must be non-null and 256-B aligned");
+    return run_scan(cb, z, B, 1, cs_out, s, static_cast<unsigned char*>(workspace), static_cast<hipStream_t>(stream_v));
+}
+
+int aae_l2_normalize(const float* z, int B, int J, float* q_out, void* stream_v) {
+    using namespace aae_host;
+    if (!z || !q_out || B < 1 || J < 1) return fail(AAE_ERR_INVALID, "aae_l2_normalize: bad argument");
+    aae::L2NormArgs n;
+    n.z = z; n.q = q_out; n.qp = nullptr; n.B = B; n.J = J; n.Jpad = J; n.Bpad = B;
+    AAE_LAUNCH((aae::l2norm_pack_kernel), dim3(ceil_div(B, 4)), dim3(256), 0, static_cast<hipStream_t>(stream_v), n);
+    AAE_HIP_TRY(hipGetLastError());
+    return AAE_OK;
+}
+
+}  // extern "C"

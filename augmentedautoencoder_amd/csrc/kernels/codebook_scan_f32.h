@@ -1,0 +1,313 @@
+// Codebook stage: L2-normalise + cosine similarity against the rotation codebook
+// + arg-max / top-k, without ever materialising the [B, N] similarity matrix
+// (the reference copies it to the host and arg-maxes in NumPy).
+//
+// Replaces (paths relative to /root/reference/auto_pose/ae/):
+//   tf.nn.l2_normalize(z, 1) ......................... codebook.py:27
+//   tf.matmul(q, embedding_normalized, transpose_b) .. codebook.py:50
+//   np.argmax(cs, axis=1) / upright stride ........... codebook.py:64-68
+//   argpartition + argsort top-n ..................... codebook.py:69-71
+//
+// Two scan kernels share one partial-result format ([ceil(N/128)] blocks x B
+// queries of (best score, best row)):
+//   scan_gemv : B <= 4.  Pure HBM stream: each half-wave reads one 512-B
+//               codebook row per load instruction (float4 per lane), dots it
+//               with the LDS/VGPR-resident queries, butterfly-reduces over the
+//               32 lanes and keeps a running (max, first index).
+//   scan_mfma : any B.  128 codebook rows x (32*NT) queries per pass on
+//               v_mfma_f32_32x32x2_f32; the 128 x J codebook tile is staged
+//               once in LDS (swizzled, coalesced 16-B loads) and reused for
+//               every query tile; the arg-max runs on the accumulators.
+// A final one-wave-per-query kernel reduces the block partials.  Ties always
+// resolve to the LOWEST row index (np.argmax semantics) at every level.
+#pragma once
+
+namespace aae {
+
+constexpr float kNegInf = -__builtin_huge_valf();
+
+// ---------------------------------------------------------------- l2 normalise
+// One wave per query.  q[b][:] = z[b][:] * (1/sqrt(max(sum z^2, 1e-12)));
+// also emits the MFMA B-operand packing qp[J/4][Bpad][4] (zero rows for b >= B).
+struct L2NormArgs {
+    const float* z;   // [B][J]
+    float* q;         // [B][J]   (may be nullptr)
+    float* qp;        // [Jpad/4][Bpad][4] (may be nullptr)
+    int B, J, Jpad, Bpad;
+};
+
+__global__ __launch_bounds__(256) void l2norm_pack_kernel(const L2NormArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= p.Bpad) return;                      // whole wave exits together
+    const bool real = b < p.B;
+    float ss = 0.f;
+    if (real)
+        for (int j = lane; j < p.J; j += 64) { const float v = p.z[(long long)b * p.J + j]; ss = fmaf(v, v, ss); }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) ss += shfl_xor(ss, m);
+    const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
+    for (int j = lane; j < p.Jpad; j += 64) {
+        const float v = (real && j < p.J) ? p.z[(long long)b * p.J + j] * inv : 0.f;
+        if (p.q && real && j < p.J) p.q[(long long)b * p.J + j] = v;
+        if (p.qp) p.qp[((long long)(j >> 2) * p.Bpad + b) * 4 + (j & 3)] = v;
+    }
+}
+
+// ------------------------------------------------------------------- scan args
+struct ScanArgs {
+    const float* E;     // [N][J] fp32, row-major
+    const float* q;     // [B][J]      normalised queries        (gemv)
+    const float* qp;    // [Jpad/4][Bpad][4] packed queries      (mfma)
+    float* pval;        // [nblk][Bstride] block-partial best score
+    int* pidx;          // [nblk][Bstride] block-partial best row
+    float* cs;          // optional full [B][N] similarity (parity / top-k path)
+    int N, J, Jpad, B, Bpad, Bstride;
+    int col_stride;     // 1, or num_cyclo for the reference's `upright` mode
+};
+
+// ------------------------------------------------------------------- scan_gemv
+template <int NQ, bool UPRIGHT>
+__global__ __launch_bounds__(256) void scan_gemv_kernel(const ScanArgs p) {
+    AAE_DYN_SMEM(smem_raw);
+    float* red_v = reinterpret_cast<float*>(smem_raw);           // [4][NQ]
+    int* red_i = reinterpret_cast<int*>(red_v + 4 * NQ);         // [4][NQ]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rs = lane >> 5, kq = lane & 31;
+    const int col = kq * 4;
+    const bool col_ok = col < p.J;                               // J <= 128, J % 4 == 0
+
+    f32x4 qv[NQ];
+#pragma unroll
+    for (int b = 0; b < NQ; ++b) {
+        qv[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (b < p.B && col_ok) qv[b] = *reinterpret_cast<const f32x4*>(p.q + (long long)b * p.J + col);
+    }
+    float best_v[NQ];
+    int best_i[NQ];
+    const int row_first = blockIdx.x * 128 + wave * 32;
+#pragma unroll
+    for (int b = 0; b < NQ; ++b) { best_v[b] = kNegInf; best_i[b] = row_first; }
+
+#pragma unroll
+    for (int it0 = 0; it0 < 16; it0 += 8) {
+        f32x4 e[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int row = row_first + (it0 + u) * 2 + rs;
+            e[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (row < p.N && col_ok) e[u] = *reinterpret_cast<const f32x4*>(p.E + (long long)row * p.J + col);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int row = row_first + (it0 + u) * 2 + rs;
+            bool cand = row < p.N;
+            if (UPRIGHT) cand = cand && (row % p.col_stride == 0);
+#pragma unroll
+            for (int b = 0; b < NQ; ++b) {
+                float d = e[u].x * qv[b].x;
+                d = fmaf(e[u].y, qv[b].y, d);
+                d = fmaf(e[u].z, qv[b].z, d);
+                d = fmaf(e[u].w, qv[b].w, d);
+#pragma unroll
+                for (int m = 16; m >= 1; m >>= 1) d += shfl_xor(d, m);
+                if (p.cs && kq == 0 && row < p.N && b < p.B) p.cs[(long long)b * p.N + row] = d;
+                if (cand && d > best_v[b]) { best_v[b] = d; best_i[b] = row; }
+            }
+        }
+    }
+    // even rows (rs=0) vs odd rows (rs=1), then the 4 waves
+#pragma unroll
+    for (int b = 0; b < NQ; ++b) {
+        const float ov = shfl_xor(best_v[b], 32);
+        const int oi = shfl_xor(best_i[b], 32);
+        if (better(ov, oi, best_v[b], best_i[b])) { best_v[b] = ov; best_i[b] = oi; }
+        if (lane == 0) { red_v[wave * NQ + b] = best_v[b]; red_i[wave * NQ + b] = best_i[b]; }
+    }
+    __syncthreads();
+    if (tid < NQ && tid < p.B) {
+        float v = red_v[tid];
+        int ix = red_i[tid];
+        for (int w = 1; w < 4; ++w)
+            if (better(red_v[w * NQ + tid], red_i[w * NQ + tid], v, ix)) { v = red_v[w * NQ + tid]; ix = red_i[w * NQ + tid]; }
+        p.pval[(long long)blockIdx.x * p.Bstride + tid] = v;
+        p.pidx[(long long)blockIdx.x * p.Bstride + tid] = ix;
+    }
+}
+
+// ------------------------------------------------------------------- scan_mfma
+// LDS: E tile [128 rows][128 k] (row stride 128 floats, 16-B slot XOR (row&15))
+//      q tile [32 slots][32*NT cols][4]
+__device__ __forceinline__ int e_tile_off(int row, int slot) { return row * 128 + ((slot ^ (row & 15)) << 2); }
+
+template <int NT>
+constexpr int scan_mfma_smem() { return (128 * 128 + 32 * 32 * NT * 4 + 2 * 4 * 32 * NT) * 4; }
+
+template <int NT, bool UPRIGHT>
+__global__ __launch_bounds__(256) void scan_mfma_kernel(const ScanArgs p) {
+    constexpr int QC = 32 * NT;                                   // queries per pass
+    AAE_DYN_SMEM(smem_raw);
+    float* Et = reinterpret_cast<float*>(smem_raw);               // [128][128]
+    float* Qt = Et + 128 * 128;                                   // [32][QC][4]
+    float* red_v = Qt + 32 * QC * 4;                              // [4][QC]
+    int* red_i = reinterpret_cast<int*>(red_v + 4 * QC);          // [4][QC]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int row0 = blockIdx.x * 128;
+
+    // stage the codebook tile once (J <= 128): 128 rows x 32 slots, 16 float4 per
+    // thread, each half-wave reads one contiguous 512-B row
+    {
+#pragma unroll
+        for (int u = 0; u < 16; ++u) {
+            const int idx = tid + 256 * u;
+            const int r = idx >> 5, slot = idx & 31;
+            const int row = row0 + r, c = slot * 4;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (row < p.N && c < p.J) v = *reinterpret_cast<const f32x4*>(p.E + (long long)row * p.J + c);
+            lds_write4(Et + e_tile_off(r, slot), v);
+        }
+        for (int qt = 0; qt < p.Bpad; qt += QC) {
+            __syncthreads();                                       // Qt / red free again
+            for (int idx = tid; idx < 32 * QC; idx += 256) {
+                const int slot = idx / QC, c = idx - slot * QC;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(p.qp + ((long long)slot * p.Bpad + qt + c) * 4);
+                lds_write4(Qt + idx * 4, v);
+            }
+            __syncthreads();
+
+            f32x16 acc[NT];
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
+#pragma unroll 4
+            for (int c = 0; c < 16; ++c) {
+                const int slot = 2 * c + h;
+                const f32x4 a = lds_read4(Et + e_tile_off(wave * 32 + i, slot));
+#pragma unroll
+                for (int ni = 0; ni < NT; ++ni) {
+                    const f32x4 b = lds_read4(Qt + (slot * QC + ni * 32 + i) * 4);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[ni] = mfma_32x32x2(a[q], b[q], acc[ni]);
+                }
+            }
+
+            // running (max, first row) per query column; rows ascend with r for fixed h
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) {
+                const int query = qt + ni * 32 + i;
+                float bv = kNegInf;
+                int bi = row0 + wave * 32 + acc_row(0, lane);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row0 + wave * 32 + acc_row(r, lane);
+                    const float v = acc[ni][r];
+                    bool cand = row < p.N;
+                    if (UPRIGHT) cand = cand && (row % p.col_stride == 0);
+                    if (p.cs && row < p.N && query < p.B) p.cs[(long long)query * p.N + row] = v;
+                    if (cand && v > bv) { bv = v; bi = row; }
+                }
+                const float ov = shfl_xor(bv, 32);
+                const int oi = shfl_xor(bi, 32);
+                if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+                if (h == 0) { red_v[wave * QC + ni * 32 + i] = bv; red_i[wave * QC + ni * 32 + i] = bi; }
+            }
+            __syncthreads();
+            if (tid < QC && qt + tid < p.B) {
+                float v = red_v[tid];
+                int ix = red_i[tid];
+                for (int w = 1; w < 4; ++w)
+                    if (better(red_v[w * QC + tid], red_i[w * QC + tid], v, ix)) { v = red_v[w * QC + tid]; ix = red_i[w * QC + tid]; }
+                p.pval[(long long)blockIdx.x * p.Bstride + qt + tid] = v;
+                p.pidx[(long long)blockIdx.x * p.Bstride + qt + tid] = ix;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------- final reduction over blocks
+struct ArgmaxReduceArgs {
+    const float* pval;
+    const int* pidx;
+    long long* idx_out;   // [B] int64 (np.argmax dtype)
+    float* score_out;     // [B]
+    int nblk, B, Bstride;
+};
+
+__global__ __launch_bounds__(64) void argmax_reduce_kernel(const ArgmaxReduceArgs p) {
+    const int b = blockIdx.x, lane = threadIdx.x;
+    float bv = kNegInf;
+    int bi = 0x7fffffff;
+    for (int k = lane; k < p.nblk; k += 64) {
+        const float v = p.pval[(long long)k * p.Bstride + b];
+        const int ix = p.pidx[(long long)k * p.Bstride + b];
+        if (better(v, ix, bv, bi)) { bv = v; bi = ix; }
+    }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const float ov = shfl_xor(bv, m);
+        const int oi = shfl_xor(bi, m);
+        if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) {
+        if (bi == 0x7fffffff) bi = 0;          // all-NaN scores: np.argmax would also answer 0
+        p.idx_out[b] = bi;
+        p.score_out[b] = bv;
+    }
+}
+
+// --------------------------------------------------------------------- top-k
+// One block per query over a materialised similarity row.  k rounds; round j
+// selects the best element strictly after round j-1's winner in the order
+// (score descending, index ascending) -- no masking writes, deterministic.
+struct TopKArgs {
+    const float* cs;       // [B][N]
+    long long* idx_out;    // [B][k]
+    float* score_out;      // [B][k]
+    int N, k;
+};
+
+__global__ __launch_bounds__(256) void topk_rows_kernel(const TopKArgs p) {
+    AAE_DYN_SMEM(smem_raw);
+    float* red_v = reinterpret_cast<float*>(smem_raw);      // [4]
+    int* red_i = reinterpret_cast<int*>(red_v + 4);         // [4]
+    float* win_v = red_v + 8;                               // [1]
+    int* win_i = reinterpret_cast<int*>(red_v + 9);         // [1]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* row = p.cs + (long long)blockIdx.x * p.N;
+    float pv = __builtin_huge_valf();
+    int pi = -1;
+    for (int j = 0; j < p.k; ++j) {
+        float bv = kNegInf;
+        int bi = 0x7fffffff;
+        for (int n = tid; n < p.N; n += 256) {
+            const float v = row[n];
+            const bool after = (v < pv) || (v == pv && n > pi);
+            if (after && better(v, n, bv, bi)) { bv = v; bi = n; }
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const float ov = shfl_xor(bv, m);
+            const int oi = shfl_xor(bi, m);
+            if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+        }
+        if (lane == 0) { red_v[wave] = bv; red_i[wave] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w = 1; w < 4; ++w)
+                if (better(red_v[w], red_i[w], bv, bi)) { bv = red_v[w]; bi = red_i[w]; }
+            win_v[0] = bv; win_i[0] = bi;
+            p.idx_out[(long long)blockIdx.x * p.k + j] = (bi == 0x7fffffff) ? 0 : bi;
+            p.score_out[(long long)blockIdx.x * p.k + j] = bv;
+        }
+        __syncthreads();
+        pv = win_v[0];
+        pi = win_i[0];
+        __syncthreads();
+    }
+}
+
+}  // namespace aae

@@ -1,0 +1,141 @@
+// First encoder layer: small-Cin convolution (Cin = 1 or 3) on the fp32 matrix
+// cores with the uint8 -> float conversion fused into the load.
+//
+// Replaces  x = x/255.            (/root/reference/auto_pose/ae/codebook.py:58-59)
+//           tf.layers.conv2d(...) (/root/reference/auto_pose/ae/encoder.py:43-50), first iteration.
+//
+// GEMM view: M = output pixels, N = Cout, K = KS*KS*C with k = kh*(KS*C) + j,
+// j = kw*C + ci -- i.e. every kernel row is one contiguous run of KS*C input
+// values in NHWC.  A block stages the input rows it needs (full width, zero
+// borders = TF 'SAME') as fp32 in LDS, so the A operand of MFMA step s is one
+// ds_read_b32 at  pixel_base + kh*rowlen + j.  Each wave owns 32 output
+// channels and keeps ALL its weights in VGPRs (ceil(K/2) registers) across a
+// run of tiles; M tile = 128 consecutive output pixels of one image.
+//
+// uint8 input goes through a 256-entry table  float32(v/255.)  -- the exact
+// value TensorFlow sees after the float64 division and the float32 feed cast.
+#pragma once
+
+namespace aae {
+
+struct ConvFirstArgs {
+    const void* x;          // [B,H,W,C] uint8 or float32
+    const float* lut;       // [256] (uint8 input only)
+    const float* w;         // HWIO [KS][KS][C][Cout] == [K][Cout]
+    const float* bias;
+    const float* bn_scale;  // or nullptr
+    const float* bn_shift;
+    float* out;             // [B,Ho,Wo,Cout]
+    int H, W, Ho, Wo, Cout;
+    int S, pt, pl;
+    int rowlen;             // staged floats per input row = ((Wo-1)*S + KS) * C
+    int tiles_per_image;    // ceil(Ho*Wo / 128)
+    int total_tiles;        // B * tiles_per_image
+    int tiles_per_block;
+    int relu;
+};
+
+template <int KS, int C, bool IN_U8>
+__global__ __launch_bounds__(256) void conv_first_f32_kernel(const ConvFirstArgs p) {
+    constexpr int KROW = KS * C;
+    constexpr int K = KS * KROW;
+    constexpr int NK2 = (K + 1) / 2;
+
+    AAE_DYN_SMEM(smem_raw);
+    float* lut_s = reinterpret_cast<float*>(smem_raw);     // [256]
+    float* patch = lut_s + 256;                            // [rows][rowlen]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int n = blockIdx.y * 128 + wave * 32 + i;
+    const bool n_ok = n < p.Cout;
+
+    if (IN_U8) lut_s[tid] = p.lut[tid];
+
+    // this wave's weights: breg[s] = W[2s+h][n]
+    float breg[NK2];
+#pragma unroll
+    for (int s = 0; s < NK2; ++s) {
+        const int k = 2 * s + h;
+        breg[s] = (n_ok && k < K) ? p.w[(long long)k * p.Cout + n] : 0.f;
+    }
+    float bias = 0.f, sc = 1.f, sh = 0.f;
+    if (n_ok) {
+        bias = p.bias[n];
+        if (p.bn_scale) { sc = p.bn_scale[n]; sh = p.bn_shift[n]; }
+    }
+
+    const int HoWo = p.Ho * p.Wo;
+    const int WC = p.W * C;
+    const int t_begin = blockIdx.x * p.tiles_per_block;
+    const int t_end = min(t_begin + p.tiles_per_block, p.total_tiles);
+
+    for (int T = t_begin; T < t_end; ++T) {
+        const int b = T / p.tiles_per_image;
+        const int p0 = (T - b * p.tiles_per_image) * 128;
+        const int pend = min(p0 + 128, HoWo);
+        const int oh_first = p0 / p.Wo;
+        const int oh_last = (pend - 1) / p.Wo;
+        const int in_row0 = oh_first * p.S - p.pt;
+        const int n_in_rows = (oh_last - oh_first) * p.S + KS;
+
+        __syncthreads();                       // previous tile's readers are done (and lut_s is visible)
+        for (int r = 0; r < n_in_rows; ++r) {
+            const int ih = in_row0 + r;
+            const bool row_ok = (unsigned)ih < (unsigned)p.H;
+            const long long row_base = ((long long)b * p.H + ih) * WC;
+            for (int c = tid; c < p.rowlen; c += 256) {
+                const int src = c - p.pl * C;
+                float v = 0.f;
+                if (row_ok && (unsigned)src < (unsigned)WC) {
+                    if (IN_U8) v = lut_s[reinterpret_cast<const unsigned char*>(p.x)[row_base + src]];
+                    else v = reinterpret_cast<const float*>(p.x)[row_base + src];
+                }
+                patch[r * p.rowlen + c] = v;
+            }
+        }
+        __syncthreads();
+
+        int abase[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) {
+            int px = p0 + mt * 32 + i;
+            px = min(px, pend - 1);            // tail lanes recompute the last pixel; masked at the store
+            const int oh = px / p.Wo, ow = px - oh * p.Wo;
+            abase[mt] = (oh - oh_first) * p.S * p.rowlen + ow * p.S * C;
+        }
+
+        f32x16 acc[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+#pragma unroll
+        for (int s = 0; s < NK2; ++s) {
+            const int k0 = 2 * s, k1 = (2 * s + 1 < K) ? 2 * s + 1 : K - 1;   // k=K (odd K pad) re-reads k=K-1 against a zero weight
+            const int off0 = (k0 / KROW) * p.rowlen + (k0 % KROW);
+            const int off1 = (k1 / KROW) * p.rowlen + (k1 % KROW);
+            const int off = h ? off1 : off0;
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt) acc[mt] = mfma_32x32x2(patch[abase[mt] + off], breg[s], acc[mt]);
+        }
+
+        if (n_ok) {
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int px = p0 + mt * 32 + acc_row(r, lane);
+                    if (px < pend) {
+                        float v = acc[mt][r] + bias;
+                        if (p.relu) v = fmaxf(v, 0.f);
+                        if (p.bn_scale) v = v * sc + sh;
+                        p.out[((long long)b * HoWo + px) * p.Cout + n] = v;
+                    }
+                }
+        }
+    }
+}
+
+}  // namespace aae

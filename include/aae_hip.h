@@ -1,0 +1,137 @@
+/* aae_hip.h -- C ABI of libaae_hip.so: the MI355X (gfx950) implementation of the
+ * AugmentedAutoencoder orientation-inference hot path.
+ *
+ * The reference has no FFI for this path: its boundary is a Python class API
+ * whose back end is tf.Session.run.  Each entry point below
+ * names the reference interface it replaces (paths relative to /root/reference).
+ * INTEGRATION.md shows the ctypes binding a maintainer would add.
+ *
+ * Conventions
+ *   - plain C types only; device buffers are raw device pointers owned by the
+ *     caller (e.g. torch tensors); `stream` is a hipStream_t passed as void*.
+ *   - every call returns AAE_OK (0) or a negative error code; the message for
+ *     the calling thread is available from aae_last_error().  Nothing exits
+ *     the process (the reference print()+exit(-1)s on fatal errors).
+ *   - handles own their device weights / codebook and are immutable after
+ *     creation (aae_codebook_update excepted); concurrent calls on distinct
+ *     streams with distinct workspaces are allowed.  No allocation happens
+ *     inside forward / nn / similarity: scratch comes from the caller-provided
+ *     workspace sized by the *_workspace_bytes queries.
+ */
+#ifndef AAE_HIP_H_
+#define AAE_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AAE_ABI_VERSION 1
+
+#define AAE_OK 0
+#define AAE_ERR_INVALID (-1)      /* bad argument                                  */
+#define AAE_ERR_UNSUPPORTED (-2)  /* shape / dtype outside what the kernels cover  */
+#define AAE_ERR_RUNTIME (-3)      /* HIP runtime error (message has the detail)    */
+#define AAE_ERR_WORKSPACE (-4)    /* workspace too small / misaligned              */
+
+#define AAE_DTYPE_U8 0            /* uint8 crops: converted as float32(v/255.)     */
+#define AAE_DTYPE_F32 1
+
+#define AAE_MAX_LAYERS 8
+
+#define AAE_SCAN_AUTO 0
+#define AAE_SCAN_GEMV 1           /* vector-ALU HBM stream, B <= 4                  */
+#define AAE_SCAN_MFMA 2           /* fp32 matrix-core tiles, any B                  */
+
+typedef struct aae_encoder aae_encoder;
+typedef struct aae_codebook aae_codebook;
+
+/* Shapes of Encoder(input, latent_space_size, num_filters, kernel_size, strides,
+ * batch_norm)  -- auto_pose/ae/encoder.py:14, filled from the [Network]/[Dataset]
+ * cfg keys exactly as ae_factory.build_encoder does (auto_pose/ae/ae_factory.py:33-48). */
+typedef struct aae_encoder_desc {
+    int32_t in_h, in_w, in_c;             /* [Dataset] H, W, C                      */
+    int32_t num_layers;
+    int32_t num_filters[AAE_MAX_LAYERS];  /* [Network] NUM_FILTER                   */
+    int32_t strides[AAE_MAX_LAYERS];      /* [Network] STRIDES                      */
+    int32_t kernel_size;                  /* [Network] KERNEL_SIZE_ENCODER          */
+    int32_t latent_size;                  /* [Network] LATENT_SPACE_SIZE            */
+    int32_t batch_norm;                   /* [Network] BATCH_NORMALIZATION (0/1)    */
+    float bn_eps;                         /* tf.layers.batch_normalization eps 1e-3 */
+} aae_encoder_desc;
+
+int aae_abi_version(void);
+const char* aae_last_error(void);
+
+/* ---- Encoder: auto_pose/ae/encoder.py:37-68 (encoder_out + z) -----------------
+ * host_weights (float32, host memory), in TF variable order:
+ *   per conv layer i : kernel HWIO [k,k,Cin,Cout], bias [Cout]
+ *                      (+ gamma, beta, moving_mean, moving_variance [Cout] if batch_norm)
+ *   then             : dense kernel [Ho*Wo*C_last, latent], dense bias [latent]
+ * Replaces graph construction + factory.restore_checkpoint (ae_factory.py:149-172). */
+int aae_encoder_create(const aae_encoder_desc* desc, const void* const* host_weights, int n_weights,
+                       aae_encoder** out);
+void aae_encoder_destroy(aae_encoder* enc);
+
+/* Launch-planning knobs (tuning / tests; set before sizing the workspace):
+ *   "splitk_min_base_blocks" (384): split the K loop of a layer only if its un-split grid
+ *                                   has fewer blocks than this (small batches);
+ *   "splitk_target_blocks"   (512): ... and then aim for about this many blocks. */
+int aae_encoder_set_option(aae_encoder* enc, const char* name, int value);
+
+size_t aae_encoder_workspace_bytes(const aae_encoder* enc, int B);
+
+/* z = Encoder.z for a batch of crops; replaces session.run(encoder.z, {encoder.x: x})
+ * (auto_pose/ae/codebook.py:145,206) and the x/255. of codebook.py:58-59.
+ * x: device [B,H,W,C] NHWC (BGR), uint8 or float32.  z_out: device [B, latent] float32. */
+int aae_encoder_forward(aae_encoder* enc, const void* x, int x_dtype, int B, float* z_out,
+                        void* workspace, size_t ws_bytes, void* stream);
+
+/* Same, with HIP events around every kernel launch on `stream` (synchronises the
+ * stream).  kernel_ms[i] receives the duration of launch i; returns the launch
+ * count through n_kernels.  Labels / algorithmic FLOPs of launch i for this B
+ * come from the two queries below (valid after any forward with the same B). */
+int aae_encoder_forward_timed(aae_encoder* enc, const void* x, int x_dtype, int B, float* z_out,
+                              void* workspace, size_t ws_bytes, void* stream,
+                              float* kernel_ms, int max_kernels, int* n_kernels);
+const char* aae_encoder_kernel_label(const aae_encoder* enc, int i);
+double aae_encoder_kernel_flops(const aae_encoder* enc, int i);
+
+/* Byte offset / element count of layer `layer`'s activation [B,Ho,Wo,Cout] inside the
+ * workspace after a forward with batch B (parity tests of encoder.py:41-54 per layer). */
+int aae_encoder_activation_info(const aae_encoder* enc, int B, int layer, size_t* offset_bytes,
+                                size_t* count);
+
+/* ---- Codebook: auto_pose/ae/codebook.py:18-51 ---------------------------------
+ * E: [N, J] float32 rows already normalised (embedding_normalized variable,
+ * codebook.py:28-36, as left by update_embedding :214-216).  Host or device source. */
+int aae_codebook_create(const void* E, int N, int J, int dtype, int src_is_device, aae_codebook** out);
+int aae_codebook_update(aae_codebook* cb, const void* E, int src_is_device, void* stream);  /* embedding_assign_op */
+void aae_codebook_destroy(aae_codebook* cb);
+int aae_codebook_set_scan_mode(aae_codebook* cb, int mode);     /* AAE_SCAN_* (tuning / tests) */
+
+size_t aae_codebook_workspace_bytes(const aae_codebook* cb, int B, int topk);
+
+/* Nearest rotation indices for un-normalised latents z [B,J] (device):
+ * l2_normalize (codebook.py:27) -> matmul transpose_b (:50) -> argmax (:64-68) or
+ * top-n (:69-71).  col_stride = 1, or num_cyclo for `upright` (:66; only with topk 1).
+ * idx_out: device int64 [B, topk]; score_out: device float32 [B, topk] (cosine).
+ * Ties resolve to the lowest index (np.argmax); top-k is score-descending,
+ * index-ascending among equal scores. */
+int aae_codebook_nn(aae_codebook* cb, const float* z, int B, int topk, int col_stride,
+                    int64_t* idx_out, float* score_out, void* workspace, size_t ws_bytes, void* stream);
+
+/* Full cosine-similarity matrix cs_out [B,N] (device) = session.run(cos_similarity)
+ * (codebook.py:63); parity / debugging path, the nn call never materialises it for topk 1. */
+int aae_codebook_similarity(aae_codebook* cb, const float* z, int B, float* cs_out,
+                            void* workspace, size_t ws_bytes, void* stream);
+
+/* normalized_embedding_query (codebook.py:27) for test_embedding(normalized=True) (:135-145). */
+int aae_l2_normalize(const float* z, int B, int J, float* q_out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AAE_HIP_H_ */

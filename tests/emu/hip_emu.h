@@ -1,0 +1,115 @@
+// CPU fiber emulator for the HIP kernels under augmentedautoencoder_amd/csrc/.
+//
+// TEST INFRASTRUCTURE ONLY.  The product library (libaae_hip.so) is compiled by
+// hipcc for gfx950 and never sees this header; the package loader refuses to
+// load anything else.  This header lets `-m "not gpu"` tests run the *same*
+// kernel sources and host launch logic on the CPU (one ucontext fiber per GPU
+// thread, wave collectives = rendez-vous of 64 fibers) so that tile index
+// math, MFMA fragment maps, masking and reductions are checked against the
+// oracle before any GPU minute is spent.  It models functional behaviour only
+// (no timing, no memory model).
+#pragma once
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <functional>
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+struct dim3 {
+    unsigned x, y, z;
+    dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct uint3_emu { unsigned x, y, z; };
+
+extern uint3_emu threadIdx, blockIdx;
+extern dim3 blockDim, gridDim;
+extern unsigned char aae_emu_dyn_smem[];
+
+#define __global__ static
+#define __device__
+#define __host__
+#define __forceinline__ inline
+#define __launch_bounds__(...)
+#define AAE_DYN_SMEM(name) unsigned char* name = aae_emu_dyn_smem
+
+void __syncthreads();
+
+using std::max;
+using std::min;
+
+namespace aae_emu {
+// All 64 lanes of the calling wave deposit `nbytes` (<= 64) and get back a view
+// of every lane's deposit: ret[lane] is that lane's bytes.
+typedef unsigned char lane_slot[64];
+const lane_slot* wave_exchange(const void* mine, int nbytes);
+void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()>& body);
+}  // namespace aae_emu
+
+namespace aae {
+
+inline int lane_id() { return threadIdx.x & 63; }
+
+inline f32x16 mfma_32x32x2(float a, float b, f32x16 c) {
+    float ab[2] = {a, b};
+    const aae_emu::lane_slot* all = aae_emu::wave_exchange(ab, sizeof(ab));
+    const int lane = lane_id();
+    const int col = lane & 31, hi = lane >> 5;
+    f32x16 d = c;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float acc = d[r];
+        for (int k = 0; k < 2; ++k) {
+            float av, bv;
+            memcpy(&av, &all[row + 32 * k][0], 4);    // A[row][k] lives in lane row+32k
+            memcpy(&bv, &all[col + 32 * k][4], 4);    // B[k][col] lives in lane col+32k
+            acc = fmaf(av, bv, acc);
+        }
+        d[r] = acc;
+    }
+    return d;
+}
+
+template <typename T>
+inline T shfl_xor(T v, int mask) {
+    static_assert(sizeof(T) == 4, "32-bit shuffles only");
+    const aae_emu::lane_slot* all = aae_emu::wave_exchange(&v, 4);
+    T out;
+    memcpy(&out, &all[lane_id() ^ mask][0], 4);
+    return out;
+}
+
+}  // namespace aae
+
+// ---- the sliver of the HIP runtime API the host-side launch code uses ----
+typedef void* hipStream_t;
+typedef int hipError_t;
+enum { hipSuccess = 0, hipErrorOutOfMemory = 2 };
+enum hipMemcpyKind { hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2, hipMemcpyDeviceToDevice = 3, hipMemcpyDefault = 4 };
+inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+inline hipError_t hipMemcpy(void* d, const void* s, size_t n, hipMemcpyKind) { memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return hipSuccess; }
+inline hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { memset(d, v, n); return hipSuccess; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+inline const char* hipGetErrorString(hipError_t) { return "emu"; }
+struct hipEvent_emu {};
+typedef hipEvent_emu* hipEvent_t;
+inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipEvent_emu; return hipSuccess; }
+inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
+inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
+inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
+enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+
+#define AAE_LAUNCH(kernel, grid, block, smem, stream, ...) \
+    aae_emu::launch((grid), (block), (smem), [&]() { kernel(__VA_ARGS__); })

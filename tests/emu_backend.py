@@ -1,0 +1,126 @@
+"""numpy front end of tests/emu/libaae_emu.so: the product kernel + launch sources
+compiled against the CPU fiber emulator (TEST INFRASTRUCTURE ONLY, see
+tests/emu/hip_emu.h).  Exposes the C ABI of include/aae_hip.h on host arrays."""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+from augmentedautoencoder_amd import _lib
+from augmentedautoencoder_amd.weights import EncoderConfig, as_pointer_array, ordered_weight_arrays
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+_EMU = None
+
+
+def lib():
+    global _EMU
+    if _EMU is None:
+        subprocess.check_call(['make', '-s', '-C', os.path.join(HERE, 'emu')])
+        _EMU = _lib.declare(ctypes.CDLL(os.path.join(HERE, 'emu', 'libaae_emu.so')))
+    return _EMU
+
+
+def _aligned(nbytes, align=256):
+    raw = np.zeros(nbytes + align, dtype=np.uint8)
+    off = (-raw.ctypes.data) % align
+    return raw[off:off + nbytes]
+
+
+class EmuEncoder(object):
+    def __init__(self, weights, cfg):
+        self.cfg = cfg
+        self.L = lib()
+        self._arrays = ordered_weight_arrays(weights, cfg)
+        h = ctypes.c_void_p()
+        desc = cfg.to_desc()
+        rc = self.L.aae_encoder_create(ctypes.byref(desc), as_pointer_array(self._arrays), len(self._arrays), ctypes.byref(h))
+        _lib.check(self.L, rc, 'aae_encoder_create')
+        self.h = h
+        self.ws = None
+
+    def set_option(self, name, value):
+        _lib.check(self.L, self.L.aae_encoder_set_option(self.h, name.encode(), int(value)), 'set_option')
+
+    def forward(self, x):
+        x = np.ascontiguousarray(x)
+        B = x.shape[0]
+        dt = _lib.AAE_DTYPE_U8 if x.dtype == np.uint8 else _lib.AAE_DTYPE_F32
+        if dt == _lib.AAE_DTYPE_F32:
+            x = x.astype(np.float32)
+        n = self.L.aae_encoder_workspace_bytes(self.h, B)
+        self.ws = _aligned(n)
+        z = np.zeros((B, self.cfg.latent_space_size), dtype=np.float32)
+        rc = self.L.aae_encoder_forward(self.h, x.ctypes.data, dt, B, z.ctypes.data, self.ws.ctypes.data, n, None)
+        _lib.check(self.L, rc, 'aae_encoder_forward')
+        self.B = B
+        return z
+
+    def activation(self, layer):
+        off, cnt = ctypes.c_size_t(), ctypes.c_size_t()
+        _lib.check(self.L, self.L.aae_encoder_activation_info(self.h, self.B, layer, ctypes.byref(off), ctypes.byref(cnt)), 'info')
+        H, W, Ci, Ho, Wo, Co = self.cfg.layer_shapes()[layer]
+        return self.ws[off.value:off.value + 4 * cnt.value].view(np.float32).reshape(self.B, Ho, Wo, Co).copy()
+
+    def labels(self):
+        out, i = [], 0
+        while True:
+            s = self.L.aae_encoder_kernel_label(self.h, i)
+            if not s:
+                return out
+            out.append(s.decode())
+            i += 1
+
+    def close(self):
+        if self.h:
+            self.L.aae_encoder_destroy(self.h)
+            self.h = None
+
+
+class EmuCodebook(object):
+    def __init__(self, E):
+        self.L = lib()
+        self.E = np.ascontiguousarray(E, dtype=np.float32)
+        h = ctypes.c_void_p()
+        rc = self.L.aae_codebook_create(self.E.ctypes.data, self.E.shape[0], self.E.shape[1], _lib.AAE_DTYPE_F32, 0, ctypes.byref(h))
+        _lib.check(self.L, rc, 'aae_codebook_create')
+        self.h = h
+
+    def set_mode(self, mode):
+        _lib.check(self.L, self.L.aae_codebook_set_scan_mode(self.h, mode), 'set_scan_mode')
+
+    def nn(self, z, topk=1, col_stride=1):
+        z = np.ascontiguousarray(z, dtype=np.float32)
+        B = z.shape[0]
+        n = self.L.aae_codebook_workspace_bytes(self.h, B, topk)
+        ws = _aligned(n)
+        idx = np.full((B, topk), -7, dtype=np.int64)
+        score = np.zeros((B, topk), dtype=np.float32)
+        rc = self.L.aae_codebook_nn(self.h, z.ctypes.data, B, topk, col_stride, idx.ctypes.data, score.ctypes.data,
+                                    ws.ctypes.data, n, None)
+        _lib.check(self.L, rc, 'aae_codebook_nn')
+        return idx, score
+
+    def similarity(self, z):
+        z = np.ascontiguousarray(z, dtype=np.float32)
+        B = z.shape[0]
+        n = self.L.aae_codebook_workspace_bytes(self.h, B, 1)
+        ws = _aligned(n)
+        cs = np.full((B, self.E.shape[0]), np.nan, dtype=np.float32)
+        rc = self.L.aae_codebook_similarity(self.h, z.ctypes.data, B, cs.ctypes.data, ws.ctypes.data, n, None)
+        _lib.check(self.L, rc, 'aae_codebook_similarity')
+        return cs
+
+    def close(self):
+        if self.h:
+            self.L.aae_codebook_destroy(self.h)
+            self.h = None
+
+
+def l2_normalize(z):
+    L = lib()
+    z = np.ascontiguousarray(z, dtype=np.float32)
+    q = np.zeros_like(z)
+    _lib.check(L, L.aae_l2_normalize(z.ctypes.data, z.shape[0], z.shape[1], q.ctypes.data, None), 'aae_l2_normalize')
+    return q
