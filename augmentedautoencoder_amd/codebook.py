@@ -1,0 +1,201 @@
+"""``Codebook`` with the method signatures of
+/root/reference/auto_pose/ae/codebook.py (nearest_rotation, auto_pose6d,
+nearest_rotation_batch, test_embedding, update_embedding), backed by the HIP
+encoder + codebook-scan engines.  ``session`` arguments are accepted and
+ignored (may be None)."""
+from __future__ import annotations
+
+import ast
+
+import numpy as np
+
+from . import session as S
+from . import utils as u
+
+
+def _parse_K(text):
+    """[Dataset] K is written as a Python list with arithmetic (``720/2``,
+    cfg/train_template.cfg:11); the reference eval()s it.  Evaluate the same
+    expression without builtins."""
+    return eval(compile(ast.parse(text.strip(), mode='eval'), '<cfg K>', 'eval'), {'__builtins__': {}}, {})
+
+
+class Codebook(object):
+
+    def __init__(self, encoder, dataset, embed_bb):
+        self._encoder = encoder
+        self._dataset = dataset
+        self.embed_bb = embed_bb
+
+        J = encoder.latent_space_size
+        embedding_size = self._dataset.embedding_size
+        # tf.Variable(np.zeros((embedding_size, J)), float32, trainable=False) -- codebook.py:28-33
+        self._embedding_host = np.zeros((embedding_size, J), dtype=np.float32)
+        self._engine = None
+        self._device = None
+
+        self.normalized_embedding_query = S.Op('normalized_embedding_query', lambda feed: self._run_query(feed, True))
+        self.embedding_normalized = S.Op('embedding_normalized', lambda feed: self.embedding_value())
+        self.embedding = S.Placeholder((embedding_size, J), 'embedding')
+        self.embedding_assign_op = S.Op('embedding_assign_op', lambda feed: self.assign_embedding(self._fed(feed, self.embedding)))
+        if embed_bb:
+            self._obj_bbs_host = np.zeros((embedding_size, 4), dtype=np.int32)
+            self.embed_obj_bbs_var = S.Op('embed_obj_bbs_var', lambda feed: self.embed_obj_bbs_value())
+            self.embed_obj_bbs = S.Placeholder((embedding_size, 4), 'embed_obj_bbs')
+            self.embed_obj_bbs_assign_op = S.Op('embed_obj_bbs_assign_op',
+                                                lambda feed: self.assign_obj_bbs(self._fed(feed, self.embed_obj_bbs)))
+            self.embed_obj_bbs_values = None
+        self.cos_similarity = S.Op('cos_similarity', lambda feed: self._run_similarity(feed))
+        self.nearest_neighbor_idx = S.Op('nearest_neighbor_idx', lambda feed: self._run_argmax(feed))
+        S.register(codebook=self)
+
+    # ---- variable plumbing ---------------------------------------------------
+    @staticmethod
+    def _fed(feed, placeholder):
+        for k, v in feed.items():
+            if k is placeholder:
+                return v
+        raise ValueError('feed_dict has no value for %r' % (placeholder,))
+
+    def embedding_value(self):
+        return self._embedding_host.copy()
+
+    def embed_obj_bbs_value(self):
+        return self._obj_bbs_host.copy()
+
+    def assign_embedding(self, normalized_embedding):
+        """embedding_assign_op: float64/float32 [N,J] -> float32 variable (codebook.py:35-36,216)."""
+        emb = np.asarray(normalized_embedding).astype(np.float32)
+        if emb.shape != self._embedding_host.shape:
+            raise ValueError('embedding has shape %s, variable is %s' % (emb.shape, self._embedding_host.shape))
+        self._embedding_host = np.ascontiguousarray(emb)
+        if self._engine is not None:
+            self._engine.update(self._embedding_host)
+        return self._embedding_host
+
+    def assign_obj_bbs(self, obj_bbs):
+        """embed_obj_bbs_assign_op: -> int32 variable (codebook.py:46-47,219)."""
+        self._obj_bbs_host = np.asarray(obj_bbs).astype(np.int32).reshape(self._embedding_host.shape[0], 4)
+        self.embed_obj_bbs_values = None
+        return self._obj_bbs_host
+
+    @property
+    def engine(self):
+        if self._engine is None:
+            from .engine import CodebookEngine
+            self._engine = CodebookEngine(self._embedding_host, device=self._encoder.engine.device)
+        return self._engine
+
+    # ---- fetchables ------------------------------------------------------------
+    def _prep(self, x):
+        """codebook.py:58-61: uint8 -> /255. (done exactly, as a 256-entry table, in the
+        first kernel), 3-D -> add the batch dimension."""
+        if getattr(x, 'ndim', None) == 3 or (hasattr(x, 'dim') and x.dim() == 3):
+            x = x[None]
+        return x
+
+    def _encode(self, x):
+        return self._encoder.engine.encode(self._prep(x))
+
+    def _run_similarity(self, feed):
+        return self.engine.similarity(self._encode(self._encoder._feed(feed))).cpu().numpy()
+
+    def _run_argmax(self, feed):
+        idx, _ = self.engine.nn(self._encode(self._encoder._feed(feed)), 1, 1)
+        return idx[:, 0].cpu().numpy()
+
+    def _run_query(self, feed, normalized):
+        z = self._encode(self._encoder._feed(feed))
+        if normalized:
+            z = self.engine.l2_normalize(z)
+        return z.cpu().numpy()
+
+    # ---- reference API -----------------------------------------------------------
+    def nearest_rotation(self, session, x, top_n=1, upright=False, return_idcs=False):
+        """R_model2cam of the nearest codebook entries (codebook.py:55-75)."""
+        z = self._encode(x)
+        if top_n == 1:
+            stride = int(self._dataset._kw['num_cyclo']) if upright else 1
+            idx, _ = self.engine.nn(z, 1, stride)
+            idcs = idx[:, 0].cpu().numpy()
+        else:
+            if z.shape[0] != 1:
+                # the reference squeezes the [B,N] similarity (codebook.py:70): only B == 1 is meaningful
+                raise ValueError('top_n > 1 needs a single crop (got a batch of %d)' % z.shape[0])
+            idx, _ = self.engine.nn(z, int(top_n), 1)
+            idcs = idx[0].cpu().numpy()
+        if return_idcs:
+            return idcs
+        return self._dataset.viewsphere_for_embedding[idcs].squeeze()
+
+    def nearest_rotation_with_scores(self, x, top_n=1, upright=False):
+        """Extension: (indices, cosine scores) without materialising the similarity."""
+        z = self._encode(x)
+        stride = int(self._dataset._kw['num_cyclo']) if (upright and top_n == 1) else 1
+        idx, score = self.engine.nn(z, int(top_n), stride)
+        return idx.cpu().numpy(), score.cpu().numpy()
+
+    def auto_pose6d(self, session, x, predicted_bb, K_test, top_n, train_args, depth_pred=None, upright=False):
+        """Rotation + translation estimate from a detector crop (codebook.py:79-129)."""
+        idcs = np.atleast_1d(self.nearest_rotation(session, x, top_n=top_n, upright=upright, return_idcs=True))
+        Rs_est = self._dataset.viewsphere_for_embedding[idcs]      # fancy index -> copy
+
+        K_train = np.array(_parse_K(train_args.get('Dataset', 'K'))).reshape(3, 3)
+        render_radius = train_args.getfloat('Dataset', 'RADIUS')
+        K_diag_ratio = np.sqrt(K_test[0, 0] ** 2 + K_test[1, 1] ** 2) / np.sqrt(K_train[0, 0] ** 2 + K_train[1, 1] ** 2)
+
+        if self.embed_obj_bbs_values is None:
+            self.embed_obj_bbs_values = self.embed_obj_bbs_value()
+
+        ts_est = np.empty((top_n, 3))
+        for i, idx in enumerate(idcs):
+            rendered_bb = self.embed_obj_bbs_values[idx].squeeze()
+            if depth_pred is None:
+                diag_ratio = np.linalg.norm(np.float32(rendered_bb[2:])) / np.linalg.norm(np.float32(predicted_bb[2:]))
+                z = diag_ratio * K_diag_ratio * render_radius
+            else:
+                z = depth_pred
+            cx_train = rendered_bb[0] + rendered_bb[2] / 2. - K_train[0, 2]
+            cy_train = rendered_bb[1] + rendered_bb[3] / 2. - K_train[1, 2]
+            cx_test = predicted_bb[0] + predicted_bb[2] / 2 - K_test[0, 2]
+            cy_test = predicted_bb[1] + predicted_bb[3] / 2 - K_test[1, 2]
+            tx = cx_test * z / K_test[0, 0] - cx_train * render_radius / K_train[0, 0]
+            ty = cy_test * z / K_test[1, 1] - cy_train * render_radius / K_train[1, 1]
+            ts_est[i] = (tx, ty, z)
+            # the codebook holds centred views; compensate for the off-centre crop
+            ay = np.arctan(tx / np.sqrt(z ** 2 + ty ** 2))
+            ax = -np.arctan(ty / z)
+            Rx = np.array([[1, 0, 0], [0, np.cos(ax), -np.sin(ax)], [0, np.sin(ax), np.cos(ax)]])
+            Ry = np.array([[np.cos(ay), 0, np.sin(ay)], [0, 1, 0], [-np.sin(ay), 0, np.cos(ay)]])
+            Rs_est[i] = np.dot(Ry, np.dot(Rx, Rs_est[i]))
+        return (Rs_est, ts_est)
+
+    def nearest_rotation_batch(self, session, x):
+        """Batched arg-max on the device (codebook.py:131-133)."""
+        idx, _ = self.engine.nn(self._encode(x), 1, 1)
+        return self._dataset.viewsphere_for_embedding[idx[:, 0].cpu().numpy()]
+
+    def test_embedding(self, sess, x, normalized=True):
+        """Latent code of a crop, optionally L2-normalised (codebook.py:135-145)."""
+        z = self._encode(x)
+        if normalized:
+            z = self.engine.l2_normalize(z)
+        return z.cpu().numpy().squeeze()
+
+    def update_embedding(self, session, batch_size):
+        """Re-embed every viewsphere rotation and store the normalised codebook
+        (codebook.py:190-219).  float64 accumulation buffer and float64 row
+        normalisation without epsilon, as in the reference."""
+        embedding_size = self._dataset.embedding_size
+        J = self._encoder.latent_space_size
+        embedding_z = np.empty((embedding_size, J))
+        obj_bbs = np.empty((embedding_size, 4))
+        for a, e in u.batch_iteration_indices(embedding_size, batch_size):
+            batch, obj_bbs_batch = self._dataset.render_embedding_image_batch(a, e)
+            embedding_z[a:e] = self._encoder.engine.encode(batch).cpu().numpy()
+            if self.embed_bb:
+                obj_bbs[a:e] = obj_bbs_batch
+        normalized_embedding = embedding_z / np.linalg.norm(embedding_z, axis=1, keepdims=True)
+        self.assign_embedding(normalized_embedding)
+        if self.embed_bb:
+            self.assign_obj_bbs(obj_bbs)

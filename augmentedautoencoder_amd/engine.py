@@ -1,0 +1,251 @@
+"""Device plumbing between the reference-shaped Python API and libaae_hip.so.
+
+torch is used for exactly three things here: device memory (tensors that own
+the buffers handed to the C ABI as raw pointers), the current HIP stream, and
+host<->device copies.  All arithmetic happens in the hand-written HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+from .weights import EncoderConfig, as_pointer_array, ordered_weight_arrays
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        raise RuntimeError('augmentedautoencoder_amd needs an AMD GPU (MI355X / gfx950); '
+                           'torch.cuda.is_available() is False and there is no CPU fallback.')
+    return torch
+
+
+def _stream_ptr(torch):
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _Workspace(object):
+    """One grow-only device scratch buffer per engine (256-B aligned by the allocator)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.buf = None
+
+    def get(self, nbytes):
+        torch = _torch()
+        if self.buf is None or self.buf.numel() < nbytes:
+            self.buf = None
+            self.buf = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=self.device)
+        off = (-self.buf.data_ptr()) % 256
+        return self.buf, self.buf.data_ptr() + off
+
+
+class EncoderEngine(object):
+    """Owns one aae_encoder handle (device weights) -- the stand-in for the encoder
+    part of the TF graph + session of the reference."""
+
+    def __init__(self, cfg: EncoderConfig, weights, device=None, max_batch=256):
+        torch = _torch()
+        self.cfg = cfg
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self.max_batch = int(max_batch)
+        self.lib = _lib.load()
+        arrays = ordered_weight_arrays(weights, cfg)
+        handle = ctypes.c_void_p()
+        desc = cfg.to_desc()
+        with torch.cuda.device(self.device):
+            rc = self.lib.aae_encoder_create(ctypes.byref(desc), as_pointer_array(arrays), len(arrays), ctypes.byref(handle))
+        _lib.check(self.lib, rc, 'aae_encoder_create')
+        self.handle = handle
+        self.ws = _Workspace(self.device)
+        self._last_B = None
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            self.lib.aae_encoder_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, name, value):
+        _lib.check(self.lib, self.lib.aae_encoder_set_option(self.handle, name.encode(), int(value)), 'aae_encoder_set_option')
+
+    # ---- input handling: codebook.py:58-61 --------------------------------
+    def to_device_batch(self, x):
+        """np.ndarray / torch.Tensor, HWC or NHWC, uint8 or float -> contiguous
+        device tensor [B,H,W,C] of dtype uint8 or float32.  uint8 is scaled by
+        1/255 inside the first kernel (exactly float32(v/255.)); float input is
+        what the reference feeds to the float32 placeholder."""
+        torch = _torch()
+        if isinstance(x, np.ndarray):
+            if x.dtype != np.uint8:
+                x = x.astype(np.float32)
+            t = torch.from_numpy(np.ascontiguousarray(x)).to(self.device, non_blocking=False)
+        elif torch.is_tensor(x):
+            t = x
+            if t.dtype != torch.uint8:
+                t = t.to(torch.float32)
+            t = t.to(self.device).contiguous()
+        else:
+            raise TypeError('crops must be a numpy array or a torch tensor, got %r' % type(x))
+        if t.dim() == 3:
+            t = t.unsqueeze(0)
+        if t.dim() != 4 or tuple(t.shape[1:]) != tuple(self.cfg.shape):
+            raise ValueError('crop batch has shape %s, encoder expects [B,%d,%d,%d]' % ((tuple(t.shape),) + tuple(self.cfg.shape)))
+        return t
+
+    def _forward_chunk(self, t, z_out, timed=False):
+        torch = _torch()
+        B = t.shape[0]
+        dt = _lib.AAE_DTYPE_U8 if t.dtype == torch.uint8 else _lib.AAE_DTYPE_F32
+        nbytes = self.lib.aae_encoder_workspace_bytes(self.handle, B)
+        _, ws_ptr = self.ws.get(nbytes)
+        self._last_B = B
+        with torch.cuda.device(self.device):
+            if not timed:
+                rc = self.lib.aae_encoder_forward(self.handle, ctypes.c_void_p(t.data_ptr()), dt, B,
+                                                  ctypes.c_void_p(z_out.data_ptr()), ctypes.c_void_p(ws_ptr), nbytes,
+                                                  _stream_ptr(torch))
+                _lib.check(self.lib, rc, 'aae_encoder_forward')
+                return None
+            ms = (ctypes.c_float * 32)()
+            n = ctypes.c_int(0)
+            rc = self.lib.aae_encoder_forward_timed(self.handle, ctypes.c_void_p(t.data_ptr()), dt, B,
+                                                    ctypes.c_void_p(z_out.data_ptr()), ctypes.c_void_p(ws_ptr), nbytes,
+                                                    _stream_ptr(torch), ms, 32, ctypes.byref(n))
+            _lib.check(self.lib, rc, 'aae_encoder_forward_timed')
+            return [(self.lib.aae_encoder_kernel_label(self.handle, i).decode(), float(ms[i]),
+                     float(self.lib.aae_encoder_kernel_flops(self.handle, i))) for i in range(n.value)]
+
+    def encode(self, x):
+        """Encoder.z for a batch: device float32 [B, J]."""
+        torch = _torch()
+        t = self.to_device_batch(x)
+        B = t.shape[0]
+        z = torch.empty((B, self.cfg.latent_space_size), dtype=torch.float32, device=self.device)
+        for a in range(0, B, self.max_batch):
+            e = min(a + self.max_batch, B)
+            self._forward_chunk(t[a:e], z[a:e])
+        return z
+
+    def encode_timed(self, x):
+        """(z, [(kernel label, ms, algorithmic flops)]) for one chunk (B <= max_batch)."""
+        torch = _torch()
+        t = self.to_device_batch(x)
+        if t.shape[0] > self.max_batch:
+            raise ValueError('encode_timed takes at most max_batch=%d crops' % self.max_batch)
+        z = torch.empty((t.shape[0], self.cfg.latent_space_size), dtype=torch.float32, device=self.device)
+        return z, self._forward_chunk(t, z, timed=True)
+
+    def activation(self, layer):
+        """Layer output [B,Ho,Wo,Cout] of the most recent (single-chunk) forward."""
+        torch = _torch()
+        off, cnt = ctypes.c_size_t(), ctypes.c_size_t()
+        _lib.check(self.lib, self.lib.aae_encoder_activation_info(self.handle, self._last_B, layer, ctypes.byref(off),
+                                                                  ctypes.byref(cnt)), 'aae_encoder_activation_info')
+        buf, ws_ptr = self.ws.get(0)
+        start = ws_ptr - buf.data_ptr() + off.value
+        _, _, _, Ho, Wo, Co = self.cfg.layer_shapes()[layer]
+        return buf[start:start + 4 * cnt.value].view(torch.float32).reshape(self._last_B, Ho, Wo, Co).clone()
+
+
+class CodebookEngine(object):
+    """Owns one aae_codebook handle: the device-resident embedding_normalized
+    variable (codebook.py:28-36) and the fused normalise + scan + arg-max."""
+
+    def __init__(self, embedding_normalized, device=None):
+        torch = _torch()
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self.lib = _lib.load()
+        handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            if torch.is_tensor(embedding_normalized):
+                E = embedding_normalized.to(self.device, torch.float32).contiguous()
+                self.N, self.J = int(E.shape[0]), int(E.shape[1])
+                torch.cuda.synchronize(self.device)
+                rc = self.lib.aae_codebook_create(ctypes.c_void_p(E.data_ptr()), self.N, self.J, _lib.AAE_DTYPE_F32, 1, ctypes.byref(handle))
+            else:
+                E = np.ascontiguousarray(np.asarray(embedding_normalized, dtype=np.float32))
+                self.N, self.J = int(E.shape[0]), int(E.shape[1])
+                rc = self.lib.aae_codebook_create(E.ctypes.data, self.N, self.J, _lib.AAE_DTYPE_F32, 0, ctypes.byref(handle))
+        _lib.check(self.lib, rc, 'aae_codebook_create')
+        self.handle = handle
+        self.ws = _Workspace(self.device)
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            self.lib.aae_codebook_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_scan_mode(self, mode):
+        _lib.check(self.lib, self.lib.aae_codebook_set_scan_mode(self.handle, int(mode)), 'aae_codebook_set_scan_mode')
+
+    def update(self, embedding_normalized):
+        torch = _torch()
+        E = np.ascontiguousarray(np.asarray(embedding_normalized, dtype=np.float32))
+        if E.shape != (self.N, self.J):
+            raise ValueError('embedding has shape %s, codebook is [%d,%d]' % (E.shape, self.N, self.J))
+        with torch.cuda.device(self.device):
+            rc = self.lib.aae_codebook_update(self.handle, E.ctypes.data, 0, _stream_ptr(torch))
+        _lib.check(self.lib, rc, 'aae_codebook_update')
+
+    def _z(self, z):
+        torch = _torch()
+        if isinstance(z, np.ndarray):
+            z = torch.from_numpy(np.ascontiguousarray(z, dtype=np.float32))
+        z = z.to(self.device, torch.float32).contiguous()
+        if z.dim() != 2 or z.shape[1] != self.J:
+            raise ValueError('latents have shape %s, expected [B,%d]' % (tuple(z.shape), self.J))
+        return z
+
+    def nn(self, z, topk=1, col_stride=1):
+        """(idx int64 [B,topk], cosine float32 [B,topk]) on the device."""
+        torch = _torch()
+        z = self._z(z)
+        B = z.shape[0]
+        idx = torch.empty((B, topk), dtype=torch.int64, device=self.device)
+        score = torch.empty((B, topk), dtype=torch.float32, device=self.device)
+        nbytes = self.lib.aae_codebook_workspace_bytes(self.handle, B, topk)
+        _, ws_ptr = self.ws.get(nbytes)
+        with torch.cuda.device(self.device):
+            rc = self.lib.aae_codebook_nn(self.handle, ctypes.c_void_p(z.data_ptr()), B, int(topk), int(col_stride),
+                                          ctypes.c_void_p(idx.data_ptr()), ctypes.c_void_p(score.data_ptr()),
+                                          ctypes.c_void_p(ws_ptr), nbytes, _stream_ptr(torch))
+        _lib.check(self.lib, rc, 'aae_codebook_nn')
+        return idx, score
+
+    def similarity(self, z):
+        """Full cos_similarity [B,N] (codebook.py:50) on the device."""
+        torch = _torch()
+        z = self._z(z)
+        B = z.shape[0]
+        cs = torch.empty((B, self.N), dtype=torch.float32, device=self.device)
+        nbytes = self.lib.aae_codebook_workspace_bytes(self.handle, B, 1)
+        _, ws_ptr = self.ws.get(nbytes)
+        with torch.cuda.device(self.device):
+            rc = self.lib.aae_codebook_similarity(self.handle, ctypes.c_void_p(z.data_ptr()), B, ctypes.c_void_p(cs.data_ptr()),
+                                                  ctypes.c_void_p(ws_ptr), nbytes, _stream_ptr(torch))
+        _lib.check(self.lib, rc, 'aae_codebook_similarity')
+        return cs
+
+    def l2_normalize(self, z):
+        torch = _torch()
+        z = self._z(z)
+        q = torch.empty_like(z)
+        with torch.cuda.device(self.device):
+            rc = self.lib.aae_l2_normalize(ctypes.c_void_p(z.data_ptr()), z.shape[0], z.shape[1], ctypes.c_void_p(q.data_ptr()),
+                                           _stream_ptr(torch))
+        _lib.check(self.lib, rc, 'aae_l2_normalize')
+        return q

@@ -1,0 +1,172 @@
+"""Just enough of the tf.Session / tf.train.Saver surface for the reference's
+call sites on this path to keep working.
+
+In the reference every method of ``Codebook`` takes a ``session`` and evaluates
+graph tensors through ``session.run(fetch, feed_dict)``; callers also fetch
+variables directly (``sess.run(codebook.embedding_normalized)``,
+/root/reference/auto_pose/eval/ae_eval.py:257).  Here the "tensors" are small
+``Op`` objects bound to the HIP engines; ``Session.run`` evaluates them.  The
+``session`` argument of the Codebook methods is accepted and ignored (it may be
+``None``), exactly as SURVEY.md section 8b specifies.
+
+``Saver`` persists what the reference keeps in its TF checkpoint (encoder
+weights + the codebook variables) as ``<prefix>-<step>.npz`` next to a
+``checkpoint`` index file (stand-in for tf.train.get_checkpoint_state).
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from . import weights as W
+
+_GRAPH = []          # [(scope, encoder, codebook-or-None)] in construction order
+_SCOPE = ['']
+
+
+class variable_scope(object):
+    """with variable_scope(experiment_name): ...  (ae_factory.py:131, ae_embed.py:53)"""
+
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        _SCOPE.append(self.name)
+        return self
+
+    def __exit__(self, *exc):
+        _SCOPE.pop()
+        return False
+
+
+def current_scope():
+    return _SCOPE[-1]
+
+
+def register(encoder=None, codebook=None):
+    _GRAPH.append((current_scope(), encoder, codebook))
+
+
+def reset_default_graph():
+    del _GRAPH[:]
+
+
+class Placeholder(object):
+    """Stand-in for tf.placeholder(tf.float32, [None, H, W, C]) (ae_factory.py:133)."""
+
+    def __init__(self, shape, name='x'):
+        self.shape = tuple(shape)
+        self.name = name
+
+    def __repr__(self):
+        return 'Placeholder(%s, shape=%s)' % (self.name, (None,) + self.shape)
+
+
+class Op(object):
+    """A fetchable: fn(feed_dict) -> np.ndarray."""
+
+    def __init__(self, name, fn):
+        self.name = name
+        self._fn = fn
+
+    def eval(self, feed_dict=None):
+        return self._fn(feed_dict or {})
+
+    def __repr__(self):
+        return 'Op(%s)' % self.name
+
+
+class Session(object):
+    def __init__(self, config=None):
+        self.config = config
+
+    def run(self, fetches, feed_dict=None):
+        if isinstance(fetches, (list, tuple)):
+            return [self.run(f, feed_dict) for f in fetches]
+        if not isinstance(fetches, Op):
+            raise TypeError('cannot fetch %r: only Encoder/Codebook ops are evaluable' % (fetches,))
+        return fetches.eval(feed_dict)
+
+    def close(self):
+        pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
+
+
+class CheckpointState(object):
+    def __init__(self, model_checkpoint_path, all_model_checkpoint_paths):
+        self.model_checkpoint_path = model_checkpoint_path
+        self.all_model_checkpoint_paths = all_model_checkpoint_paths
+
+
+def get_checkpoint_state(ckpt_dir):
+    index = os.path.join(ckpt_dir, 'checkpoint')
+    if not os.path.exists(index):
+        return None
+    paths = []
+    with open(index) as f:
+        for line in f:
+            line = line.strip()
+            if line:
+                p = line if os.path.isabs(line) else os.path.join(ckpt_dir, line)
+                paths.append(p)
+    if not paths:
+        return None
+    return CheckpointState(paths[-1], paths)
+
+
+class Saver(object):
+    """Saver(scope=...) covers the modules built under that variable scope (the
+    reference builds one scoped Saver per object, m3_interface/ae_pose_estimator.py:76-78);
+    scope=None covers everything built so far."""
+
+    def __init__(self, var_list=None, save_relative_paths=True, scope=None):
+        self.scope = scope
+
+    def _members(self):
+        return [(s, e, c) for (s, e, c) in _GRAPH if self.scope is None or s == self.scope]
+
+    def save(self, session, save_path, global_step=None):
+        path = save_path if global_step is None else '%s-%d' % (save_path, int(global_step))
+        encoder = codebook = None
+        for _, e, c in self._members():
+            encoder = e if e is not None else encoder
+            codebook = c if c is not None else codebook
+        if encoder is None or encoder.weights is None:
+            raise RuntimeError('Saver.save: no encoder with weights under scope %r' % self.scope)
+        emb = bbs = None
+        if codebook is not None:
+            emb = codebook.embedding_value()
+            bbs = codebook.embed_obj_bbs_value() if codebook.embed_bb else None
+        W.save_npz(path + '.npz', encoder.weights, emb, bbs)
+        ckpt_dir = os.path.dirname(path)
+        index = os.path.join(ckpt_dir, 'checkpoint')
+        existing = []
+        if os.path.exists(index):
+            with open(index) as f:
+                existing = [l.strip() for l in f if l.strip()]
+        rel = os.path.basename(path) + '.npz'
+        if rel in existing:
+            existing.remove(rel)
+        existing.append(rel)
+        with open(index, 'w') as f:
+            f.write('\n'.join(existing) + '\n')
+        return path
+
+    def restore(self, session, ckpt_path):
+        if not ckpt_path.endswith('.npz'):
+            ckpt_path = ckpt_path + '.npz'
+        weights, emb, bbs = W.load_npz(ckpt_path)
+        for _, e, c in self._members():
+            if e is not None:
+                e.load_weights(weights)
+            if c is not None:
+                if emb is not None:
+                    c.assign_embedding(emb)
+                if bbs is not None and c.embed_bb:
+                    c.assign_obj_bbs(bbs)

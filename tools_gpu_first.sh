@@ -1,0 +1,15 @@
+#!/bin/bash
+# first GPU contact: smoke -> parity tests -> bench -> rocprof kernel trace
+set -x
+mkdir -p gpurun_out
+export TMPDIR=/tmp
+rocminfo 2>/dev/null | grep -E "Marketing Name|Compute Unit|Max Clock" | head -6 > gpurun_out/rocminfo.txt
+nproc >> gpurun_out/rocminfo.txt; lscpu | grep "Model name" >> gpurun_out/rocminfo.txt
+timeout 300 python __graft_entry__.py smoke > gpurun_out/smoke.log 2>&1; echo "smoke rc=$?" >> gpurun_out/smoke.log
+tail -5 gpurun_out/smoke.log
+timeout 900 python -m pytest tests -m gpu -q -x --timeout 600 > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> gpurun_out/pytest_gpu.log
+tail -30 gpurun_out/pytest_gpu.log
+timeout 300 python bench.py --steps 20 --warmup 5 > gpurun_out/bench.log 2>&1; echo "bench rc=$?" >> gpurun_out/bench.log
+tail -5 gpurun_out/bench.log
+cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $GRAFT_REPO_ROOT/gpurun_out/prof_r1 -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 10 --warmup 3 --no-cpu-baseline --profile-steps 1 > $GRAFT_REPO_ROOT/gpurun_out/rocprof.log 2>&1
+cd $GRAFT_REPO_ROOT; ls -R gpurun_out/prof_r1 | head -20
