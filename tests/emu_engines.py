@@ -1,0 +1,58 @@
+"""Engine doubles that run the emulated kernels (tests/emu/) behind the same interface as
+augmentedautoencoder_amd.engine -- injected into Encoder/Codebook by CPU tests of the
+reference-shaped Python API.  Not importable from the product package."""
+import numpy as np
+import torch
+
+import emu_backend as eb
+
+
+class EmuEncoderEngine(object):
+    device = torch.device('cpu')
+
+    def __init__(self, cfg, weights):
+        self.cfg = cfg
+        self._e = eb.EmuEncoder(weights, cfg)
+
+    def encode(self, x):
+        if torch.is_tensor(x):
+            x = x.numpy()
+        x = np.asarray(x)
+        if x.ndim == 3:
+            x = x[None]
+        if x.dtype != np.uint8:
+            x = x.astype(np.float32)
+        return torch.from_numpy(self._e.forward(x))
+
+    def activation(self, layer):
+        return torch.from_numpy(self._e.activation(layer))
+
+    def close(self):
+        self._e.close()
+
+
+class EmuCodebookEngine(object):
+    device = torch.device('cpu')
+
+    def __init__(self, E):
+        self._c = eb.EmuCodebook(E)
+
+    def update(self, E):
+        self._c.close()
+        self._c = eb.EmuCodebook(E)
+
+    def nn(self, z, topk=1, col_stride=1):
+        z = z.numpy() if torch.is_tensor(z) else np.asarray(z)
+        idx, score = self._c.nn(z, topk, col_stride)
+        return torch.from_numpy(idx), torch.from_numpy(score)
+
+    def similarity(self, z):
+        z = z.numpy() if torch.is_tensor(z) else np.asarray(z)
+        return torch.from_numpy(self._c.similarity(z))
+
+    def l2_normalize(self, z):
+        z = z.numpy() if torch.is_tensor(z) else np.asarray(z)
+        return torch.from_numpy(eb.l2_normalize(z))
+
+    def close(self):
+        self._c.close()

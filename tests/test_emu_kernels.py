@@ -1,0 +1,99 @@
+"""The HIP kernel sources + launch planning, executed on the CPU fiber emulator
+(tests/emu/) against the fp64 oracle: tile index math, MFMA fragment maps, SAME
+padding, masking of partial tiles, split-K, BN epilogue, scan/argmax/top-k.  Sizes are
+tiny (the emulator runs one fiber per GPU thread); full sizes run under -m gpu."""
+import numpy as np
+import pytest
+
+import emu_backend as eb
+from augmentedautoencoder_amd import _lib
+from augmentedautoencoder_amd.weights import EncoderConfig
+from oracle import reference_cpu as ref
+from oracle import synth
+
+
+def _run(cfg, B, seed, f32_in=False, nosplit=False):
+    w = synth.make_weights(seed=seed, shape=cfg.shape, num_filter=cfg.num_filter, strides=cfg.strides,
+                           latent=cfg.latent_space_size, batch_norm=cfg.batch_norm, kernel_size=cfg.kernel_size)
+    x = synth.make_crops(B, seed=seed + 1, shape=cfg.shape)
+    xin = ref.input_to_float(x).astype(np.float32) if f32_in else x
+    enc = eb.EmuEncoder(w, cfg)
+    if nosplit:
+        enc.set_option('splitk_min_base_blocks', 0)
+    z = enc.forward(xin)
+    z64, acts = ref.encoder_forward_np(ref.input_to_float(x), w, cfg.strides, cfg.batch_norm, return_activations=True)
+    for i, a in enumerate(acts):
+        err = np.abs(enc.activation(i) - a).max() / max(np.abs(a).max(), 1e-9)
+        assert err < 5e-6, 'layer %d rel err %.2e (%s)' % (i, err, enc.labels())
+    assert np.abs(z - z64).max() / np.abs(z64).max() < 5e-6
+    labels = enc.labels()
+    enc.close()
+    return labels
+
+
+def test_first_layer_mfma_igemm_splitk_and_dense():
+    labels = _run(EncoderConfig((16, 16, 3), [32, 64], [2, 2], 5, 128), 3, 1)
+    assert 'conv_first_f32' in labels[0] and 'splitk' in labels[1] and labels[-1].endswith('splitk_reduce')
+
+
+def test_unsplit_igemm_epilogue_with_batchnorm():
+    labels = _run(EncoderConfig((16, 16, 3), [32, 64], [2, 2], 5, 128, True), 2, 41, nosplit=True)
+    assert all('splitk' not in l for l in labels)
+
+
+def test_partial_tiles_row_straddling_and_odd_channel_counts():
+    # conv1 output 20x12 = 240 px: one full 128-px tile + a partial one, rows straddle tiles;
+    # Cout 48 (not a multiple of 32/128); layer 2 falls back to the generic kernel (Cin 48)
+    labels = _run(EncoderConfig((40, 24, 3), [48, 32], [2, 2], 5, 20, True), 2, 11, f32_in=True)
+    assert 'conv_direct_generic' in labels[1]
+
+
+def test_grayscale_stride1_and_two_channel_blocks():
+    _run(EncoderConfig((12, 12, 1), [160, 32], [1, 2], 5, 128), 1, 21)
+
+
+def test_generic_fallback_everything():
+    labels = _run(EncoderConfig((10, 14, 3), [24, 8], [2, 1], 3, 12, True), 2, 31)
+    assert all('generic' in l for l in labels)
+
+
+@pytest.mark.parametrize('B,mode', [(1, _lib.AAE_SCAN_GEMV), (4, _lib.AAE_SCAN_GEMV), (3, _lib.AAE_SCAN_MFMA),
+                                    (33, _lib.AAE_SCAN_AUTO), (70, _lib.AAE_SCAN_AUTO)])
+def test_codebook_scan_kernels(B, mode):
+    N, J = 36 * 11 + 5, 128                                   # 401 rows: 3 full 128-row blocks + a partial one
+    E = synth.make_codebook(N, J, seed=7, planted_duplicates=11)
+    assert np.array_equal(E[36 * 3], E[36 * 3 + 35])
+    cb = eb.EmuCodebook(E)
+    cb.set_mode(mode)
+    rows = np.random.default_rng(B).integers(0, N, B)
+    z = synth.make_queries_near_rows(E, rows, noise=0.3, seed=B)
+    z[0] = E[36 * 3 + 35] * 3.0                               # exact tie between rows 108 and 143
+    idx, score = cb.nn(z)
+    cs = cb.similarity(z)
+    cs64 = ref.cos_similarity(z, E)
+    assert np.abs(cs - cs64).max() < 2e-6
+    assert np.array_equal(idx[:, 0], np.argmax(cs, axis=1))
+    assert idx[0, 0] == 108                                   # lower-index twin wins
+    assert np.abs(score[:, 0] - cs64.max(axis=1)).max() < 2e-6
+    up, _ = cb.nn(z, col_stride=36)
+    assert np.array_equal(up[:, 0], ref.nearest_indices_reference(cs, 1, upright=True, num_cyclo=36))
+    if B <= 4:
+        ik, sk = cb.nn(z, topk=5)
+        assert np.array_equal(ik, ref.topk_canonical(cs, 5))
+        assert np.all(np.diff(sk, axis=1) <= 0)
+    cb.close()
+
+
+def test_small_latent_and_l2_normalize():
+    E = synth.make_codebook(36 * 4, 32, seed=3, planted_duplicates=2)
+    cb = eb.EmuCodebook(E)
+    z = np.random.default_rng(1).standard_normal((5, 32)).astype(np.float32)
+    z[4] = 0.0                                                 # zero latent: eps path, all scores 0 -> index 0
+    for mode in (_lib.AAE_SCAN_MFMA,):
+        cb.set_mode(mode)
+        idx, score = cb.nn(z)
+        cs64 = ref.cos_similarity(z, E)
+        assert np.array_equal(idx[:4, 0], np.argmax(cs64[:4], axis=1))
+        assert idx[4, 0] == 0 and score[4, 0] == 0.0
+    assert np.abs(eb.l2_normalize(z) - ref.l2_normalize(z)).max() < 1e-7
+    cb.close()
