@@ -90,6 +90,7 @@ struct aae_encoder {
     std::vector<aae_host::KernelRecord> records;   // of the most recent forward
     int splitk_min_base_blocks = 384;      // split K only when the un-split grid is smaller than this
     int splitk_target_blocks = 512;        // ... and then aim for about this many blocks
+    int igemm_stagger = 0;                 // kcycles of start delay for every 2nd block generation of the igemm (0 = off)
 };
 
 struct aae_codebook {
@@ -112,11 +113,19 @@ static int upload(aae_encoder* enc, const float* host, size_t count, float** dev
 
 // HWIO / [F][J] kernel -> [K/4][CoutPad][4]; k = (kh*KS + kw)*Cin + ci is already
 // the row index of the HWIO array flattened to [K][Cout].
-static std::vector<float> pack_weights(const float* w, long long K, int Cout, int CoutPad) {
+// The kernel walks K as (32-channel chunk, kh, kw, channel-in-chunk): packed row
+// k' = (cc*taps + tap)*32 + j holds HWIO row k = tap*Cin + cc*32 + j.
+static std::vector<float> pack_weights(const float* w, int taps, int Cin, int Cout, int CoutPad) {
+    const long long K = (long long)taps * Cin;
     std::vector<float> out((size_t)K * CoutPad, 0.f);
-    for (long long k = 0; k < K; ++k)
-        for (int n = 0; n < Cout; ++n)
-            out[((size_t)(k >> 2) * CoutPad + n) * 4 + (k & 3)] = w[(size_t)k * Cout + n];
+    for (int cc = 0; cc < Cin / 32; ++cc)
+        for (int tap = 0; tap < taps; ++tap)
+            for (int j = 0; j < 32; ++j) {
+                const long long k = (long long)tap * Cin + cc * 32 + j;
+                const long long kp = ((long long)cc * taps + tap) * 32 + j;
+                for (int n = 0; n < Cout; ++n)
+                    out[((size_t)(kp >> 2) * CoutPad + n) * 4 + (kp & 3)] = w[(size_t)k * Cout + n];
+            }
     return out;
 }
 
@@ -195,7 +204,11 @@ static int launch_igemm(aae_encoder* enc, const Layer& L, const float* x, int M,
     aae::ConvIgemmArgs a;
     a.x = x; a.wp = L.wp; a.bias = L.bias; a.bn_scale = L.bn_scale; a.bn_shift = L.bn_shift;
     a.H = L.H; a.W = L.W; a.Cin = L.Cin; a.Ho = L.Ho; a.Wo = L.Wo; a.Cout = L.Cout; a.CoutPad = L.CoutPad;
-    a.KS = L.KS; a.S = L.S; a.pt = L.pt; a.pl = L.pl; a.M = M; a.relu = L.relu;
+    a.KS = L.KS; a.S = L.S; a.pt = L.pt; a.pl = L.pl; a.M = M; a.relu = L.relu; a.stagger = enc->igemm_stagger;
+    const unsigned long long x_bytes = (unsigned long long)(M / (L.Ho * L.Wo)) * L.H * L.W * L.Cin * sizeof(float);
+    if (x_bytes >= 0xFFFFFFF0ull)
+        return fail(AAE_ERR_UNSUPPORTED, "%s: input activation of %llu bytes exceeds the 4 GiB buffer view; use a smaller batch", name, x_bytes);
+    a.x_bytes = (unsigned)x_bytes;
     a.slabs_total = (int)(L.K() / 32);
     a.num_mt = ceil_div(M, 128);
     a.num_nt = L.CoutPad / 128;
@@ -220,9 +233,9 @@ static int launch_igemm(aae_encoder* enc, const Layer& L, const float* x, int M,
     aae::SplitKReduceArgs r;
     r.partial = partial; r.bias = L.bias; r.bn_scale = L.bn_scale; r.bn_shift = L.bn_shift; r.out = out;
     r.MN = (long long)M * L.Cout; r.Cout = L.Cout; r.splits = a.splits; r.relu = L.relu;
-    long long blocks = (r.MN + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    AAE_LAUNCH((aae::splitk_reduce_kernel), dim3((unsigned)blocks), dim3(256), 0, stream, r);
+    long long blocks = (r.MN + 63) / 64;
+    if (blocks > 4096) blocks = 4096;
+    AAE_LAUNCH((aae::splitk_reduce_kernel), dim3((unsigned)blocks), dim3(512), aae::kReduceGroups * 64 * (int)sizeof(float), stream, r);
     snprintf(label, sizeof(label), "%s:splitk_reduce", name);
     enc->records.push_back({label, 0.0});
     AAE_HIP_TRY(hipGetLastError());
@@ -315,7 +328,7 @@ static int forward_impl(aae_encoder* enc, const void* x, int x_dtype, int B, flo
 // --------------------------------------------------------------- codebook side
 struct ScanPlan {
     int nblk, Bpad, Bstride, Jpad, NT;
-    bool gemv;
+    bool gemv, stream;
     size_t q_off, qp_off, pval_off, pidx_off, cs_off, total;
 };
 
@@ -323,8 +336,8 @@ static ScanPlan plan_scan(const aae_codebook* cb, int B, int topk) {
     ScanPlan s;
     s.nblk = ceil_div(cb->N, 128);
     s.Jpad = 128;
-    s.gemv = (cb->scan_mode == AAE_SCAN_GEMV) || (cb->scan_mode == AAE_SCAN_AUTO && B <= 4);
-    if (B > 4) s.gemv = false;
+    s.stream = B <= 4 && (cb->scan_mode == AAE_SCAN_STREAM || cb->scan_mode == AAE_SCAN_AUTO);
+    s.gemv = B <= 4 && cb->scan_mode == AAE_SCAN_GEMV;
     s.NT = B <= 32 ? 1 : (B <= 64 ? 2 : 4);
     s.Bpad = (int)align_up((size_t)B, (size_t)(32 * s.NT));
     s.Bstride = s.Bpad;
@@ -351,16 +364,26 @@ static void launch_scan_mfma_t(const aae::ScanArgs& a, bool upright, int nblk, h
     }
 }
 
+template <int NQ>
+static void launch_scan_stream_t(const aae::ScanArgs& a, bool upright, int nblk, hipStream_t stream) {
+    const int smem = 2 * 4 * NQ * (int)sizeof(float);
+    if (upright) AAE_LAUNCH((aae::scan_stream_kernel<NQ, true>), dim3(nblk), dim3(256), smem, stream, a);
+    else AAE_LAUNCH((aae::scan_stream_kernel<NQ, false>), dim3(nblk), dim3(256), smem, stream, a);
+}
+
 static int run_scan(aae_codebook* cb, const float* z, int B, int col_stride, float* cs_out, const ScanPlan& s,
                     unsigned char* base, hipStream_t stream) {
     float* q = reinterpret_cast<float*>(base + s.q_off);
     float* qp = reinterpret_cast<float*>(base + s.qp_off);
-    aae::L2NormArgs n;
-    n.z = z; n.q = q; n.qp = s.gemv ? nullptr : qp; n.B = B; n.J = cb->J; n.Jpad = s.Jpad; n.Bpad = s.gemv ? B : s.Bpad;
-    AAE_LAUNCH((aae::l2norm_pack_kernel), dim3(ceil_div(n.Bpad, 4)), dim3(256), 0, stream, n);
-    AAE_HIP_TRY(hipGetLastError());
+    if (!s.stream) {                     // the stream kernel normalises the queries itself
+        aae::L2NormArgs n;
+        n.z = z; n.q = q; n.qp = s.gemv ? nullptr : qp; n.B = B; n.J = cb->J; n.Jpad = s.Jpad; n.Bpad = s.gemv ? B : s.Bpad;
+        AAE_LAUNCH((aae::l2norm_pack_kernel), dim3(ceil_div(n.Bpad, 4)), dim3(256), 0, stream, n);
+        AAE_HIP_TRY(hipGetLastError());
+    }
 
     aae::ScanArgs a;
+    a.z = z; a.e_bytes = (unsigned)((size_t)cb->N * cb->J * sizeof(float));
     a.E = cb->E; a.q = q; a.qp = qp;
     a.pval = reinterpret_cast<float*>(base + s.pval_off);
     a.pidx = reinterpret_cast<int*>(base + s.pidx_off);
@@ -368,7 +391,11 @@ static int run_scan(aae_codebook* cb, const float* z, int B, int col_stride, flo
     a.N = cb->N; a.J = cb->J; a.Jpad = s.Jpad; a.B = B; a.Bpad = s.Bpad; a.Bstride = s.Bstride;
     a.col_stride = col_stride;
     const bool upright = col_stride > 1;
-    if (s.gemv) {
+    if (s.stream) {
+        if (B == 1) launch_scan_stream_t<1>(a, upright, s.nblk, stream);
+        else if (B == 2) launch_scan_stream_t<2>(a, upright, s.nblk, stream);
+        else launch_scan_stream_t<4>(a, upright, s.nblk, stream);
+    } else if (s.gemv) {
         const int smem = 2 * 4 * 4 * (int)sizeof(float);
         if (upright) AAE_LAUNCH((aae::scan_gemv_kernel<4, true>), dim3(s.nblk), dim3(256), smem, stream, a);
         else AAE_LAUNCH((aae::scan_gemv_kernel<4, false>), dim3(s.nblk), dim3(256), smem, stream, a);
@@ -441,7 +468,7 @@ int aae_encoder_create(const aae_encoder_desc* d, const void* const* hw, int n_w
         }
         if (L.kind == KIND_GENERIC && L.Cin % 32 == 0) {
             L.kind = KIND_IGEMM;
-            const std::vector<float> packed = pack_weights(k, L.K(), L.Cout, L.CoutPad);
+            const std::vector<float> packed = pack_weights(k, L.KS * L.KS, L.Cin, L.Cout, L.CoutPad);
             if (int rc = upload(enc, packed.data(), packed.size(), &L.wp)) return bail(rc);
         }
         enc->layers.push_back(L);
@@ -458,7 +485,7 @@ int aae_encoder_create(const aae_encoder_desc* d, const void* const* hw, int n_w
         if (int rc = upload(enc, b, D.Cout, &D.bias)) return bail(rc);
         if (D.Cin % 32 == 0) {
             D.kind = KIND_IGEMM;
-            const std::vector<float> packed = pack_weights(k, D.K(), D.Cout, D.CoutPad);
+            const std::vector<float> packed = pack_weights(k, 1, D.Cin, D.Cout, D.CoutPad);
             if (int rc = upload(enc, packed.data(), packed.size(), &D.wp)) return bail(rc);
         } else {
             D.kind = KIND_GENERIC;
@@ -489,6 +516,7 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
     if (!enc || !name) return fail(AAE_ERR_INVALID, "aae_encoder_set_option: null argument");
     if (!strcmp(name, "splitk_min_base_blocks")) enc->splitk_min_base_blocks = value;
     else if (!strcmp(name, "splitk_target_blocks")) enc->splitk_target_blocks = value;
+    else if (!strcmp(name, "igemm_stagger")) enc->igemm_stagger = value;
     else return fail(AAE_ERR_INVALID, "unknown encoder option '%s'", name);
     return AAE_OK;
 }
@@ -556,6 +584,7 @@ int aae_codebook_create(const void* E, int N, int J, int dtype, int src_is_devic
     if (N < 1 || J < 1) return fail(AAE_ERR_INVALID, "codebook shape [%d,%d]", N, J);
     if (dtype != AAE_DTYPE_F32) return fail(AAE_ERR_UNSUPPORTED, "codebook dtype %d: only float32 is implemented", dtype);
     if (J % 4 != 0 || J > 128) return fail(AAE_ERR_UNSUPPORTED, "latent size %d: the scan kernels need J %% 4 == 0 and J <= 128", J);
+    if ((unsigned long long)N * J * sizeof(float) >= 0xFFFFFFF0ull) return fail(AAE_ERR_UNSUPPORTED, "codebook of %d x %d floats exceeds the 4 GiB buffer view", N, J);
     aae_codebook* cb = new aae_codebook();
     cb->N = N; cb->J = J;
     void* p = nullptr;
@@ -586,7 +615,7 @@ void aae_codebook_destroy(aae_codebook* cb) {
 int aae_codebook_set_scan_mode(aae_codebook* cb, int mode) {
     using namespace aae_host;
     if (!cb) return fail(AAE_ERR_INVALID, "aae_codebook_set_scan_mode: null handle");
-    if (mode != AAE_SCAN_AUTO && mode != AAE_SCAN_GEMV && mode != AAE_SCAN_MFMA) return fail(AAE_ERR_INVALID, "scan mode %d", mode);
+    if (mode != AAE_SCAN_AUTO && mode != AAE_SCAN_GEMV && mode != AAE_SCAN_MFMA && mode != AAE_SCAN_STREAM) return fail(AAE_ERR_INVALID, "scan mode %d", mode);
     cb->scan_mode = mode;
     return AAE_OK;
 }
@@ -616,7 +645,7 @@ int aae_codebook_nn(aae_codebook* cb, const float* z, int B, int topk, int col_s
         r.pidx = reinterpret_cast<int*>(base + s.pidx_off);
         r.idx_out = reinterpret_cast<long long*>(idx_out);
         r.score_out = score_out; r.nblk = s.nblk; r.B = B; r.Bstride = s.Bstride;
-        AAE_LAUNCH((aae::argmax_reduce_kernel), dim3(B), dim3(64), 0, stream, r);
+        AAE_LAUNCH((aae::argmax_reduce_kernel), dim3(B), dim3(256), 64, stream, r);
     } else {
         aae::TopKArgs t;
         t.cs = cs; t.idx_out = reinterpret_cast<long long*>(idx_out); t.score_out = score_out; t.N = cb->N; t.k = topk;

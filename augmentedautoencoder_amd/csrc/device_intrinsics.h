@@ -20,6 +20,43 @@ __device__ __forceinline__ f32x16 mfma_32x32x2(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+// Raw buffer view with hardware bounds checking: a 16-B load whose byte offset is >= the
+// buffer size returns zeros.  The implicit-GEMM loader uses that for TF 'SAME' zero padding
+// (out-of-image taps get offset kOobOffset) so the im2col gather has no branches.
+typedef __amdgpu_buffer_rsrc_t buffer_rsrc;
+constexpr uint32_t kOobOffset = 0xFFFFFFF0u;
+__device__ __forceinline__ buffer_rsrc make_buffer(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buffer_load4(buffer_rsrc r, uint32_t byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
+}
+
+// Cross-lane add through the DPP path (no LDS crossbar).  Lanes whose source is outside
+// the row / masked out contribute 0.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_take(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
+// Sum over each 32-lane half of the wave.  The total is valid in lanes 16..31 (lanes 0..31)
+// and 48..63 (lanes 32..63); the other lanes hold partial sums.
+__device__ __forceinline__ float half_wave_sum(float v) {
+    v += dpp_take<0xB1, 0xF>(v);     // quad_perm [1,0,3,2]
+    v += dpp_take<0x4E, 0xF>(v);     // quad_perm [2,3,0,1]
+    v += dpp_take<0x141, 0xF>(v);    // row_half_mirror
+    v += dpp_take<0x140, 0xF>(v);    // row_mirror
+    v += dpp_take<0x142, 0xA>(v);    // row_bcast15 -> rows 1 and 3
+    return v;
+}
+
+// instruction-scheduling fence: nothing is moved across it by the compiler's scheduler
+__device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+
+// coarse start delay: n x 1024 shader cycles
+__device__ __forceinline__ void sleep_kcycles(int n) {
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);
+}
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 __device__ __forceinline__ float shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }

@@ -64,7 +64,97 @@ struct ScanArgs {
     float* cs;          // optional full [B][N] similarity (parity / top-k path)
     int N, J, Jpad, B, Bpad, Bstride;
     int col_stride;     // 1, or num_cyclo for the reference's `upright` mode
+    const float* z;     // [B][J] raw latents                    (stream: normalisation fused)
+    unsigned e_bytes;   // N*J*4                                 (stream: bounds-checked view of E)
 };
+
+// ----------------------------------------------------------------- scan_stream
+// B <= 4, the reference's real usage (one crop per detection).  One launch does the
+// L2-normalisation AND the scan; the codebook is the only HBM stream:
+//   * every wave owns 32 consecutive rows and issues all 16 of its 1-KiB row-pair loads
+//     (16 B per lane, one 512-B row per half-wave) before it touches any of them, so the
+//     whole 47 MB codebook is in flight at once across the chip;
+//   * loads go through a bounds-checked buffer view (rows >= N read zeros): no branches,
+//     no early vmcnt waits;
+//   * while they fly, the wave normalises the <= 4 queries in registers;
+//   * each row's dot product is finished with 5 DPP adds (no LDS traffic); lanes 31 / 63
+//     keep the running (max, first row) for the even / odd rows of the wave.
+template <int NQ, bool UPRIGHT>
+__global__ __launch_bounds__(256) void scan_stream_kernel(const ScanArgs p) {
+    AAE_DYN_SMEM(smem_raw);
+    float* red_v = reinterpret_cast<float*>(smem_raw);           // [4][NQ]
+    int* red_i = reinterpret_cast<int*>(red_v + 4 * NQ);         // [4][NQ]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rs = lane >> 5, kq = lane & 31;
+    const int col = kq * 4;
+    const bool col_ok = col < p.J;                               // J <= 128, J % 4 == 0
+    const int row_first = blockIdx.x * 128 + wave * 32;
+
+    const buffer_rsrc ebuf = make_buffer(p.E, p.e_bytes);
+    f32x4 e[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int row = row_first + 2 * u + rs;
+        const bool ok = row < p.N && col_ok;
+        e[u] = buffer_load4(ebuf, ok ? (unsigned)(row * p.J + col) * 4u : kOobOffset);
+    }
+
+    // tf.nn.l2_normalize(z, 1) (codebook.py:27), per query, replicated in every lane
+    f32x4 qv[NQ];
+#pragma unroll
+    for (int b = 0; b < NQ; ++b) {
+        f32x4 zv = {0.f, 0.f, 0.f, 0.f};
+        if (b < p.B && col_ok) zv = *reinterpret_cast<const f32x4*>(p.z + (long long)b * p.J + col);
+        float ss = zv.x * zv.x;
+        ss = fmaf(zv.y, zv.y, ss);
+        ss = fmaf(zv.z, zv.z, ss);
+        ss = fmaf(zv.w, zv.w, ss);
+#pragma unroll
+        for (int m = 16; m >= 1; m >>= 1) ss += shfl_xor(ss, m);
+        const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
+        qv[b] = zv * inv;
+    }
+
+    float best_v[NQ];
+    int best_i[NQ];
+#pragma unroll
+    for (int b = 0; b < NQ; ++b) { best_v[b] = kNegInf; best_i[b] = row_first + rs; }
+
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int row = row_first + 2 * u + rs;
+        bool cand = row < p.N;
+        if (UPRIGHT) cand = cand && (row % p.col_stride == 0);
+#pragma unroll
+        for (int b = 0; b < NQ; ++b) {
+            float d = e[u].x * qv[b].x;
+            d = fmaf(e[u].y, qv[b].y, d);
+            d = fmaf(e[u].z, qv[b].z, d);
+            d = fmaf(e[u].w, qv[b].w, d);
+            d = half_wave_sum(d);                                // total valid in lanes 16-31 / 48-63
+            if (p.cs && kq == 31 && row < p.N && b < p.B) p.cs[(long long)b * p.N + row] = d;
+            if (cand && d > best_v[b]) { best_v[b] = d; best_i[b] = row; }
+        }
+    }
+    // lane 31: even rows, lane 63: odd rows -> lane 63 combines, then the 4 waves
+#pragma unroll
+    for (int b = 0; b < NQ; ++b) {
+        const float ov = shfl_xor(best_v[b], 32);
+        const int oi = shfl_xor(best_i[b], 32);
+        if (better(ov, oi, best_v[b], best_i[b])) { best_v[b] = ov; best_i[b] = oi; }
+        if (lane == 63) { red_v[wave * NQ + b] = best_v[b]; red_i[wave * NQ + b] = best_i[b]; }
+    }
+    __syncthreads();
+    if (tid < NQ && tid < p.B) {
+        float v = red_v[tid];
+        int ix = red_i[tid];
+        for (int w = 1; w < 4; ++w)
+            if (better(red_v[w * NQ + tid], red_i[w * NQ + tid], v, ix)) { v = red_v[w * NQ + tid]; ix = red_i[w * NQ + tid]; }
+        p.pval[(long long)blockIdx.x * p.Bstride + tid] = v;
+        p.pidx[(long long)blockIdx.x * p.Bstride + tid] = ix;
+    }
+}
 
 // ------------------------------------------------------------------- scan_gemv
 template <int NQ, bool UPRIGHT>
@@ -237,14 +327,26 @@ struct ArgmaxReduceArgs {
     int nblk, B, Bstride;
 };
 
-__global__ __launch_bounds__(64) void argmax_reduce_kernel(const ArgmaxReduceArgs p) {
-    const int b = blockIdx.x, lane = threadIdx.x;
+__global__ __launch_bounds__(256) void argmax_reduce_kernel(const ArgmaxReduceArgs p) {
+    AAE_DYN_SMEM(smem_raw);
+    float* red_v = reinterpret_cast<float*>(smem_raw);      // [4]
+    int* red_i = reinterpret_cast<int*>(red_v + 4);         // [4]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float bv = kNegInf;
     int bi = 0x7fffffff;
-    for (int k = lane; k < p.nblk; k += 64) {
-        const float v = p.pval[(long long)k * p.Bstride + b];
-        const int ix = p.pidx[(long long)k * p.Bstride + b];
-        if (better(v, ix, bv, bi)) { bv = v; bi = ix; }
+    for (int k0 = tid; k0 < p.nblk; k0 += 4 * 256) {        // 4 independent loads in flight per thread
+        float v[4];
+        int ix[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int k = k0 + u * 256;
+            v[u] = kNegInf;
+            ix[u] = 0x7fffffff;
+            if (k < p.nblk) { v[u] = p.pval[(long long)k * p.Bstride + b]; ix[u] = p.pidx[(long long)k * p.Bstride + b]; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (better(v[u], ix[u], bv, bi)) { bv = v[u]; bi = ix[u]; }
     }
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
@@ -252,7 +354,11 @@ __global__ __launch_bounds__(64) void argmax_reduce_kernel(const ArgmaxReduceArg
         const int oi = shfl_xor(bi, m);
         if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
     }
-    if (lane == 0) {
+    if (lane == 0) { red_v[wave] = bv; red_i[wave] = bi; }
+    __syncthreads();
+    if (tid == 0) {
+        for (int w = 1; w < 4; ++w)
+            if (better(red_v[w], red_i[w], bv, bi)) { bv = red_v[w]; bi = red_i[w]; }
         if (bi == 0x7fffffff) bi = 0;          // all-NaN scores: np.argmax would also answer 0
         p.idx_out[b] = bi;
         p.score_out[b] = bv;

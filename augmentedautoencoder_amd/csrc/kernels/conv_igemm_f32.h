@@ -8,7 +8,8 @@
 //   C[M, N] = A[M, K] * W[K, N],  M = B*Ho*Wo, N = Cout, K = KS*KS*Cin
 //   A is never materialised: row m = (b, oh, ow), k = (kh, kw, ci) reads
 //   x[b, oh*S-pt+kh, ow*S-pl+kw, ci] (zero outside the image: TF 'SAME').
-//   W is pre-packed on the host as [K/4][CoutPad][4] (CoutPad = 128-multiple).
+//   W is pre-packed on the host as [K/4][CoutPad][4] (CoutPad = 128-multiple) in the
+//   kernel's K order: k' = (cc*KS*KS + kh*KS + kw)*32 + j for channel ci = cc*32 + j.
 //
 // Block = 256 threads = 4 waves (2x2), tile 128x128, K-slab 32 (one tap, 32
 // channels), each wave 64x64 = 2x2 accumulators of v_mfma_f32_32x32x2_f32.
@@ -21,6 +22,7 @@ namespace aae {
 
 struct ConvIgemmArgs {
     const float* x;         // [B, H, W, Cin] NHWC
+    unsigned x_bytes;       // size of x in bytes (< 4 GiB: bounds-checked buffer view)
     const float* wp;        // [K/4][CoutPad][4]
     const float* bias;      // [Cout]            (epilogue mode only)
     const float* bn_scale;  // [Cout] or nullptr
@@ -33,6 +35,7 @@ struct ConvIgemmArgs {
     int slabs_per_split;
     int num_mt, num_nt, splits;
     int relu;
+    int stagger;            // kcycles of start delay for every second block generation (0 = off)
 };
 
 constexpr int kConvIgemmSmem = 2 * (kSlabFloatsA + 8 * 128 * 4) * 4;   // 64 KiB
@@ -57,7 +60,11 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvIgemmArgs
     // ---- A loader: thread -> 4 (row, slot) pairs, row = tid/8 + 32*q -------
     const int a_slot = tid & 7;
     const int a_row = tid >> 3;
-    const float* a_ptr[4];
+    // The activation tensor is read through a bounds-checked buffer view: taps that fall in
+    // the SAME padding (or rows >= M) get the out-of-range offset and the hardware returns
+    // zeros -- no branch around the load, so nothing forces an early vmcnt wait.
+    const buffer_rsrc xbuf = make_buffer(p.x, p.x_bytes);
+    unsigned a_off[4];          // byte offset of (b, ih0, iw0, slot*4); may wrap for ih0/iw0 < 0, only used when in range
     int a_ih0[4], a_iw0[4];
     bool a_ok[4];
 #pragma unroll
@@ -70,33 +77,38 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvIgemmArgs
         const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
         a_ih0[q] = oh * p.S - p.pt;
         a_iw0[q] = ow * p.S - p.pl;
-        a_ptr[q] = p.x + (((long long)b * p.H + a_ih0[q]) * p.W + a_iw0[q]) * (long long)p.Cin + a_slot * 4;
+        a_off[q] = (unsigned)(((((long long)b * p.H + a_ih0[q]) * p.W + a_iw0[q]) * (long long)p.Cin + a_slot * 4) * 4);
     }
     // ---- B loader: thread -> 4 (slot, col) pairs, idx = tid + 256*q ----------
     const float* b_ptr = p.wp + ((long long)nt * 128 + (tid & 127)) * 4 + (long long)(tid >> 7) * p.CoutPad * 4;
     const long long b_slot_stride = (long long)p.CoutPad * 4;      // floats per k-slot row
 
-    const int cpt = p.Cin >> 5;                   // slabs per tap
-    int tap = slab0 / cpt;
-    int cc = slab0 - tap * cpt;
+    // K order: 32-channel chunk outermost, then kh, then kw (fastest).  For one channel chunk
+    // the KS*KS taps of an M tile touch the same few input rows, so the working set the
+    // co-resident tiles of an XCD keep re-reading stays inside its 4 MB L2.
+    const int taps = p.KS * p.KS;
+    int cc = slab0 / taps;
+    const int tap = slab0 - cc * taps;
     int kh = tap / p.KS, kw = tap - kh * p.KS;
+    // Blocks p and p+256 share a CU (observed dispatch) and would otherwise run in lockstep:
+    // identical work, so their load/barrier phases coincide and the matrix pipe idles in both.
+    // Delaying every second generation by about half a slab interleaves them.
+    if (p.stagger > 0 && ((blockIdx.x >> 8) & 1)) sleep_kcycles(p.stagger);
 
     f32x4 ra[4], rb[4];
     auto fetch = [&](int slab) {
-        const int tap_off = (kh * p.W + kw) * p.Cin + cc * 32;
+        const unsigned tap_off = (unsigned)(((kh * p.W + kw) * p.Cin + cc * 32) * 4);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const bool ok = a_ok[q] && (unsigned)(a_ih0[q] + kh) < (unsigned)p.H &&
                             (unsigned)(a_iw0[q] + kw) < (unsigned)p.W;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = *reinterpret_cast<const f32x4*>(a_ptr[q] + tap_off);
-            ra[q] = v;
+            ra[q] = buffer_load4(xbuf, ok ? a_off[q] + tap_off : kOobOffset);
         }
         const float* bp = b_ptr + (long long)slab * 8 * b_slot_stride;
 #pragma unroll
         for (int q = 0; q < 4; ++q) rb[q] = *reinterpret_cast<const f32x4*>(bp + (long long)(2 * q) * b_slot_stride);
-        // advance the (kh, kw, cc) counters to the next slab
-        if (++cc == cpt) { cc = 0; if (++kw == p.KS) { kw = 0; ++kh; } }
+        // advance the (cc, kh, kw) counters to the next slab
+        if (++kw == p.KS) { kw = 0; if (++kh == p.KS) { kh = 0; ++cc; } }
     };
     auto stash = [&](int buf) {
         float* A = As + buf * kSlabFloatsA;
@@ -123,8 +135,28 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvIgemmArgs
         for (int t = slab0; t < slab1; ++t) {
             const bool more = (t + 1) < slab1;
             if (more) fetch(t + 1);
-            mfma_slab<2, 2>(As + buf * kSlabFloatsA, Bs + buf * (8 * 128 * 4), 128, wm * 64, wn * 64, lane, acc);
+            const float* A = As + buf * kSlabFloatsA;
+            const float* Bt = Bs + buf * (8 * 128 * 4);
+            // two fragment sets: the LDS reads of k-group c+1 are issued before the 16 MFMAs
+            // of group c; the next slab's LDS stores go between groups 2 and 3, when its
+            // global loads (issued ~3000 cycles earlier) have long landed.
+            f32x4 fa0[2], fb0[2], fa1[2], fb1[2];
+            frag_load<2, 2>(A, Bt, 128, wm * 64, wn * 64, lane, 0, fa0, fb0);
+            frag_load<2, 2>(A, Bt, 128, wm * 64, wn * 64, lane, 1, fa1, fb1);
+            sched_fence();                       // keep the read-ahead ahead: hipcc otherwise sinks it to 2 MFMAs before use
+            frag_mfma<2, 2>(fa0, fb0, acc);
+            sched_fence();
+            frag_load<2, 2>(A, Bt, 128, wm * 64, wn * 64, lane, 2, fa0, fb0);
+            sched_fence();
+            frag_mfma<2, 2>(fa1, fb1, acc);
+            sched_fence();
+            frag_load<2, 2>(A, Bt, 128, wm * 64, wn * 64, lane, 3, fa1, fb1);
+            sched_fence();
+            frag_mfma<2, 2>(fa0, fb0, acc);
+            sched_fence();
             if (more) stash(buf ^ 1);
+            sched_fence();
+            frag_mfma<2, 2>(fa1, fb1, acc);
             __syncthreads();
             buf ^= 1;
         }
@@ -173,16 +205,41 @@ struct SplitKReduceArgs {
     int Cout, splits, relu;
 };
 
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const SplitKReduceArgs p) {
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < p.MN; e += stride) {
-        const int n = (int)(e % p.Cout);
-        float v = 0.f;
-        for (int s = 0; s < p.splits; ++s) v += p.partial[(long long)s * p.MN + e];
-        v += p.bias[n];
-        if (p.relu) v = fmaxf(v, 0.f);
-        if (p.bn_scale) v = v * p.bn_scale[n] + p.bn_shift[n];
-        p.out[e] = v;
+// 512 threads = 8 split-groups x 64 consecutive outputs.  Group g sums the partials
+// s = g, g+8, g+16, ... (4 independent loads in flight per thread), the 8 group sums are
+// then added in order g = 0..7 -- a fixed tree, independent of launch geometry.
+constexpr int kReduceGroups = 8;
+
+__global__ __launch_bounds__(512) void splitk_reduce_kernel(const SplitKReduceArgs p) {
+    AAE_DYN_SMEM(smem_raw);
+    float* part = reinterpret_cast<float*>(smem_raw);            // [8][64]
+    const int l = threadIdx.x & 63, g = threadIdx.x >> 6;
+    for (long long e0 = (long long)blockIdx.x * 64; e0 < p.MN; e0 += (long long)gridDim.x * 64) {
+        const long long e = e0 + l;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        if (e < p.MN) {
+            int s = g;
+            for (; s + 3 * kReduceGroups < p.splits; s += 4 * kReduceGroups) {
+                v0 += p.partial[(long long)s * p.MN + e];
+                v1 += p.partial[(long long)(s + kReduceGroups) * p.MN + e];
+                v2 += p.partial[(long long)(s + 2 * kReduceGroups) * p.MN + e];
+                v3 += p.partial[(long long)(s + 3 * kReduceGroups) * p.MN + e];
+            }
+            for (; s < p.splits; s += kReduceGroups) v0 += p.partial[(long long)s * p.MN + e];
+        }
+        part[g * 64 + l] = (v0 + v1) + (v2 + v3);
+        __syncthreads();
+        if (g == 0 && e < p.MN) {
+            float v = part[l];
+#pragma unroll
+            for (int k = 1; k < kReduceGroups; ++k) v += part[k * 64 + l];
+            const int n = (int)(e % p.Cout);
+            v += p.bias[n];
+            if (p.relu) v = fmaxf(v, 0.f);
+            if (p.bn_scale) v = v * p.bn_scale[n] + p.bn_shift[n];
+            p.out[e] = v;
+        }
+        __syncthreads();
     }
 }
 

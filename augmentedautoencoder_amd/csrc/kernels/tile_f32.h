@@ -61,6 +61,29 @@ __device__ __forceinline__ void mfma_slab(const float* As, const float* Bs, int 
     }
 }
 
+// The same slab split into its 4 k-groups, so a caller can keep two fragment sets in
+// registers (reads for group c+1 in flight under the 16 MFMAs of group c) and slot other
+// work (LDS stores of the next slab) between groups.
+template <int MT, int NT>
+__device__ __forceinline__ void frag_load(const float* As, const float* Bs, int b_cols, int a_row0, int b_col0, int lane,
+                                          int c, f32x4 (&a)[MT], f32x4 (&b)[NT]) {
+    const int i = lane & 31, slot = 2 * c + (lane >> 5);
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) a[mi] = lds_read4(As + a_slab_off(a_row0 + 32 * mi + i, slot));
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) b[ni] = lds_read4(Bs + (slot * b_cols + b_col0 + 32 * ni + i) * 4);
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ void frag_mfma(const f32x4 (&a)[MT], const f32x4 (&b)[NT], f32x16 (&acc)[MT][NT]) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = mfma_32x32x2(a[mi][q], b[ni][q], acc[mi][ni]);
+}
+
 // accumulator register r of a 32x32 tile -> row inside the tile
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 

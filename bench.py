@@ -34,7 +34,10 @@ def cpu_baseline(weights, E, crops, min_seconds=10.0, max_iters=8):
     import numpy as np
     import torch
     from oracle import reference_cpu as ref
-    nthreads = os.cpu_count() or 1
+    # thread count: the best point of a sweep on the MI355X box's host (2 x EPYC 9575F, 256
+    # hardware threads): 8 -> 151, 16 -> 189, 32 -> 223, 64 -> 126, 128 -> 58, 256 -> 14 crops/s
+    # (tools/bench_extra.py cpu); oneDNN oversubscribes badly beyond 32 threads at this size.
+    nthreads = min(32, os.cpu_count() or 1)
     torch.set_num_threads(nthreads)
     sample = crops[:64]
     ref.encoder_forward_torch(ref.input_to_float(sample[:8]), weights, [2, 2, 2, 2], False, 'float32')   # warm-up

@@ -55,6 +55,17 @@ void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()
 namespace aae {
 
 inline int lane_id() { return threadIdx.x & 63; }
+inline void sleep_kcycles(int) {}
+inline void sched_fence() {}
+
+struct buffer_rsrc { const unsigned char* base; uint32_t bytes; };
+constexpr uint32_t kOobOffset = 0xFFFFFFF0u;
+inline buffer_rsrc make_buffer(const void* base, uint32_t bytes) { return buffer_rsrc{static_cast<const unsigned char*>(base), bytes}; }
+inline f32x4 buffer_load4(buffer_rsrc r, uint32_t byte_off) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if ((uint64_t)byte_off + 16 <= r.bytes) memcpy(&v, r.base + byte_off, 16);     // hardware range check
+    return v;
+}
 
 inline f32x16 mfma_32x32x2(float a, float b, f32x16 c) {
     float ab[2] = {a, b};
@@ -83,6 +94,23 @@ inline T shfl_xor(T v, int mask) {
     T out;
     memcpy(&out, &all[lane_id() ^ mask][0], 4);
     return out;
+}
+
+// DPP add tree of device_intrinsics.h::half_wave_sum, same partner order.
+inline float half_wave_sum(float v) {
+    const int lane = lane_id();
+    auto step = [&](int partner, bool enabled) {
+        const aae_emu::lane_slot* all = aae_emu::wave_exchange(&v, 4);
+        float o;
+        memcpy(&o, &all[partner][0], 4);
+        if (enabled) v += o;
+    };
+    step(lane ^ 1, true);                                        // quad_perm [1,0,3,2]
+    step(lane ^ 2, true);                                        // quad_perm [2,3,0,1]
+    step((lane & ~7) | (7 - (lane & 7)), true);                  // row_half_mirror
+    step((lane & ~15) | (15 - (lane & 15)), true);               // row_mirror
+    step(((lane >> 4) - 1) * 16 + 15 < 0 ? 0 : ((lane >> 4) - 1) * 16 + 15, ((lane >> 4) & 1) == 1);   // row_bcast15, rows 1 and 3
+    return v;
 }
 
 }  // namespace aae

@@ -58,6 +58,7 @@ def test_generic_fallback_everything():
 
 
 @pytest.mark.parametrize('B,mode', [(1, _lib.AAE_SCAN_GEMV), (4, _lib.AAE_SCAN_GEMV), (3, _lib.AAE_SCAN_MFMA),
+                                    (1, _lib.AAE_SCAN_STREAM), (2, _lib.AAE_SCAN_STREAM), (3, _lib.AAE_SCAN_AUTO),
                                     (33, _lib.AAE_SCAN_AUTO), (70, _lib.AAE_SCAN_AUTO)])
 def test_codebook_scan_kernels(B, mode):
     N, J = 36 * 11 + 5, 128                                   # 401 rows: 3 full 128-row blocks + a partial one

@@ -101,12 +101,15 @@ def test_scan_kernels_agree_and_ties_take_lowest_index(default_model):
     z = (E[rows] * np.linspace(0.5, 9.0, len(rows))[:, None]).astype(np.float32)     # exact scaled rows -> exact ties on duplicates
     want = rows.copy()
     want[:3] -= 35                                    # lower-index twin must win
-    for mode in (_lib.AAE_SCAN_MFMA, _lib.AAE_SCAN_GEMV, _lib.AAE_SCAN_AUTO):
+    for mode in (_lib.AAE_SCAN_MFMA, _lib.AAE_SCAN_GEMV, _lib.AAE_SCAN_STREAM, _lib.AAE_SCAN_AUTO):
         eng.set_scan_mode(mode)
         for a in range(0, len(rows), 4):
             idx, score = eng.nn(z[a:a + 4], 1, 1)
             assert np.array_equal(idx[:, 0].cpu().numpy(), want[a:a + 4]), 'mode %d' % mode
             assert np.abs(score[:, 0].cpu().numpy() - 1.0).max() < 1e-6
+        for nq in (1, 3):                                 # NQ = 1 and the padded NQ = 4 instantiations
+            idx, _ = eng.nn(z[:nq], 1, 1)
+            assert np.array_equal(idx[:, 0].cpu().numpy(), want[:nq]), 'mode %d B=%d' % (mode, nq)
     eng.set_scan_mode(_lib.AAE_SCAN_MFMA)
     i_m, s_m = eng.nn(z[:4], 1, 1)
     eng.set_scan_mode(_lib.AAE_SCAN_GEMV)

@@ -1,0 +1,109 @@
+#!/usr/bin/env python
+"""Secondary measurements on the MI355X box (not the headline bench): small-batch latency,
+scan-kernel bandwidth per mode, encoder-only throughput (config 3), CPU thread sweep.
+Writes one JSON object per line to stdout."""
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+
+from augmentedautoencoder_amd import _lib
+from augmentedautoencoder_amd.engine import CodebookEngine, EncoderEngine
+from augmentedautoencoder_amd.weights import EncoderConfig
+from oracle import synth
+
+
+def timeit(fn, reps, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def main():
+    what = sys.argv[1:] or ['latency', 'scan', 'embed']
+    cfg = EncoderConfig()
+    weights = synth.make_weights(seed=2024)
+    E = synth.make_codebook(92232, 128, seed=7)
+    enc = EncoderEngine(cfg, weights, max_batch=1024)
+    cb = CodebookEngine(E)
+    nbytes = E.size * 4
+    if 'latency' in what:
+        for B in (1, 2, 4, 8, 16, 32, 64, 128, 256, 512):
+            x = torch.from_numpy(synth.make_crops(B, seed=B)).cuda()
+            ms_enc = timeit(lambda: enc.encode(x), 20 if B >= 64 else 50)
+            z = enc.encode(x)
+            ms_nn = timeit(lambda: cb.nn(z, 1, 1), 50)
+            ms_all = timeit(lambda: cb.nn(enc.encode(x), 1, 1), 20 if B >= 64 else 50)
+            _, recs = enc.encode_timed(x)
+            print(json.dumps({'what': 'latency', 'B': B, 'encode_ms': round(ms_enc, 4), 'nn_ms': round(ms_nn, 4),
+                              'encode+nn_ms': round(ms_all, 4), 'crops_per_s': round(B / ms_all * 1e3, 1),
+                              'kernels': [(l.split(':')[0] + ':' + l.split(':')[1].split()[0], round(ms, 4)) for l, ms, _ in recs]}))
+    if 'scan' in what:
+        for B in (1, 2, 4, 8, 32, 64, 256):
+            z = torch.randn(B, 128, device='cuda')
+            for mode, name in ((_lib.AAE_SCAN_STREAM, 'stream'), (_lib.AAE_SCAN_GEMV, 'gemv'), (_lib.AAE_SCAN_MFMA, 'mfma')):
+                if mode != _lib.AAE_SCAN_MFMA and B > 4:
+                    continue
+                cb.set_scan_mode(mode)
+                ms = timeit(lambda: cb.nn(z, 1, 1), 100)
+                print(json.dumps({'what': 'scan', 'B': B, 'mode': name, 'ms': round(ms, 4),
+                                  'algorithmic_GBps': round(nbytes / ms / 1e6, 1), 'frac_of_8TBps': round(nbytes / ms / 1e6 / 8000, 3)}))
+            cb.set_scan_mode(_lib.AAE_SCAN_AUTO)
+    if 'stagger' in what:
+        x = torch.from_numpy(synth.make_crops(256, seed=1)).cuda()
+        for rep in range(2):
+            for st in (0, 1, 2, 3, 4, 6):
+                enc.set_option('igemm_stagger', st)
+                ms = timeit(lambda: enc.encode(x), 10)
+                print(json.dumps({'what': 'stagger', 'kcycles': st, 'rep': rep, 'encode_ms': round(ms, 4),
+                                  'encoder_tflops': round(cfg.flops_per_crop() * 256 / ms / 1e9, 2)}))
+        enc.set_option('igemm_stagger', 0)
+    if 'scanprof' in what:
+        # few launches of each small-batch scan variant, for a rocprofv3 --kernel-trace --stats wrapper
+        for B in (1, 4):
+            z = torch.randn(B, 128, device='cuda')
+            for mode in (_lib.AAE_SCAN_STREAM, _lib.AAE_SCAN_GEMV, _lib.AAE_SCAN_MFMA):
+                cb.set_scan_mode(mode)
+                for _ in range(20):
+                    cb.nn(z, 1, 1)
+        torch.cuda.synchronize()
+        cb.set_scan_mode(_lib.AAE_SCAN_AUTO)
+    if 'embed' in what:
+        # config 3: encoder-only over 92232 views in batches of 64 (reference BATCH_SIZE) / 256 / 1024
+        for bs in (64, 256, 1024):
+            x = torch.from_numpy(synth.make_crops(bs, seed=3)).cuda()
+            n_batches = -(-92232 // bs)
+            ms = timeit(lambda: enc.encode(x), 10)
+            print(json.dumps({'what': 'embed', 'batch': bs, 'ms_per_batch': round(ms, 4), 'crops_per_s': round(bs / ms * 1e3, 1),
+                              'seconds_for_92232_views': round(n_batches * ms * 1e-3, 3)}))
+    if 'cpu' in what:
+        from oracle import reference_cpu as ref
+        crops = synth.make_crops(64, seed=1)
+        xf = ref.input_to_float(crops)
+        for nt in (8, 16, 32, 64, 128, 256):
+            if nt > (os.cpu_count() or 1):
+                continue
+            torch.set_num_threads(nt)
+            ref.encoder_forward_torch(xf[:8], weights, [2, 2, 2, 2], False, 'float32')
+            t0 = time.perf_counter()
+            reps = 2
+            for _ in range(reps):
+                ref.encoder_forward_torch(xf, weights, [2, 2, 2, 2], False, 'float32')
+            dt = (time.perf_counter() - t0) / reps
+            print(json.dumps({'what': 'cpu', 'threads': nt, 'batch': 64, 'crops_per_s': round(64 / dt, 1)}))
+
+
+if __name__ == '__main__':
+    main()
