@@ -95,28 +95,23 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvIgemmArgs
     // Delaying every second generation by about half a slab interleaves them.
     if (p.stagger > 0 && ((blockIdx.x >> 8) & 1)) sleep_kcycles(p.stagger);
 
+    // Loader state.  fetch_piece(slab, q) computes one A address + issues one A and one B
+    // 16-B load; stash_piece(buf, q) stores that pair into the LDS slab.  They are issued in
+    // four pieces so they can sit in the shadow of individual MFMAs (see the main loop).
     f32x4 ra[4], rb[4];
-    auto fetch = [&](int slab) {
-        const unsigned tap_off = (unsigned)(((kh * p.W + kw) * p.Cin + cc * 32) * 4);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const bool ok = a_ok[q] && (unsigned)(a_ih0[q] + kh) < (unsigned)p.H &&
-                            (unsigned)(a_iw0[q] + kw) < (unsigned)p.W;
-            ra[q] = buffer_load4(xbuf, ok ? a_off[q] + tap_off : kOobOffset);
+    unsigned tap_off = 0;
+    auto fetch_piece = [&](int slab, int q) {
+        if (q == 0) tap_off = (unsigned)(((kh * p.W + kw) * p.Cin + cc * 32) * 4);
+        const bool ok = a_ok[q] && (unsigned)(a_ih0[q] + kh) < (unsigned)p.H && (unsigned)(a_iw0[q] + kw) < (unsigned)p.W;
+        ra[q] = buffer_load4(xbuf, ok ? a_off[q] + tap_off : kOobOffset);
+        rb[q] = *reinterpret_cast<const f32x4*>(b_ptr + ((long long)slab * 8 + 2 * q) * b_slot_stride);
+        if (q == 3) {                            // advance the (cc, kh, kw) counters to the next slab
+            if (++kw == p.KS) { kw = 0; if (++kh == p.KS) { kh = 0; ++cc; } }
         }
-        const float* bp = b_ptr + (long long)slab * 8 * b_slot_stride;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) rb[q] = *reinterpret_cast<const f32x4*>(bp + (long long)(2 * q) * b_slot_stride);
-        // advance the (cc, kh, kw) counters to the next slab
-        if (++kw == p.KS) { kw = 0; if (++kh == p.KS) { kh = 0; ++cc; } }
     };
-    auto stash = [&](int buf) {
-        float* A = As + buf * kSlabFloatsA;
-        float* Bt = Bs + buf * (8 * 128 * 4);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) lds_write4(A + a_slab_off(a_row + 32 * q, a_slot), ra[q]);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) lds_write4(Bt + (tid + 256 * q) * 4, rb[q]);
+    auto stash_piece = [&](int buf, int q) {
+        lds_write4(As + buf * kSlabFloatsA + a_slab_off(a_row + 32 * q, a_slot), ra[q]);
+        lds_write4(Bs + buf * (8 * 128 * 4) + (tid + 256 * q) * 4, rb[q]);
     };
 
     f32x16 acc[2][2];
@@ -128,36 +123,58 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvIgemmArgs
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
     if (slab0 < slab1) {
-        fetch(slab0);
-        stash(0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) fetch_piece(slab0, q);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) stash_piece(0, q);
         __syncthreads();
         int buf = 0;
+        // Software pipeline over the 4 k-groups (4 q-steps x 4 MFMAs each) of every slab with two
+        // fragment sets S0/S1 in registers.  The matrix pipe never waits on LDS, on address
+        // arithmetic or on the barrier:
+        //   g0 (S0): after each q-step one fetch piece of slab t+1 (address VALU + 2 loads)
+        //            issues in the shadow of the q-step's last MFMA;   then S0 <- (t, c2)
+        //   g1 (S1):                                                    then S1 <- (t, c3)
+        //   g2 (S0): after each q-step one stash piece of slab t+1 (2 LDS stores; its global
+        //            loads were issued ~3000 cycles earlier)
+        //   barrier: slab t+1 visible, every wave has its slab-t fragments in registers
+        //   S0 <- (t+1, c0);  g3 (S1) runs while that read is in flight;  S1 <- (t+1, c1)
+        f32x4 fa0[2], fb0[2], fa1[2], fb1[2];
+        frag_load<2, 2>(As, Bs, 128, wm * 64, wn * 64, lane, 0, fa0, fb0);
+        frag_load<2, 2>(As, Bs, 128, wm * 64, wn * 64, lane, 1, fa1, fb1);
         for (int t = slab0; t < slab1; ++t) {
             const bool more = (t + 1) < slab1;
-            if (more) fetch(t + 1);
             const float* A = As + buf * kSlabFloatsA;
             const float* Bt = Bs + buf * (8 * 128 * 4);
-            // two fragment sets: the LDS reads of k-group c+1 are issued before the 16 MFMAs
-            // of group c; the next slab's LDS stores go between groups 2 and 3, when its
-            // global loads (issued ~3000 cycles earlier) have long landed.
-            f32x4 fa0[2], fb0[2], fa1[2], fb1[2];
-            frag_load<2, 2>(A, Bt, 128, wm * 64, wn * 64, lane, 0, fa0, fb0);
-            frag_load<2, 2>(A, Bt, 128, wm * 64, wn * 64, lane, 1, fa1, fb1);
-            sched_fence();                       // keep the read-ahead ahead: hipcc otherwise sinks it to 2 MFMAs before use
-            frag_mfma<2, 2>(fa0, fb0, acc);
+            const float* An = As + (buf ^ 1) * kSlabFloatsA;
+            const float* Btn = Bs + (buf ^ 1) * (8 * 128 * 4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {        // group 0
+                sched_fence();
+                frag_mfma_q<2, 2>(fa0, fb0, q, acc);
+                sched_fence();
+                if (more) fetch_piece(t + 1, q);
+            }
             sched_fence();
             frag_load<2, 2>(A, Bt, 128, wm * 64, wn * 64, lane, 2, fa0, fb0);
             sched_fence();
-            frag_mfma<2, 2>(fa1, fb1, acc);
+            frag_mfma<2, 2>(fa1, fb1, acc);      // group 1
             sched_fence();
             frag_load<2, 2>(A, Bt, 128, wm * 64, wn * 64, lane, 3, fa1, fb1);
-            sched_fence();
-            frag_mfma<2, 2>(fa0, fb0, acc);
-            sched_fence();
-            if (more) stash(buf ^ 1);
-            sched_fence();
-            frag_mfma<2, 2>(fa1, fb1, acc);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {        // group 2
+                sched_fence();
+                frag_mfma_q<2, 2>(fa0, fb0, q, acc);
+                sched_fence();
+                if (more) stash_piece(buf ^ 1, q);
+            }
             __syncthreads();
+            sched_fence();
+            if (more) frag_load<2, 2>(An, Btn, 128, wm * 64, wn * 64, lane, 0, fa0, fb0);
+            sched_fence();
+            frag_mfma<2, 2>(fa1, fb1, acc);      // group 3
+            sched_fence();
+            if (more) frag_load<2, 2>(An, Btn, 128, wm * 64, wn * 64, lane, 1, fa1, fb1);
             buf ^= 1;
         }
     }

@@ -84,6 +84,15 @@ __device__ __forceinline__ void frag_mfma(const f32x4 (&a)[MT], const f32x4 (&b)
             for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = mfma_32x32x2(a[mi][q], b[ni][q], acc[mi][ni]);
 }
 
+// one q-step (MT*NT MFMAs) of a k-group
+template <int MT, int NT>
+__device__ __forceinline__ void frag_mfma_q(const f32x4 (&a)[MT], const f32x4 (&b)[NT], int q, f32x16 (&acc)[MT][NT]) {
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = mfma_32x32x2(a[mi][q], b[ni][q], acc[mi][ni]);
+}
+
 // accumulator register r of a 32x32 tile -> row inside the tile
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
