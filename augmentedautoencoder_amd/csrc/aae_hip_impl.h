@@ -19,6 +19,7 @@
 #include "../../include/aae_hip.h"
 #include "kernels/tile_f32.h"
 #include "kernels/conv_igemm_f32.h"
+#include "kernels/conv_igemm_x3h.h"
 #include "kernels/conv_first_f32.h"
 #include "kernels/conv_direct_generic.h"
 #include "kernels/codebook_scan_f32.h"
@@ -66,6 +67,8 @@ struct Layer {
     LayerKind kind = KIND_GENERIC;
     float* w_hwio = nullptr;    // device [KS*KS*Cin][Cout]
     float* wp = nullptr;        // device [K/4][CoutPad][4]      (igemm)
+    unsigned* wp16 = nullptr;   // device [slabs][8][CoutPad][4 dwords]: (hi, lo) halves of w*2^w_shift (f32x3h)
+    int w_shift = 0;
     float* bias = nullptr;
     float* bn_scale = nullptr;  // folded inference BN: x*scale + shift
     float* bn_shift = nullptr;
@@ -90,6 +93,8 @@ struct aae_encoder {
     std::vector<aae_host::KernelRecord> records;   // of the most recent forward
     int splitk_min_base_blocks = 384;      // split K only when the un-split grid is smaller than this
     int splitk_target_blocks = 512;        // ... and then aim for about this many blocks
+    int precision = 0;                     // 0: exact fp32 MFMA; 1: f32x3h split-precision igemm (explicit opt-in)
+    int x3h_act_shift = 4;                 // activations travel as halves of x*2^shift in f32x3h mode (|x| < 4094 exact range)
     int igemm_stagger = 0;                 // kcycles of start delay for every 2nd block generation of the igemm (0 = off)
 };
 
@@ -126,6 +131,39 @@ static std::vector<float> pack_weights(const float* w, int taps, int Cin, int Co
                 for (int n = 0; n < Cout; ++n)
                     out[((size_t)(kp >> 2) * CoutPad + n) * 4 + (kp & 3)] = w[(size_t)k * Cout + n];
             }
+    return out;
+}
+
+// f32x3h weights: w*2^shift split into (hi, lo) halves, packed per K-slab as
+// [8 slots][CoutPad][8 halves] with slot = plane*4 + kgroup8 (kernel K order, see pack_weights).
+static std::vector<unsigned short> pack_weights_x3h(const float* w, int taps, int Cin, int Cout, int CoutPad, int* shift_out) {
+    const long long K = (long long)taps * Cin;
+    float maxw = 0.f;
+    for (long long i = 0; i < K * Cout; ++i) maxw = fmaxf(maxw, fabsf(w[i]));
+    int e = 0;
+    if (maxw > 0.f) (void)frexpf(maxw, &e);                  // maxw = m * 2^e, m in [0.5, 1)
+    const int shift = 10 - e;                                // max |w| * 2^shift in [512, 1024)
+    *shift_out = shift;
+    const long long slabs = K / 32;
+    std::vector<unsigned short> out((size_t)slabs * 8 * CoutPad * 8, 0);
+    for (int cc = 0; cc < Cin / 32; ++cc)
+        for (int tap = 0; tap < taps; ++tap) {
+            const long long slab = (long long)cc * taps + tap;
+            for (int j = 0; j < 32; ++j) {
+                const long long k = (long long)tap * Cin + cc * 32 + j;
+                const int kg = j >> 3, el = j & 7;
+                for (int n = 0; n < Cout; ++n) {
+                    const float v = ldexpf(w[(size_t)k * Cout + n], shift);
+                    const _Float16 h = (_Float16)v;
+                    const _Float16 l = (_Float16)(v - (float)h);
+                    unsigned short hb, lb;
+                    memcpy(&hb, &h, 2);
+                    memcpy(&lb, &l, 2);
+                    out[(((size_t)slab * 8 + kg) * CoutPad + n) * 8 + el] = hb;
+                    out[(((size_t)slab * 8 + 4 + kg) * CoutPad + n) * 8 + el] = lb;
+                }
+            }
+        }
     return out;
 }
 
@@ -233,6 +271,56 @@ static int launch_igemm(aae_encoder* enc, const Layer& L, const float* x, int M,
     aae::SplitKReduceArgs r;
     r.partial = partial; r.bias = L.bias; r.bn_scale = L.bn_scale; r.bn_shift = L.bn_shift; r.out = out;
     r.MN = (long long)M * L.Cout; r.Cout = L.Cout; r.splits = a.splits; r.relu = L.relu;
+    r.out_planes = 0; r.out_scale = 1.f;
+    long long blocks = (r.MN + 63) / 64;
+    if (blocks > 4096) blocks = 4096;
+    AAE_LAUNCH((aae::splitk_reduce_kernel), dim3((unsigned)blocks), dim3(512), aae::kReduceGroups * 64 * (int)sizeof(float), stream, r);
+    snprintf(label, sizeof(label), "%s:splitk_reduce", name);
+    enc->records.push_back({label, 0.0});
+    AAE_HIP_TRY(hipGetLastError());
+    return tm.mark();
+}
+
+// f32x3h variant: x and (unless out_f32) out are fp16 hi/lo planes of value * 2^x3h_act_shift.
+static int launch_igemm_x3h(aae_encoder* enc, const Layer& L, const void* x, int M, void* out, bool out_f32, float* partial,
+                            hipStream_t stream, Timer& tm, const char* name) {
+    aae::ConvIgemmX3hArgs a;
+    a.x = static_cast<const unsigned short*>(x); a.wp = L.wp16; a.bias = L.bias; a.bn_scale = L.bn_scale; a.bn_shift = L.bn_shift;
+    a.H = L.H; a.W = L.W; a.Cin = L.Cin; a.Ho = L.Ho; a.Wo = L.Wo; a.Cout = L.Cout; a.CoutPad = L.CoutPad;
+    a.KS = L.KS; a.S = L.S; a.pt = L.pt; a.pl = L.pl; a.M = M; a.relu = L.relu;
+    const unsigned long long plane = (unsigned long long)(M / (L.Ho * L.Wo)) * L.H * L.W * L.Cin * 2;
+    if (2 * plane >= 0xFFFFFFF0ull)
+        return fail(AAE_ERR_UNSUPPORTED, "%s: input activation of %llu bytes exceeds the 4 GiB buffer view; use a smaller batch", name, 2 * plane);
+    a.plane_bytes = (unsigned)plane;
+    a.x_bytes = (unsigned)(2 * plane);
+    a.inv_scale = ldexpf(1.f, -(enc->x3h_act_shift + L.w_shift));
+    a.out_scale = ldexpf(1.f, enc->x3h_act_shift);
+    a.slabs_total = (int)(L.K() / 32);
+    a.num_mt = ceil_div(M, 128);
+    a.num_nt = L.CoutPad / 128;
+    choose_splits(enc, a.num_mt * a.num_nt, a.slabs_total, &a.splits, &a.slabs_per_split);
+    const int nblk = a.num_mt * a.num_nt * a.splits;
+    const double flops = 2.0 * (double)M * (double)L.K() * (double)L.Cout;
+    char label[96];
+    if (a.splits == 1) {
+        a.out = out;
+        if (out_f32) AAE_LAUNCH((aae::conv_igemm_x3h_kernel<aae::X3H_OUT_F32>), dim3(nblk), dim3(256), aae::kConvIgemmSmem, stream, a);
+        else AAE_LAUNCH((aae::conv_igemm_x3h_kernel<aae::X3H_OUT_PLANES>), dim3(nblk), dim3(256), aae::kConvIgemmSmem, stream, a);
+        snprintf(label, sizeof(label), "%s:conv_igemm_x3h M=%d N=%d K=%lld", name, M, L.Cout, L.K());
+        enc->records.push_back({label, flops});
+        AAE_HIP_TRY(hipGetLastError());
+        return tm.mark();
+    }
+    a.out = partial;
+    AAE_LAUNCH((aae::conv_igemm_x3h_kernel<aae::X3H_OUT_PARTIAL>), dim3(nblk), dim3(256), aae::kConvIgemmSmem, stream, a);
+    snprintf(label, sizeof(label), "%s:conv_igemm_x3h_splitk%d M=%d N=%d K=%lld", name, a.splits, M, L.Cout, L.K());
+    enc->records.push_back({label, flops});
+    AAE_HIP_TRY(hipGetLastError());
+    if (int rc = tm.mark()) return rc;
+    aae::SplitKReduceArgs r;
+    r.partial = partial; r.bias = L.bias; r.bn_scale = L.bn_scale; r.bn_shift = L.bn_shift; r.out = static_cast<float*>(out);
+    r.MN = (long long)M * L.Cout; r.Cout = L.Cout; r.splits = a.splits; r.relu = L.relu;
+    r.out_planes = out_f32 ? 0 : 1; r.out_scale = a.out_scale;
     long long blocks = (r.MN + 63) / 64;
     if (blocks > 4096) blocks = 4096;
     AAE_LAUNCH((aae::splitk_reduce_kernel), dim3((unsigned)blocks), dim3(512), aae::kReduceGroups * 64 * (int)sizeof(float), stream, r);
@@ -243,17 +331,23 @@ static int launch_igemm(aae_encoder* enc, const Layer& L, const float* x, int M,
 }
 
 template <int KS, int C>
-static void launch_first_t(const aae::ConvFirstArgs& a, bool u8, dim3 grid, int smem, hipStream_t stream) {
-    if (u8) AAE_LAUNCH((aae::conv_first_f32_kernel<KS, C, true>), grid, dim3(256), smem, stream, a);
-    else AAE_LAUNCH((aae::conv_first_f32_kernel<KS, C, false>), grid, dim3(256), smem, stream, a);
+static void launch_first_t(const aae::ConvFirstArgs& a, bool u8, bool planes, dim3 grid, int smem, hipStream_t stream) {
+    if (planes) {
+        if (u8) AAE_LAUNCH((aae::conv_first_f32_kernel<KS, C, true, true>), grid, dim3(256), smem, stream, a);
+        else AAE_LAUNCH((aae::conv_first_f32_kernel<KS, C, false, true>), grid, dim3(256), smem, stream, a);
+    } else {
+        if (u8) AAE_LAUNCH((aae::conv_first_f32_kernel<KS, C, true, false>), grid, dim3(256), smem, stream, a);
+        else AAE_LAUNCH((aae::conv_first_f32_kernel<KS, C, false, false>), grid, dim3(256), smem, stream, a);
+    }
 }
 
-static int launch_first(aae_encoder* enc, const Layer& L, const void* x, bool u8, int B, float* out,
+static int launch_first(aae_encoder* enc, const Layer& L, const void* x, bool u8, int B, float* out, bool planes,
                         hipStream_t stream, Timer& tm) {
     aae::ConvFirstArgs a;
     a.x = x; a.lut = enc->lut; a.w = L.w_hwio; a.bias = L.bias; a.bn_scale = L.bn_scale; a.bn_shift = L.bn_shift;
     a.out = out; a.H = L.H; a.W = L.W; a.Ho = L.Ho; a.Wo = L.Wo; a.Cout = L.Cout;
     a.S = L.S; a.pt = L.pt; a.pl = L.pl; a.rowlen = L.rowlen; a.relu = L.relu;
+    a.out_scale = ldexpf(1.f, enc->x3h_act_shift);
     a.tiles_per_image = ceil_div(L.Ho * L.Wo, 128);
     a.total_tiles = B * a.tiles_per_image;
     int tpb = ceil_div(a.total_tiles, 1024);
@@ -261,8 +355,8 @@ static int launch_first(aae_encoder* enc, const Layer& L, const void* x, bool u8
     if (tpb > 8) tpb = 8;
     a.tiles_per_block = tpb;
     const dim3 grid(ceil_div(a.total_tiles, tpb), ceil_div(L.Cout, 128));
-    if (L.Cin == 3) launch_first_t<5, 3>(a, u8, grid, L.first_smem, stream);
-    else launch_first_t<5, 1>(a, u8, grid, L.first_smem, stream);
+    if (L.Cin == 3) launch_first_t<5, 3>(a, u8, planes, grid, L.first_smem, stream);
+    else launch_first_t<5, 1>(a, u8, planes, grid, L.first_smem, stream);
     char label[96];
     snprintf(label, sizeof(label), "conv1:conv_first_f32 M=%d N=%d K=%lld", B * L.Ho * L.Wo, L.Cout, L.K());
     enc->records.push_back({label, 2.0 * (double)B * L.Ho * L.Wo * (double)L.K() * L.Cout});
@@ -306,13 +400,29 @@ static int forward_impl(aae_encoder* enc, const void* x, int x_dtype, int B, flo
 
     const void* cur = x;
     bool cur_u8 = (x_dtype == AAE_DTYPE_U8);
+    if (enc->precision == 1) {
+        // f32x3h: conv1 (fp32 MFMA, K = 75) emits fp16 hi/lo planes, every later layer runs the
+        // split-precision igemm on planes; only the latent z comes back as fp32.
+        for (size_t li = 0; li < enc->layers.size(); ++li) {
+            const Layer& L = enc->layers[li];
+            float* out = reinterpret_cast<float*>(base + ws.act_off[li]);
+            char name[16];
+            snprintf(name, sizeof(name), "conv%zu", li + 1);
+            int rc;
+            if (li == 0) rc = launch_first(enc, L, cur, cur_u8, B, out, true, stream, tm);
+            else rc = launch_igemm_x3h(enc, L, cur, B * L.Ho * L.Wo, out, false, partial, stream, tm, name);
+            if (rc) return rc;
+            cur = out;
+        }
+        return launch_igemm_x3h(enc, enc->dense, cur, B, z_out, true, partial, stream, tm, "dense");
+    }
     for (size_t li = 0; li < enc->layers.size(); ++li) {
         const Layer& L = enc->layers[li];
         float* out = reinterpret_cast<float*>(base + ws.act_off[li]);
         char name[16];
         snprintf(name, sizeof(name), "conv%zu", li + 1);
         int rc;
-        if (li == 0 && L.kind == KIND_FIRST_MFMA) rc = launch_first(enc, L, cur, cur_u8, B, out, stream, tm);
+        if (li == 0 && L.kind == KIND_FIRST_MFMA) rc = launch_first(enc, L, cur, cur_u8, B, out, false, stream, tm);
         else if (L.kind == KIND_IGEMM && !cur_u8)
             rc = launch_igemm(enc, L, static_cast<const float*>(cur), B * L.Ho * L.Wo, out, partial, stream, tm, name);
         else rc = launch_generic(enc, L, cur, cur_u8, B, out, stream, tm, name);
@@ -470,6 +580,8 @@ int aae_encoder_create(const aae_encoder_desc* d, const void* const* hw, int n_w
             L.kind = KIND_IGEMM;
             const std::vector<float> packed = pack_weights(k, L.KS * L.KS, L.Cin, L.Cout, L.CoutPad);
             if (int rc = upload(enc, packed.data(), packed.size(), &L.wp)) return bail(rc);
+            const std::vector<unsigned short> p16 = pack_weights_x3h(k, L.KS * L.KS, L.Cin, L.Cout, L.CoutPad, &L.w_shift);
+            if (int rc = upload(enc, reinterpret_cast<const float*>(p16.data()), p16.size() / 2, reinterpret_cast<float**>(&L.wp16))) return bail(rc);
         }
         enc->layers.push_back(L);
         H = L.Ho; W = L.Wo; C = L.Cout;
@@ -487,6 +599,8 @@ int aae_encoder_create(const aae_encoder_desc* d, const void* const* hw, int n_w
             D.kind = KIND_IGEMM;
             const std::vector<float> packed = pack_weights(k, 1, D.Cin, D.Cout, D.CoutPad);
             if (int rc = upload(enc, packed.data(), packed.size(), &D.wp)) return bail(rc);
+            const std::vector<unsigned short> p16 = pack_weights_x3h(k, 1, D.Cin, D.Cout, D.CoutPad, &D.w_shift);
+            if (int rc = upload(enc, reinterpret_cast<const float*>(p16.data()), p16.size() / 2, reinterpret_cast<float**>(&D.wp16))) return bail(rc);
         } else {
             D.kind = KIND_GENERIC;
             if (int rc = upload(enc, k, (size_t)D.K() * D.Cout, &D.w_hwio)) return bail(rc);
@@ -494,12 +608,19 @@ int aae_encoder_create(const aae_encoder_desc* d, const void* const* hw, int n_w
     }
     (void)hipFuncSetAttribute((const void*)aae::conv_igemm_f32_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
     (void)hipFuncSetAttribute((const void*)aae::conv_igemm_f32_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
+    (void)hipFuncSetAttribute((const void*)aae::conv_igemm_x3h_kernel<aae::X3H_OUT_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
+    (void)hipFuncSetAttribute((const void*)aae::conv_igemm_x3h_kernel<aae::X3H_OUT_PLANES>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
+    (void)hipFuncSetAttribute((const void*)aae::conv_igemm_x3h_kernel<aae::X3H_OUT_PARTIAL>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
     if (enc->layers[0].kind == KIND_FIRST_MFMA) {
         const int sm = enc->layers[0].first_smem;
-        (void)hipFuncSetAttribute((const void*)aae::conv_first_f32_kernel<5, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
-        (void)hipFuncSetAttribute((const void*)aae::conv_first_f32_kernel<5, 3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
-        (void)hipFuncSetAttribute((const void*)aae::conv_first_f32_kernel<5, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
-        (void)hipFuncSetAttribute((const void*)aae::conv_first_f32_kernel<5, 1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
+        (void)hipFuncSetAttribute((const void*)aae::conv_first_f32_kernel<5, 3, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
+        (void)hipFuncSetAttribute((const void*)aae::conv_first_f32_kernel<5, 3, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
+        (void)hipFuncSetAttribute((const void*)aae::conv_first_f32_kernel<5, 1, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
+        (void)hipFuncSetAttribute((const void*)aae::conv_first_f32_kernel<5, 1, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
+        (void)hipFuncSetAttribute((const void*)aae::conv_first_f32_kernel<5, 3, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
+        (void)hipFuncSetAttribute((const void*)aae::conv_first_f32_kernel<5, 3, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
+        (void)hipFuncSetAttribute((const void*)aae::conv_first_f32_kernel<5, 1, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
+        (void)hipFuncSetAttribute((const void*)aae::conv_first_f32_kernel<5, 1, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
     }
     *out = enc;
     return AAE_OK;
@@ -517,6 +638,18 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
     if (!strcmp(name, "splitk_min_base_blocks")) enc->splitk_min_base_blocks = value;
     else if (!strcmp(name, "splitk_target_blocks")) enc->splitk_target_blocks = value;
     else if (!strcmp(name, "igemm_stagger")) enc->igemm_stagger = value;
+    else if (!strcmp(name, "x3h_act_shift")) {
+        if (value < -8 || value > 12) return fail(AAE_ERR_INVALID, "x3h_act_shift %d outside [-8, 12]", value);
+        enc->x3h_act_shift = value;
+    } else if (!strcmp(name, "precision")) {
+        if (value != 0 && value != 1) return fail(AAE_ERR_INVALID, "precision %d: 0 = fp32, 1 = f32x3h", value);
+        if (value == 1) {
+            bool ok = enc->layers[0].kind == KIND_FIRST_MFMA && enc->dense.kind == KIND_IGEMM;
+            for (size_t i = 1; i < enc->layers.size(); ++i) ok = ok && enc->layers[i].kind == KIND_IGEMM;
+            if (!ok) return fail(AAE_ERR_UNSUPPORTED, "f32x3h needs the matrix-core kernels on every layer (first layer 5x5 with C in {1,3}, later Cin %% 32 == 0)");
+        }
+        enc->precision = value;
+    }
     else return fail(AAE_ERR_INVALID, "unknown encoder option '%s'", name);
     return AAE_OK;
 }

@@ -20,6 +20,22 @@ __device__ __forceinline__ f32x16 mfma_32x32x2(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
+// v_mfma_f32_32x32x16_f16: D = A(32x16) * B(16x32) + C with fp32 accumulation.
+// lane l holds 8 halves of A row l&31 / B column l&31 for k = 8*(l>>5) .. 8*(l>>5)+7.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 mfma_32x32x16_f16(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// fp32 -> (hi, lo) half pair: hi = rn16(v), lo = rn16(v - hi); hi + lo carries >= 22 bits of v.
+// |v| beyond the fp16 range saturates hi (the remainder spills into lo) instead of producing inf.
+__device__ __forceinline__ void split_f16(float v, unsigned short& hi, unsigned short& lo) {
+    const float c = fminf(fmaxf(v, -65504.f), 65504.f);
+    const _Float16 h = (_Float16)c;
+    const float r = fminf(fmaxf(v - (float)h, -65504.f), 65504.f);
+    hi = __builtin_bit_cast(unsigned short, h);
+    lo = __builtin_bit_cast(unsigned short, (_Float16)r);
+}
+
 // Raw buffer view with hardware bounds checking: a 16-B load whose byte offset is >= the
 // buffer size returns zeros.  The implicit-GEMM loader uses that for TF 'SAME' zero padding
 // (out-of-image taps get offset kOobOffset) so the im2col gather has no branches.

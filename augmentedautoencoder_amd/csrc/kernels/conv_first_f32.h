@@ -33,9 +33,12 @@ struct ConvFirstArgs {
     int total_tiles;        // B * tiles_per_image
     int tiles_per_block;
     int relu;
+    float out_scale;        // OUT_PLANES: 2^act_shift of the f32x3h activation format
 };
 
-template <int KS, int C, bool IN_U8>
+// OUT_PLANES: write the activation as two fp16 planes (hi, lo of v*out_scale) for the f32x3h
+// implicit GEMM (conv_igemm_x3h.h) instead of fp32.
+template <int KS, int C, bool IN_U8, bool OUT_PLANES>
 __global__ __launch_bounds__(256) void conv_first_f32_kernel(const ConvFirstArgs p) {
     constexpr int KROW = KS * C;
     constexpr int K = KS * KROW;
@@ -131,7 +134,16 @@ __global__ __launch_bounds__(256) void conv_first_f32_kernel(const ConvFirstArgs
                         float v = acc[mt][r] + bias;
                         if (p.relu) v = fmaxf(v, 0.f);
                         if (p.bn_scale) v = v * sc + sh;
-                        p.out[((long long)b * HoWo + px) * p.Cout + n] = v;
+                        const long long o = ((long long)b * HoWo + px) * p.Cout + n;
+                        if (OUT_PLANES) {
+                            unsigned short hi, lo;
+                            split_f16(v * p.out_scale, hi, lo);
+                            unsigned short* op = reinterpret_cast<unsigned short*>(p.out);
+                            op[o] = hi;
+                            op[(long long)p.total_tiles / p.tiles_per_image * HoWo * p.Cout + o] = lo;
+                        } else {
+                            p.out[o] = v;
+                        }
                     }
                 }
         }

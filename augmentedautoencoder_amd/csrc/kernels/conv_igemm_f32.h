@@ -220,6 +220,8 @@ struct SplitKReduceArgs {
     float* out;             // [M][Cout]
     long long MN;           // M*Cout
     int Cout, splits, relu;
+    int out_planes;         // 1: write two fp16 planes of v*out_scale (f32x3h activation format)
+    float out_scale;
 };
 
 // 512 threads = 8 split-groups x 64 consecutive outputs.  Group g sums the partials
@@ -254,7 +256,15 @@ __global__ __launch_bounds__(512) void splitk_reduce_kernel(const SplitKReduceAr
             v += p.bias[n];
             if (p.relu) v = fmaxf(v, 0.f);
             if (p.bn_scale) v = v * p.bn_scale[n] + p.bn_shift[n];
-            p.out[e] = v;
+            if (p.out_planes) {
+                unsigned short hi, lo;
+                split_f16(v * p.out_scale, hi, lo);
+                unsigned short* op = reinterpret_cast<unsigned short*>(p.out);
+                op[e] = hi;
+                op[p.MN + e] = lo;
+            } else {
+                p.out[e] = v;
+            }
         }
         __syncthreads();
     }

@@ -1,0 +1,248 @@
+// Implicit-GEMM convolution / dense layer in "f32x3h" split precision: fp32 in, fp32 out,
+// contraction on the fp16 matrix cores (v_mfma_f32_32x32x16_f16, 16x the fp32 MFMA rate)
+// with every operand carried as a (hi, lo) pair of halves and fp32 accumulation:
+//
+//     a*b  ~=  a_hi*b_hi + a_hi*b_lo + a_lo*b_hi          (a_lo*b_lo ~ 2^-22 relative, dropped)
+//
+// hi = rn16(x*2^s), lo = rn16(x*2^s - hi): the pair carries >= 22 significant bits, so the
+// result stays inside the fp32-roundoff class the 1e-5 cosine tolerance asks for (measured
+// against the fp64 oracle in tests/), at 16/3 = 5.3x the fp32 matrix-core peak.  This is an
+// explicitly selected mode (encoder option "precision" = 1); the default path is exact fp32.
+//
+// Same layer semantics as conv_igemm_f32.h (/root/reference/auto_pose/ae/encoder.py:41-52,62-66).
+// Differences in data layout:
+//   * activations travel between layers as two fp16 planes [M][C] (hi plane, then lo plane,
+//     same bytes as fp32) of x * 2^act_shift, written by the producer's epilogue -- the
+//     consumer's operand loads are straight 16-B copies, no conversion in the K loop;
+//   * weights are split on the host after scaling by 2^w_shift and packed per K-slab as
+//     [8 slots][CoutPad][8 halves], slot = plane*4 + kgroup8.
+//   * LDS slab images: A [128 rows][8 slots x 16 B] (hi slots 0-3, lo slots 4-7, XOR swizzle as
+//     the fp32 kernel), B [8 slots][128 cols][16 B].
+// K-slab = 32 channels of one tap = two MFMA k16-steps; per wave and slab 24 MFMAs.
+// Register staging runs two slabs ahead of the LDS ring (global latency ~2 slabs of MFMA time).
+#pragma once
+
+#include <type_traits>
+
+namespace aae {
+
+struct ConvIgemmX3hArgs {
+    const unsigned short* x;  // activation planes: hi [Min][Cin], lo [Min][Cin] (halves of x*2^act_shift)
+    unsigned x_bytes;         // both planes
+    unsigned plane_bytes;     // one plane = Min*Cin*2
+    const unsigned* wp;       // [slabs][8][CoutPad][4 dwords]
+    const float* bias;
+    const float* bn_scale;
+    const float* bn_shift;
+    void* out;                // OUT_PLANES: two half planes [M][Cout]; OUT_F32: float [M][Cout]; split-K: float partials
+    int H, W, Cin, Ho, Wo, Cout, CoutPad;
+    int KS, S, pt, pl;
+    int M;
+    int slabs_total, slabs_per_split;
+    int num_mt, num_nt, splits;
+    int relu;
+    float inv_scale;          // 2^-(act_shift_in + w_shift)
+    float out_scale;          // 2^act_shift_out (OUT_PLANES)
+};
+
+enum { X3H_OUT_F32 = 0, X3H_OUT_PLANES = 1, X3H_OUT_PARTIAL = 2 };
+
+struct X3hFrag {              // one k16-step of a 64x64 wave tile
+    u32x4 ah[2], al[2], bh[2], bl[2];
+};
+
+__device__ __forceinline__ void x3h_frag_load(const float* As, const float* Bs, int a_row0, int b_col0, int lane, int s,
+                                              X3hFrag& f) {
+    const int i = lane & 31, slot = 2 * s + (lane >> 5);
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi) {
+        f.ah[mi] = __builtin_bit_cast(u32x4, lds_read4(As + a_slab_off(a_row0 + 32 * mi + i, slot)));
+        f.al[mi] = __builtin_bit_cast(u32x4, lds_read4(As + a_slab_off(a_row0 + 32 * mi + i, 4 + slot)));
+    }
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        f.bh[ni] = __builtin_bit_cast(u32x4, lds_read4(Bs + (slot * 128 + b_col0 + 32 * ni + i) * 4));
+        f.bl[ni] = __builtin_bit_cast(u32x4, lds_read4(Bs + ((4 + slot) * 128 + b_col0 + 32 * ni + i) * 4));
+    }
+}
+
+// the three products of one 32x32 tile (q = 2*mi + ni)
+__device__ __forceinline__ void x3h_mfma_tile(const X3hFrag& f, int q, f32x16 (&acc)[2][2]) {
+    const int mi = q >> 1, ni = q & 1;
+    acc[mi][ni] = mfma_32x32x16_f16(f.al[mi], f.bh[ni], acc[mi][ni]);
+    acc[mi][ni] = mfma_32x32x16_f16(f.ah[mi], f.bl[ni], acc[mi][ni]);
+    acc[mi][ni] = mfma_32x32x16_f16(f.ah[mi], f.bh[ni], acc[mi][ni]);
+}
+
+template <int OUT>
+__global__ __launch_bounds__(256) void conv_igemm_x3h_kernel(const ConvIgemmX3hArgs p) {
+    AAE_DYN_SMEM(smem_raw);
+    float* As = reinterpret_cast<float*>(smem_raw);            // [2][128 rows][32 dwords]
+    float* Bs = As + 2 * kSlabFloatsA;                         // [2][8 slots][128 cols][4 dwords]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int nblk = p.num_mt * p.num_nt * p.splits;
+    const int L = xcd_remap(blockIdx.x, nblk);
+    const int nt = L % p.num_nt;
+    const int mt = (L / p.num_nt) % p.num_mt;
+    const int split = L / (p.num_nt * p.num_mt);
+    const int slab0 = split * p.slabs_per_split;
+    const int slab1 = min(slab0 + p.slabs_per_split, p.slabs_total);
+    const int nslab = slab1 - slab0;
+
+    // ---- A loader: thread -> 4 (row, chunk) pairs; chunk = plane*4 + kgroup8 = LDS slot --------
+    const int a_slot = tid & 7;
+    const int a_row = tid >> 3;
+    const buffer_rsrc xbuf = make_buffer(p.x, p.x_bytes);
+    unsigned a_off[4];
+    int a_ih0[4], a_iw0[4];
+    bool a_ok[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int m = mt * kBM + a_row + 32 * q;
+        a_ok[q] = m < p.M;
+        const int mm = a_ok[q] ? m : 0;
+        const int b = mm / (p.Ho * p.Wo);
+        const int rem = mm - b * (p.Ho * p.Wo);
+        const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+        a_ih0[q] = oh * p.S - p.pt;
+        a_iw0[q] = ow * p.S - p.pl;
+        a_off[q] = (unsigned)((((long long)b * p.H + a_ih0[q]) * p.W + a_iw0[q]) * (long long)p.Cin * 2) +
+                   (unsigned)(a_slot & 3) * 16u + (unsigned)(a_slot >> 2) * p.plane_bytes;
+    }
+    // ---- B loader: idx = tid + 256*q -> slot = idx>>7, col = idx&127 ------------------------------
+    const unsigned* b_ptr = p.wp + ((long long)nt * 128 + (tid & 127)) * 4 + (long long)(tid >> 7) * p.CoutPad * 4;
+    const long long b_slot_stride = (long long)p.CoutPad * 4;      // dwords per slot row
+
+    const int taps = p.KS * p.KS;
+    int cc = slab0 / taps;
+    const int tap0 = slab0 - cc * taps;
+    int kh = tap0 / p.KS, kw = tap0 - kh * p.KS;
+
+    u32x4 ra[2][4], rb[2][4];
+    unsigned tap_off = 0;
+    auto fetch_piece = [&](auto PAR, int slab, int q) {
+        constexpr int P = decltype(PAR)::value;
+        if (q == 0) tap_off = (unsigned)(((kh * p.W + kw) * p.Cin + cc * 32) * 2);
+        const bool ok = a_ok[q] && (unsigned)(a_ih0[q] + kh) < (unsigned)p.H && (unsigned)(a_iw0[q] + kw) < (unsigned)p.W;
+        ra[P][q] = __builtin_bit_cast(u32x4, buffer_load4(xbuf, ok ? a_off[q] + tap_off : kOobOffset));
+        rb[P][q] = *reinterpret_cast<const u32x4*>(b_ptr + ((long long)slab * 8 + 2 * q) * b_slot_stride);
+        if (q == 3) {
+            if (++kw == p.KS) { kw = 0; if (++kh == p.KS) { kh = 0; ++cc; } }
+        }
+    };
+    auto stash_piece = [&](auto PAR, int buf, int q) {
+        constexpr int P = decltype(PAR)::value;
+        lds_write4(As + buf * kSlabFloatsA + a_slab_off(a_row + 32 * q, a_slot), __builtin_bit_cast(f32x4, ra[P][q]));
+        lds_write4(Bs + buf * (8 * 128 * 4) + (tid + 256 * q) * 4, __builtin_bit_cast(f32x4, rb[P][q]));
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    if (nslab > 0) {
+        using P0 = std::integral_constant<int, 0>;
+        using P1 = std::integral_constant<int, 1>;
+        // prologue: slab 0 -> R[0] -> LDS buffer 0; slab 1 -> R[1] (stays in registers)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) fetch_piece(P0{}, slab0, q);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) stash_piece(P0{}, 0, q);
+        if (nslab > 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) fetch_piece(P1{}, slab0 + 1, q);
+        }
+        __syncthreads();
+        X3hFrag f0, f1;
+        x3h_frag_load(As, Bs, wm * 64, wn * 64, lane, 0, f0);
+        x3h_frag_load(As, Bs, wm * 64, wn * 64, lane, 1, f1);
+
+        // iteration `it` (slab it, LDS buffer it&1), P = it&1:
+        //   step 0 (12 MFMAs): issue the global loads of slab it+2 into R[P], one piece per tile
+        //   step 1 tiles 0,1 : store slab it+1 from R[P^1] (fetched last iteration) into buffer (it+1)&1
+        //   barrier; f0 <- (slab it+1, step 0); step 1 tiles 2,3 cover that read; f1 <- (it+1, step 1)
+        auto iteration = [&](auto PAR, int it) {
+            constexpr int P = decltype(PAR)::value;
+            using Pc = std::integral_constant<int, P>;
+            using Pn = std::integral_constant<int, P ^ 1>;
+            const bool has1 = it + 1 < nslab, has2 = it + 2 < nslab;
+            const float* An = As + (P ^ 1) * kSlabFloatsA;
+            const float* Btn = Bs + (P ^ 1) * (8 * 128 * 4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                sched_fence();
+                x3h_mfma_tile(f0, q, acc);
+                sched_fence();
+                if (has2) fetch_piece(Pc{}, slab0 + it + 2, q);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                sched_fence();
+                x3h_mfma_tile(f1, q, acc);
+                sched_fence();
+                if (has1) { stash_piece(Pn{}, P ^ 1, 2 * q); stash_piece(Pn{}, P ^ 1, 2 * q + 1); }
+            }
+            __syncthreads();
+            sched_fence();
+            if (has1) x3h_frag_load(An, Btn, wm * 64, wn * 64, lane, 0, f0);
+            sched_fence();
+            x3h_mfma_tile(f1, 2, acc);
+            x3h_mfma_tile(f1, 3, acc);
+            sched_fence();
+            if (has1) x3h_frag_load(An, Btn, wm * 64, wn * 64, lane, 1, f1);
+        };
+        int it = 0;
+        for (; it + 1 < nslab; it += 2) {
+            iteration(P0{}, it);
+            iteration(P1{}, it + 1);
+        }
+        if (it < nslab) iteration(P0{}, it);
+    }
+
+    // ---- epilogue -----------------------------------------------------------------------------
+    const int i = lane & 31;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int n = nt * 128 + wn * 64 + ni * 32 + i;
+        if (n >= p.Cout) continue;
+        float bias = 0.f, sc = 1.f, sh = 0.f;
+        if (OUT != X3H_OUT_PARTIAL) {
+            bias = p.bias[n];
+            if (p.bn_scale) { sc = p.bn_scale[n]; sh = p.bn_shift[n]; }
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mt * kBM + wm * 64 + mi * 32 + acc_row(r, lane);
+                if (m >= p.M) continue;
+                float v = acc[mi][ni][r] * p.inv_scale;
+                if (OUT == X3H_OUT_PARTIAL) {
+                    reinterpret_cast<float*>(p.out)[((long long)split * p.M + m) * p.Cout + n] = v;
+                } else {
+                    v += bias;
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (p.bn_scale) v = v * sc + sh;
+                    if (OUT == X3H_OUT_F32) {
+                        reinterpret_cast<float*>(p.out)[(long long)m * p.Cout + n] = v;
+                    } else {
+                        unsigned short hi, lo;
+                        split_f16(v * p.out_scale, hi, lo);
+                        unsigned short* o = reinterpret_cast<unsigned short*>(p.out);
+                        o[(long long)m * p.Cout + n] = hi;
+                        o[(long long)p.M * p.Cout + (long long)m * p.Cout + n] = lo;
+                    }
+                }
+            }
+        }
+    }
+}
+
+}  // namespace aae

@@ -61,6 +61,7 @@ class EncoderEngine(object):
         self.handle = handle
         self.ws = _Workspace(self.device)
         self._last_B = None
+        self.options = {}
 
     def close(self):
         if getattr(self, 'handle', None):
@@ -74,7 +75,11 @@ class EncoderEngine(object):
             pass
 
     def set_option(self, name, value):
+        """Launch-planning / precision knobs of aae_encoder_set_option, e.g.
+        ('precision', 1) selects the f32x3h split-precision matrix-core path
+        (fp32 in/out, 3 fp16 MFMAs per product, fp32 accumulate); default 0 = exact fp32."""
         _lib.check(self.lib, self.lib.aae_encoder_set_option(self.handle, name.encode(), int(value)), 'aae_encoder_set_option')
+        self.options[name] = int(value)
 
     # ---- input handling: codebook.py:58-61 --------------------------------
     def to_device_batch(self, x):
@@ -152,7 +157,12 @@ class EncoderEngine(object):
         buf, ws_ptr = self.ws.get(0)
         start = ws_ptr - buf.data_ptr() + off.value
         _, _, _, Ho, Wo, Co = self.cfg.layer_shapes()[layer]
-        return buf[start:start + 4 * cnt.value].view(torch.float32).reshape(self._last_B, Ho, Wo, Co).clone()
+        raw = buf[start:start + 4 * cnt.value]
+        if self.options.get('precision', 0) == 1:
+            # f32x3h keeps activations as two fp16 planes (hi, lo) of value * 2^shift
+            planes = raw.view(torch.float16).reshape(2, self._last_B, Ho, Wo, Co).to(torch.float64)
+            return ((planes[0] + planes[1]) / 2.0 ** self.options.get('x3h_act_shift', 4)).to(torch.float32)
+        return raw.view(torch.float32).reshape(self._last_B, Ho, Wo, Co).clone()
 
 
 class CodebookEngine(object):

@@ -25,6 +25,7 @@ if ROOT not in sys.path:
 BATCH = 256
 N_ROWS = 92232
 PEAK_F32_TFLOPS = 157.3      # MI355X fp32 matrix peak (MI355X_MICROARCH.md)
+PEAK_X3H_TFLOPS = 2500.0 / 3  # f32x3h: dense fp16 MFMA peak / 3 products per fp32-equivalent FMA
 PEAK_HBM_GBPS = 8000.0       # HBM3E spec
 
 
@@ -62,6 +63,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=BATCH)
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--precision', choices=['f32', 'f32x3h'], default='f32',
+                    help='f32 (default, exact fp32 MFMA) or f32x3h (split-precision: 3 fp16 MFMAs per product, fp32 accumulate)')
     ap.add_argument('--profile-steps', type=int, default=5, help='instrumented per-kernel timing passes after the timed region')
     args = ap.parse_args()
 
@@ -89,6 +92,8 @@ def main():
     E = synth.make_codebook(N_ROWS, 128, seed=7 + rank)       # ... and its own codebook
     crops = synth.make_crops(B, seed=1234 + rank)
     enc = EncoderEngine(cfg, weights, device=dev, max_batch=B)
+    if args.precision == 'f32x3h':
+        enc.set_option('precision', 1)
     cb = CodebookEngine(E, device=dev)
     x = torch.from_numpy(crops).to(dev)                       # inputs resident in HBM before the timed region
     packed = torch.empty((B, 2), dtype=torch.int64, device=dev)
@@ -152,6 +157,13 @@ def main():
     dom = max(kernels, key=lambda k: k['ms'])
     dom_flops = per[dom['kernel']][1]
     achieved = dom_flops / (dom['ms'] * 1e-3) / 1e12
+    peak = PEAK_F32_TFLOPS if args.precision == 'f32' else PEAK_X3H_TFLOPS
+    traffic = None
+    try:      # HBM-side bytes per launch from the committed rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE)
+        with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
+            traffic = json.load(f).get(args.precision, {}).get(dom['kernel'].split(':')[0])
+    except Exception:
+        traffic = None
 
     if rank == 0:
         out = {
@@ -161,13 +173,14 @@ def main():
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': round(elapsed / args.steps * 1e3, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
+            'dtype': 'f32' if args.precision == 'f32' else 'f32 in/out, 3xfp16-split MFMA with fp32 accumulate (f32x3h)',
+            'data': 'synthetic',
             'config': {'workload': 'configs[1]: single object per GPU, batch=%d uint8 128x128x3 crops, HIP 4-conv encoder -> 128-d + '
                                    'cosine-NN vs %dx128 fp32 codebook, top-1' % (B, N_ROWS),
                        'batch_per_gpu': B, 'codebook_rows': N_ROWS, 'latent': 128,
                        'parallelism': 'objects sharded 1 per GPU; all_gather of (idx, score) only' if world > 1 else 'single GPU'},
-            'roofline': {'bound': 'mfma', 'kernel': dom['kernel'], 'achieved': round(achieved, 2), 'peak': PEAK_F32_TFLOPS,
-                         'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_TFLOPS, 4), 'traffic': None,
+            'roofline': {'bound': 'mfma', 'kernel': dom['kernel'], 'achieved': round(achieved, 2), 'peak': round(peak, 1),
+                         'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4), 'traffic': traffic,
                          'flops_per_launch': dom_flops, 'avg_ms': dom['ms']},
             'encoder_tflops': round(cfg.flops_per_crop() * B / (sum(k['ms'] for k in kernels) * 1e-3) / 1e12, 2),
             'kernels': kernels,

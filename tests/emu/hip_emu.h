@@ -87,6 +87,36 @@ inline f32x16 mfma_32x32x2(float a, float b, f32x16 c) {
     return d;
 }
 
+// v_mfma_f32_32x32x16_f16 model: fp32 fma chain over k (the hardware's internal order is
+// not specified; tests compare against the fp64 oracle with a tolerance, never bitwise).
+inline f32x16 mfma_32x32x16_f16(u32x4 a, u32x4 b, f32x16 c) {
+    struct { u32x4 a, b; } mine = {a, b};
+    const aae_emu::lane_slot* all = aae_emu::wave_exchange(&mine, sizeof(mine));
+    const int lane = lane_id();
+    const int col = lane & 31, hi = lane >> 5;
+    f32x16 d = c;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float acc = d[r];
+        for (int k = 0; k < 16; ++k) {
+            _Float16 av, bv;
+            memcpy(&av, &all[row + 32 * (k >> 3)][2 * (k & 7)], 2);         // A[row][k]: lane row+32*(k/8), half k%8
+            memcpy(&bv, &all[col + 32 * (k >> 3)][16 + 2 * (k & 7)], 2);    // B[k][col]
+            acc = fmaf((float)av, (float)bv, acc);
+        }
+        d[r] = acc;
+    }
+    return d;
+}
+inline void split_f16(float v, unsigned short& hi, unsigned short& lo) {
+    const float c = fminf(fmaxf(v, -65504.f), 65504.f);
+    const _Float16 h = (_Float16)c;
+    const float r = fminf(fmaxf(v - (float)h, -65504.f), 65504.f);
+    const _Float16 l = (_Float16)r;
+    memcpy(&hi, &h, 2);
+    memcpy(&lo, &l, 2);
+}
+
 template <typename T>
 inline T shfl_xor(T v, int mask) {
     static_assert(sizeof(T) == 4, "32-bit shuffles only");

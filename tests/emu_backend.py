@@ -39,9 +39,11 @@ class EmuEncoder(object):
         _lib.check(self.L, rc, 'aae_encoder_create')
         self.h = h
         self.ws = None
+        self.options = {}
 
     def set_option(self, name, value):
         _lib.check(self.L, self.L.aae_encoder_set_option(self.h, name.encode(), int(value)), 'set_option')
+        self.options[name] = int(value)
 
     def forward(self, x):
         x = np.ascontiguousarray(x)
@@ -61,7 +63,11 @@ class EmuEncoder(object):
         off, cnt = ctypes.c_size_t(), ctypes.c_size_t()
         _lib.check(self.L, self.L.aae_encoder_activation_info(self.h, self.B, layer, ctypes.byref(off), ctypes.byref(cnt)), 'info')
         H, W, Ci, Ho, Wo, Co = self.cfg.layer_shapes()[layer]
-        return self.ws[off.value:off.value + 4 * cnt.value].view(np.float32).reshape(self.B, Ho, Wo, Co).copy()
+        raw = self.ws[off.value:off.value + 4 * cnt.value]
+        if self.options.get('precision', 0) == 1:      # f32x3h: two fp16 planes of value * 2^shift
+            planes = raw.view(np.float16).reshape(2, self.B, Ho, Wo, Co).astype(np.float64)
+            return ((planes[0] + planes[1]) / 2.0 ** self.options.get('x3h_act_shift', 4)).astype(np.float32)
+        return raw.view(np.float32).reshape(self.B, Ho, Wo, Co).copy()
 
     def labels(self):
         out, i = [], 0

@@ -98,3 +98,32 @@ def test_small_latent_and_l2_normalize():
         assert idx[4, 0] == 0 and score[4, 0] == 0.0
     assert np.abs(eb.l2_normalize(z) - ref.l2_normalize(z)).max() < 1e-7
     cb.close()
+
+
+@pytest.mark.parametrize('cfg,B,nosplit', [
+    (EncoderConfig((16, 16, 3), [32, 64], [2, 2], 5, 128), 3, False),
+    (EncoderConfig((16, 16, 3), [32, 64], [2, 2], 5, 128, True), 2, True),
+    (EncoderConfig((12, 12, 1), [160, 32], [1, 2], 5, 128), 1, False),
+])
+def test_split_precision_f32x3h_path(cfg, B, nosplit):
+    """f32x3h (3 fp16 MFMAs per product on (hi, lo) operand pairs, fp32 accumulate): same
+    fp32-roundoff error class as the exact fp32 path, measured against the fp64 oracle."""
+    w = synth.make_weights(seed=5, shape=cfg.shape, num_filter=cfg.num_filter, strides=cfg.strides,
+                           latent=cfg.latent_space_size, batch_norm=cfg.batch_norm)
+    x = synth.make_crops(B, seed=6, shape=cfg.shape)
+    enc = eb.EmuEncoder(w, cfg)
+    enc.set_option('precision', 1)
+    if nosplit:
+        enc.set_option('splitk_min_base_blocks', 0)
+    z = enc.forward(x)
+    assert any('x3h' in l for l in enc.labels())
+    z64, acts = ref.encoder_forward_np(ref.input_to_float(x), w, cfg.strides, cfg.batch_norm, return_activations=True)
+    for i, a in enumerate(acts):
+        assert np.abs(enc.activation(i) - a).max() / np.abs(a).max() < 5e-6, 'layer %d' % i
+    assert np.abs(z - z64).max() / np.abs(z64).max() < 5e-6
+    enc.close()
+    gen = eb.EmuEncoder(synth.make_weights(seed=1, shape=(10, 14, 3), num_filter=[24, 8], strides=[2, 1], kernel_size=3, latent=12),
+                        EncoderConfig((10, 14, 3), [24, 8], [2, 1], 3, 12))
+    with pytest.raises(ValueError, match='f32x3h'):
+        gen.set_option('precision', 1)                     # needs the matrix-core kernels on every layer
+    gen.close()

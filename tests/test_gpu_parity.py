@@ -233,3 +233,37 @@ def test_update_embedding_rebuilds_codebook():
     idcs = cb.nearest_rotation(None, batch[rows], return_idcs=True)
     for got, want_row in zip(idcs, rows):
         assert got == want_row or abs(int(got) - int(want_row)) == 35
+
+
+def test_split_precision_f32x3h_mode_meets_the_same_tolerances():
+    """Opt-in f32x3h mode (fp16 hi/lo operand pairs, 3 MFMAs per product, fp32 accumulate):
+    same acceptance as the fp32 path -- cosine within 1e-5, indices tie-aware equal."""
+    from augmentedautoencoder_amd.engine import CodebookEngine, EncoderEngine
+    from augmentedautoencoder_amd.weights import EncoderConfig
+    weights = synth.make_weights(seed=2024)
+    E = synth.make_codebook(92232, 128, seed=7, planted_duplicates=64)
+    enc = EncoderEngine(EncoderConfig(), weights)
+    enc.set_option('precision', 1)
+    cb = CodebookEngine(E)
+    for B in (1, 5, 32):
+        crops = synth.make_crops(B, seed=300 + B)
+        z = enc.encode(crops)
+        z64, acts = ref.encoder_forward_torch(ref.input_to_float(crops), weights, STRIDES, False, 'float64', return_activations=True)
+        if B == 5:
+            for i, a in enumerate(acts):
+                g = enc.activation(i).cpu().numpy()
+                assert np.abs(g - a).max() / np.abs(a).max() < 2e-5, 'layer %d' % i
+        assert np.abs(z.cpu().numpy() - z64).max() / np.abs(z64).max() < 2e-5
+        cs64 = ref.cos_similarity(z64, E)
+        cs = cb.similarity(z).cpu().numpy()
+        assert np.abs(cs - cs64).max() <= COS_TOL
+        idx, _ = cb.nn(z, 1, 1)
+        _check_indices(idx[:, 0].cpu().numpy(), cs64)
+    crops = synth.make_crops(256, seed=77)
+    z_a = enc.encode(crops).cpu().numpy()
+    z_b = enc.encode(crops).cpu().numpy()
+    assert np.array_equal(z_a, z_b)                       # deterministic
+    enc.set_option('precision', 0)
+    z_f32 = enc.encode(crops).cpu().numpy()
+    assert np.abs(z_a - z_f32).max() / np.abs(z_f32).max() < 1e-5
+    enc.close()
