@@ -13,6 +13,7 @@ from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int
 AAE_OK = 0
 AAE_DTYPE_U8 = 0
 AAE_DTYPE_F32 = 1
+AAE_DTYPE_BF16 = 2
 AAE_MAX_LAYERS = 8
 AAE_SCAN_AUTO, AAE_SCAN_GEMV, AAE_SCAN_MFMA, AAE_SCAN_STREAM = 0, 1, 2, 3
 AAE_ABI_VERSION = 1

@@ -83,7 +83,10 @@ class Codebook(object):
     def engine(self):
         if self._engine is None:
             from .engine import CodebookEngine
-            self._engine = CodebookEngine(self._embedding_host, device=self._encoder.engine.device)
+            # extension: set codebook.codebook_dtype = 'bf16' before first use to hold the rows as
+            # bfloat16 on the device (half the HBM bytes per scan; default 'f32' = reference storage)
+            self._engine = CodebookEngine(self._embedding_host, device=self._encoder.engine.device,
+                                          dtype=getattr(self, 'codebook_dtype', 'f32'))
         return self._engine
 
     # ---- fetchables ------------------------------------------------------------

@@ -23,6 +23,7 @@
 #include "kernels/conv_first_f32.h"
 #include "kernels/conv_direct_generic.h"
 #include "kernels/codebook_scan_f32.h"
+#include "kernels/codebook_scan_bf16.h"
 
 namespace aae_host {
 
@@ -99,7 +100,8 @@ struct aae_encoder {
 };
 
 struct aae_codebook {
-    float* E = nullptr;    // device [N][J]
+    float* E = nullptr;    // device [N][J] (fp32 codebook), or the bf16 rows when dtype == AAE_DTYPE_BF16
+    int dtype = AAE_DTYPE_F32;
     int N = 0, J = 0;
     int scan_mode = AAE_SCAN_AUTO;
 };
@@ -450,10 +452,14 @@ static ScanPlan plan_scan(const aae_codebook* cb, int B, int topk) {
     s.gemv = B <= 4 && cb->scan_mode == AAE_SCAN_GEMV;
     s.NT = B <= 32 ? 1 : (B <= 64 ? 2 : 4);
     s.Bpad = (int)align_up((size_t)B, (size_t)(32 * s.NT));
+    if (cb->dtype == AAE_DTYPE_BF16) {           // one kernel for every B: 64 queries per pass, 3 bf16 query terms
+        s.stream = s.gemv = false;
+        s.Bpad = (int)align_up((size_t)B, (size_t)aae::kScanBf16QC);
+    }
     s.Bstride = s.Bpad;
     size_t off = 0;
     s.q_off = off;    off += align_up((size_t)B * cb->J * sizeof(float), 256);
-    s.qp_off = off;   off += align_up((size_t)(s.Jpad / 4) * s.Bpad * 4 * sizeof(float), 256);
+    s.qp_off = off;   off += align_up((size_t)s.Jpad * s.Bpad * 6, 256);   // fp32 packing: 4 B/elem; bf16: 3 terms x 2 B
     s.pval_off = off; off += align_up((size_t)s.nblk * s.Bstride * sizeof(float), 256);
     s.pidx_off = off; off += align_up((size_t)s.nblk * s.Bstride * sizeof(int), 256);
     s.cs_off = off;
@@ -485,6 +491,29 @@ static int run_scan(aae_codebook* cb, const float* z, int B, int col_stride, flo
                     unsigned char* base, hipStream_t stream) {
     float* q = reinterpret_cast<float*>(base + s.q_off);
     float* qp = reinterpret_cast<float*>(base + s.qp_off);
+    if (cb->dtype == AAE_DTYPE_BF16) {
+        aae::L2NormBf16Args n;
+        n.z = z; n.qp3 = reinterpret_cast<unsigned short*>(qp); n.B = B; n.J = cb->J; n.Jpad = 128; n.Bpad = s.Bpad;
+        AAE_LAUNCH((aae::l2norm_pack_bf16x3_kernel), dim3(ceil_div(s.Bpad, 4)), dim3(256), 0, stream, n);
+        AAE_HIP_TRY(hipGetLastError());
+        aae::ScanBf16Args a;
+        a.E = reinterpret_cast<const unsigned short*>(cb->E);
+        a.e_bytes = (unsigned)((size_t)cb->N * cb->J * 2);
+        a.qp3 = n.qp3;
+        a.pval = reinterpret_cast<float*>(base + s.pval_off);
+        a.pidx = reinterpret_cast<int*>(base + s.pidx_off);
+        a.cs = cs_out;
+        a.N = cb->N; a.B = B; a.Bpad = s.Bpad; a.Bstride = s.Bstride; a.col_stride = col_stride;
+        if (col_stride > 1) {
+            (void)hipFuncSetAttribute((const void*)aae::scan_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kScanBf16Smem);
+            AAE_LAUNCH((aae::scan_bf16_kernel<true>), dim3(s.nblk), dim3(256), aae::kScanBf16Smem, stream, a);
+        } else {
+            (void)hipFuncSetAttribute((const void*)aae::scan_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kScanBf16Smem);
+            AAE_LAUNCH((aae::scan_bf16_kernel<false>), dim3(s.nblk), dim3(256), aae::kScanBf16Smem, stream, a);
+        }
+        AAE_HIP_TRY(hipGetLastError());
+        return AAE_OK;
+    }
     if (!s.stream) {                     // the stream kernel normalises the queries itself
         aae::L2NormArgs n;
         n.z = z; n.q = q; n.qp = s.gemv ? nullptr : qp; n.B = B; n.J = cb->J; n.Jpad = s.Jpad; n.Bpad = s.gemv ? B : s.Bpad;
@@ -715,16 +744,19 @@ int aae_codebook_create(const void* E, int N, int J, int dtype, int src_is_devic
     using namespace aae_host;
     if (!E || !out) return fail(AAE_ERR_INVALID, "aae_codebook_create: null argument");
     if (N < 1 || J < 1) return fail(AAE_ERR_INVALID, "codebook shape [%d,%d]", N, J);
-    if (dtype != AAE_DTYPE_F32) return fail(AAE_ERR_UNSUPPORTED, "codebook dtype %d: only float32 is implemented", dtype);
+    if (dtype != AAE_DTYPE_F32 && dtype != AAE_DTYPE_BF16)
+        return fail(AAE_ERR_UNSUPPORTED, "codebook dtype %d: float32 (AAE_DTYPE_F32) and bfloat16 (AAE_DTYPE_BF16) are implemented", dtype);
     if (J % 4 != 0 || J > 128) return fail(AAE_ERR_UNSUPPORTED, "latent size %d: the scan kernels need J %% 4 == 0 and J <= 128", J);
+    if (dtype == AAE_DTYPE_BF16 && J != 128) return fail(AAE_ERR_UNSUPPORTED, "latent size %d: the bf16 scan kernel is built for J == 128", J);
     if ((unsigned long long)N * J * sizeof(float) >= 0xFFFFFFF0ull) return fail(AAE_ERR_UNSUPPORTED, "codebook of %d x %d floats exceeds the 4 GiB buffer view", N, J);
     aae_codebook* cb = new aae_codebook();
-    cb->N = N; cb->J = J;
+    cb->N = N; cb->J = J; cb->dtype = dtype;
+    const size_t bytes = (size_t)N * J * (dtype == AAE_DTYPE_BF16 ? 2 : 4);
     void* p = nullptr;
-    hipError_t e = hipMalloc(&p, (size_t)N * J * sizeof(float));
+    hipError_t e = hipMalloc(&p, bytes);
     if (e != hipSuccess) { delete cb; return fail(AAE_ERR_RUNTIME, "hipMalloc(codebook): %s", hipGetErrorString(e)); }
     cb->E = static_cast<float*>(p);
-    e = hipMemcpy(cb->E, E, (size_t)N * J * sizeof(float), src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice);
+    e = hipMemcpy(cb->E, E, bytes, src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice);
     if (e != hipSuccess) { aae_codebook_destroy(cb); return fail(AAE_ERR_RUNTIME, "hipMemcpy(codebook): %s", hipGetErrorString(e)); }
     *out = cb;
     return AAE_OK;
@@ -733,7 +765,7 @@ int aae_codebook_create(const void* E, int N, int J, int dtype, int src_is_devic
 int aae_codebook_update(aae_codebook* cb, const void* E, int src_is_device, void* stream) {
     using namespace aae_host;
     if (!cb || !E) return fail(AAE_ERR_INVALID, "aae_codebook_update: null argument");
-    AAE_HIP_TRY(hipMemcpyAsync(cb->E, E, (size_t)cb->N * cb->J * sizeof(float),
+    AAE_HIP_TRY(hipMemcpyAsync(cb->E, E, (size_t)cb->N * cb->J * (cb->dtype == AAE_DTYPE_BF16 ? 2 : 4),
                                src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
     AAE_HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
     return AAE_OK;

@@ -36,6 +36,25 @@ __device__ __forceinline__ void split_f16(float v, unsigned short& hi, unsigned 
     lo = __builtin_bit_cast(unsigned short, (_Float16)r);
 }
 
+// v_mfma_f32_32x32x16_bf16, same fragment maps as the f16 form.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ f32x16 mfma_32x32x16_bf16(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// fp32 -> three bf16 terms (round-to-nearest-even each): v = t0 + t1 + t2 to fp32 accuracy.
+__device__ __forceinline__ unsigned short bf16_rn(float v) {
+    unsigned u = __builtin_bit_cast(unsigned, v);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
+__device__ __forceinline__ void split_bf16x3(float v, unsigned short& t0, unsigned short& t1, unsigned short& t2) {
+    t0 = bf16_rn(v);
+    const float r1 = v - bf16_to_f32(t0);
+    t1 = bf16_rn(r1);
+    t2 = bf16_rn(r1 - bf16_to_f32(t1));
+}
+
 // Raw buffer view with hardware bounds checking: a 16-B load whose byte offset is >= the
 // buffer size returns zeros.  The implicit-GEMM loader uses that for TF 'SAME' zero padding
 // (out-of-image taps get offset kOobOffset) so the im2col gather has no branches.

@@ -1,0 +1,143 @@
+// Codebook scan against a bf16 codebook (BASELINE config 5: 4x rows, bf16 storage, batched
+// queries on the bf16 matrix cores).  Same contract as codebook_scan_f32.h
+// (/root/reference/auto_pose/ae/codebook.py:27,50,64-71) -- the codebook rows are bf16, the
+// cosine is still accurate to fp32 roundoff: each normalised query is carried as THREE bf16
+// terms q = t0 + t1 + t2 (24 significant bits) and every 32x32x16 tile takes three
+// v_mfma_f32_32x32x16_bf16 with fp32 accumulation; the bf16 rows are used exactly as stored.
+//
+// Block = 128 codebook rows (32 KB, staged once in LDS with coalesced 16-B loads, XOR
+// swizzled so the fragment reads are conflict-free) x passes of 64 queries; the running
+// (max, first row) reduction and the partial-result format are those of the fp32 scan.
+#pragma once
+
+namespace aae {
+
+struct L2NormBf16Args {
+    const float* z;          // [B][J]
+    unsigned short* qp3;     // [3 terms][Jpad/8 slots][Bpad][8] bf16
+    int B, J, Jpad, Bpad;
+};
+
+// one wave per query row b < Bpad (rows >= B are written as zeros)
+__global__ __launch_bounds__(256) void l2norm_pack_bf16x3_kernel(const L2NormBf16Args p) {
+    const int lane = threadIdx.x & 63;
+    const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (b >= p.Bpad) return;
+    const bool real = b < p.B;
+    float ss = 0.f;
+    if (real)
+        for (int j = lane; j < p.J; j += 64) { const float v = p.z[(long long)b * p.J + j]; ss = fmaf(v, v, ss); }
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) ss += shfl_xor(ss, m);
+    const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
+    const long long plane = (long long)(p.Jpad / 8) * p.Bpad * 8;
+    for (int j = lane; j < p.Jpad; j += 64) {
+        const float v = (real && j < p.J) ? p.z[(long long)b * p.J + j] * inv : 0.f;
+        unsigned short t0, t1, t2;
+        split_bf16x3(v, t0, t1, t2);
+        const long long o = ((long long)(j >> 3) * p.Bpad + b) * 8 + (j & 7);
+        p.qp3[o] = t0;
+        p.qp3[plane + o] = t1;
+        p.qp3[2 * plane + o] = t2;
+    }
+}
+
+struct ScanBf16Args {
+    const unsigned short* E;   // [N][J] bf16 row-major, J == 128
+    unsigned e_bytes;
+    const unsigned short* qp3; // [3][16][Bpad][8]
+    float* pval;
+    int* pidx;
+    float* cs;                 // optional [B][N]
+    int N, B, Bpad, Bstride;
+    int col_stride;
+};
+
+constexpr int kScanBf16QC = 64;                                   // queries per pass
+constexpr int kScanBf16Smem = 128 * 256 + 3 * 16 * kScanBf16QC * 16 + 2 * 4 * kScanBf16QC * 4;
+
+__device__ __forceinline__ int e16_tile_off(int row, int slot) { return row * 64 + ((slot ^ (row & 15)) << 2); }   // dwords
+
+template <bool UPRIGHT>
+__global__ __launch_bounds__(256) void scan_bf16_kernel(const ScanBf16Args p) {
+    constexpr int QC = kScanBf16QC;
+    AAE_DYN_SMEM(smem_raw);
+    float* Et = reinterpret_cast<float*>(smem_raw);                // [128 rows][16 slots x 16 B]
+    float* Qt = Et + 128 * 64;                                     // [3][16 slots][QC][16 B]
+    float* red_v = Qt + 3 * 16 * QC * 4;                           // [4][QC]
+    int* red_i = reinterpret_cast<int*>(red_v + 4 * QC);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int row0 = blockIdx.x * 128;
+
+    const buffer_rsrc ebuf = make_buffer(p.E, p.e_bytes);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {                                  // 128 rows x 16 slots = 2048 16-B pieces
+        const int idx = tid + 256 * u;
+        const int r = idx >> 4, slot = idx & 15;
+        const int row = row0 + r;
+        const f32x4 v = buffer_load4(ebuf, row < p.N ? (unsigned)(row * 256 + slot * 16) : kOobOffset);
+        lds_write4(Et + e16_tile_off(r, slot), v);
+    }
+    const long long qplane = (long long)16 * p.Bpad * 8;           // halves per term plane
+    for (int qt = 0; qt < p.Bpad; qt += QC) {
+        __syncthreads();
+        for (int idx = tid; idx < 3 * 16 * QC; idx += 256) {
+            const int term = idx / (16 * QC), rem = idx - term * (16 * QC);
+            const int slot = rem / QC, c = rem - slot * QC;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p.qp3 + term * qplane + ((long long)slot * p.Bpad + qt + c) * 8);
+            lds_write4(Qt + idx * 4, v);
+        }
+        __syncthreads();
+
+        f32x16 acc[2];
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[ni][r] = 0.f;
+#pragma unroll 2
+        for (int s = 0; s < 8; ++s) {
+            const int slot = 2 * s + h;
+            const u32x4 a = __builtin_bit_cast(u32x4, lds_read4(Et + e16_tile_off(wave * 32 + i, slot)));
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+                for (int term = 2; term >= 0; --term) {            // smallest term first
+                    const u32x4 b = __builtin_bit_cast(u32x4, lds_read4(Qt + ((term * 16 + slot) * QC + ni * 32 + i) * 4));
+                    acc[ni] = mfma_32x32x16_bf16(a, b, acc[ni]);
+                }
+            }
+        }
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            const int query = qt + ni * 32 + i;
+            float bv = kNegInf;
+            int bi = row0 + wave * 32 + acc_row(0, lane);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = row0 + wave * 32 + acc_row(r, lane);
+                const float v = acc[ni][r];
+                bool cand = row < p.N;
+                if (UPRIGHT) cand = cand && (row % p.col_stride == 0);
+                if (p.cs && row < p.N && query < p.B) p.cs[(long long)query * p.N + row] = v;
+                if (cand && v > bv) { bv = v; bi = row; }
+            }
+            const float ov = shfl_xor(bv, 32);
+            const int oi = shfl_xor(bi, 32);
+            if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+            if (h == 0) { red_v[wave * QC + ni * 32 + i] = bv; red_i[wave * QC + ni * 32 + i] = bi; }
+        }
+        __syncthreads();
+        if (tid < QC && qt + tid < p.B) {
+            float v = red_v[tid];
+            int ix = red_i[tid];
+            for (int w = 1; w < 4; ++w)
+                if (better(red_v[w * QC + tid], red_i[w * QC + tid], v, ix)) { v = red_v[w * QC + tid]; ix = red_i[w * QC + tid]; }
+            p.pval[(long long)blockIdx.x * p.Bstride + qt + tid] = v;
+            p.pidx[(long long)blockIdx.x * p.Bstride + qt + tid] = ix;
+        }
+    }
+}
+
+}  // namespace aae

@@ -169,13 +169,25 @@ class CodebookEngine(object):
     """Owns one aae_codebook handle: the device-resident embedding_normalized
     variable (codebook.py:28-36) and the fused normalise + scan + arg-max."""
 
-    def __init__(self, embedding_normalized, device=None):
+    def __init__(self, embedding_normalized, device=None, dtype='f32'):
+        """dtype 'f32' (reference storage) or 'bf16' (half the bytes per row: the float32
+        codebook is rounded to bfloat16 once, queries keep fp32 accuracy -- see
+        csrc/kernels/codebook_scan_bf16.h)."""
         torch = _torch()
         self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
         self.lib = _lib.load()
+        self.dtype = dtype
         handle = ctypes.c_void_p()
         with torch.cuda.device(self.device):
-            if torch.is_tensor(embedding_normalized):
+            if dtype == 'bf16':
+                from .weights import to_bf16_bits
+                src = embedding_normalized.cpu().numpy() if torch.is_tensor(embedding_normalized) else embedding_normalized
+                E = to_bf16_bits(src)
+                self.N, self.J = int(E.shape[0]), int(E.shape[1])
+                rc = self.lib.aae_codebook_create(E.ctypes.data, self.N, self.J, _lib.AAE_DTYPE_BF16, 0, ctypes.byref(handle))
+            elif dtype != 'f32':
+                raise ValueError("codebook dtype must be 'f32' or 'bf16', got %r" % (dtype,))
+            elif torch.is_tensor(embedding_normalized):
                 E = embedding_normalized.to(self.device, torch.float32).contiguous()
                 self.N, self.J = int(E.shape[0]), int(E.shape[1])
                 torch.cuda.synchronize(self.device)
@@ -207,6 +219,9 @@ class CodebookEngine(object):
         E = np.ascontiguousarray(np.asarray(embedding_normalized, dtype=np.float32))
         if E.shape != (self.N, self.J):
             raise ValueError('embedding has shape %s, codebook is [%d,%d]' % (E.shape, self.N, self.J))
+        if self.dtype == 'bf16':
+            from .weights import to_bf16_bits
+            E = to_bf16_bits(E)
         with torch.cuda.device(self.device):
             rc = self.lib.aae_codebook_update(self.handle, E.ctypes.data, 0, _stream_ptr(torch))
         _lib.check(self.lib, rc, 'aae_codebook_update')

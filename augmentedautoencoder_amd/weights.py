@@ -147,6 +147,18 @@ def save_npz(path, weights, embedding_normalized=None, embed_obj_bbs=None):
     np.savez(path, **blob)
 
 
+def to_bf16_bits(a):
+    """float32 array -> uint16 bfloat16 bit patterns, round-to-nearest-even (the storage
+    format of a bf16 codebook, BASELINE config 5)."""
+    u = np.ascontiguousarray(np.asarray(a, dtype=np.float32)).view(np.uint32)
+    r = u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))
+    return (r >> np.uint32(16)).astype(np.uint16)
+
+
+def bf16_bits_to_f32(b):
+    return (np.asarray(b, dtype=np.uint16).astype(np.uint32) << np.uint32(16)).view(np.float32)
+
+
 def load_npz(path):
     """Returns (weights dict, embedding_normalized or None, embed_obj_bbs or None)."""
     with np.load(path) as f:

@@ -38,6 +38,7 @@ extern "C" {
 
 #define AAE_DTYPE_U8 0            /* uint8 crops: converted as float32(v/255.)     */
 #define AAE_DTYPE_F32 1
+#define AAE_DTYPE_BF16 2          /* codebook storage only: bfloat16 rows (2 B/elem), J == 128 */
 
 #define AAE_MAX_LAYERS 8
 

@@ -108,6 +108,43 @@ inline f32x16 mfma_32x32x16_f16(u32x4 a, u32x4 b, f32x16 c) {
     }
     return d;
 }
+inline unsigned short bf16_rn(float v) {
+    unsigned u;
+    memcpy(&u, &v, 4);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+inline float bf16_to_f32(unsigned short h) {
+    const unsigned u = (unsigned)h << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+inline void split_bf16x3(float v, unsigned short& t0, unsigned short& t1, unsigned short& t2) {
+    t0 = bf16_rn(v);
+    const float r1 = v - bf16_to_f32(t0);
+    t1 = bf16_rn(r1);
+    t2 = bf16_rn(r1 - bf16_to_f32(t1));
+}
+inline f32x16 mfma_32x32x16_bf16(u32x4 a, u32x4 b, f32x16 c) {
+    struct { u32x4 a, b; } mine = {a, b};
+    const aae_emu::lane_slot* all = aae_emu::wave_exchange(&mine, sizeof(mine));
+    const int lane = lane_id();
+    const int col = lane & 31, hi = lane >> 5;
+    f32x16 d = c;
+    for (int r = 0; r < 16; ++r) {
+        const int row = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        float acc = d[r];
+        for (int k = 0; k < 16; ++k) {
+            unsigned short av, bv;
+            memcpy(&av, &all[row + 32 * (k >> 3)][2 * (k & 7)], 2);
+            memcpy(&bv, &all[col + 32 * (k >> 3)][16 + 2 * (k & 7)], 2);
+            acc = fmaf(bf16_to_f32(av), bf16_to_f32(bv), acc);
+        }
+        d[r] = acc;
+    }
+    return d;
+}
 inline void split_f16(float v, unsigned short& hi, unsigned short& lo) {
     const float c = fminf(fmaxf(v, -65504.f), 65504.f);
     const _Float16 h = (_Float16)c;

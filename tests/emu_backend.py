@@ -85,11 +85,16 @@ class EmuEncoder(object):
 
 
 class EmuCodebook(object):
-    def __init__(self, E):
+    def __init__(self, E, dtype='f32'):
         self.L = lib()
         self.E = np.ascontiguousarray(E, dtype=np.float32)
         h = ctypes.c_void_p()
-        rc = self.L.aae_codebook_create(self.E.ctypes.data, self.E.shape[0], self.E.shape[1], _lib.AAE_DTYPE_F32, 0, ctypes.byref(h))
+        if dtype == 'bf16':
+            from augmentedautoencoder_amd.weights import to_bf16_bits
+            bits = to_bf16_bits(self.E)
+            rc = self.L.aae_codebook_create(bits.ctypes.data, self.E.shape[0], self.E.shape[1], _lib.AAE_DTYPE_BF16, 0, ctypes.byref(h))
+        else:
+            rc = self.L.aae_codebook_create(self.E.ctypes.data, self.E.shape[0], self.E.shape[1], _lib.AAE_DTYPE_F32, 0, ctypes.byref(h))
         _lib.check(self.L, rc, 'aae_codebook_create')
         self.h = h
 

@@ -127,3 +127,31 @@ def test_split_precision_f32x3h_path(cfg, B, nosplit):
     with pytest.raises(ValueError, match='f32x3h'):
         gen.set_option('precision', 1)                     # needs the matrix-core kernels on every layer
     gen.close()
+
+
+@pytest.mark.parametrize('B', [1, 5, 70])
+def test_bf16_codebook_scan(B):
+    """BASELINE config 5 in miniature: bf16 codebook rows, queries as three bf16 terms on the
+    bf16 matrix cores; parity against the fp64 oracle evaluated on the bf16-rounded codebook."""
+    from augmentedautoencoder_amd.weights import bf16_bits_to_f32, to_bf16_bits
+    N, J = 36 * 11 + 5, 128
+    E = synth.make_codebook(N, J, seed=7, planted_duplicates=11)
+    Eb = bf16_bits_to_f32(to_bf16_bits(E))
+    assert np.abs(Eb - E).max() < 2.0 ** -8 and np.array_equal(to_bf16_bits(Eb), to_bf16_bits(E))
+    cb = eb.EmuCodebook(E, dtype='bf16')
+    rows = np.random.default_rng(B).integers(0, N, B)
+    z = synth.make_queries_near_rows(E, rows, noise=0.3, seed=B)
+    z[0] = Eb[36 * 3 + 35] * 3.0                              # exact tie between rows 108 and 143
+    idx, score = cb.nn(z)
+    cs = cb.similarity(z)
+    cs64 = ref.cos_similarity(z, Eb)
+    assert np.abs(cs - cs64).max() < 2e-6
+    assert np.array_equal(idx[:, 0], np.argmax(cs, axis=1)) and idx[0, 0] == 108
+    up, _ = cb.nn(z, col_stride=36)
+    assert np.array_equal(up[:, 0], ref.nearest_indices_reference(cs, 1, upright=True, num_cyclo=36))
+    if B <= 5:
+        ik, sk = cb.nn(z, topk=5)
+        assert np.array_equal(ik, ref.topk_canonical(cs, 5)) and np.all(np.diff(sk, axis=1) <= 0)
+    cb.close()
+    with pytest.raises(ValueError, match='J == 128'):
+        eb.EmuCodebook(synth.make_codebook(72, 32, seed=1), dtype='bf16')

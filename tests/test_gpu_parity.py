@@ -267,3 +267,41 @@ def test_split_precision_f32x3h_mode_meets_the_same_tolerances():
     z_f32 = enc.encode(crops).cpu().numpy()
     assert np.abs(z_a - z_f32).max() / np.abs(z_f32).max() < 1e-5
     enc.close()
+
+
+def test_config5_large_bf16_codebook_topk():
+    """BASELINE config 5: 368928 (4x) entries x 128-d stored as bf16, 256 batched queries on the
+    bf16 matrix cores, arg-max and top-k = 5 (score-descending, lowest index first on ties).
+    Oracle: fp64 on the bf16-ROUNDED codebook."""
+    from augmentedautoencoder_amd.engine import CodebookEngine
+    from augmentedautoencoder_amd.weights import bf16_bits_to_f32, to_bf16_bits
+    N, B, K = 368928, 256, 5
+    E = synth.make_codebook(N, 128, seed=11, planted_duplicates=256)
+    Eb = bf16_bits_to_f32(to_bf16_bits(E))
+    cb = CodebookEngine(E, dtype='bf16')
+    rng = np.random.default_rng(5)
+    z = rng.standard_normal((B, 128)).astype(np.float32) * rng.uniform(0.1, 30.0, (B, 1)).astype(np.float32)
+    dup = [r for r in range(35, N, 36) if np.array_equal(Eb[r], Eb[r - 35])][:8]
+    z[:8] = Eb[dup] * 2.0                                      # exact ties: the lower-index twin must win
+    idx1, sc1 = cb.nn(z, 1, 1)
+    idx1, sc1 = idx1[:, 0].cpu().numpy(), sc1[:, 0].cpu().numpy()
+    idxk, sck = cb.nn(z, K, 1)
+    idxk, sck = idxk.cpu().numpy(), sck.cpu().numpy()
+    assert idxk.shape == (B, K) and np.array_equal(idxk[:, 0], idx1) and np.all(np.diff(sck, axis=1) <= 0)
+    assert np.array_equal(idx1[:8], np.array(dup) - 35)
+    assert np.array_equal(idxk[:8, 1], np.array(dup))          # ... and the twin itself comes second
+    Bo = 24
+    cs64 = ref.cos_similarity(z[:Bo], Eb)
+    cs = cb.similarity(z[:Bo]).cpu().numpy()
+    assert np.abs(cs - cs64).max() <= COS_TOL
+    _check_indices(idx1[:Bo], cs64)
+    assert np.abs(sc1[:Bo] - cs64.max(axis=1)).max() <= COS_TOL
+    want = ref.topk_canonical(cs64, K)
+    for b in range(Bo):                                        # tie-aware: equal sets unless fp64 gaps are tiny
+        if not np.array_equal(idxk[b], want[b]):
+            s = np.sort(cs64[b])[::-1][:K + 1]
+            assert np.min(-np.diff(s)) < GAP_TOL, (b, idxk[b], want[b])
+    assert np.array_equal(idxk[:Bo], ref.topk_canonical(cs, K))   # exact w.r.t. the kernel's own scores
+    up, _ = cb.nn(z[:Bo], 1, 36)
+    assert np.array_equal(up[:, 0].cpu().numpy(), ref.nearest_indices_reference(cs, 1, upright=True, num_cyclo=36))
+    cb.close()

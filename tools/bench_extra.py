@@ -90,6 +90,18 @@ def main():
                               'crops_per_s': round(256 / ms * 1e3, 1), 'encoder_tflops_equiv': round(cfg.flops_per_crop() * 256 / ms / 1e9, 2),
                               'kernels': [(l.split(':')[0] + ':' + l.split(':')[1].split()[0], round(t, 4), round(f / t / 1e9, 1) if t > 0 else 0) for l, t, f in recs]}))
         enc.set_option('precision', 0)
+    if 'config5' in what:
+        # 368928 x 128 bf16 codebook (94.4 MB), batched queries, arg-max and top-5
+        E5 = synth.make_codebook(368928, 128, seed=11)
+        cb5 = CodebookEngine(E5, dtype='bf16')
+        for B in (1, 32, 256):
+            z = torch.randn(B, 128, device='cuda')
+            ms1 = timeit(lambda: cb5.nn(z, 1, 1), 30)
+            ms5 = timeit(lambda: cb5.nn(z, 5, 1), 10)
+            print(json.dumps({'what': 'config5', 'B': B, 'argmax_ms': round(ms1, 4), 'top5_ms': round(ms5, 4),
+                              'argmax_algorithmic_GBps': round(368928 * 128 * 2 / ms1 / 1e6, 1),
+                              'argmax_tflops_fp32_equiv': round(2.0 * B * 368928 * 128 / ms1 / 1e9, 2)}))
+        cb5.close()
     if 'embed' in what:
         # config 3: encoder-only over 92232 views in batches of 64 (reference BATCH_SIZE) / 256 / 1024
         for bs in (64, 256, 1024):
