@@ -77,10 +77,18 @@ int aae_encoder_create(const aae_encoder_desc* desc, const void* const* host_wei
                        aae_encoder** out);
 void aae_encoder_destroy(aae_encoder* enc);
 
-/* Launch-planning knobs (tuning / tests; set before sizing the workspace):
+/* Options (set before sizing the workspace):
+ *   "precision" (0): 0 = exact fp32 matrix-core arithmetic (bitwise an fp32 fma chain);
+ *                    1 = "f32x3h": fp32 in/out, every product of conv2..dense evaluated as three
+ *                        fp16 MFMAs on (hi, lo) operand pairs with fp32 accumulation (>= 22-bit
+ *                        operands).  Explicit opt-in; same parity tolerances; activations then
+ *                        live in the workspace as two fp16 planes of x * 2^x3h_act_shift.
+ *   "x3h_act_shift" (4): power-of-two activation pre-scale of the f32x3h format (|x| < 4094
+ *                        keeps full accuracy; larger values saturate gracefully up to 2x).
  *   "splitk_min_base_blocks" (384): split the K loop of a layer only if its un-split grid
  *                                   has fewer blocks than this (small batches);
- *   "splitk_target_blocks"   (512): ... and then aim for about this many blocks. */
+ *   "splitk_target_blocks"   (512): ... and then aim for about this many blocks;
+ *   "igemm_stagger" (0): experimental start delay (kcycles) for every 2nd block generation. */
 int aae_encoder_set_option(aae_encoder* enc, const char* name, int value);
 
 size_t aae_encoder_workspace_bytes(const aae_encoder* enc, int B);
@@ -107,8 +115,10 @@ int aae_encoder_activation_info(const aae_encoder* enc, int B, int layer, size_t
                                 size_t* count);
 
 /* ---- Codebook: auto_pose/ae/codebook.py:18-51 ---------------------------------
- * E: [N, J] float32 rows already normalised (embedding_normalized variable,
- * codebook.py:28-36, as left by update_embedding :214-216).  Host or device source. */
+ * E: [N, J] rows already normalised (embedding_normalized variable, codebook.py:28-36, as left
+ * by update_embedding :214-216); float32 (AAE_DTYPE_F32, the reference's storage) or bfloat16
+ * bit patterns (AAE_DTYPE_BF16, J == 128: half the HBM bytes per scan; queries keep fp32
+ * accuracy as three bf16 terms).  Host or device source. */
 int aae_codebook_create(const void* E, int N, int J, int dtype, int src_is_device, aae_codebook** out);
 int aae_codebook_update(aae_codebook* cb, const void* E, int src_is_device, void* stream);  /* embedding_assign_op */
 void aae_codebook_destroy(aae_codebook* cb);
