@@ -28,6 +28,7 @@ EXPORTED_SYMBOLS = (
     'aae_encoder_activation_info',
     'aae_codebook_create', 'aae_codebook_update', 'aae_codebook_destroy', 'aae_codebook_set_scan_mode',
     'aae_codebook_workspace_bytes', 'aae_codebook_nn', 'aae_codebook_similarity', 'aae_l2_normalize',
+    'aae_crop_resize_u8',
 )
 
 
@@ -87,6 +88,8 @@ def declare(lib):
     lib.aae_codebook_similarity.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]
     lib.aae_l2_normalize.restype = c_int
     lib.aae_l2_normalize.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p]
+    lib.aae_crop_resize_u8.restype = c_int
+    lib.aae_crop_resize_u8.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
     return lib
 
 

@@ -141,6 +141,13 @@ class Codebook(object):
     def auto_pose6d(self, session, x, predicted_bb, K_test, top_n, train_args, depth_pred=None, upright=False):
         """Rotation + translation estimate from a detector crop (codebook.py:79-129)."""
         idcs = np.atleast_1d(self.nearest_rotation(session, x, top_n=top_n, upright=upright, return_idcs=True))
+        return self.pose_from_indices(idcs, predicted_bb, K_test, train_args, depth_pred=depth_pred)
+
+    def pose_from_indices(self, idcs, predicted_bb, K_test, train_args, depth_pred=None):
+        """The geometry half of auto_pose6d (codebook.py:82-129) for already-matched codebook
+        rows -- what the batched estimator calls after one encode+scan over all detections."""
+        idcs = np.atleast_1d(idcs)
+        top_n = len(idcs)
         Rs_est = self._dataset.viewsphere_for_embedding[idcs]      # fancy index -> copy
 
         K_train = np.array(_parse_K(train_args.get('Dataset', 'K'))).reshape(3, 3)

@@ -24,6 +24,7 @@
 #include "kernels/conv_direct_generic.h"
 #include "kernels/codebook_scan_f32.h"
 #include "kernels/codebook_scan_bf16.h"
+#include "kernels/crop_resize_u8.h"
 
 namespace aae_host {
 
@@ -837,6 +838,22 @@ int aae_l2_normalize(const float* z, int B, int J, float* q_out, void* stream_v)
     aae::L2NormArgs n;
     n.z = z; n.q = q_out; n.qp = nullptr; n.B = B; n.J = J; n.Jpad = J; n.Bpad = B;
     AAE_LAUNCH((aae::l2norm_pack_kernel), dim3(ceil_div(B, 4)), dim3(256), 0, static_cast<hipStream_t>(stream_v), n);
+    AAE_HIP_TRY(hipGetLastError());
+    return AAE_OK;
+}
+
+int aae_crop_resize_u8(const void* img, int H, int W, int C, const int32_t* boxes, int D, int out_h, int out_w,
+                       void* out, void* stream_v) {
+    using namespace aae_host;
+    if (!img || !boxes || !out) return fail(AAE_ERR_INVALID, "aae_crop_resize_u8: null argument");
+    if (H < 1 || W < 1 || C < 1 || D < 1 || out_h < 1 || out_w < 1)
+        return fail(AAE_ERR_INVALID, "aae_crop_resize_u8: image %dx%dx%d, %d boxes, output %dx%d", H, W, C, D, out_h, out_w);
+    if (D > 65535) return fail(AAE_ERR_UNSUPPORTED, "aae_crop_resize_u8: at most 65535 boxes per call");
+    aae::CropResizeArgs a;
+    a.img = static_cast<const unsigned char*>(img); a.boxes = boxes; a.out = static_cast<unsigned char*>(out);
+    a.H = H; a.W = W; a.C = C; a.D = D; a.OH = out_h; a.OW = out_w;
+    AAE_LAUNCH((aae::crop_resize_bilinear_u8_kernel), dim3(ceil_div(out_h * out_w, 256), D), dim3(256), 0,
+               static_cast<hipStream_t>(stream_v), a);
     AAE_HIP_TRY(hipGetLastError());
     return AAE_OK;
 }

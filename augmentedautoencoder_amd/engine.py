@@ -274,3 +274,35 @@ class CodebookEngine(object):
                                            _stream_ptr(torch))
         _lib.check(self.lib, rc, 'aae_l2_normalize')
         return q
+
+
+def crop_resize(image, boxes_xywh_size, out_hw, device=None):
+    """All detector crops of one image in one launch (extract_square_patch(black_borders=True) +
+    cv2.resize(INTER_LINEAR), m3_interface/ae_pose_estimator.py:106-131).
+    image: uint8 [H,W,C] numpy array or device tensor; boxes_xywh_size: int [D,5] rows
+    (x, y, w, h, size); returns a device uint8 tensor [D, out_h, out_w, C]."""
+    torch = _torch()
+    lib = _lib.load()
+    dev = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+    if isinstance(image, np.ndarray):
+        if image.dtype != np.uint8:
+            raise TypeError('crop_resize needs a uint8 image, got %s' % image.dtype)
+        img = torch.from_numpy(np.ascontiguousarray(image)).to(dev)
+    else:
+        if image.dtype != torch.uint8:
+            raise TypeError('crop_resize needs a uint8 image, got %s' % image.dtype)
+        img = image.to(dev).contiguous()
+    if img.dim() != 3:
+        raise ValueError('image must be [H,W,C], got shape %s' % (tuple(img.shape),))
+    boxes = torch.from_numpy(np.ascontiguousarray(np.asarray(boxes_xywh_size, dtype=np.int32).reshape(-1, 5))).to(dev)
+    D = int(boxes.shape[0])
+    oh, ow = int(out_hw[0]), int(out_hw[1])
+    out = torch.empty((D, oh, ow, int(img.shape[2])), dtype=torch.uint8, device=dev)
+    if D == 0:
+        return out
+    with torch.cuda.device(dev):
+        rc = lib.aae_crop_resize_u8(ctypes.c_void_p(img.data_ptr()), int(img.shape[0]), int(img.shape[1]), int(img.shape[2]),
+                                    ctypes.c_void_p(boxes.data_ptr()), D, oh, ow, ctypes.c_void_p(out.data_ptr()),
+                                    _stream_ptr(torch))
+    _lib.check(lib, rc, 'aae_crop_resize_u8')
+    return out

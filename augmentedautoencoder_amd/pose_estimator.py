@@ -1,0 +1,158 @@
+"""Batched multi-object pose estimator -- the consumer of the hot path.
+
+Same interface as the reference's m3vision plugin
+(/root/reference/auto_pose/m3_interface/ae_pose_estimator.py:16-232:
+``AePoseEstimator(test_config_path).process(bboxes, color_img, camK, ...)``), but
+instead of one ``session.run`` per detection (ae_pose_estimator.py:143-170) all
+detections of an image are handled together:
+
+  1. every crop is cut and bilinearly resized on the GPU in one launch
+     (extract_square_patch(black_borders=True) + cv2.resize(INTER_LINEAR));
+  2. the crops of each object class go through that object's encoder + codebook
+     scan as ONE batch;
+  3. the translation / rotation-correction geometry of auto_pose6d runs on the
+     host per detection (float64, as in the reference).
+
+The results are returned in detection order, one ``PoseEstimate`` per accepted box.
+"""
+from __future__ import annotations
+
+import ast
+import configparser
+import os
+
+import numpy as np
+
+from . import ae_factory as factory
+from . import session as S
+from . import utils as u
+
+
+class PoseEstimate(object):
+    """m3_interface/m3_interfaces.py:57-85."""
+
+    def __init__(self, name='SLC', trafo=np.identity(4), quality=1.0):
+        self.name = name
+        self.trafo = trafo
+        self.quality = quality
+
+
+class BoundingBox(object):
+    """Detection in relative image coordinates with per-class scores
+    (m3_interface/m3_interfaces.py BoundingBox: xmin, xmax, ymin, ymax, classes)."""
+
+    def __init__(self, xmin=0., xmax=0., ymin=0., ymax=0., classes=None):
+        self.xmin, self.xmax, self.ymin, self.ymax = xmin, xmax, ymin, ymax
+        self.classes = classes if classes is not None else {}
+
+
+class AePoseEstimator(object):
+
+    def __init__(self, test_config_path=None, codebooks=None, train_args=None, upright=False, topk=1, camPose=False):
+        """Either ``test_config_path`` (the m3 cfg with an [auto_pose] section, as in the
+        reference) or explicit ``codebooks`` / ``train_args`` dicts keyed by class name."""
+        self._process_requirements = ['color_img', 'camK', 'bboxes']
+        self.all_codebooks, self.all_train_args, self.pad_factors, self.patch_sizes = {}, {}, {}, {}
+        self.sess = S.Session()
+        if test_config_path is not None:
+            test_args = configparser.ConfigParser(inline_comment_prefixes="#")
+            if not test_args.read(test_config_path):
+                raise FileNotFoundError('test config not found: %s' % test_config_path)
+            workspace_path = os.environ.get('AE_WORKSPACE_PATH')
+            if workspace_path is None:
+                raise RuntimeError('Please define a workspace path: export AE_WORKSPACE_PATH=/path/to/workspace')
+            camPose = test_args.getboolean('auto_pose', 'camPose')
+            upright = test_args.getboolean('auto_pose', 'upright')
+            topk = test_args.getint('auto_pose', 'topk')
+            self.class_2_encoder = ast.literal_eval(test_args.get('auto_pose', 'class_2_encoder'))
+            for clas_name, experiment in self.class_2_encoder.items():
+                full_name = experiment.split('/')
+                experiment_name = full_name.pop()
+                experiment_group = full_name.pop() if len(full_name) > 0 else ''
+                log_dir = u.get_log_dir(workspace_path, experiment_name, experiment_group)
+                ckpt_dir = u.get_checkpoint_dir(log_dir)
+                targs = configparser.ConfigParser(inline_comment_prefixes="#")
+                targs.read(u.get_train_config_exp_file_path(log_dir, experiment_name))
+                self._register(clas_name, factory.build_codebook_from_name(experiment_name, experiment_group), targs)
+                factory.restore_checkpoint(self.sess, S.Saver(scope=experiment_name), ckpt_dir)
+        else:
+            if not codebooks or not train_args:
+                raise ValueError('pass a test config path, or codebooks= and train_args= dicts keyed by class name')
+            self.class_2_encoder = {k: k for k in codebooks}
+            for k in codebooks:
+                self._register(k, codebooks[k], train_args[k])
+        if topk > 1:
+            raise NotImplementedError('topk > 1 not implemented (as in the reference, ae_pose_estimator.py:36-39)')
+        self._camPose, self._upright, self._topk = bool(camPose), bool(upright), int(topk)
+        if self._camPose:
+            self._process_requirements.append('camPose')
+
+    def _register(self, clas_name, codebook, targs):
+        self.all_codebooks[clas_name] = codebook
+        self.all_train_args[clas_name] = targs
+        self.pad_factors[clas_name] = targs.getfloat('Dataset', 'PAD_FACTOR')
+        self.patch_sizes[clas_name] = (targs.getint('Dataset', 'W'), targs.getint('Dataset', 'H'))
+
+    def set_parameter(self, string_name, string_val):
+        pass
+
+    def query_process_requirements(self):
+        return self._process_requirements
+
+    def query_image_format(self):
+        return {'color_format': 'bgr', 'color_data_type': np.uint8, 'depth_data_type': np.float32}
+
+    # ------------------------------------------------------------------ crops
+    @staticmethod
+    def box_rows(boxes_xywh, pad_factor):
+        """[x, y, w, h, size] int32 rows exactly as extract_square_patch derives them
+        (ae_pose_estimator.py:108-109): astype(int32) truncation, size = int(max(h, w) * pad)."""
+        rows = np.empty((len(boxes_xywh), 5), dtype=np.int32)
+        for i, bb in enumerate(boxes_xywh):
+            x, y, w, h = np.array(bb).astype(np.int32)
+            rows[i] = (x, y, w, h, int(np.maximum(h, w) * pad_factor))
+        return rows
+
+    def extract_square_patches(self, scene_img, boxes_xywh, pad_factor, resize=(128, 128)):
+        """Batched extract_square_patch(..., INTER_LINEAR, black_borders=True): device uint8
+        [D, resize[1], resize[0], C].  ``resize`` is (W, H) as in cv2."""
+        from .engine import crop_resize
+        return crop_resize(scene_img, self.box_rows(boxes_xywh, pad_factor), (resize[1], resize[0]))
+
+    # ---------------------------------------------------------------- process
+    def process(self, bboxes, color_img, camK, depth_img=None, camPose=None, rois3ds=[], mm=False):
+        H, W = color_img.shape[:2]
+        accepted = []                                   # (detection index, class, box_xywh)
+        for j, box in enumerate(bboxes):
+            pred_clas = max(box.classes, key=box.classes.get)
+            if pred_clas not in self.class_2_encoder:
+                print('%s not contained in config class_names %s' % (pred_clas, list(self.class_2_encoder.keys())))
+                continue
+            box_xywh = [box.xmin * W, box.ymin * H, (box.xmax - box.xmin) * W, (box.ymax - box.ymin) * H]
+            if np.any(np.array(box_xywh) < 0):
+                print('invalid bb', box_xywh)
+                continue
+            accepted.append((j, pred_clas, box_xywh))
+        if not accepted:
+            return []
+
+        image_dev = None
+        poses = {}
+        for clas in sorted(set(c for _, c, _ in accepted)):
+            members = [(j, bb) for j, c, bb in accepted if c == clas]
+            codebook = self.all_codebooks[clas]
+            if image_dev is None:
+                import torch
+                image_dev = torch.from_numpy(np.ascontiguousarray(color_img)).to(codebook._encoder.engine.device)
+            crops = self.extract_square_patches(image_dev, [bb for _, bb in members], self.pad_factors[clas],
+                                                resize=self.patch_sizes[clas])
+            idcs = np.atleast_1d(codebook.nearest_rotation(self.sess, crops, top_n=1, upright=self._upright, return_idcs=True))
+            for (j, bb), idx in zip(members, idcs):
+                Rs_est, ts_est = codebook.pose_from_indices([idx], bb, camK, self.all_train_args[clas])
+                H_est = np.eye(4)
+                H_est[:3, :3] = Rs_est.squeeze()
+                H_est[:3, 3] = ts_est.squeeze() if mm else ts_est.squeeze() / 1000.
+                if self._camPose:
+                    H_est = np.dot(camPose, H_est)
+                poses[j] = PoseEstimate(name=clas, trafo=H_est)
+        return [poses[j] for j in sorted(poses)]

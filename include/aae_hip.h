@@ -143,6 +143,14 @@ int aae_codebook_similarity(aae_codebook* cb, const float* z, int B, float* cs_o
 /* normalized_embedding_query (codebook.py:27) for test_embedding(normalized=True) (:135-145). */
 int aae_l2_normalize(const float* z, int B, int J, float* q_out, void* stream);
 
+/* ---- Caller side ("next" row N1): detector crops for a whole image in one launch -------------
+ * AePoseEstimator.extract_square_patch(black_borders=True) + cv2.resize(INTER_LINEAR)
+ * (auto_pose/m3_interface/ae_pose_estimator.py:106-131,157-162).
+ * img: device uint8 [H,W,C]; boxes: device int32 [D,5] = x, y, w, h, size with
+ * size = int(max(h, w) * pad_factor); out: device uint8 [D,out_h,out_w,C]. */
+int aae_crop_resize_u8(const void* img, int H, int W, int C, const int32_t* boxes, int D,
+                       int out_h, int out_w, void* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

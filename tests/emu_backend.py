@@ -129,6 +129,17 @@ class EmuCodebook(object):
             self.h = None
 
 
+def crop_resize(img, boxes_xywh_size, out_hw):
+    L = lib()
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    boxes = np.ascontiguousarray(np.asarray(boxes_xywh_size, dtype=np.int32).reshape(-1, 5))
+    out = np.full((boxes.shape[0], out_hw[0], out_hw[1], img.shape[2]), 123, dtype=np.uint8)
+    rc = L.aae_crop_resize_u8(img.ctypes.data, img.shape[0], img.shape[1], img.shape[2], boxes.ctypes.data, boxes.shape[0],
+                              out_hw[0], out_hw[1], out.ctypes.data, None)
+    _lib.check(L, rc, 'aae_crop_resize_u8')
+    return out
+
+
 def l2_normalize(z):
     L = lib()
     z = np.ascontiguousarray(z, dtype=np.float32)

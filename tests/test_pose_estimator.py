@@ -1,0 +1,215 @@
+"""N1: batched multi-object estimator (augmentedautoencoder_amd/pose_estimator.py) -- crop
+extraction kernel against the oracle's restatement of extract_square_patch + cv2 bilinear
+resize (bit-exact, integer work), and process() against the oracle pipeline run detection by
+detection the way the reference does (m3_interface/ae_pose_estimator.py:143-222).
+CPU tests run the kernels on the emulator; the gpu-marked ones on the MI355X."""
+import configparser
+
+import numpy as np
+import pytest
+
+from augmentedautoencoder_amd import session as S
+from augmentedautoencoder_amd.codebook import Codebook, _parse_K
+from augmentedautoencoder_amd.dataset import Dataset
+from augmentedautoencoder_amd.encoder import Encoder
+from augmentedautoencoder_amd.pose_estimator import AePoseEstimator, BoundingBox, PoseEstimate
+from oracle import reference_cpu as ref
+from oracle import synth
+
+TRAIN_CFG = """
+[Dataset]
+H: {h}
+W: {w}
+C: 3
+RADIUS: 700
+PAD_FACTOR: 1.2
+K: [1075.65, 0, 720/2, 0, 1073.90, 540/2, 0, 0, 1]
+[Embedding]
+EMBED_BB: True
+MIN_N_VIEWS: 12
+NUM_CYCLO: 6
+"""
+
+
+def _scene(seed=0, H=240, W=320):
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:H, 0:W]
+    img = np.stack([(xx * 3 + yy) % 256, (yy * 5 + xx // 2) % 256, (xx + yy * 2) % 256], -1).astype(np.float64)
+    img += rng.normal(0, 20, img.shape)
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+BOXES = [[40.7, 30.2, 90.9, 60.1], [0.0, 0.0, 50.5, 120.0], [200.3, 100.9, 119.6, 139.0],   # touches right/bottom edge
+         [150.0, 80.0, 20.0, 33.0],                                                          # small box: up-scaling
+         [10.2, 200.8, 300.0, 39.1]]                                                         # wide box
+
+
+def test_cv_resize_restatement_properties():
+    img = _scene(1, 90, 70)
+    assert np.array_equal(ref.cv_resize_linear_u8(img, (70, 90)), img)                     # identity
+    assert np.unique(ref.cv_resize_linear_u8(np.full((200, 200, 3), 77, np.uint8), (128, 128))).tolist() == [77]
+    half = ref.cv_resize_linear_u8(img[:64, :64], (32, 32))                                # exact 2x decimation = 2x2 box mean (+rounding)
+    box = img[:64, :64].astype(np.int64).reshape(32, 2, 32, 2, 3).sum(axis=(1, 3))
+    assert np.abs(half.astype(np.int64) - (box + 2) // 4).max() <= 1
+
+
+@pytest.mark.parametrize('out_hw', [(128, 128), (16, 24)])
+def test_crop_kernel_bit_exact_on_emulator(out_hw):
+    import emu_backend as eb
+    img = _scene(2)
+    rows = AePoseEstimator.box_rows(BOXES, 1.2)
+    got = eb.crop_resize(img, rows, out_hw)
+    for i, bb in enumerate(BOXES):
+        want = ref.extract_square_patch_black_borders(img, bb, 1.2, resize=(out_hw[1], out_hw[0]))
+        assert np.array_equal(got[i], want), 'box %d' % i
+
+
+def _tiny_estimator(engine_factory, crop_fn=None):
+    """Two object classes with a 16x16 encoder; engines injected by the caller."""
+    S.reset_default_graph()
+    targs = configparser.ConfigParser()
+    targs.read_string(TRAIN_CFG.format(h=16, w=16))
+    codebooks, train_args, weights, embeds = {}, {}, {}, {}
+    for k, name in enumerate(['obj_a', 'obj_b']):
+        ds = Dataset('', h=16, w=16, c=3, min_n_views=12, radius=700, num_cyclo=6)
+        with S.variable_scope(name):
+            enc = Encoder(S.Placeholder((16, 16, 3)), 128, [32, 64], 5, [2, 2], False)
+            cb = Codebook(enc, ds, True)
+        w = synth.make_weights(seed=20 + k, shape=(16, 16, 3), num_filter=[32, 64], strides=[2, 2], latent=128)
+        enc.load_weights(w)
+        E = synth.make_codebook(ds.embedding_size, 128, seed=30 + k, planted_duplicates=2, num_cyclo=6)
+        cb.assign_embedding(E)
+        rng = np.random.default_rng(40 + k)
+        bbs = np.stack([rng.integers(250, 350, 72), rng.integers(180, 260, 72), rng.integers(80, 200, 72), rng.integers(80, 200, 72)], 1)
+        cb.assign_obj_bbs(bbs)
+        engine_factory(enc, cb, w, E)
+        codebooks[name], train_args[name], weights[name], embeds[name] = cb, targs, w, (E, bbs, ds)
+    est = AePoseEstimator(codebooks=codebooks, train_args=train_args, upright=False)
+    if crop_fn is not None:
+        est.extract_square_patches = crop_fn
+    return est, weights, embeds
+
+
+def _detections(W=320, H=240):
+    dets = []
+    classes = ['obj_a', 'obj_b', 'obj_a', 'unknown', 'obj_b', 'obj_a']
+    boxes = BOXES + [[-5.0, 10.0, 30.0, 30.0]]                       # last one invalid (negative) -> skipped
+    for c, (x, y, w, h) in zip(classes, boxes):
+        dets.append(BoundingBox(xmin=x / W, xmax=(x + w) / W, ymin=y / H, ymax=(y + h) / H, classes={c: 0.9, 'zzz': 0.1}))
+    return dets
+
+
+def _oracle_process(img, dets, weights, embeds, camK, mm):
+    """The reference's per-detection loop, on the oracle."""
+    H, W = img.shape[:2]
+    out = []
+    K_train = np.array(_parse_K('[1075.65, 0, 720/2, 0, 1073.90, 540/2, 0, 0, 1]')).reshape(3, 3)
+    for box in dets:
+        clas = max(box.classes, key=box.classes.get)
+        if clas not in weights:
+            continue
+        bb = [box.xmin * W, box.ymin * H, (box.xmax - box.xmin) * W, (box.ymax - box.ymin) * H]
+        if np.any(np.array(bb) < 0):
+            continue
+        crop = ref.extract_square_patch_black_borders(img, bb, 1.2, resize=(16, 16))
+        E, bbs, ds = embeds[clas]
+        z = ref.encoder_forward_np(ref.input_to_float(crop), weights[clas], [2, 2])
+        idx = ref.nearest_indices_reference(ref.cos_similarity(z, E), 1)
+        R, t = ref.auto_pose6d_geometry(idx, ds.viewsphere_for_embedding, bbs.astype(np.int32), bb, camK, K_train, 700.0)
+        Hm = np.eye(4)
+        Hm[:3, :3] = R.squeeze()
+        Hm[:3, 3] = t.squeeze() if mm else t.squeeze() / 1000.
+        out.append((clas, Hm))
+    return out
+
+
+def test_process_batched_equals_per_detection_oracle_cpu():
+    import emu_backend as eb
+    from emu_engines import EmuCodebookEngine, EmuEncoderEngine
+    import torch
+
+    def inject(enc, cb, w, E):
+        enc._engine = EmuEncoderEngine(enc.config, w)
+        cb._engine = EmuCodebookEngine(E)
+
+    def crop_fn(scene_img, boxes_xywh, pad_factor, resize=(128, 128)):
+        img = scene_img.numpy() if torch.is_tensor(scene_img) else scene_img
+        return torch.from_numpy(eb.crop_resize(img, AePoseEstimator.box_rows(boxes_xywh, pad_factor), (resize[1], resize[0])))
+
+    est, weights, embeds = _tiny_estimator(inject, crop_fn)
+    img = _scene(3)
+    camK = np.array([[572.4, 0, 160.0], [0, 573.6, 120.0], [0, 0, 1]])
+    dets = _detections()
+    for mm in (False, True):
+        got = est.process(dets, img, camK, mm=mm)
+        want = _oracle_process(img, dets, weights, embeds, camK, mm)
+        assert len(got) == len(want) == 4 and all(isinstance(g, PoseEstimate) for g in got)
+        for g, (clas, Hm) in zip(got, want):
+            assert g.name == clas and g.trafo.shape == (4, 4)
+            assert np.allclose(g.trafo, Hm, atol=1e-9)
+    assert est.process([], img, camK) == []
+    assert est.query_process_requirements() == ['color_img', 'camK', 'bboxes']
+    with pytest.raises(NotImplementedError):
+        AePoseEstimator(codebooks=est.all_codebooks, train_args=est.all_train_args, topk=2)
+
+
+@pytest.mark.gpu
+def test_crop_kernel_bit_exact_on_gpu():
+    from augmentedautoencoder_amd.engine import crop_resize
+    img = _scene(5, 480, 640)
+    rng = np.random.default_rng(1)
+    boxes = [[float(rng.uniform(0, 500)), float(rng.uniform(0, 350)), float(rng.uniform(8, 300)), float(rng.uniform(8, 300))] for _ in range(24)]
+    boxes += [[600.0, 440.0, 100.0, 100.0], [0.0, 0.0, 640.0, 480.0], [100.0, 100.0, 3.0, 2.0]]
+    rows = AePoseEstimator.box_rows(boxes, 1.2)
+    got = crop_resize(img, rows, (128, 128)).cpu().numpy()
+    for i, bb in enumerate(boxes):
+        want = ref.extract_square_patch_black_borders(img, bb, 1.2, resize=(128, 128))
+        assert np.array_equal(got[i], want), 'box %d %s' % (i, bb)
+
+
+@pytest.mark.gpu
+def test_process_on_gpu_full_size_two_objects():
+    """Default 128x128 network, two objects, 12 detections in one 480x640 image."""
+    S.reset_default_graph()
+    targs = configparser.ConfigParser()
+    targs.read_string(TRAIN_CFG.format(h=128, w=128).replace('MIN_N_VIEWS: 12', 'MIN_N_VIEWS: 162').replace('NUM_CYCLO: 6', 'NUM_CYCLO: 36'))
+    codebooks, train_args, info = {}, {}, {}
+    for k, name in enumerate(['obj_a', 'obj_b']):
+        ds = Dataset('', h=128, w=128, c=3, min_n_views=162, radius=700, num_cyclo=36)
+        with S.variable_scope(name):
+            enc = Encoder(S.Placeholder((128, 128, 3)), 128, synth.DEFAULT_NUM_FILTER, 5, [2, 2, 2, 2], False)
+            cb = Codebook(enc, ds, True)
+        w = synth.make_weights(seed=50 + k)
+        enc.load_weights(w)
+        E = synth.make_codebook(ds.embedding_size, 128, seed=60 + k, planted_duplicates=8)
+        cb.assign_embedding(E)
+        rng = np.random.default_rng(70 + k)
+        bbs = np.stack([rng.integers(250, 350, len(E)), rng.integers(180, 260, len(E)), rng.integers(80, 200, len(E)), rng.integers(80, 200, len(E))], 1)
+        cb.assign_obj_bbs(bbs)
+        codebooks[name], train_args[name], info[name] = cb, targs, (w, E, bbs, ds)
+    est = AePoseEstimator(codebooks=codebooks, train_args=train_args)
+    img = _scene(9, 480, 640)
+    rng = np.random.default_rng(2)
+    dets, raw = [], []
+    for i in range(12):
+        x, y, w, h = rng.uniform(0, 400), rng.uniform(0, 300), rng.uniform(40, 200), rng.uniform(40, 170)
+        c = 'obj_a' if i % 3 else 'obj_b'
+        dets.append(BoundingBox(xmin=x / 640, xmax=(x + w) / 640, ymin=y / 480, ymax=(y + h) / 480, classes={c: 1.0}))
+        raw.append((c, [x / 640 * 640, y / 480 * 480, (x + w) / 640 * 640 - x / 640 * 640, (y + h) / 480 * 480 - y / 480 * 480]))
+    camK = np.array([[1075.65, 0, 320.0], [0, 1073.9, 240.0], [0, 0, 1]])
+    got = est.process(dets, img, camK, mm=True)
+    assert len(got) == 12
+    K_train = np.array(_parse_K('[1075.65, 0, 720/2, 0, 1073.90, 540/2, 0, 0, 1]')).reshape(3, 3)
+    for g, box in zip(got, dets):
+        c = max(box.classes, key=box.classes.get)
+        w, E, bbs, ds = info[c]
+        bb = [box.xmin * 640, box.ymin * 480, (box.xmax - box.xmin) * 640, (box.ymax - box.ymin) * 480]
+        crop = ref.extract_square_patch_black_borders(img, bb, 1.2, resize=(128, 128))
+        z64 = ref.encoder_forward_torch(ref.input_to_float(crop), w, [2, 2, 2, 2], False, 'float64')
+        cs64 = ref.cos_similarity(z64, E)
+        idx = ref.nearest_indices_reference(cs64, 1)
+        srt = np.sort(cs64[0])
+        R, t = ref.auto_pose6d_geometry(idx, ds.viewsphere_for_embedding, bbs.astype(np.int32), bb, camK, K_train, 700.0)
+        assert g.name == c
+        if srt[-1] - srt[-2] >= 2e-5:                       # away from near-ties the whole pose must agree
+            assert np.allclose(g.trafo[:3, :3], R.squeeze(), atol=1e-9) and np.allclose(g.trafo[:3, 3], t.squeeze(), atol=1e-6)

@@ -102,6 +102,17 @@ def main():
                               'argmax_algorithmic_GBps': round(368928 * 128 * 2 / ms1 / 1e6, 1),
                               'argmax_tflops_fp32_equiv': round(2.0 * B * 368928 * 128 / ms1 / 1e9, 2)}))
         cb5.close()
+    if 'crops' in what:
+        from augmentedautoencoder_amd.engine import crop_resize
+        from augmentedautoencoder_amd.pose_estimator import AePoseEstimator
+        rng = np.random.default_rng(0)
+        img = torch.from_numpy(rng.integers(0, 256, (1080, 1920, 3), dtype=np.uint8)).cuda()
+        for D in (1, 16, 64, 256):
+            boxes = [[float(rng.uniform(0, 1500)), float(rng.uniform(0, 800)), float(rng.uniform(60, 400)), float(rng.uniform(60, 280))] for _ in range(D)]
+            rows = AePoseEstimator.box_rows(boxes, 1.2)
+            ms = timeit(lambda: crop_resize(img, rows, (128, 128)), 30)
+            print(json.dumps({'what': 'crops', 'detections': D, 'ms': round(ms, 4), 'crops_per_s': round(D / ms * 1e3, 1),
+                              'out_GBps': round(D * 49152 / ms / 1e6, 2)}))
     if 'embed' in what:
         # config 3: encoder-only over 92232 views in batches of 64 (reference BATCH_SIZE) / 256 / 1024
         for bs in (64, 256, 1024):
