@@ -96,6 +96,7 @@ struct aae_encoder {
     int splitk_min_base_blocks = 384;      // split K only when the un-split grid is smaller than this
     int splitk_target_blocks = 512;        // ... and then aim for about this many blocks
     int precision = 0;                     // 0: exact fp32 MFMA; 1: f32x3h split-precision igemm (explicit opt-in)
+    int x3h_dma = 1;                       // f32x3h operand slabs by LDS-DMA (buffer_load ... lds); 0 = register-staged variant
     int x3h_act_shift = 4;                 // activations travel as halves of x*2^shift in f32x3h mode (|x| < 4094 exact range)
     int igemm_stagger = 0;                 // kcycles of start delay for every 2nd block generation of the igemm (0 = off)
 };
@@ -299,24 +300,33 @@ static int launch_igemm_x3h(aae_encoder* enc, const Layer& L, const void* x, int
     a.inv_scale = ldexpf(1.f, -(enc->x3h_act_shift + L.w_shift));
     a.out_scale = ldexpf(1.f, enc->x3h_act_shift);
     a.slabs_total = (int)(L.K() / 32);
+    a.wp_bytes = (unsigned)((unsigned long long)a.slabs_total * 8ull * L.CoutPad * 16ull);
     a.num_mt = ceil_div(M, 128);
     a.num_nt = L.CoutPad / 128;
     choose_splits(enc, a.num_mt * a.num_nt, a.slabs_total, &a.splits, &a.slabs_per_split);
     const int nblk = a.num_mt * a.num_nt * a.splits;
     const double flops = 2.0 * (double)M * (double)L.K() * (double)L.Cout;
+    const bool dma = enc->x3h_dma != 0;
+    const char* kname = dma ? "conv_igemm_x3h_dma" : "conv_igemm_x3h";
     char label[96];
     if (a.splits == 1) {
         a.out = out;
-        if (out_f32) AAE_LAUNCH((aae::conv_igemm_x3h_kernel<aae::X3H_OUT_F32>), dim3(nblk), dim3(256), aae::kConvIgemmSmem, stream, a);
-        else AAE_LAUNCH((aae::conv_igemm_x3h_kernel<aae::X3H_OUT_PLANES>), dim3(nblk), dim3(256), aae::kConvIgemmSmem, stream, a);
-        snprintf(label, sizeof(label), "%s:conv_igemm_x3h M=%d N=%d K=%lld", name, M, L.Cout, L.K());
+        if (dma) {
+            if (out_f32) AAE_LAUNCH((aae::conv_igemm_x3h_dma_kernel<aae::X3H_OUT_F32>), dim3(nblk), dim3(256), aae::kConvIgemmSmem, stream, a);
+            else AAE_LAUNCH((aae::conv_igemm_x3h_dma_kernel<aae::X3H_OUT_PLANES>), dim3(nblk), dim3(256), aae::kConvIgemmSmem, stream, a);
+        } else {
+            if (out_f32) AAE_LAUNCH((aae::conv_igemm_x3h_kernel<aae::X3H_OUT_F32>), dim3(nblk), dim3(256), aae::kConvIgemmSmem, stream, a);
+            else AAE_LAUNCH((aae::conv_igemm_x3h_kernel<aae::X3H_OUT_PLANES>), dim3(nblk), dim3(256), aae::kConvIgemmSmem, stream, a);
+        }
+        snprintf(label, sizeof(label), "%s:%s M=%d N=%d K=%lld", name, kname, M, L.Cout, L.K());
         enc->records.push_back({label, flops});
         AAE_HIP_TRY(hipGetLastError());
         return tm.mark();
     }
     a.out = partial;
-    AAE_LAUNCH((aae::conv_igemm_x3h_kernel<aae::X3H_OUT_PARTIAL>), dim3(nblk), dim3(256), aae::kConvIgemmSmem, stream, a);
-    snprintf(label, sizeof(label), "%s:conv_igemm_x3h_splitk%d M=%d N=%d K=%lld", name, a.splits, M, L.Cout, L.K());
+    if (dma) AAE_LAUNCH((aae::conv_igemm_x3h_dma_kernel<aae::X3H_OUT_PARTIAL>), dim3(nblk), dim3(256), aae::kConvIgemmSmem, stream, a);
+    else AAE_LAUNCH((aae::conv_igemm_x3h_kernel<aae::X3H_OUT_PARTIAL>), dim3(nblk), dim3(256), aae::kConvIgemmSmem, stream, a);
+    snprintf(label, sizeof(label), "%s:%s_splitk%d M=%d N=%d K=%lld", name, kname, a.splits, M, L.Cout, L.K());
     enc->records.push_back({label, flops});
     AAE_HIP_TRY(hipGetLastError());
     if (int rc = tm.mark()) return rc;
@@ -641,6 +651,9 @@ int aae_encoder_create(const aae_encoder_desc* d, const void* const* hw, int n_w
     (void)hipFuncSetAttribute((const void*)aae::conv_igemm_x3h_kernel<aae::X3H_OUT_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
     (void)hipFuncSetAttribute((const void*)aae::conv_igemm_x3h_kernel<aae::X3H_OUT_PLANES>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
     (void)hipFuncSetAttribute((const void*)aae::conv_igemm_x3h_kernel<aae::X3H_OUT_PARTIAL>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
+    (void)hipFuncSetAttribute((const void*)aae::conv_igemm_x3h_dma_kernel<aae::X3H_OUT_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
+    (void)hipFuncSetAttribute((const void*)aae::conv_igemm_x3h_dma_kernel<aae::X3H_OUT_PLANES>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
+    (void)hipFuncSetAttribute((const void*)aae::conv_igemm_x3h_dma_kernel<aae::X3H_OUT_PARTIAL>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
     if (enc->layers[0].kind == KIND_FIRST_MFMA) {
         const int sm = enc->layers[0].first_smem;
         (void)hipFuncSetAttribute((const void*)aae::conv_first_f32_kernel<5, 3, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
@@ -668,6 +681,7 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
     if (!strcmp(name, "splitk_min_base_blocks")) enc->splitk_min_base_blocks = value;
     else if (!strcmp(name, "splitk_target_blocks")) enc->splitk_target_blocks = value;
     else if (!strcmp(name, "igemm_stagger")) enc->igemm_stagger = value;
+    else if (!strcmp(name, "x3h_dma")) enc->x3h_dma = value ? 1 : 0;
     else if (!strcmp(name, "x3h_act_shift")) {
         if (value < -8 || value > 12) return fail(AAE_ERR_INVALID, "x3h_act_shift %d outside [-8, 12]", value);
         enc->x3h_act_shift = value;

@@ -67,6 +67,16 @@ __device__ __forceinline__ f32x4 buffer_load4(buffer_rsrc r, uint32_t byte_off) 
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
 }
 
+// LDS-DMA: buffer_load_dwordx4 ... lds.  Lane l's 16 bytes go straight from the buffer view to
+// LDS at lds_wave_base + 16*l (no VGPR staging, no ds_write); out-of-range lanes deposit zeros.
+// lds_wave_base must be wave-uniform.  Completion is counted by vmcnt: a consumer may read the
+// bytes only after every issuing wave has passed wait_dma_and_lds() and a barrier.
+__device__ __forceinline__ void lds_dma16(buffer_rsrc r, uint32_t byte_off, float* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)byte_off, 0, 0, 0);
+}
+__device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ void wait_dma_and_lds() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
+
 // Cross-lane add through the DPP path (no LDS crossbar).  Lanes whose source is outside
 // the row / masked out contribute 0.
 template <int CTRL, int ROW_MASK>

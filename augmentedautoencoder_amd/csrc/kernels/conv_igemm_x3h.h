@@ -43,6 +43,7 @@ struct ConvIgemmX3hArgs {
     int relu;
     float inv_scale;          // 2^-(act_shift_in + w_shift)
     float out_scale;          // 2^act_shift_out (OUT_PLANES)
+    unsigned wp_bytes;        // size of wp (LDS-DMA variant reads it through a buffer view)
 };
 
 enum { X3H_OUT_F32 = 0, X3H_OUT_PLANES = 1, X3H_OUT_PARTIAL = 2 };
@@ -72,6 +73,48 @@ __device__ __forceinline__ void x3h_mfma_tile(const X3hFrag& f, int q, f32x16 (&
     acc[mi][ni] = mfma_32x32x16_f16(f.al[mi], f.bh[ni], acc[mi][ni]);
     acc[mi][ni] = mfma_32x32x16_f16(f.ah[mi], f.bl[ni], acc[mi][ni]);
     acc[mi][ni] = mfma_32x32x16_f16(f.ah[mi], f.bh[ni], acc[mi][ni]);
+}
+
+// bias / ReLU / folded BN and the store of a wave's 64x64 accumulator tile in the layout OUT names
+template <int OUT>
+__device__ __forceinline__ void x3h_epilogue(const ConvIgemmX3hArgs& p, const f32x16 (&acc)[2][2], int mt, int nt, int split,
+                                             int wm, int wn, int lane) {
+    const int i = lane & 31;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+        const int n = nt * 128 + wn * 64 + ni * 32 + i;
+        if (n >= p.Cout) continue;
+        float bias = 0.f, sc = 1.f, sh = 0.f;
+        if (OUT != X3H_OUT_PARTIAL) {
+            bias = p.bias[n];
+            if (p.bn_scale) { sc = p.bn_scale[n]; sh = p.bn_shift[n]; }
+        }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mt * kBM + wm * 64 + mi * 32 + acc_row(r, lane);
+                if (m >= p.M) continue;
+                float v = acc[mi][ni][r] * p.inv_scale;
+                if (OUT == X3H_OUT_PARTIAL) {
+                    reinterpret_cast<float*>(p.out)[((long long)split * p.M + m) * p.Cout + n] = v;
+                } else {
+                    v += bias;
+                    if (p.relu) v = fmaxf(v, 0.f);
+                    if (p.bn_scale) v = v * sc + sh;
+                    if (OUT == X3H_OUT_F32) {
+                        reinterpret_cast<float*>(p.out)[(long long)m * p.Cout + n] = v;
+                    } else {
+                        unsigned short hi, lo;
+                        split_f16(v * p.out_scale, hi, lo);
+                        unsigned short* o = reinterpret_cast<unsigned short*>(p.out);
+                        o[(long long)m * p.Cout + n] = hi;
+                        o[(long long)p.M * p.Cout + (long long)m * p.Cout + n] = lo;
+                    }
+                }
+            }
+        }
+    }
 }
 
 template <int OUT>
@@ -206,43 +249,148 @@ __global__ __launch_bounds__(256) void conv_igemm_x3h_kernel(const ConvIgemmX3hA
         if (it < nslab) iteration(P0{}, it);
     }
 
-    // ---- epilogue -----------------------------------------------------------------------------
-    const int i = lane & 31;
+    x3h_epilogue<OUT>(p, acc, mt, nt, split, wm, wn, lane);
+}
+
+// ---- LDS-DMA variant ------------------------------------------------------------------------
+// Same tiles, same LDS slab images, same arithmetic; the operand slabs travel global -> LDS with
+// buffer_load_dwordx4 ... lds (no staging registers, no ds_write_b128: the 16-B LDS stores are
+// what saturates the LDS path in the kernel above -- 13 cycles per wave-store against 4 per
+// fragment read).  A DMA piece is lane-linear in LDS (lane l -> base + 16 l), so the XOR swizzle of
+// the A image is applied on the source side: the lane that owns physical slot ps of row r fetches
+// logical slot ps ^ ((r>>1)&7).
+//
+// Two LDS buffers, one barrier per slab, the DMA runs two slabs ahead:
+//   iteration it (slab it, P = it&1; its fragments are already in registers):
+//     step 0 (12 MFMAs on f0)
+//     wait vmcnt/lgkmcnt, barrier   -> slab it+1 has landed in buffer P^1 (issued one iteration ago)
+//                                      and every wave is done reading buffer P
+//     read the fragments of slab it+1 from P^1 (all ds_reads first: nothing the compiler could
+//     order behind a DMA), then issue the 8 DMA pieces of slab it+2 into buffer P, all under
+//     step 1 (12 MFMAs on f1[P]).
+template <int OUT>
+__global__ __launch_bounds__(256) void conv_igemm_x3h_dma_kernel(const ConvIgemmX3hArgs p) {
+    AAE_DYN_SMEM(smem_raw);
+    float* As = reinterpret_cast<float*>(smem_raw);            // [2][128 rows][32 dwords]
+    float* Bs = As + 2 * kSlabFloatsA;                         // [2][8 slots][128 cols][4 dwords]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    const int nblk = p.num_mt * p.num_nt * p.splits;
+    const int L = xcd_remap(blockIdx.x, nblk);
+    const int nt = L % p.num_nt;
+    const int mt = (L / p.num_nt) % p.num_mt;
+    const int split = L / (p.num_nt * p.num_mt);
+    const int slab0 = split * p.slabs_per_split;
+    const int slab1 = min(slab0 + p.slabs_per_split, p.slabs_total);
+    const int nslab = slab1 - slab0;
+
+    // ---- A pieces: piece q of wave w fills rows 32q + 8w .. +7 (8 lanes per row) --------------------
+    const int a_row = tid >> 3;                                    // + 32 q
+    const int a_slot = (tid & 7) ^ ((a_row >> 1) & 7);             // logical slot for this LDS position
+    const buffer_rsrc xbuf = make_buffer(p.x, p.x_bytes);
+    const buffer_rsrc wbuf = make_buffer(p.wp, p.wp_bytes);
+    unsigned a_off[4];
+    int a_ih0[4], a_iw0[4];
+    bool a_ok[4];
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int n = nt * 128 + wn * 64 + ni * 32 + i;
-        if (n >= p.Cout) continue;
-        float bias = 0.f, sc = 1.f, sh = 0.f;
-        if (OUT != X3H_OUT_PARTIAL) {
-            bias = p.bias[n];
-            if (p.bn_scale) { sc = p.bn_scale[n]; sh = p.bn_shift[n]; }
-        }
-#pragma unroll
-        for (int mi = 0; mi < 2; ++mi) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mt * kBM + wm * 64 + mi * 32 + acc_row(r, lane);
-                if (m >= p.M) continue;
-                float v = acc[mi][ni][r] * p.inv_scale;
-                if (OUT == X3H_OUT_PARTIAL) {
-                    reinterpret_cast<float*>(p.out)[((long long)split * p.M + m) * p.Cout + n] = v;
-                } else {
-                    v += bias;
-                    if (p.relu) v = fmaxf(v, 0.f);
-                    if (p.bn_scale) v = v * sc + sh;
-                    if (OUT == X3H_OUT_F32) {
-                        reinterpret_cast<float*>(p.out)[(long long)m * p.Cout + n] = v;
-                    } else {
-                        unsigned short hi, lo;
-                        split_f16(v * p.out_scale, hi, lo);
-                        unsigned short* o = reinterpret_cast<unsigned short*>(p.out);
-                        o[(long long)m * p.Cout + n] = hi;
-                        o[(long long)p.M * p.Cout + (long long)m * p.Cout + n] = lo;
-                    }
-                }
-            }
-        }
+    for (int q = 0; q < 4; ++q) {
+        const int m = mt * kBM + a_row + 32 * q;
+        a_ok[q] = m < p.M;
+        const int mm = a_ok[q] ? m : 0;
+        const int b = mm / (p.Ho * p.Wo);
+        const int rem = mm - b * (p.Ho * p.Wo);
+        const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+        a_ih0[q] = oh * p.S - p.pt;
+        a_iw0[q] = ow * p.S - p.pl;
+        a_off[q] = (unsigned)((((long long)b * p.H + a_ih0[q]) * p.W + a_iw0[q]) * (long long)p.Cin * 2) +
+                   (unsigned)(a_slot & 3) * 16u + (unsigned)(a_slot >> 2) * p.plane_bytes;
     }
+    // ---- B pieces: idx = tid + 256 q -> slot = idx>>7, col = idx&127, LDS position idx ------------
+    const unsigned b_off0 = (unsigned)(((tid >> 7) * p.CoutPad + nt * 128 + (tid & 127)) * 16);
+    const unsigned b_piece_stride = (unsigned)(2 * p.CoutPad * 16);   // two slot rows per piece
+
+    const int taps = p.KS * p.KS;
+    int cc = slab0 / taps;
+    const int tap0 = slab0 - cc * taps;
+    int kh = tap0 / p.KS, kw = tap0 - kh * p.KS;
+    unsigned tap_off = 0;
+
+    auto dma_piece = [&](int slab, int buf, int q) {
+        if (q == 0) tap_off = (unsigned)(((kh * p.W + kw) * p.Cin + cc * 32) * 2);
+        const bool ok = a_ok[q] && (unsigned)(a_ih0[q] + kh) < (unsigned)p.H && (unsigned)(a_iw0[q] + kw) < (unsigned)p.W;
+        lds_dma16(xbuf, ok ? a_off[q] + tap_off : kOobOffset, As + buf * kSlabFloatsA + (32 * q + 8 * wave) * kBK);
+        lds_dma16(wbuf, b_off0 + (unsigned)(slab * 4 + q) * b_piece_stride, Bs + buf * (8 * 128 * 4) + (256 * q + 64 * wave) * 4);
+        if (q == 3) {
+            if (++kw == p.KS) { kw = 0; if (++kh == p.KS) { kh = 0; ++cc; } }
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    if (nslab > 0) {
+        using P0 = std::integral_constant<int, 0>;
+        using P1 = std::integral_constant<int, 1>;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dma_piece(slab0, 0, q);
+        wait_dma_and_lds();
+        __syncthreads();
+        X3hFrag f0, f1[2];
+        x3h_frag_load(As, Bs, wm * 64, wn * 64, lane, 0, f0);
+        x3h_frag_load(As, Bs, wm * 64, wn * 64, lane, 1, f1[0]);
+        sched_fence();
+        if (nslab > 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dma_piece(slab0 + 1, 1, q);
+        }
+
+        auto iteration = [&](auto PAR, int it) {
+            constexpr int P = decltype(PAR)::value;
+            const bool has1 = it + 1 < nslab, has2 = it + 2 < nslab;
+            const float* An = As + (P ^ 1) * kSlabFloatsA;
+            const float* Btn = Bs + (P ^ 1) * (8 * 128 * 4);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                sched_fence();
+                x3h_mfma_tile(f0, q, acc);
+            }
+            sched_fence();
+            if (has1) {
+                wait_dma_and_lds();
+                __syncthreads();
+                sched_fence();
+                x3h_frag_load(An, Btn, wm * 64, wn * 64, lane, 0, f0);
+            }
+            sched_fence();
+            x3h_mfma_tile(f1[P], 0, acc);
+            sched_fence();
+            if (has1) x3h_frag_load(An, Btn, wm * 64, wn * 64, lane, 1, f1[P ^ 1]);
+            sched_fence();
+            x3h_mfma_tile(f1[P], 1, acc);
+            sched_fence();
+            if (has2) { dma_piece(slab0 + it + 2, P, 0); dma_piece(slab0 + it + 2, P, 1); }
+            sched_fence();
+            x3h_mfma_tile(f1[P], 2, acc);
+            sched_fence();
+            if (has2) { dma_piece(slab0 + it + 2, P, 2); dma_piece(slab0 + it + 2, P, 3); }
+            sched_fence();
+            x3h_mfma_tile(f1[P], 3, acc);
+        };
+        int it = 0;
+        for (; it + 1 < nslab; it += 2) {
+            iteration(P0{}, it);
+            iteration(P1{}, it + 1);
+        }
+        if (it < nslab) iteration(P0{}, it);
+    }
+    x3h_epilogue<OUT>(p, acc, mt, nt, split, wm, wn, lane);
 }
 
 }  // namespace aae

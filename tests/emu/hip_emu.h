@@ -67,6 +67,16 @@ inline f32x4 buffer_load4(buffer_rsrc r, uint32_t byte_off) {
     return v;
 }
 
+// buffer_load_dwordx4 ... lds model: lane l's 16 bytes land at wave_base + 16*l (zeros when
+// out of range).  The emulator completes it at issue; the landing order on hardware is
+// covered by wait_dma_and_lds() + barrier in the kernels and by the GPU parity tests.
+inline void lds_dma16(buffer_rsrc r, uint32_t byte_off, float* lds_wave_base) {
+    const f32x4 v = buffer_load4(r, byte_off);
+    memcpy(reinterpret_cast<unsigned char*>(lds_wave_base) + 16 * lane_id(), &v, 16);
+}
+inline void wait_dma_and_lds() {}
+inline int wave_uniform(int v) { return v; }
+
 inline f32x16 mfma_32x32x2(float a, float b, f32x16 c) {
     float ab[2] = {a, b};
     const aae_emu::lane_slot* all = aae_emu::wave_exchange(ab, sizeof(ab));

@@ -100,12 +100,13 @@ def test_small_latent_and_l2_normalize():
     cb.close()
 
 
+@pytest.mark.parametrize('dma', [0, 1])
 @pytest.mark.parametrize('cfg,B,nosplit', [
     (EncoderConfig((16, 16, 3), [32, 64], [2, 2], 5, 128), 3, False),
     (EncoderConfig((16, 16, 3), [32, 64], [2, 2], 5, 128, True), 2, True),
     (EncoderConfig((12, 12, 1), [160, 32], [1, 2], 5, 128), 1, False),
 ])
-def test_split_precision_f32x3h_path(cfg, B, nosplit):
+def test_split_precision_f32x3h_path(cfg, B, nosplit, dma):
     """f32x3h (3 fp16 MFMAs per product on (hi, lo) operand pairs, fp32 accumulate): same
     fp32-roundoff error class as the exact fp32 path, measured against the fp64 oracle."""
     w = synth.make_weights(seed=5, shape=cfg.shape, num_filter=cfg.num_filter, strides=cfg.strides,
@@ -113,10 +114,11 @@ def test_split_precision_f32x3h_path(cfg, B, nosplit):
     x = synth.make_crops(B, seed=6, shape=cfg.shape)
     enc = eb.EmuEncoder(w, cfg)
     enc.set_option('precision', 1)
+    enc.set_option('x3h_dma', dma)       # operand slabs by LDS-DMA instead of register staging
     if nosplit:
         enc.set_option('splitk_min_base_blocks', 0)
     z = enc.forward(x)
-    assert any('x3h' in l for l in enc.labels())
+    assert any(('x3h_dma' if dma else 'x3h') in l for l in enc.labels())
     z64, acts = ref.encoder_forward_np(ref.input_to_float(x), w, cfg.strides, cfg.batch_norm, return_activations=True)
     for i, a in enumerate(acts):
         assert np.abs(enc.activation(i) - a).max() / np.abs(a).max() < 5e-6, 'layer %d' % i

@@ -235,15 +235,18 @@ def test_update_embedding_rebuilds_codebook():
         assert got == want_row or abs(int(got) - int(want_row)) == 35
 
 
-def test_split_precision_f32x3h_mode_meets_the_same_tolerances():
+@pytest.mark.parametrize('dma', [0, 1])
+def test_split_precision_f32x3h_mode_meets_the_same_tolerances(dma):
     """Opt-in f32x3h mode (fp16 hi/lo operand pairs, 3 MFMAs per product, fp32 accumulate):
-    same acceptance as the fp32 path -- cosine within 1e-5, indices tie-aware equal."""
+    same acceptance as the fp32 path -- cosine within 1e-5, indices tie-aware equal.
+    dma=1: operand slabs by LDS-DMA; same MFMA sequence, so bit-identical to dma=0."""
     from augmentedautoencoder_amd.engine import CodebookEngine, EncoderEngine
     from augmentedautoencoder_amd.weights import EncoderConfig
     weights = synth.make_weights(seed=2024)
     E = synth.make_codebook(92232, 128, seed=7, planted_duplicates=64)
     enc = EncoderEngine(EncoderConfig(), weights)
     enc.set_option('precision', 1)
+    enc.set_option('x3h_dma', dma)
     cb = CodebookEngine(E)
     for B in (1, 5, 32):
         crops = synth.make_crops(B, seed=300 + B)
@@ -263,6 +266,12 @@ def test_split_precision_f32x3h_mode_meets_the_same_tolerances():
     z_a = enc.encode(crops).cpu().numpy()
     z_b = enc.encode(crops).cpu().numpy()
     assert np.array_equal(z_a, z_b)                       # deterministic
+    if dma:
+        enc.set_option('x3h_dma', 0)
+        z_staged = enc.encode(crops).cpu().numpy()
+        enc.set_option('x3h_dma', 1)
+        for _ in range(5):                                # landing-order races would show up as flipped bits
+            assert np.array_equal(enc.encode(crops).cpu().numpy(), z_staged)
     enc.set_option('precision', 0)
     z_f32 = enc.encode(crops).cpu().numpy()
     assert np.abs(z_a - z_f32).max() / np.abs(z_f32).max() < 1e-5

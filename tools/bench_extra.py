@@ -82,11 +82,12 @@ def main():
         cb.set_scan_mode(_lib.AAE_SCAN_AUTO)
     if 'x3h' in what:
         x = torch.from_numpy(synth.make_crops(256, seed=1)).cuda()
-        for prec in (0, 1):
+        for prec, dma in ((0, 0), (1, 0), (1, 1), (1, 0), (1, 1)):
             enc.set_option('precision', prec)
+            enc.set_option('x3h_dma', dma)
             ms = timeit(lambda: enc.encode(x), 10)
             _, recs = enc.encode_timed(x)
-            print(json.dumps({'what': 'x3h', 'precision': prec, 'B': 256, 'encode_ms': round(ms, 4),
+            print(json.dumps({'what': 'x3h', 'precision': prec, 'dma': dma, 'B': 256, 'encode_ms': round(ms, 4),
                               'crops_per_s': round(256 / ms * 1e3, 1), 'encoder_tflops_equiv': round(cfg.flops_per_crop() * 256 / ms / 1e9, 2),
                               'kernels': [(l.split(':')[0] + ':' + l.split(':')[1].split()[0], round(t, 4), round(f / t / 1e9, 1) if t > 0 else 0) for l, t, f in recs]}))
         enc.set_option('precision', 0)
