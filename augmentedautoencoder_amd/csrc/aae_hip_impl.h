@@ -96,6 +96,7 @@ struct aae_encoder {
     int splitk_min_base_blocks = 384;      // split K only when the un-split grid is smaller than this
     int splitk_target_blocks = 512;        // ... and then aim for about this many blocks
     int precision = 0;                     // 0: exact fp32 MFMA; 1: f32x3h split-precision igemm (explicit opt-in)
+    int igemm_dma = 1;                     // fp32 igemm operand slabs by LDS-DMA (buffer_load ... lds); 0 = register-staged variant
     int x3h_dma = 1;                       // f32x3h operand slabs by LDS-DMA (buffer_load ... lds); 0 = register-staged variant
     int x3h_act_shift = 4;                 // activations travel as halves of x*2^shift in f32x3h mode (|x| < 4094 exact range)
     int igemm_stagger = 0;                 // kcycles of start delay for every 2nd block generation of the igemm (0 = off)
@@ -252,23 +253,28 @@ static int launch_igemm(aae_encoder* enc, const Layer& L, const float* x, int M,
         return fail(AAE_ERR_UNSUPPORTED, "%s: input activation of %llu bytes exceeds the 4 GiB buffer view; use a smaller batch", name, x_bytes);
     a.x_bytes = (unsigned)x_bytes;
     a.slabs_total = (int)(L.K() / 32);
+    a.wp_bytes = (unsigned)((unsigned long long)a.slabs_total * 8ull * L.CoutPad * 16ull);
     a.num_mt = ceil_div(M, 128);
     a.num_nt = L.CoutPad / 128;
     choose_splits(enc, a.num_mt * a.num_nt, a.slabs_total, &a.splits, &a.slabs_per_split);
     const int nblk = a.num_mt * a.num_nt * a.splits;
     const double flops = 2.0 * (double)M * (double)L.K() * (double)L.Cout;
+    const bool dma = enc->igemm_dma != 0;
+    const char* kname = dma ? "conv_igemm_f32_dma" : "conv_igemm_f32";
     char label[96];
     if (a.splits == 1) {
         a.out = out;
-        AAE_LAUNCH((aae::conv_igemm_f32_kernel<false>), dim3(nblk), dim3(256), aae::kConvIgemmSmem, stream, a);
-        snprintf(label, sizeof(label), "%s:conv_igemm_f32 M=%d N=%d K=%lld", name, M, L.Cout, L.K());
+        if (dma) AAE_LAUNCH((aae::conv_igemm_f32_kernel<false, true>), dim3(nblk), dim3(256), aae::kConvIgemmSmem, stream, a);
+        else AAE_LAUNCH((aae::conv_igemm_f32_kernel<false, false>), dim3(nblk), dim3(256), aae::kConvIgemmSmem, stream, a);
+        snprintf(label, sizeof(label), "%s:%s M=%d N=%d K=%lld", name, kname, M, L.Cout, L.K());
         enc->records.push_back({label, flops});
         AAE_HIP_TRY(hipGetLastError());
         return tm.mark();
     }
     a.out = partial;
-    AAE_LAUNCH((aae::conv_igemm_f32_kernel<true>), dim3(nblk), dim3(256), aae::kConvIgemmSmem, stream, a);
-    snprintf(label, sizeof(label), "%s:conv_igemm_f32_splitk%d M=%d N=%d K=%lld", name, a.splits, M, L.Cout, L.K());
+    if (dma) AAE_LAUNCH((aae::conv_igemm_f32_kernel<true, true>), dim3(nblk), dim3(256), aae::kConvIgemmSmem, stream, a);
+    else AAE_LAUNCH((aae::conv_igemm_f32_kernel<true, false>), dim3(nblk), dim3(256), aae::kConvIgemmSmem, stream, a);
+    snprintf(label, sizeof(label), "%s:%s_splitk%d M=%d N=%d K=%lld", name, kname, a.splits, M, L.Cout, L.K());
     enc->records.push_back({label, flops});
     AAE_HIP_TRY(hipGetLastError());
     if (int rc = tm.mark()) return rc;
@@ -648,6 +654,8 @@ int aae_encoder_create(const aae_encoder_desc* d, const void* const* hw, int n_w
     }
     (void)hipFuncSetAttribute((const void*)aae::conv_igemm_f32_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
     (void)hipFuncSetAttribute((const void*)aae::conv_igemm_f32_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
+    (void)hipFuncSetAttribute((const void*)aae::conv_igemm_f32_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
+    (void)hipFuncSetAttribute((const void*)aae::conv_igemm_f32_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
     (void)hipFuncSetAttribute((const void*)aae::conv_igemm_x3h_kernel<aae::X3H_OUT_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
     (void)hipFuncSetAttribute((const void*)aae::conv_igemm_x3h_kernel<aae::X3H_OUT_PLANES>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
     (void)hipFuncSetAttribute((const void*)aae::conv_igemm_x3h_kernel<aae::X3H_OUT_PARTIAL>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
@@ -682,6 +690,7 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
     else if (!strcmp(name, "splitk_target_blocks")) enc->splitk_target_blocks = value;
     else if (!strcmp(name, "igemm_stagger")) enc->igemm_stagger = value;
     else if (!strcmp(name, "x3h_dma")) enc->x3h_dma = value ? 1 : 0;
+    else if (!strcmp(name, "igemm_dma")) enc->igemm_dma = value ? 1 : 0;
     else if (!strcmp(name, "x3h_act_shift")) {
         if (value < -8 || value > 12) return fail(AAE_ERR_INVALID, "x3h_act_shift %d outside [-8, 12]", value);
         enc->x3h_act_shift = value;

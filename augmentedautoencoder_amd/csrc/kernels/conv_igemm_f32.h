@@ -36,17 +36,24 @@ struct ConvIgemmArgs {
     int num_mt, num_nt, splits;
     int relu;
     int stagger;            // kcycles of start delay for every second block generation (0 = off)
+    unsigned wp_bytes;      // size of wp (the LDS-DMA variant reads it through a buffer view)
 };
 
 constexpr int kConvIgemmSmem = 2 * (kSlabFloatsA + 8 * 128 * 4) * 4;   // 64 KiB
 
-template <bool SPLITK>
+// DMA = true: the operand slabs go global -> LDS with buffer_load_dwordx4 ... lds (lds_dma16)
+// instead of through staging registers and ds_write_b128.  A DMA piece is lane-linear in LDS,
+// so the A image's XOR swizzle moves to the source side: the lane that owns physical slot ps
+// of row r fetches logical slot ps ^ ((r>>1)&7).  Slab t+1 is issued under group 0 of slab t
+// into the other buffer (free since the barrier of slab t-1) and is waited for (vmcnt) by
+// every wave right before the barrier of slab t.  Same MFMA sequence, bit-identical results.
+template <bool SPLITK, bool DMA = false>
 __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvIgemmArgs p) {
     AAE_DYN_SMEM(smem_raw);
     float* As = reinterpret_cast<float*>(smem_raw);            // [2][128*32]
     float* Bs = As + 2 * kSlabFloatsA;                         // [2][8*128*4]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = DMA ? wave_uniform(tid >> 6) : tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
 
     const int nblk = p.num_mt * p.num_nt * p.splits;
@@ -58,8 +65,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvIgemmArgs
     const int slab1 = min(slab0 + p.slabs_per_split, p.slabs_total);
 
     // ---- A loader: thread -> 4 (row, slot) pairs, row = tid/8 + 32*q -------
-    const int a_slot = tid & 7;
     const int a_row = tid >> 3;
+    const int a_slot = DMA ? (tid & 7) ^ ((a_row >> 1) & 7) : tid & 7;
     // The activation tensor is read through a bounds-checked buffer view: taps that fall in
     // the SAME padding (or rows >= M) get the out-of-range offset and the hardware returns
     // zeros -- no branch around the load, so nothing forces an early vmcnt wait.
@@ -82,6 +89,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvIgemmArgs
     // ---- B loader: thread -> 4 (slot, col) pairs, idx = tid + 256*q ----------
     const float* b_ptr = p.wp + ((long long)nt * 128 + (tid & 127)) * 4 + (long long)(tid >> 7) * p.CoutPad * 4;
     const long long b_slot_stride = (long long)p.CoutPad * 4;      // floats per k-slot row
+    const buffer_rsrc wbuf = make_buffer(p.wp, DMA ? p.wp_bytes : 0u);
+    const unsigned b_off0 = (unsigned)(((tid >> 7) * p.CoutPad + nt * 128 + (tid & 127)) * 16);
+    const unsigned b_piece_stride = (unsigned)(2 * p.CoutPad * 16);
 
     // K order: 32-channel chunk outermost, then kh, then kw (fastest).  For one channel chunk
     // the KS*KS taps of an M tile touch the same few input rows, so the working set the
@@ -100,16 +110,22 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvIgemmArgs
     // four pieces so they can sit in the shadow of individual MFMAs (see the main loop).
     f32x4 ra[4], rb[4];
     unsigned tap_off = 0;
-    auto fetch_piece = [&](int slab, int q) {
+    auto fetch_piece = [&](int slab, int q, int buf) {
         if (q == 0) tap_off = (unsigned)(((kh * p.W + kw) * p.Cin + cc * 32) * 4);
         const bool ok = a_ok[q] && (unsigned)(a_ih0[q] + kh) < (unsigned)p.H && (unsigned)(a_iw0[q] + kw) < (unsigned)p.W;
-        ra[q] = buffer_load4(xbuf, ok ? a_off[q] + tap_off : kOobOffset);
-        rb[q] = *reinterpret_cast<const f32x4*>(b_ptr + ((long long)slab * 8 + 2 * q) * b_slot_stride);
+        if (DMA) {
+            lds_dma16(xbuf, ok ? a_off[q] + tap_off : kOobOffset, As + buf * kSlabFloatsA + (32 * q + 8 * wave) * kBK);
+            lds_dma16(wbuf, b_off0 + (unsigned)(slab * 4 + q) * b_piece_stride, Bs + buf * (8 * 128 * 4) + (256 * q + 64 * wave) * 4);
+        } else {
+            ra[q] = buffer_load4(xbuf, ok ? a_off[q] + tap_off : kOobOffset);
+            rb[q] = *reinterpret_cast<const f32x4*>(b_ptr + ((long long)slab * 8 + 2 * q) * b_slot_stride);
+        }
         if (q == 3) {                            // advance the (cc, kh, kw) counters to the next slab
             if (++kw == p.KS) { kw = 0; if (++kh == p.KS) { kh = 0; ++cc; } }
         }
     };
     auto stash_piece = [&](int buf, int q) {
+        if (DMA) return;
         lds_write4(As + buf * kSlabFloatsA + a_slab_off(a_row + 32 * q, a_slot), ra[q]);
         lds_write4(Bs + buf * (8 * 128 * 4) + (tid + 256 * q) * 4, rb[q]);
     };
@@ -124,9 +140,10 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvIgemmArgs
 
     if (slab0 < slab1) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) fetch_piece(slab0, q);
+        for (int q = 0; q < 4; ++q) fetch_piece(slab0, q, 0);
 #pragma unroll
         for (int q = 0; q < 4; ++q) stash_piece(0, q);
+        if (DMA) wait_dma_and_lds();
         __syncthreads();
         int buf = 0;
         // Software pipeline over the 4 k-groups (4 q-steps x 4 MFMAs each) of every slab with two
@@ -153,7 +170,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvIgemmArgs
                 sched_fence();
                 frag_mfma_q<2, 2>(fa0, fb0, q, acc);
                 sched_fence();
-                if (more) fetch_piece(t + 1, q);
+                if (more) fetch_piece(t + 1, q, buf ^ 1);
             }
             sched_fence();
             frag_load<2, 2>(A, Bt, 128, wm * 64, wn * 64, lane, 2, fa0, fb0);
@@ -168,6 +185,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvIgemmArgs
                 sched_fence();
                 if (more) stash_piece(buf ^ 1, q);
             }
+            if (DMA) wait_dma_and_lds();
             __syncthreads();
             sched_fence();
             if (more) frag_load<2, 2>(An, Btn, 128, wm * 64, wn * 64, lane, 0, fa0, fb0);

@@ -12,7 +12,7 @@ from oracle import reference_cpu as ref
 from oracle import synth
 
 
-def _run(cfg, B, seed, f32_in=False, nosplit=False):
+def _run(cfg, B, seed, f32_in=False, nosplit=False, dma=0):
     w = synth.make_weights(seed=seed, shape=cfg.shape, num_filter=cfg.num_filter, strides=cfg.strides,
                            latent=cfg.latent_space_size, batch_norm=cfg.batch_norm, kernel_size=cfg.kernel_size)
     x = synth.make_crops(B, seed=seed + 1, shape=cfg.shape)
@@ -20,6 +20,7 @@ def _run(cfg, B, seed, f32_in=False, nosplit=False):
     enc = eb.EmuEncoder(w, cfg)
     if nosplit:
         enc.set_option('splitk_min_base_blocks', 0)
+    enc.set_option('igemm_dma', dma)           # operand slabs by LDS-DMA instead of register staging
     z = enc.forward(xin)
     z64, acts = ref.encoder_forward_np(ref.input_to_float(x), w, cfg.strides, cfg.batch_norm, return_activations=True)
     for i, a in enumerate(acts):
@@ -31,13 +32,16 @@ def _run(cfg, B, seed, f32_in=False, nosplit=False):
     return labels
 
 
-def test_first_layer_mfma_igemm_splitk_and_dense():
-    labels = _run(EncoderConfig((16, 16, 3), [32, 64], [2, 2], 5, 128), 3, 1)
+@pytest.mark.parametrize('dma', [0, 1])
+def test_first_layer_mfma_igemm_splitk_and_dense(dma):
+    labels = _run(EncoderConfig((16, 16, 3), [32, 64], [2, 2], 5, 128), 3, 1, dma=dma)
     assert 'conv_first_f32' in labels[0] and 'splitk' in labels[1] and labels[-1].endswith('splitk_reduce')
+    assert ('f32_dma' in labels[1]) == bool(dma)
 
 
-def test_unsplit_igemm_epilogue_with_batchnorm():
-    labels = _run(EncoderConfig((16, 16, 3), [32, 64], [2, 2], 5, 128, True), 2, 41, nosplit=True)
+@pytest.mark.parametrize('dma', [0, 1])
+def test_unsplit_igemm_epilogue_with_batchnorm(dma):
+    labels = _run(EncoderConfig((16, 16, 3), [32, 64], [2, 2], 5, 128, True), 2, 41, nosplit=True, dma=dma)
     assert all('splitk' not in l for l in labels)
 
 
@@ -48,8 +52,9 @@ def test_partial_tiles_row_straddling_and_odd_channel_counts():
     assert 'conv_direct_generic' in labels[1]
 
 
-def test_grayscale_stride1_and_two_channel_blocks():
-    _run(EncoderConfig((12, 12, 1), [160, 32], [1, 2], 5, 128), 1, 21)
+@pytest.mark.parametrize('dma', [0, 1])
+def test_grayscale_stride1_and_two_channel_blocks(dma):
+    _run(EncoderConfig((12, 12, 1), [160, 32], [1, 2], 5, 128), 1, 21, dma=dma)
 
 
 def test_generic_fallback_everything():

@@ -235,6 +235,28 @@ def test_update_embedding_rebuilds_codebook():
         assert got == want_row or abs(int(got) - int(want_row)) == 35
 
 
+def test_fp32_igemm_lds_dma_variant_is_bit_identical():
+    """igemm_dma=1 moves the operand slabs global -> LDS by DMA (no staging registers); the MFMA
+    sequence is unchanged, so every output bit must match the register-staged kernel.  Repeats
+    catch landing-order races (a slab read before its DMA arrived)."""
+    from augmentedautoencoder_amd.engine import EncoderEngine
+    from augmentedautoencoder_amd.weights import EncoderConfig
+    weights = synth.make_weights(seed=2024)
+    enc = EncoderEngine(EncoderConfig(), weights)
+    for B in (1, 5, 256):
+        crops = synth.make_crops(B, seed=500 + B)
+        enc.set_option('igemm_dma', 0)
+        z0 = enc.encode(crops).cpu().numpy()
+        acts0 = [enc.activation(i).cpu().numpy() for i in range(4)] if B == 5 else []
+        enc.set_option('igemm_dma', 1)
+        for _ in range(4):
+            assert np.array_equal(enc.encode(crops).cpu().numpy(), z0)
+        for i, a in enumerate(acts0):
+            assert np.array_equal(enc.activation(i).cpu().numpy(), a), 'layer %d' % i
+        assert any('f32_dma' in l for l, _, _ in enc.encode_timed(crops)[1])
+    enc.close()
+
+
 @pytest.mark.parametrize('dma', [0, 1])
 def test_split_precision_f32x3h_mode_meets_the_same_tolerances(dma):
     """Opt-in f32x3h mode (fp16 hi/lo operand pairs, 3 MFMAs per product, fp32 accumulate):

@@ -91,6 +91,16 @@ def main():
                               'crops_per_s': round(256 / ms * 1e3, 1), 'encoder_tflops_equiv': round(cfg.flops_per_crop() * 256 / ms / 1e9, 2),
                               'kernels': [(l.split(':')[0] + ':' + l.split(':')[1].split()[0], round(t, 4), round(f / t / 1e9, 1) if t > 0 else 0) for l, t, f in recs]}))
         enc.set_option('precision', 0)
+    if 'dma' in what:
+        x = torch.from_numpy(synth.make_crops(256, seed=1)).cuda()
+        for dma in (0, 1, 0, 1):
+            enc.set_option('igemm_dma', dma)
+            ms = timeit(lambda: enc.encode(x), 10)
+            _, recs = enc.encode_timed(x)
+            print(json.dumps({'what': 'dma', 'igemm_dma': dma, 'B': 256, 'encode_ms': round(ms, 4),
+                              'crops_per_s': round(256 / ms * 1e3, 1), 'encoder_tflops': round(cfg.flops_per_crop() * 256 / ms / 1e9, 2),
+                              'kernels': [(l.split(':')[0] + ':' + l.split(':')[1].split()[0], round(t, 4), round(f / t / 1e9, 1) if t > 0 else 0) for l, t, f in recs]}))
+        enc.set_option('igemm_dma', 0)
     if 'config5' in what:
         # 368928 x 128 bf16 codebook (94.4 MB), batched queries, arg-max and top-5
         E5 = synth.make_codebook(368928, 128, seed=11)
