@@ -96,6 +96,8 @@ struct aae_encoder {
     int splitk_min_base_blocks = 384;      // split K only when the un-split grid is smaller than this
     int splitk_target_blocks = 512;        // ... and then aim for about this many blocks
     int precision = 0;                     // 0: exact fp32 MFMA; 1: f32x3h split-precision igemm (explicit opt-in)
+    int first_target_blocks = 1024;        // conv1 grid size aimed at (x N tiles); 2 blocks fit a CU
+    int first_max_tiles_per_block = 8;     // conv1: consecutive 128-pixel tiles one block walks with its weights in registers
     int igemm_dma = 1;                     // fp32 igemm operand slabs by LDS-DMA (buffer_load ... lds); 0 = register-staged variant
     int x3h_dma = 1;                       // f32x3h operand slabs by LDS-DMA (buffer_load ... lds); 0 = register-staged variant
     int x3h_act_shift = 4;                 // activations travel as halves of x*2^shift in f32x3h mode (|x| < 4094 exact range)
@@ -369,9 +371,9 @@ static int launch_first(aae_encoder* enc, const Layer& L, const void* x, bool u8
     a.out_scale = ldexpf(1.f, enc->x3h_act_shift);
     a.tiles_per_image = ceil_div(L.Ho * L.Wo, 128);
     a.total_tiles = B * a.tiles_per_image;
-    int tpb = ceil_div(a.total_tiles, 1024);
+    int tpb = ceil_div(a.total_tiles, enc->first_target_blocks);
     if (tpb < 1) tpb = 1;
-    if (tpb > 8) tpb = 8;
+    if (tpb > enc->first_max_tiles_per_block) tpb = enc->first_max_tiles_per_block;
     a.tiles_per_block = tpb;
     const dim3 grid(ceil_div(a.total_tiles, tpb), ceil_div(L.Cout, 128));
     if (L.Cin == 3) launch_first_t<5, 3>(a, u8, planes, grid, L.first_smem, stream);
@@ -691,6 +693,8 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
     else if (!strcmp(name, "igemm_stagger")) enc->igemm_stagger = value;
     else if (!strcmp(name, "x3h_dma")) enc->x3h_dma = value ? 1 : 0;
     else if (!strcmp(name, "igemm_dma")) enc->igemm_dma = value ? 1 : 0;
+    else if (!strcmp(name, "first_target_blocks")) enc->first_target_blocks = value < 1 ? 1 : value;
+    else if (!strcmp(name, "first_max_tiles_per_block")) enc->first_max_tiles_per_block = value < 1 ? 1 : value;
     else if (!strcmp(name, "x3h_act_shift")) {
         if (value < -8 || value > 12) return fail(AAE_ERR_INVALID, "x3h_act_shift %d outside [-8, 12]", value);
         enc->x3h_act_shift = value;

@@ -8,6 +8,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint16_t u16x4 __attribute__((ext_vector_type(4)));
 
 #define AAE_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
 

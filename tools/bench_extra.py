@@ -101,6 +101,18 @@ def main():
                               'crops_per_s': round(256 / ms * 1e3, 1), 'encoder_tflops': round(cfg.flops_per_crop() * 256 / ms / 1e9, 2),
                               'kernels': [(l.split(':')[0] + ':' + l.split(':')[1].split()[0], round(t, 4), round(f / t / 1e9, 1) if t > 0 else 0) for l, t, f in recs]}))
         enc.set_option('igemm_dma', 0)
+    if 'conv1' in what:
+        x = torch.from_numpy(synth.make_crops(256, seed=1)).cuda()
+        for tpb, tb in ((8, 1024), (16, 512), (32, 256), (4, 2048), (2, 4096), (8, 1024), (16, 512)):
+            enc.set_option('first_max_tiles_per_block', tpb)
+            enc.set_option('first_target_blocks', tb)
+            ts = []
+            for _ in range(5):
+                _, recs = enc.encode_timed(x)
+                ts.append(recs[0][1])
+            print(json.dumps({'what': 'conv1', 'max_tiles_per_block': tpb, 'target_blocks': tb, 'conv1_ms': [round(t, 4) for t in ts]}))
+        enc.set_option('first_max_tiles_per_block', 8)
+        enc.set_option('first_target_blocks', 1024)
     if 'config5' in what:
         # 368928 x 128 bf16 codebook (94.4 MB), batched queries, arg-max and top-5
         E5 = synth.make_codebook(368928, 128, seed=11)
