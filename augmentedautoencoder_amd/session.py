@@ -105,16 +105,23 @@ class CheckpointState(object):
 
 
 def get_checkpoint_state(ckpt_dir):
+    """tf.train.get_checkpoint_state stand-in.  Understands both the text CheckpointState
+    proto TensorFlow writes (model_checkpoint_path: "chkpt-30000" ...) and this package's
+    plain list of .npz files."""
     index = os.path.join(ckpt_dir, 'checkpoint')
     if not os.path.exists(index):
         return None
-    paths = []
     with open(index) as f:
-        for line in f:
-            line = line.strip()
-            if line:
-                p = line if os.path.isabs(line) else os.path.join(ckpt_dir, line)
-                paths.append(p)
+        text = f.read()
+
+    def absolute(p):
+        return p if os.path.isabs(p) else os.path.join(ckpt_dir, p)
+
+    from .tf_checkpoint import parse_checkpoint_state
+    latest, every = parse_checkpoint_state(text)
+    if latest is not None:
+        return CheckpointState(absolute(latest), [absolute(p) for p in (every or [latest])])
+    paths = [absolute(line.strip()) for line in text.splitlines() if line.strip()]
     if not paths:
         return None
     return CheckpointState(paths[-1], paths)
@@ -159,9 +166,20 @@ class Saver(object):
         return path
 
     def restore(self, session, ckpt_path):
-        if not ckpt_path.endswith('.npz'):
-            ckpt_path = ckpt_path + '.npz'
-        weights, emb, bbs = W.load_npz(ckpt_path)
+        """ckpt_path: a native '<prefix>.npz' (extension optional) or the prefix of a TensorFlow
+        checkpoint-v2 ('<prefix>.index' + '<prefix>.data-*'), read without TensorFlow by
+        tf_checkpoint.load_aae_variables under this saver's variable scope."""
+        if not ckpt_path.endswith('.npz') and os.path.exists(ckpt_path + '.index'):
+            from .tf_checkpoint import load_aae_variables
+            scope = self.scope
+            if scope is None:
+                scopes = sorted({s for (s, _, _) in self._members() if s})
+                scope = scopes[0] if len(scopes) == 1 else None
+            weights, emb, bbs = load_aae_variables(ckpt_path, scope)
+        else:
+            if not ckpt_path.endswith('.npz'):
+                ckpt_path = ckpt_path + '.npz'
+            weights, emb, bbs = W.load_npz(ckpt_path)
         for _, e, c in self._members():
             if e is not None:
                 e.load_weights(weights)
