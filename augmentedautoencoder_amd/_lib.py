@@ -29,12 +29,27 @@ EXPORTED_SYMBOLS = (
     'aae_codebook_create', 'aae_codebook_update', 'aae_codebook_destroy', 'aae_codebook_set_scan_mode',
     'aae_codebook_workspace_bytes', 'aae_codebook_nn', 'aae_codebook_similarity', 'aae_l2_normalize',
     'aae_crop_resize_u8',
+    'aae_decoder_create', 'aae_decoder_destroy', 'aae_decoder_workspace_bytes', 'aae_decoder_forward',
+    'aae_decoder_forward_timed', 'aae_decoder_kernel_label', 'aae_decoder_kernel_flops', 'aae_decoder_activation_info',
 )
 
 
 class EncoderDesc(Structure):
     _fields_ = [
         ('in_h', c_int32), ('in_w', c_int32), ('in_c', c_int32),
+        ('num_layers', c_int32),
+        ('num_filters', c_int32 * AAE_MAX_LAYERS),
+        ('strides', c_int32 * AAE_MAX_LAYERS),
+        ('kernel_size', c_int32),
+        ('latent_size', c_int32),
+        ('batch_norm', c_int32),
+        ('bn_eps', c_float),
+    ]
+
+
+class DecoderDesc(Structure):
+    _fields_ = [
+        ('out_h', c_int32), ('out_w', c_int32), ('out_c', c_int32),
         ('num_layers', c_int32),
         ('num_filters', c_int32 * AAE_MAX_LAYERS),
         ('strides', c_int32 * AAE_MAX_LAYERS),
@@ -90,6 +105,24 @@ def declare(lib):
     lib.aae_l2_normalize.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p]
     lib.aae_crop_resize_u8.restype = c_int
     lib.aae_crop_resize_u8.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
+
+    lib.aae_decoder_create.restype = c_int
+    lib.aae_decoder_create.argtypes = [POINTER(DecoderDesc), POINTER(c_void_p), c_int, POINTER(c_void_p)]
+    lib.aae_decoder_destroy.restype = None
+    lib.aae_decoder_destroy.argtypes = [c_void_p]
+    lib.aae_decoder_workspace_bytes.restype = c_size_t
+    lib.aae_decoder_workspace_bytes.argtypes = [c_void_p, c_int]
+    lib.aae_decoder_forward.restype = c_int
+    lib.aae_decoder_forward.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.aae_decoder_forward_timed.restype = c_int
+    lib.aae_decoder_forward_timed.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p,
+                                              POINTER(c_float), c_int, POINTER(c_int)]
+    lib.aae_decoder_kernel_label.restype = c_char_p
+    lib.aae_decoder_kernel_label.argtypes = [c_void_p, c_int]
+    lib.aae_decoder_kernel_flops.restype = c_double
+    lib.aae_decoder_kernel_flops.argtypes = [c_void_p, c_int]
+    lib.aae_decoder_activation_info.restype = c_int
+    lib.aae_decoder_activation_info.argtypes = [c_void_p, c_int, c_int, POINTER(c_size_t), POINTER(c_size_t)]
     return lib
 
 

@@ -1,7 +1,7 @@
 """Builders with the signatures of /root/reference/auto_pose/ae/ae_factory.py
-for the inference path (dataset, encoder, codebook, build_codebook_from_name,
-restore_checkpoint).  Training builders (decoder, ae, train_op, queue) are out
-of scope and raise NotImplementedError."""
+for the inference path (dataset, encoder, codebook, decoder, build_codebook_from_name,
+restore_checkpoint).  Training builders (ae, train_op, queue) are out of scope and raise
+NotImplementedError."""
 from __future__ import annotations
 
 import ast
@@ -12,6 +12,7 @@ from . import session as S
 from . import utils as u
 from .codebook import Codebook
 from .dataset import Dataset
+from .decoder import Decoder
 from .encoder import Encoder
 
 
@@ -49,7 +50,23 @@ def _out_of_scope(name):
 
 
 build_queue = _out_of_scope('build_queue')
-build_decoder = _out_of_scope('build_decoder')
+
+
+def build_decoder(reconstruction_target, encoder, args, is_training=False):
+    """ae_factory.py:50-70, inference form: reversed NUM_FILTER / STRIDES, KERNEL_SIZE_DECODER;
+    the variational sampling branch only exists while training."""
+    NUM_FILTER = ast.literal_eval(args.get('Network', 'NUM_FILTER'))
+    KERNEL_SIZE_DECODER = args.getint('Network', 'KERNEL_SIZE_DECODER')
+    STRIDES = ast.literal_eval(args.get('Network', 'STRIDES'))
+    LOSS = args.get('Network', 'LOSS', fallback='L2')
+    BOOTSTRAP_RATIO = args.getint('Network', 'BOOTSTRAP_RATIO', fallback=1)
+    AUXILIARY_MASK = args.getboolean('Network', 'AUXILIARY_MASK', fallback=False)
+    BATCH_NORM = args.getboolean('Network', 'BATCH_NORMALIZATION')
+    return Decoder(reconstruction_target, encoder.z, list(reversed(NUM_FILTER)), KERNEL_SIZE_DECODER,
+                   list(reversed(STRIDES)), LOSS, BOOTSTRAP_RATIO, AUXILIARY_MASK, BATCH_NORM,
+                   is_training=is_training, encoder=encoder)
+
+
 build_ae = _out_of_scope('build_ae')
 build_train_op = _out_of_scope('build_train_op')
 
@@ -60,9 +77,6 @@ def build_codebook_from_name(experiment_name, experiment_group='', return_datase
     workspace_path = os.environ.get('AE_WORKSPACE_PATH')
     if workspace_path is None:
         raise RuntimeError('Please define a workspace path: export AE_WORKSPACE_PATH=/path/to/workspace')
-    if return_decoder:
-        raise NotImplementedError('the decoder (reconstruction visualisation) is out of scope of this package')
-
     log_dir = u.get_log_dir(workspace_path, experiment_name, experiment_group)
     cfg_file_path = u.get_train_config_exp_file_path(log_dir, experiment_name)
     dataset_path = u.get_dataset_path(workspace_path)
@@ -76,8 +90,11 @@ def build_codebook_from_name(experiment_name, experiment_group='', return_datase
         x = S.Placeholder(dataset.shape, 'x')
         encoder = build_encoder(x, args)
         codebook = build_codebook(encoder, dataset, args)
+        decoder = build_decoder(S.Placeholder(dataset.shape, 'reconst_target'), encoder, args) if return_decoder else None
 
     if return_dataset:
+        if return_decoder:
+            return codebook, dataset, decoder
         return codebook, dataset
     return codebook
 

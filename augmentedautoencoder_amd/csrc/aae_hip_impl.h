@@ -13,6 +13,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -886,3 +887,5 @@ int aae_crop_resize_u8(const void* img, int H, int W, int C, const int32_t* boxe
 }
 
 }  // extern "C"
+
+#include "aae_decoder_impl.h"

@@ -37,6 +37,12 @@ struct ConvIgemmArgs {
     int relu;
     int stagger;            // kcycles of start delay for every second block generation (0 = off)
     unsigned wp_bytes;      // size of wp (the LDS-DMA variant reads it through a buffer view)
+    // SCATTER mode (decoder: 2x nearest-neighbour upsampling folded into four phase problems,
+    // kernels/decoder_f32.h): the grid's third index is the output phase (py, px) instead of a
+    // K split; phase ph reads weights wp + ph*wp_phase_floats, pads by ph_pt[py] / ph_pl[px] and
+    // stores row (b, oh, ow) at out[b][2*oh+py][2*ow+px][:] of a [B, 2*Ho, 2*Wo, Cout] tensor.
+    long long wp_phase_floats;
+    int ph_pt[2], ph_pl[2];
 };
 
 constexpr int kConvIgemmSmem = 2 * (kSlabFloatsA + 8 * 128 * 4) * 4;   // 64 KiB
@@ -47,7 +53,7 @@ constexpr int kConvIgemmSmem = 2 * (kSlabFloatsA + 8 * 128 * 4) * 4;   // 64 KiB
 // of row r fetches logical slot ps ^ ((r>>1)&7).  Slab t+1 is issued under group 0 of slab t
 // into the other buffer (free since the barrier of slab t-1) and is waited for (vmcnt) by
 // every wave right before the barrier of slab t.  Same MFMA sequence, bit-identical results.
-template <bool SPLITK, bool DMA = false>
+template <bool SPLITK, bool DMA = false, bool SCATTER = false>
 __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvIgemmArgs p) {
     AAE_DYN_SMEM(smem_raw);
     float* As = reinterpret_cast<float*>(smem_raw);            // [2][128*32]
@@ -61,8 +67,11 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvIgemmArgs
     const int nt = L % p.num_nt;
     const int mt = (L / p.num_nt) % p.num_mt;
     const int split = L / (p.num_nt * p.num_mt);
-    const int slab0 = split * p.slabs_per_split;
-    const int slab1 = min(slab0 + p.slabs_per_split, p.slabs_total);
+    const int slab0 = SCATTER ? 0 : split * p.slabs_per_split;
+    const int slab1 = SCATTER ? p.slabs_total : min(slab0 + p.slabs_per_split, p.slabs_total);
+    const int pt = SCATTER ? p.ph_pt[split >> 1] : p.pt;
+    const int pl = SCATTER ? p.ph_pl[split & 1] : p.pl;
+    const float* wp = SCATTER ? p.wp + split * p.wp_phase_floats : p.wp;
 
     // ---- A loader: thread -> 4 (row, slot) pairs, row = tid/8 + 32*q -------
     const int a_row = tid >> 3;
@@ -82,14 +91,14 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvIgemmArgs
         const int b = mm / (p.Ho * p.Wo);
         const int rem = mm - b * (p.Ho * p.Wo);
         const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
-        a_ih0[q] = oh * p.S - p.pt;
-        a_iw0[q] = ow * p.S - p.pl;
+        a_ih0[q] = oh * p.S - pt;
+        a_iw0[q] = ow * p.S - pl;
         a_off[q] = (unsigned)(((((long long)b * p.H + a_ih0[q]) * p.W + a_iw0[q]) * (long long)p.Cin + a_slot * 4) * 4);
     }
     // ---- B loader: thread -> 4 (slot, col) pairs, idx = tid + 256*q ----------
-    const float* b_ptr = p.wp + ((long long)nt * 128 + (tid & 127)) * 4 + (long long)(tid >> 7) * p.CoutPad * 4;
+    const float* b_ptr = wp + ((long long)nt * 128 + (tid & 127)) * 4 + (long long)(tid >> 7) * p.CoutPad * 4;
     const long long b_slot_stride = (long long)p.CoutPad * 4;      // floats per k-slot row
-    const buffer_rsrc wbuf = make_buffer(p.wp, DMA ? p.wp_bytes : 0u);
+    const buffer_rsrc wbuf = make_buffer(wp, DMA ? p.wp_bytes : 0u);
     const unsigned b_off0 = (unsigned)(((tid >> 7) * p.CoutPad + nt * 128 + (tid & 127)) * 16);
     const unsigned b_piece_stride = (unsigned)(2 * p.CoutPad * 16);
 
@@ -221,7 +230,14 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvIgemmArgs
                     v += bias;
                     if (p.relu) v = fmaxf(v, 0.f);
                     if (p.bn_scale) v = v * sc + sh;
-                    p.out[(long long)m * p.Cout + n] = v;
+                    long long orow = m;
+                    if (SCATTER) {
+                        const int b = m / (p.Ho * p.Wo);
+                        const int rem = m - b * (p.Ho * p.Wo);
+                        const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+                        orow = ((long long)b * (2 * p.Ho) + 2 * oh + (split >> 1)) * (2 * p.Wo) + 2 * ow + (split & 1);
+                    }
+                    p.out[orow * p.Cout + n] = v;
                 }
             }
         }

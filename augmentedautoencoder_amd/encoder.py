@@ -28,6 +28,7 @@ class Encoder(object):
         self._engine = None
         self._device = None
         self._z_op = S.Op('encoder/z', lambda feed: self.engine.encode(self._feed(feed)).cpu().numpy())
+        self._z_op.owner = self                  # lets Decoder(latent_code=encoder.z) find its encoder
         S.register(encoder=self)
 
     # -- reference properties ------------------------------------------------

@@ -306,3 +306,99 @@ def crop_resize(image, boxes_xywh_size, out_hw, device=None):
                                     _stream_ptr(torch))
     _lib.check(lib, rc, 'aae_crop_resize_u8')
     return out
+
+
+class DecoderEngine(object):
+    """Owns one aae_decoder handle: Decoder.x of /root/reference/auto_pose/ae/decoder.py:36-84
+    (dense -> [nearest-neighbour resize -> conv]* -> sigmoid) for batches of latent codes."""
+
+    def __init__(self, cfg, weights, device=None, max_batch=256):
+        from .weights import ordered_decoder_weight_arrays
+        torch = _torch()
+        self.cfg = cfg
+        self.device = torch.device('cuda', torch.cuda.current_device()) if device is None else torch.device(device)
+        self.max_batch = int(max_batch)
+        self.lib = _lib.load()
+        arrays = ordered_decoder_weight_arrays(weights, cfg)
+        handle = ctypes.c_void_p()
+        desc = cfg.to_desc()
+        with torch.cuda.device(self.device):
+            rc = self.lib.aae_decoder_create(ctypes.byref(desc), as_pointer_array(arrays), len(arrays), ctypes.byref(handle))
+        _lib.check(self.lib, rc, 'aae_decoder_create')
+        self.handle = handle
+        self.ws = _Workspace(self.device)
+        self._last_B = None
+
+    def close(self):
+        if getattr(self, 'handle', None):
+            self.lib.aae_decoder_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _z(self, z):
+        torch = _torch()
+        if isinstance(z, np.ndarray):
+            z = torch.from_numpy(np.ascontiguousarray(z, dtype=np.float32))
+        z = z.to(self.device, torch.float32).contiguous()
+        if z.dim() == 1:
+            z = z.unsqueeze(0)
+        if z.dim() != 2 or z.shape[1] != self.cfg.latent_space_size:
+            raise ValueError('latent batch has shape %s, decoder expects [B,%d]' % (tuple(z.shape), self.cfg.latent_space_size))
+        return z
+
+    def _chunk(self, z, out, timed=False):
+        torch = _torch()
+        B = z.shape[0]
+        nbytes = self.lib.aae_decoder_workspace_bytes(self.handle, B)
+        _, ws_ptr = self.ws.get(nbytes)
+        self._last_B = B
+        with torch.cuda.device(self.device):
+            if not timed:
+                rc = self.lib.aae_decoder_forward(self.handle, ctypes.c_void_p(z.data_ptr()), B, ctypes.c_void_p(out.data_ptr()),
+                                                  ctypes.c_void_p(ws_ptr), nbytes, _stream_ptr(torch))
+                _lib.check(self.lib, rc, 'aae_decoder_forward')
+                return None
+            ms = (ctypes.c_float * 32)()
+            n = ctypes.c_int(0)
+            rc = self.lib.aae_decoder_forward_timed(self.handle, ctypes.c_void_p(z.data_ptr()), B, ctypes.c_void_p(out.data_ptr()),
+                                                    ctypes.c_void_p(ws_ptr), nbytes, _stream_ptr(torch), ms, 32, ctypes.byref(n))
+            _lib.check(self.lib, rc, 'aae_decoder_forward_timed')
+            return [(self.lib.aae_decoder_kernel_label(self.handle, i).decode(), float(ms[i]),
+                     float(self.lib.aae_decoder_kernel_flops(self.handle, i))) for i in range(n.value)]
+
+    def decode(self, z):
+        """Decoder.x: device float32 [B,H,W,C] in [0,1]."""
+        torch = _torch()
+        z = self._z(z)
+        B = z.shape[0]
+        out = torch.empty((B,) + tuple(self.cfg.shape), dtype=torch.float32, device=self.device)
+        for a in range(0, B, self.max_batch):
+            e = min(a + self.max_batch, B)
+            self._chunk(z[a:e], out[a:e])
+        return out
+
+    def decode_timed(self, z):
+        torch = _torch()
+        z = self._z(z)
+        if z.shape[0] > self.max_batch:
+            raise ValueError('decode_timed takes at most max_batch=%d codes' % self.max_batch)
+        out = torch.empty((z.shape[0],) + tuple(self.cfg.shape), dtype=torch.float32, device=self.device)
+        return out, self._chunk(z, out, timed=True)
+
+    def activation(self, stage):
+        """Hidden activation of the most recent single-chunk decode: stage 0 = dense output
+        [B,h0,w0,F0], stage i = output of the i-th hidden convolution."""
+        torch = _torch()
+        off, cnt = ctypes.c_size_t(), ctypes.c_size_t()
+        _lib.check(self.lib, self.lib.aae_decoder_activation_info(self.handle, self._last_B, stage, ctypes.byref(off),
+                                                                  ctypes.byref(cnt)), 'aae_decoder_activation_info')
+        buf, ws_ptr = self.ws.get(0)
+        start = ws_ptr - buf.data_ptr() + off.value
+        dims = self.cfg.layer_dimensions()[stage]
+        return buf[start:start + 4 * cnt.value].view(torch.float32).reshape(self._last_B, dims[0], dims[1],
+                                                                              self.cfg.num_filters[stage]).clone()

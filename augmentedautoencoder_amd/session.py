@@ -21,7 +21,7 @@ import numpy as np
 
 from . import weights as W
 
-_GRAPH = []          # [(scope, encoder, codebook-or-None)] in construction order
+_GRAPH = []          # [(scope, encoder, codebook, decoder)] (one of the three set) in construction order
 _SCOPE = ['']
 
 
@@ -44,8 +44,8 @@ def current_scope():
     return _SCOPE[-1]
 
 
-def register(encoder=None, codebook=None):
-    _GRAPH.append((current_scope(), encoder, codebook))
+def register(encoder=None, codebook=None, decoder=None):
+    _GRAPH.append((current_scope(), encoder, codebook, decoder))
 
 
 def reset_default_graph():
@@ -136,21 +136,25 @@ class Saver(object):
         self.scope = scope
 
     def _members(self):
-        return [(s, e, c) for (s, e, c) in _GRAPH if self.scope is None or s == self.scope]
+        return [(s, e, c, d) for (s, e, c, d) in _GRAPH if self.scope is None or s == self.scope]
 
     def save(self, session, save_path, global_step=None):
         path = save_path if global_step is None else '%s-%d' % (save_path, int(global_step))
-        encoder = codebook = None
-        for _, e, c in self._members():
+        encoder = codebook = decoder = None
+        for _, e, c, d in self._members():
             encoder = e if e is not None else encoder
             codebook = c if c is not None else codebook
+            decoder = d if d is not None else decoder
         if encoder is None or encoder.weights is None:
             raise RuntimeError('Saver.save: no encoder with weights under scope %r' % self.scope)
         emb = bbs = None
         if codebook is not None:
             emb = codebook.embedding_value()
             bbs = codebook.embed_obj_bbs_value() if codebook.embed_bb else None
-        W.save_npz(path + '.npz', encoder.weights, emb, bbs)
+        weights = dict(encoder.weights)
+        if decoder is not None and decoder.weights is not None:
+            weights.update(decoder.weights)
+        W.save_npz(path + '.npz', weights, emb, bbs)
         ckpt_dir = os.path.dirname(path)
         index = os.path.join(ckpt_dir, 'checkpoint')
         existing = []
@@ -173,16 +177,18 @@ class Saver(object):
             from .tf_checkpoint import load_aae_variables
             scope = self.scope
             if scope is None:
-                scopes = sorted({s for (s, _, _) in self._members() if s})
+                scopes = sorted({m[0] for m in self._members() if m[0]})
                 scope = scopes[0] if len(scopes) == 1 else None
             weights, emb, bbs = load_aae_variables(ckpt_path, scope)
         else:
             if not ckpt_path.endswith('.npz'):
                 ckpt_path = ckpt_path + '.npz'
             weights, emb, bbs = W.load_npz(ckpt_path)
-        for _, e, c in self._members():
+        for _, e, c, d in self._members():
             if e is not None:
                 e.load_weights(weights)
+            if d is not None:
+                d.load_weights(weights)
             if c is not None:
                 if emb is not None:
                     c.assign_embedding(emb)

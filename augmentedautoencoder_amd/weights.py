@@ -166,3 +166,119 @@ def load_npz(path):
     emb = blob.pop('embedding_normalized', None)
     bbs = blob.pop('embed_obj_bbs_var', None)
     return blob, emb, bbs
+
+
+class DecoderConfig(object):
+    """Shapes of Decoder(reconstruction_target, latent_code, num_filters, kernel_size, strides, ...)
+    as ae_factory.build_decoder fills it (/root/reference/auto_pose/ae/ae_factory.py:50-70):
+    num_filter / strides are given in cfg (encoder) order and used reversed."""
+
+    def __init__(self, shape=(128, 128, 3), num_filter=(128, 256, 512, 512), strides=(2, 2, 2, 2),
+                 kernel_size=5, latent_space_size=128, batch_norm=False, auxiliary_mask=False):
+        self.shape = tuple(int(v) for v in shape)
+        self.num_filters = [int(v) for v in reversed(list(num_filter))]
+        self.strides = [int(v) for v in reversed(list(strides))]
+        self.kernel_size = int(kernel_size)
+        self.latent_space_size = int(latent_space_size)
+        self.batch_norm = bool(batch_norm)
+        self.auxiliary_mask = bool(auxiliary_mask)
+        if len(self.num_filters) != len(self.strides):
+            raise ValueError('NUM_FILTER and STRIDES differ in length')
+        if not 1 <= len(self.num_filters) <= _lib.AAE_MAX_LAYERS:
+            raise ValueError('between 1 and %d layers supported' % _lib.AAE_MAX_LAYERS)
+
+    @classmethod
+    def from_cfg(cls, args):
+        return cls(
+            shape=(args.getint('Dataset', 'H'), args.getint('Dataset', 'W'), args.getint('Dataset', 'C')),
+            num_filter=ast.literal_eval(args.get('Network', 'NUM_FILTER')),
+            strides=ast.literal_eval(args.get('Network', 'STRIDES')),
+            kernel_size=args.getint('Network', 'KERNEL_SIZE_DECODER'),
+            latent_space_size=args.getint('Network', 'LATENT_SPACE_SIZE'),
+            batch_norm=args.getboolean('Network', 'BATCH_NORMALIZATION'),
+            auxiliary_mask=args.getboolean('Network', 'AUXILIARY_MASK', fallback=False),
+        )
+
+    @property
+    def num_layers(self):
+        return len(self.num_filters)
+
+    def layer_dimensions(self):
+        """[[h_i, w_i]] = int(H / prod(strides[i:]))  (decoder.py:41)."""
+        h, w = self.shape[:2]
+        out = []
+        for i in range(self.num_layers):
+            p = 1
+            for s in self.strides[i:]:
+                p *= s
+            out.append([int(h / p), int(w / p)])
+        return out
+
+    def variable_names(self):
+        """(dense, [hidden convs], final conv, [batch norms]) -- TF auto-names in a graph whose
+        encoder was built first (ae_factory.py:134-139)."""
+        L = self.num_layers
+        convs = ['conv2d_%d' % (L + i) for i in range(L - 1)]
+        final = 'conv2d_%d' % (2 * L - 1 + (1 if self.auxiliary_mask else 0))
+        bns = ['batch_normalization_%d' % (L + i) for i in range(L)] if self.batch_norm else []
+        return 'dense_1', convs, final, bns
+
+    def flops_per_image(self):
+        """Nominal multiply-add count x2 of Decoder.x (upsampled-resolution convolutions)."""
+        dims = self.layer_dimensions()
+        k = self.kernel_size
+        f = 2 * self.latent_space_size * dims[0][0] * dims[0][1] * self.num_filters[0]
+        cin = self.num_filters[0]
+        for i in range(1, self.num_layers):
+            f += 2 * dims[i][0] * dims[i][1] * k * k * cin * self.num_filters[i]
+            cin = self.num_filters[i]
+        return f + 2 * self.shape[0] * self.shape[1] * k * k * cin * self.shape[2]
+
+    def to_desc(self):
+        d = _lib.DecoderDesc()
+        d.out_h, d.out_w, d.out_c = self.shape
+        d.num_layers = self.num_layers
+        for i in range(self.num_layers):
+            d.num_filters[i] = self.num_filters[i]
+            d.strides[i] = self.strides[i]
+        d.kernel_size = self.kernel_size
+        d.latent_size = self.latent_space_size
+        d.batch_norm = 1 if self.batch_norm else 0
+        d.bn_eps = 1e-3
+        return d
+
+
+def ordered_decoder_weight_arrays(weights, cfg):
+    """{name: array} -> the array order aae_decoder_create expects, shapes validated."""
+    out = []
+    dense, convs, final, bns = cfg.variable_names()
+    dims = cfg.layer_dimensions()
+    k = cfg.kernel_size
+
+    def take(name, shape):
+        if name not in weights:
+            raise ValueError('missing decoder weight %r' % name)
+        a = np.ascontiguousarray(np.asarray(weights[name], dtype=np.float32))
+        if tuple(a.shape) != tuple(shape):
+            raise ValueError('decoder weight %r has shape %s, expected %s' % (name, a.shape, tuple(shape)))
+        out.append(a)
+
+    def take_bn(name, c):
+        for n in ('gamma', 'beta', 'moving_mean', 'moving_variance'):
+            take(name + '/' + n, (c,))
+
+    units = dims[0][0] * dims[0][1] * cfg.num_filters[0]
+    take(dense + '/kernel', (cfg.latent_space_size, units))
+    take(dense + '/bias', (units,))
+    if cfg.batch_norm:
+        take_bn(bns[0], units)
+    cin = cfg.num_filters[0]
+    for i in range(1, cfg.num_layers):
+        take(convs[i - 1] + '/kernel', (k, k, cin, cfg.num_filters[i]))
+        take(convs[i - 1] + '/bias', (cfg.num_filters[i],))
+        if cfg.batch_norm:
+            take_bn(bns[i], cfg.num_filters[i])
+        cin = cfg.num_filters[i]
+    take(final + '/kernel', (k, k, cin, cfg.shape[2]))
+    take(final + '/bias', (cfg.shape[2],))
+    return out

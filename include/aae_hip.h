@@ -49,6 +49,7 @@ extern "C" {
 
 typedef struct aae_encoder aae_encoder;
 typedef struct aae_codebook aae_codebook;
+typedef struct aae_decoder aae_decoder;
 
 /* Shapes of Encoder(input, latent_space_size, num_filters, kernel_size, strides,
  * batch_norm)  -- auto_pose/ae/encoder.py:14, filled from the [Network]/[Dataset]
@@ -88,7 +89,11 @@ void aae_encoder_destroy(aae_encoder* enc);
  *   "splitk_min_base_blocks" (384): split the K loop of a layer only if its un-split grid
  *                                   has fewer blocks than this (small batches);
  *   "splitk_target_blocks"   (512): ... and then aim for about this many blocks;
- *   "igemm_stagger" (0): experimental start delay (kcycles) for every 2nd block generation. */
+ *   "igemm_stagger" (0): experimental start delay (kcycles) for every 2nd block generation;
+ *   "igemm_dma" (1) / "x3h_dma" (1): operand slabs of the implicit GEMM travel global -> LDS by
+ *                        LDS-DMA (buffer_load ... lds); 0 selects the register-staged variant
+ *                        (bit-identical results, kept for A/B measurements);
+ *   "first_target_blocks" (1024), "first_max_tiles_per_block" (8): conv1 grid shaping. */
 int aae_encoder_set_option(aae_encoder* enc, const char* name, int value);
 
 size_t aae_encoder_workspace_bytes(const aae_encoder* enc, int B);
@@ -150,6 +155,48 @@ int aae_l2_normalize(const float* z, int B, int J, float* q_out, void* stream);
  * size = int(max(h, w) * pad_factor); out: device uint8 [D,out_h,out_w,C]. */
 int aae_crop_resize_u8(const void* img, int H, int W, int C, const int32_t* boxes, int D,
                        int out_h, int out_w, void* out, void* stream);
+
+/* ---- Decoder ("next" row N4): auto_pose/ae/decoder.py:36-84 (Decoder.x), inference only ---------
+ * Decoder(reconstruction_target, latent_code, num_filters, kernel_size, strides, ...) as
+ * ae_factory.build_decoder fills it (auto_pose/ae/ae_factory.py:50-70): num_filters / strides
+ * are the REVERSED [Network] NUM_FILTER / STRIDES.
+ *   dense(latent -> h0*w0*F0, relu)[+BN] -> reshape [h0,w0,F0]
+ *   for F_i, size_i: resize_nearest_neighbor(size_i) -> conv2d(F_i, k, 'same', relu)[+BN]
+ *   resize_nearest_neighbor([H,W]) -> conv2d(C, k, 'same', sigmoid)
+ * with size_i = [H / prod(strides[i:]), W / prod(strides[i:])] (decoder.py:41).
+ * host_weights (float32, host), TF variable order:
+ *   dense kernel [latent, h0*w0*F0], bias (+ gamma, beta, moving_mean, moving_variance if BN)
+ *   per hidden conv i = 1..L-1: kernel HWIO [k,k,F_{i-1},F_i], bias (+ 4 BN arrays)
+ *   output conv: kernel [k,k,F_{L-1},C], bias.
+ * The auxiliary mask head (decoder.py:66-73) does not feed Decoder.x and is not evaluated. */
+typedef struct aae_decoder_desc {
+    int32_t out_h, out_w, out_c;          /* reconstruction target shape = [Dataset] H, W, C */
+    int32_t num_layers;                   /* len(NUM_FILTER)                                 */
+    int32_t num_filters[AAE_MAX_LAYERS];  /* reversed [Network] NUM_FILTER                   */
+    int32_t strides[AAE_MAX_LAYERS];      /* reversed [Network] STRIDES                      */
+    int32_t kernel_size;                  /* [Network] KERNEL_SIZE_DECODER                   */
+    int32_t latent_size;
+    int32_t batch_norm;
+    float bn_eps;
+} aae_decoder_desc;
+
+int aae_decoder_create(const aae_decoder_desc* desc, const void* const* host_weights, int n_weights,
+                       aae_decoder** out);
+void aae_decoder_destroy(aae_decoder* dec);
+size_t aae_decoder_workspace_bytes(const aae_decoder* dec, int B);
+
+/* x = Decoder.x for a batch of latent codes; replaces session.run(decoder.x, {encoder.x: ...})
+ * after the encoder (auto_pose/eval/eval_plots.py:33,59) and
+ * session.run(decoder.x, {decoder._latent_code: z}) (eval_plots.py:78).
+ * z: device [B, latent] float32 (NOT normalised).  x_out: device [B,H,W,C] float32 in [0,1]. */
+int aae_decoder_forward(aae_decoder* dec, const float* z, int B, float* x_out, void* workspace,
+                        size_t ws_bytes, void* stream);
+int aae_decoder_forward_timed(aae_decoder* dec, const float* z, int B, float* x_out, void* workspace,
+                              size_t ws_bytes, void* stream, float* kernel_ms, int max_kernels, int* n_kernels);
+const char* aae_decoder_kernel_label(const aae_decoder* dec, int i);
+double aae_decoder_kernel_flops(const aae_decoder* dec, int i);
+/* workspace region of hidden activation `stage` (0 = dense output, i = i-th hidden conv) */
+int aae_decoder_activation_info(const aae_decoder* dec, int B, int stage, size_t* offset_bytes, size_t* count);
 
 #ifdef __cplusplus
 }

@@ -146,3 +146,48 @@ def l2_normalize(z):
     q = np.zeros_like(z)
     _lib.check(L, L.aae_l2_normalize(z.ctypes.data, z.shape[0], z.shape[1], q.ctypes.data, None), 'aae_l2_normalize')
     return q
+
+
+class EmuDecoder(object):
+    def __init__(self, weights, cfg):
+        from augmentedautoencoder_amd.weights import ordered_decoder_weight_arrays
+        self.cfg = cfg
+        self.L = lib()
+        self._arrays = ordered_decoder_weight_arrays(weights, cfg)
+        h = ctypes.c_void_p()
+        desc = cfg.to_desc()
+        rc = self.L.aae_decoder_create(ctypes.byref(desc), as_pointer_array(self._arrays), len(self._arrays), ctypes.byref(h))
+        _lib.check(self.L, rc, 'aae_decoder_create')
+        self.h = h
+
+    def forward(self, z):
+        z = np.ascontiguousarray(z, dtype=np.float32)
+        B = z.shape[0]
+        n = self.L.aae_decoder_workspace_bytes(self.h, B)
+        self.ws = _aligned(n)
+        out = np.full((B,) + tuple(self.cfg.shape), np.nan, dtype=np.float32)
+        rc = self.L.aae_decoder_forward(self.h, z.ctypes.data, B, out.ctypes.data, self.ws.ctypes.data, n, None)
+        _lib.check(self.L, rc, 'aae_decoder_forward')
+        self.B = B
+        return out
+
+    def activation(self, stage):
+        off, cnt = ctypes.c_size_t(), ctypes.c_size_t()
+        _lib.check(self.L, self.L.aae_decoder_activation_info(self.h, self.B, stage, ctypes.byref(off), ctypes.byref(cnt)), 'info')
+        dims = self.cfg.layer_dimensions()[stage]
+        return self.ws[off.value:off.value + 4 * cnt.value].view(np.float32).reshape(self.B, dims[0], dims[1],
+                                                                                      self.cfg.num_filters[stage]).copy()
+
+    def labels(self):
+        out, i = [], 0
+        while True:
+            s = self.L.aae_decoder_kernel_label(self.h, i)
+            if not s:
+                return out
+            out.append(s.decode())
+            i += 1
+
+    def close(self):
+        if self.h:
+            self.L.aae_decoder_destroy(self.h)
+            self.h = None

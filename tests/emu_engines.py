@@ -56,3 +56,20 @@ class EmuCodebookEngine(object):
 
     def close(self):
         self._c.close()
+
+
+class EmuDecoderEngine(object):
+    device = torch.device('cpu')
+
+    def __init__(self, cfg, weights):
+        self.cfg = cfg
+        self._d = eb.EmuDecoder(weights, cfg)
+
+    def decode(self, z):
+        z = z.numpy() if torch.is_tensor(z) else np.asarray(z)
+        if z.ndim == 1:
+            z = z[None]
+        return torch.from_numpy(self._d.forward(z))
+
+    def close(self):
+        self._d.close()

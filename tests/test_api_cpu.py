@@ -198,3 +198,54 @@ def test_ae_embed_cli_argument_errors(tmp_path, monkeypatch):
     monkeypatch.setenv('AE_WORKSPACE_PATH', str(tmp_path))
     with pytest.raises(SystemExit, match='config'):
         ae_embed.main(['grp/obj'])
+
+
+DEC_CFG = CFG.replace('KERNEL_SIZE_ENCODER: 5', 'KERNEL_SIZE_ENCODER: 5\nKERNEL_SIZE_DECODER: 5\nLOSS: L2\nBOOTSTRAP_RATIO: 4\nAUXILIARY_MASK: False\nVARIATIONAL: 0')
+
+
+def test_decoder_api_reconstruction_calls_of_eval_plots(tmp_path, monkeypatch):
+    """sess.run(decoder.x, {encoder.x: x}) and sess.run(decoder.x, {decoder._latent_code: z})
+    (auto_pose/eval/eval_plots.py:33,59,78) through build_codebook_from_name(return_decoder=True)
+    (auto_pose/eval/ae_eval.py:76) and a TF-style checkpoint holding encoder + decoder variables."""
+    from augmentedautoencoder_amd import tf_checkpoint as T
+    from augmentedautoencoder_amd.decoder import Decoder
+    from emu_engines import EmuDecoderEngine
+    from oracle import decoder_cpu as dref
+    S.reset_default_graph()
+    ws = tmp_path / 'ws'
+    log_dir = u.get_log_dir(str(ws), 'obj', 'grp')
+    os.makedirs(log_dir)
+    monkeypatch.setenv('AE_WORKSPACE_PATH', str(ws))
+    with open(u.get_train_config_exp_file_path(log_dir, 'obj'), 'w') as f:
+        f.write(DEC_CFG)
+    cb, ds, dec = factory.build_codebook_from_name('obj', 'grp', return_dataset=True, return_decoder=True)
+    assert isinstance(dec, Decoder) and dec.config.num_filters == [64, 32] and dec.reconstruction_target.shape == (16, 16, 3)
+    with pytest.raises(RuntimeError, match='no weights'):
+        dec.engine
+    w_enc = synth.make_weights(seed=3, shape=(16, 16, 3), num_filter=[32, 64], strides=[2, 2], latent=128)
+    w_dec = dref.make_decoder_weights(seed=4, out_shape=(16, 16, 3), num_filter=[32, 64], strides=[2, 2], latent=128)
+    assert set(w_dec) == {'dense_1/kernel', 'dense_1/bias', 'conv2d_2/kernel', 'conv2d_2/bias', 'conv2d_3/kernel', 'conv2d_3/bias'}
+    ckpt_dir = u.get_checkpoint_dir(log_dir)
+    os.makedirs(ckpt_dir)
+    blob = {'obj/' + k: v for k, v in list(w_enc.items()) + list(w_dec.items())}
+    T.write_bundle(os.path.join(ckpt_dir, 'chkpt-30000'), blob)
+    with open(os.path.join(ckpt_dir, 'checkpoint'), 'w') as f:
+        f.write('model_checkpoint_path: "chkpt-30000"\nall_model_checkpoint_paths: "chkpt-30000"\n')
+    factory.restore_checkpoint(None, S.Saver(scope='obj'), ckpt_dir)
+    enc = cb._encoder
+    enc._engine = EmuEncoderEngine(enc.config, enc.weights)
+    dec._engine = EmuDecoderEngine(dec.config, dec.weights)
+    sess = S.Session()
+    x = synth.make_crops(2, seed=8, shape=(16, 16, 3))
+    reconst = sess.run(dec.x, feed_dict={enc.x: x / 255.})
+    z64 = ref.encoder_forward_np(ref.input_to_float(x), w_enc, [2, 2])
+    want = dref.decoder_forward_np(z64, w_dec, (16, 16, 3), [64, 32], [2, 2])
+    assert reconst.shape == (2, 16, 16, 3) and reconst.dtype == np.float32 and np.abs(reconst - want).max() < 5e-6
+    code = np.random.default_rng(2).standard_normal((1, 128)).astype(np.float32)
+    reconst2 = sess.run(dec.x, feed_dict={dec._latent_code: code})
+    assert np.abs(reconst2 - dref.decoder_forward_np(code, w_dec, (16, 16, 3), [64, 32], [2, 2])).max() < 5e-6
+    # the native container keeps the decoder variables too
+    S.Saver(scope='obj').save(None, os.path.join(str(tmp_path), 'native'), global_step=1)
+    weights, _, _ = W.load_npz(os.path.join(str(tmp_path), 'native-1.npz'))
+    assert 'dense_1/kernel' in weights and 'conv2d/kernel' in weights
+    S.reset_default_graph()

@@ -113,6 +113,29 @@ def main():
             print(json.dumps({'what': 'conv1', 'max_tiles_per_block': tpb, 'target_blocks': tb, 'conv1_ms': [round(t, 4) for t in ts]}))
         enc.set_option('first_max_tiles_per_block', 8)
         enc.set_option('first_target_blocks', 1024)
+    if 'decoder' in what:
+        # next row N4: Decoder.x for batches of latent codes (default shapes), kernel split + torch-CPU reference beside it
+        from augmentedautoencoder_amd.engine import DecoderEngine
+        from augmentedautoencoder_amd.weights import DecoderConfig
+        from oracle import decoder_cpu as dref
+        dcfg = DecoderConfig()
+        wd = dref.make_decoder_weights(seed=4242)
+        dec = DecoderEngine(dcfg, wd)
+        for B in (1, 16, 256):
+            z = torch.randn(B, 128, device='cuda') * 0.5
+            ms = timeit(lambda: dec.decode(z), 10 if B >= 64 else 30)
+            _, recs = dec.decode_timed(z)
+            print(json.dumps({'what': 'decoder', 'B': B, 'ms': round(ms, 4), 'images_per_s': round(B / ms * 1e3, 1),
+                              'nominal_tflops': round(dcfg.flops_per_image() * B / ms / 1e9, 2),
+                              'kernels': [(l.split(' ')[0], round(t, 4), round(f / t / 1e9, 1) if t > 0 else 0) for l, t, f in recs]}))
+        torch.set_num_threads(min(32, os.cpu_count() or 1))
+        zc = np.random.default_rng(0).standard_normal((8, 128)).astype(np.float32)
+        dref.decoder_forward_torch(zc[:2], wd, dcfg.shape, dcfg.num_filters, dcfg.strides)
+        t0 = time.perf_counter()
+        dref.decoder_forward_torch(zc, wd, dcfg.shape, dcfg.num_filters, dcfg.strides)
+        dt = time.perf_counter() - t0
+        print(json.dumps({'what': 'decoder_cpu', 'threads': torch.get_num_threads(), 'batch': 8, 'images_per_s': round(8 / dt, 2)}))
+        dec.close()
     if 'config5' in what:
         # 368928 x 128 bf16 codebook (94.4 MB), batched queries, arg-max and top-5
         E5 = synth.make_codebook(368928, 128, seed=11)
