@@ -461,7 +461,7 @@ static int forward_impl(aae_encoder* enc, const void* x, int x_dtype, int B, flo
 struct ScanPlan {
     int nblk, Bpad, Bstride, Jpad, NT;
     bool gemv, stream;
-    size_t q_off, qp_off, pval_off, pidx_off, cs_off, total;
+    size_t q_off, qp_off, pval_off, pidx_off, cs_off, cand_off, total;
 };
 
 static ScanPlan plan_scan(const aae_codebook* cb, int B, int topk) {
@@ -484,6 +484,8 @@ static ScanPlan plan_scan(const aae_codebook* cb, int B, int topk) {
     s.pidx_off = off; off += align_up((size_t)s.nblk * s.Bstride * sizeof(int), 256);
     s.cs_off = off;
     if (topk > 1) off += align_up((size_t)B * cb->N * sizeof(float), 256);
+    s.cand_off = off;
+    if (topk > 1) off += 2 * align_up((size_t)B * ceil_div(cb->N, aae::kTopKChunk) * topk * sizeof(float), 256);
     s.total = off;
     return s;
 }
@@ -843,7 +845,11 @@ int aae_codebook_nn(aae_codebook* cb, const float* z, int B, int topk, int col_s
     } else {
         aae::TopKArgs t;
         t.cs = cs; t.idx_out = reinterpret_cast<long long*>(idx_out); t.score_out = score_out; t.N = cb->N; t.k = topk;
-        AAE_LAUNCH((aae::topk_rows_kernel), dim3(B), dim3(256), 64, stream, t);
+        t.chunks = ceil_div(cb->N, aae::kTopKChunk);
+        t.cand_v = reinterpret_cast<float*>(base + s.cand_off);
+        t.cand_i = reinterpret_cast<int*>(base + s.cand_off + align_up((size_t)B * t.chunks * topk * sizeof(float), 256));
+        AAE_LAUNCH((aae::topk_chunks_kernel), dim3(t.chunks, B), dim3(256), 64, stream, t);
+        AAE_LAUNCH((aae::topk_merge_kernel), dim3(B), dim3(256), 64, stream, t);
     }
     AAE_HIP_TRY(hipGetLastError());
     return AAE_OK;

@@ -369,50 +369,98 @@ __global__ __launch_bounds__(256) void argmax_reduce_kernel(const ArgmaxReduceAr
 // One block per query over a materialised similarity row.  k rounds; round j
 // selects the best element strictly after round j-1's winner in the order
 // (score descending, index ascending) -- no masking writes, deterministic.
+// ---- top-k (codebook.py:69-71: argpartition + sort, here in canonical order: score descending,
+// lower index first on ties) over a materialised similarity matrix, in two parallel levels:
+//   topk_chunks_kernel : grid (chunks, B); a block selects the k best of its 2048-entry chunk
+//                        (8 values per thread in registers, k argmax passes with exclusion);
+//   topk_merge_kernel  : grid B; the same selection over the chunks*k candidates.
+// Selection pass j picks the best entry strictly after winner j-1 in the canonical order, so
+// no state other than the previous winner is carried.
 struct TopKArgs {
     const float* cs;       // [B][N]
+    float* cand_v;         // [B][chunks][k]
+    int* cand_i;
     long long* idx_out;    // [B][k]
     float* score_out;      // [B][k]
-    int N, k;
+    int N, k, chunks;
 };
 
-__global__ __launch_bounds__(256) void topk_rows_kernel(const TopKArgs p) {
+constexpr int kTopKChunk = 2048;
+
+// block-wide (value, index) arg-best; result broadcast to every thread.  red: 10 dwords of LDS.
+__device__ __forceinline__ void block_best(float& bv, int& bi, float* red) {
+    int* red_i = reinterpret_cast<int*>(red + 4);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const float ov = shfl_xor(bv, m);
+        const int oi = shfl_xor(bi, m);
+        if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) { red[wave] = bv; red_i[wave] = bi; }
+    __syncthreads();
+    bv = red[0]; bi = red_i[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+        if (better(red[w], red_i[w], bv, bi)) { bv = red[w]; bi = red_i[w]; }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void topk_chunks_kernel(const TopKArgs p) {
     AAE_DYN_SMEM(smem_raw);
-    float* red_v = reinterpret_cast<float*>(smem_raw);      // [4]
-    int* red_i = reinterpret_cast<int*>(red_v + 4);         // [4]
-    float* win_v = red_v + 8;                               // [1]
-    int* win_i = reinterpret_cast<int*>(red_v + 9);         // [1]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* row = p.cs + (long long)blockIdx.x * p.N;
+    float* red = reinterpret_cast<float*>(smem_raw);
+    const int tid = threadIdx.x;
+    const int n0 = blockIdx.x * kTopKChunk;
+    const float* row = p.cs + (long long)blockIdx.y * p.N;
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const int n = n0 + tid + 256 * u;
+        v[u] = n < p.N ? row[n] : kNegInf;
+    }
+    float pv = __builtin_huge_valf();
+    int pi = -1;
+    const long long obase = ((long long)blockIdx.y * p.chunks + blockIdx.x) * p.k;
+    for (int j = 0; j < p.k; ++j) {
+        float bv = kNegInf;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int n = n0 + tid + 256 * u;
+            const bool after = n < p.N && ((v[u] < pv) || (v[u] == pv && n > pi));
+            if (after && better(v[u], n, bv, bi)) { bv = v[u]; bi = n; }
+        }
+        block_best(bv, bi, red);
+        if (tid == 0) { p.cand_v[obase + j] = bv; p.cand_i[obase + j] = bi; }
+        pv = bv; pi = bi;
+        if (bi == 0x7fffffff) pv = kNegInf;          // chunk exhausted: later passes emit sentinels too
+    }
+}
+
+__global__ __launch_bounds__(256) void topk_merge_kernel(const TopKArgs p) {
+    AAE_DYN_SMEM(smem_raw);
+    float* red = reinterpret_cast<float*>(smem_raw);
+    const int tid = threadIdx.x;
+    const int total = p.chunks * p.k;
+    const float* cv = p.cand_v + (long long)blockIdx.x * total;
+    const int* ci = p.cand_i + (long long)blockIdx.x * total;
     float pv = __builtin_huge_valf();
     int pi = -1;
     for (int j = 0; j < p.k; ++j) {
         float bv = kNegInf;
         int bi = 0x7fffffff;
-        for (int n = tid; n < p.N; n += 256) {
-            const float v = row[n];
-            const bool after = (v < pv) || (v == pv && n > pi);
+        for (int c = tid; c < total; c += 256) {
+            const float v = cv[c];
+            const int n = ci[c];
+            const bool after = n != 0x7fffffff && ((v < pv) || (v == pv && n > pi));
             if (after && better(v, n, bv, bi)) { bv = v; bi = n; }
         }
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-            const float ov = shfl_xor(bv, m);
-            const int oi = shfl_xor(bi, m);
-            if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
-        }
-        if (lane == 0) { red_v[wave] = bv; red_i[wave] = bi; }
-        __syncthreads();
+        block_best(bv, bi, red);
         if (tid == 0) {
-            for (int w = 1; w < 4; ++w)
-                if (better(red_v[w], red_i[w], bv, bi)) { bv = red_v[w]; bi = red_i[w]; }
-            win_v[0] = bv; win_i[0] = bi;
             p.idx_out[(long long)blockIdx.x * p.k + j] = (bi == 0x7fffffff) ? 0 : bi;
             p.score_out[(long long)blockIdx.x * p.k + j] = bv;
         }
-        __syncthreads();
-        pv = win_v[0];
-        pi = win_i[0];
-        __syncthreads();
+        pv = bv; pi = bi;
     }
 }
 

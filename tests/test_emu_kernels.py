@@ -162,3 +162,22 @@ def test_bf16_codebook_scan(B):
     cb.close()
     with pytest.raises(ValueError, match='J == 128'):
         eb.EmuCodebook(synth.make_codebook(72, 32, seed=1), dtype='bf16')
+
+
+def test_topk_two_level_selection_across_chunks():
+    """top-k over several 2048-entry chunks (tail chunk of 77 rows, k larger than the tail, ties that
+    straddle a chunk boundary): canonical order = score descending, lower index first."""
+    N, J = 2 * 2048 + 77, 128
+    E = synth.make_codebook(N, J, seed=3, planted_duplicates=0)
+    E[2047] = E[2048] = E[5]                                   # three identical rows, two of them across the chunk edge
+    E[N - 1] = E[4100]                                         # a tie inside the tail chunk
+    cb = eb.EmuCodebook(E)
+    z = np.stack([E[5] * 2.0, E[4100] * 0.5 + 0.01 * E[7], np.random.default_rng(0).standard_normal(J).astype(np.float32)])
+    cs = cb.similarity(z)
+    for k in (1, 7, 100):
+        ik, sk = cb.nn(z, topk=k)
+        assert np.array_equal(ik, ref.topk_canonical(cs, k)), k
+        assert np.array_equal(sk, np.take_along_axis(cs, ik, axis=1))
+    ik, _ = cb.nn(z, topk=7)
+    assert list(ik[0, :3]) == [5, 2047, 2048]
+    cb.close()

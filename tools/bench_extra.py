@@ -136,6 +136,21 @@ def main():
         dt = time.perf_counter() - t0
         print(json.dumps({'what': 'decoder_cpu', 'threads': torch.get_num_threads(), 'batch': 8, 'images_per_s': round(8 / dt, 2)}))
         dec.close()
+    if 'graph' in what:
+        # small-batch latency: eager launches vs one HIP-graph replay (CapturedNearestNeighbour)
+        from augmentedautoencoder_amd.engine import CapturedNearestNeighbour
+        for B in (1, 2, 4, 8, 16):
+            x = torch.from_numpy(synth.make_crops(B, seed=B)).cuda()
+            ms_eager = timeit(lambda: cb.nn(enc.encode(x), 1, 1), 100, warm=5)
+            cap = CapturedNearestNeighbour(enc, cb, B)
+            i0, s0 = cb.nn(enc.encode(x), 1, 1)
+            i1, s1 = cap(x)
+            same = bool(torch.equal(i0, i1) and torch.equal(s0, s1))
+            ms_graph = timeit(lambda: cap(x), 100, warm=5)
+            _, recs = enc.encode_timed(x)
+            print(json.dumps({'what': 'graph', 'B': B, 'eager_ms': round(ms_eager, 4), 'graph_ms': round(ms_graph, 4),
+                              'identical': same, 'encoder_kernel_ms_sum': round(sum(t for _, t, _ in recs), 4),
+                              'crops_per_s_graph': round(B / ms_graph * 1e3, 1)}))
     if 'config5' in what:
         # 368928 x 128 bf16 codebook (94.4 MB), batched queries, arg-max and top-5
         E5 = synth.make_codebook(368928, 128, seed=11)
