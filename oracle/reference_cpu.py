@@ -5,17 +5,24 @@
 (augmentedautoencoder_amd) never imports it and fails loudly when the HIP
 library is missing.
 
-PARITY UNPINNED: the arithmetic of the reference path lives in TensorFlow
-(tensorflow 2.6.0 pinned in /root/reference/aae_py37_tf26.yml:102-105), which is
-neither vendored in the reference tree nor installed here, and the reference
-ships no golden vectors / known-answer tests for this path.
-The oracle is therefore pinned only
-  (a) against itself through three independent implementations that must agree
-      (numpy-im2col fp64 here, torch.conv2d fp32/fp64 here, plain-C direct loops
-      in oracle/aae_oracle.c), and
-  (b) for the codebook-row -> rotation mapping against the output of the
-      reference's own importable view_sampler.py (tests/golden/, generated by
-      tests/golden/make_viewsphere_golden.py).
+PARITY UNPINNED for the TensorFlow arithmetic: conv2d / dense / batch-norm /
+l2_normalize / matmul live in TensorFlow (tensorflow 2.6.0 pinned in
+/root/reference/aae_py37_tf26.yml:102-105), which is neither vendored in the
+reference tree nor installed here, and the reference ships no golden vectors /
+known-answer tests for this path.  Those functions are
+pinned only against themselves through three independent implementations that
+must agree (numpy-im2col fp64 here, torch.conv2d fp32/fp64 here, plain-C direct
+loops in oracle/aae_oracle.c).
+PINNED against outputs of the reference's own code run in the build container
+(fixtures + generators under tests/golden/):
+  (a) codebook-row -> rotation table: pysixd_stuff/view_sampler.py and
+      Dataset.viewsphere_for_embedding (all 92232 x 3 x 3 doubles by digest);
+  (b) everything between "similarity matrix" and "pose": input /255 and batch
+      handling, np.argmax / upright / top-n index selection, squeeze behaviour,
+      auto_pose6d geometry, batch iteration -- recorded from
+      auto_pose/ae/{codebook,dataset,utils}.py with TF/cv2 stubbed and
+      session.run answering from a provided similarity matrix
+      (tests/golden/make_codebook_logic_golden.py, tests/test_golden_codebook_logic.py).
 
 Every function cites the reference file:line it follows (paths relative to
 /root/reference).  Semantics that come from TensorFlow's documented op
