@@ -4,6 +4,7 @@ resize (bit-exact, integer work), and process() against the oracle pipeline run 
 detection the way the reference does (m3_interface/ae_pose_estimator.py:143-222).
 CPU tests run the kernels on the emulator; the gpu-marked ones on the MI355X."""
 import configparser
+import os
 
 import numpy as np
 import pytest
@@ -213,3 +214,84 @@ def test_process_on_gpu_full_size_two_objects():
         assert g.name == c
         if srt[-1] - srt[-2] >= 2e-5:                       # away from near-ties the whole pose must agree
             assert np.allclose(g.trafo[:3, :3], R.squeeze(), atol=1e-9) and np.allclose(g.trafo[:3, 3], t.squeeze(), atol=1e-6)
+
+
+# ---- golden fixtures recorded from the reference's own estimator code (tests/golden/make_pose_estimator_golden.py:
+# ae_pose_estimator.py loaded with TF / cv2 / m3vision stubbed, cv2.resize returning its input, auto_pose6d a logger) ----
+PG = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'pose_estimator_ref.npz'))
+
+
+def _golden_pixel_boxes():
+    H, W = PG['img'].shape[:2]
+    rel = PG['boxes_rel']
+    return [[xmin * W, ymin * H, (xmax - xmin) * W, (ymax - ymin) * H] for xmin, xmax, ymin, ymax in rel]
+
+
+def test_square_patch_geometry_matches_reference_extract_square_patch():
+    """The black-bordered square patch the reference hands to cv2.resize (before interpolation) == the
+    oracle's crop == the HIP crop kernel (emulated) asked for an output of the patch's own size, where its
+    bilinear stage is an identity."""
+    import emu_backend as eb
+    img = PG['img']
+    assert np.array_equal(PG['m_call_boxes'], np.array([b for b, c in zip(_golden_pixel_boxes(), PG['box_classes'])
+                                                        if c in ('obj_a', 'obj_b') and min(b) >= 0]))
+    for i in range(int(PG['n_patches'])):
+        want = PG['patch_%d' % i]
+        size = want.shape[0]
+        bb, pad = PG['m_call_boxes'][i], float(PG['pad_factors'][i])
+        assert AePoseEstimator.box_rows([bb], pad)[0, 4] == size
+        assert np.array_equal(ref.extract_square_patch_black_borders(img, bb, pad, resize=(size, size)), want), i
+        got = eb.crop_resize(img, AePoseEstimator.box_rows([bb], pad), (size, size))
+        assert np.array_equal(got[0], want), i
+        assert list(PG['patch_%d_dsize_interp' % i][:2]) == ([128, 128] if PG['m_call_classes'][i] == 'obj_a' else [64, 64])
+        assert PG['patch_%d_dsize_interp' % i][2] == 1                       # cv2.INTER_LINEAR
+
+
+class _ScriptedCodebook(object):
+    """Stands where a Codebook stands in AePoseEstimator: answers with the (R, t) the reference run was fed."""
+
+    class _E(object):
+        class engine(object):
+            import torch as _t
+            device = _t.device('cpu')
+    _encoder = _E()
+
+    def __init__(self, Rs, ts):
+        self.Rs, self.ts, self.n, self.seen = Rs, ts, 0, []
+
+    def nearest_rotation(self, session, crops, top_n=1, upright=False, return_idcs=False):
+        assert top_n == 1 and return_idcs
+        self.seen.append((len(crops), upright))
+        out = np.arange(self.n, self.n + len(crops))
+        self.n += len(crops)
+        return out
+
+    def pose_from_indices(self, idcs, predicted_bb, K_test, train_args, depth_pred=None):
+        i = int(idcs[0])
+        return self.Rs[i][None].copy(), self.ts[i][None].copy()
+
+
+def test_process_bookkeeping_matches_reference_process():
+    """Class filter, relative -> pixel boxes, invalid-box skip, detection order, 4x4 assembly, mm vs m,
+    camPose composition: AePoseEstimator.process against the trafos the reference's process() produced."""
+    import torch
+    img, camK = PG['img'], PG['camK']
+    dets = [BoundingBox(xmin=r[0], xmax=r[1], ymin=r[2], ymax=r[3], classes={c: 0.8, 'other': 0.15})
+            for r, c in zip(PG['boxes_rel'], PG['box_classes'])]
+    targs = configparser.ConfigParser()
+    targs.read_string(TRAIN_CFG.format(h=16, w=16))
+    for tag, mm, use_pose in (('m', False, False), ('mm', True, False), ('campose', False, True)):
+        cls = PG['%s_call_classes' % tag]
+        books = {n: _ScriptedCodebook(PG['%s_returned_R' % tag][cls == n], PG['%s_returned_t' % tag][cls == n]) for n in ('obj_a', 'obj_b')}
+        est = AePoseEstimator(codebooks=books, train_args={'obj_a': targs, 'obj_b': targs}, upright=(tag == 'mm'), camPose=use_pose)
+        crops_seen = []
+
+        def crop_fn(scene_img, boxes_xywh, pad_factor, resize=(128, 128)):
+            crops_seen.extend(boxes_xywh)
+            return torch.zeros((len(boxes_xywh), resize[1], resize[0], 3), dtype=torch.uint8)
+        est.extract_square_patches = crop_fn
+        got = est.process(dets, img, camK, camPose=PG['camPose'] if use_pose else None, mm=mm)
+        assert [g.name for g in got] == [str(n) for n in PG['%s_names' % tag]]
+        assert np.array_equal(np.stack([g.trafo for g in got]), PG['%s_trafos' % tag])
+        assert sorted(map(tuple, crops_seen)) == sorted(map(tuple, PG['%s_call_boxes' % tag]))     # same boxes reach the crop stage
+        assert all(up == bool(PG['%s_call_upright' % tag][0]) for b in books.values() for _, up in b.seen)
