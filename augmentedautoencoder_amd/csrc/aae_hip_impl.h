@@ -828,6 +828,7 @@ int aae_codebook_nn(aae_codebook* cb, const float* z, int B, int topk, int col_s
     if (B < 1 || topk < 1 || topk > cb->N) return fail(AAE_ERR_INVALID, "aae_codebook_nn: B=%d topk=%d N=%d", B, topk, cb->N);
     if (col_stride < 1) return fail(AAE_ERR_INVALID, "col_stride %d < 1", col_stride);
     if (topk > 1 && col_stride != 1) return fail(AAE_ERR_INVALID, "upright (col_stride>1) is defined for topk == 1 only (codebook.py:65-66)");
+    if (topk > 1 && B > 65535) return fail(AAE_ERR_UNSUPPORTED, "top-k for more than 65535 queries per call (got %d): split the batch", B);
     const ScanPlan s = plan_scan(cb, B, topk);
     if (ws_bytes < s.total) return fail(AAE_ERR_WORKSPACE, "workspace %zu B < required %zu B", ws_bytes, s.total);
     if (!workspace || ((uintptr_t)workspace & 255)) return fail(AAE_ERR_WORKSPACE, "workspace must be non-null and 256-B aligned");
