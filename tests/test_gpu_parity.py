@@ -336,3 +336,34 @@ def test_config5_large_bf16_codebook_topk():
     up, _ = cb.nn(z[:Bo], 1, 36)
     assert np.array_equal(up[:, 0].cpu().numpy(), ref.nearest_indices_reference(cs, 1, upright=True, num_cyclo=36))
     cb.close()
+
+
+def test_captured_graph_and_streaming_pipelines_equal_the_eager_calls():
+    """engine.CapturedNearestNeighbour (one HIP-graph replay per query batch) and
+    engine.StreamingNearestNeighbour (H2D of batch i+1 overlapped with compute of batch i) run the
+    same kernels in the same order as the eager calls: indices and scores must be bit-identical."""
+    import torch
+    from augmentedautoencoder_amd.engine import (CapturedNearestNeighbour, CodebookEngine, EncoderEngine,
+                                                  StreamingNearestNeighbour)
+    from augmentedautoencoder_amd.weights import EncoderConfig
+    enc = EncoderEngine(EncoderConfig(), synth.make_weights(seed=2024))
+    cb = CodebookEngine(synth.make_codebook(92232, 128, seed=7, planted_duplicates=64))
+    for B in (1, 6):
+        cap = CapturedNearestNeighbour(enc, cb, B)
+        for seed in (1, 2, 3):
+            x = synth.make_crops(B, seed=700 + seed)
+            i0, s0 = cb.nn(enc.encode(x), 1, 1)
+            i1, s1 = cap(x if B > 1 else x[0])
+            assert torch.equal(i0, i1) and torch.equal(s0, s1)
+        with pytest.raises(ValueError):
+            cap(synth.make_crops(B + 1, seed=1))
+    batches = [synth.make_crops(n, seed=800 + k) for k, n in enumerate((64, 64, 17, 64, 1))]      # ragged tail batches
+    sp = StreamingNearestNeighbour(enc, cb, 64)
+    got = list(sp.run(batches))
+    assert len(got) == len(batches)
+    for x, (idx, score) in zip(batches, got):
+        i0, s0 = cb.nn(enc.encode(x), 1, 1)
+        assert np.array_equal(idx, i0.cpu().numpy()) and np.array_equal(score, s0.cpu().numpy())
+    assert list(sp.run([])) == []
+    enc.close()
+    cb.close()

@@ -151,6 +151,36 @@ def main():
             print(json.dumps({'what': 'graph', 'B': B, 'eager_ms': round(ms_eager, 4), 'graph_ms': round(ms_graph, 4),
                               'identical': same, 'encoder_kernel_ms_sum': round(sum(t for _, t, _ in recs), 4),
                               'crops_per_s_graph': round(B / ms_graph * 1e3, 1)}))
+    if 'stream' in what:
+        # PCIe-inclusive throughput: host uint8 batches, H2D overlapped with compute (StreamingNearestNeighbour)
+        from augmentedautoencoder_amd.engine import StreamingNearestNeighbour
+        host = [synth.make_crops(256, seed=100 + i) for i in range(4)]
+        nb = 40
+        def gen():
+            for i in range(nb):
+                yield host[i % 4]
+        sp = StreamingNearestNeighbour(enc, cb, 256)
+        for _ in sp.run(host[:2]):
+            pass
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        got = [r for r in sp.run(gen())]
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        xdev = [torch.from_numpy(h).cuda() for h in host]
+        ok = all(np.array_equal(got[i][0], cb.nn(enc.encode(xdev[i % 4]), 1, 1)[0].cpu().numpy()) for i in range(4))
+        # serial form: copy, then compute, per batch
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(nb):
+            x = torch.from_numpy(host[i % 4]).cuda()
+            idx, sc = cb.nn(enc.encode(x), 1, 1)
+            idx.cpu()
+        torch.cuda.synchronize()
+        dt_serial = time.perf_counter() - t0
+        print(json.dumps({'what': 'stream', 'batches': nb, 'batch': 256, 'overlapped_crops_per_s': round(nb * 256 / dt, 1),
+                          'overlapped_ms_per_batch': round(dt / nb * 1e3, 4), 'serial_crops_per_s': round(nb * 256 / dt_serial, 1),
+                          'serial_ms_per_batch': round(dt_serial / nb * 1e3, 4), 'identical_to_resident': bool(ok)}))
     if 'config5' in what:
         # 368928 x 128 bf16 codebook (94.4 MB), batched queries, arg-max and top-5
         E5 = synth.make_codebook(368928, 128, seed=11)
