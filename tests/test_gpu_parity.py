@@ -249,8 +249,28 @@ def test_fp32_igemm_lds_dma_variant_is_bit_identical():
         z0 = enc.encode(crops).cpu().numpy()
         acts0 = [enc.activation(i).cpu().numpy() for i in range(4)] if B == 5 else []
         enc.set_option('igemm_dma', 1)
-        for _ in range(4):
+        for _ in range(25):
             assert np.array_equal(enc.encode(crops).cpu().numpy(), z0)
+        if B == 256:
+            # ... and again while a second stream saturates HBM with copies (stretches the DMA landing times)
+            import torch
+            side = torch.cuda.Stream()
+            big_a = torch.empty(512 << 20, dtype=torch.uint8, device='cuda')
+            big_b = torch.zeros(512 << 20, dtype=torch.uint8, device='cuda')
+            for precision in (0, 1):
+                enc.set_option('precision', precision)
+                enc.set_option('igemm_dma', 0)
+                enc.set_option('x3h_dma', 0)
+                z_quiet = enc.encode(crops).cpu().numpy()
+                enc.set_option('igemm_dma', 1)
+                enc.set_option('x3h_dma', 1)
+                with torch.cuda.stream(side):
+                    for _ in range(60):
+                        big_a.copy_(big_b)
+                for _ in range(12):
+                    assert np.array_equal(enc.encode(crops).cpu().numpy(), z_quiet), 'precision %d under memory load' % precision
+                torch.cuda.synchronize()
+            enc.set_option('precision', 0)
         for i, a in enumerate(acts0):
             assert np.array_equal(enc.activation(i).cpu().numpy(), a), 'layer %d' % i
         assert any('f32_dma' in l for l, _, _ in enc.encode_timed(crops)[1])
@@ -292,7 +312,7 @@ def test_split_precision_f32x3h_mode_meets_the_same_tolerances(dma):
         enc.set_option('x3h_dma', 0)
         z_staged = enc.encode(crops).cpu().numpy()
         enc.set_option('x3h_dma', 1)
-        for _ in range(5):                                # landing-order races would show up as flipped bits
+        for _ in range(40):                               # landing-order races would show up as flipped bits
             assert np.array_equal(enc.encode(crops).cpu().numpy(), z_staged)
     enc.set_option('precision', 0)
     z_f32 = enc.encode(crops).cpu().numpy()
