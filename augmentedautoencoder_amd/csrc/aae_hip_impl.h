@@ -246,7 +246,7 @@ struct Timer {
 };
 
 static int launch_igemm(aae_encoder* enc, const Layer& L, const float* x, int M, float* out, float* partial,
-                        hipStream_t stream, Timer& tm, const char* name) {
+                        hipStream_t stream, Timer& tm, const char* name, int tag = 0) {
     aae::ConvIgemmArgs a;
     a.x = x; a.wp = L.wp; a.bias = L.bias; a.bn_scale = L.bn_scale; a.bn_shift = L.bn_shift;
     a.H = L.H; a.W = L.W; a.Cin = L.Cin; a.Ho = L.Ho; a.Wo = L.Wo; a.Cout = L.Cout; a.CoutPad = L.CoutPad;
@@ -267,7 +267,10 @@ static int launch_igemm(aae_encoder* enc, const Layer& L, const float* x, int M,
     char label[96];
     if (a.splits == 1) {
         a.out = out;
-        if (dma) AAE_LAUNCH((aae::conv_igemm_f32_kernel<false, true>), dim3(nblk), dim3(256), aae::kConvIgemmSmem, stream, a);
+        if (dma && tag == 1) AAE_LAUNCH((aae::conv_igemm_f32_kernel<false, true, false, 1>), dim3(nblk), dim3(256), aae::kConvIgemmSmem, stream, a);
+        else if (dma && tag == 2) AAE_LAUNCH((aae::conv_igemm_f32_kernel<false, true, false, 2>), dim3(nblk), dim3(256), aae::kConvIgemmSmem, stream, a);
+        else if (dma && tag == 3) AAE_LAUNCH((aae::conv_igemm_f32_kernel<false, true, false, 3>), dim3(nblk), dim3(256), aae::kConvIgemmSmem, stream, a);
+        else if (dma) AAE_LAUNCH((aae::conv_igemm_f32_kernel<false, true>), dim3(nblk), dim3(256), aae::kConvIgemmSmem, stream, a);
         else AAE_LAUNCH((aae::conv_igemm_f32_kernel<false, false>), dim3(nblk), dim3(256), aae::kConvIgemmSmem, stream, a);
         snprintf(label, sizeof(label), "%s:%s M=%d N=%d K=%lld", name, kname, M, L.Cout, L.K());
         enc->records.push_back({label, flops});
@@ -296,7 +299,7 @@ static int launch_igemm(aae_encoder* enc, const Layer& L, const float* x, int M,
 
 // f32x3h variant: x and (unless out_f32) out are fp16 hi/lo planes of value * 2^x3h_act_shift.
 static int launch_igemm_x3h(aae_encoder* enc, const Layer& L, const void* x, int M, void* out, bool out_f32, float* partial,
-                            hipStream_t stream, Timer& tm, const char* name) {
+                            hipStream_t stream, Timer& tm, const char* name, int tag = 0) {
     aae::ConvIgemmX3hArgs a;
     a.x = static_cast<const unsigned short*>(x); a.wp = L.wp16; a.bias = L.bias; a.bn_scale = L.bn_scale; a.bn_shift = L.bn_shift;
     a.H = L.H; a.W = L.W; a.Cin = L.Cin; a.Ho = L.Ho; a.Wo = L.Wo; a.Cout = L.Cout; a.CoutPad = L.CoutPad;
@@ -322,6 +325,9 @@ static int launch_igemm_x3h(aae_encoder* enc, const Layer& L, const void* x, int
         a.out = out;
         if (dma) {
             if (out_f32) AAE_LAUNCH((aae::conv_igemm_x3h_dma_kernel<aae::X3H_OUT_F32>), dim3(nblk), dim3(256), aae::kConvIgemmSmem, stream, a);
+            else if (tag == 1) AAE_LAUNCH((aae::conv_igemm_x3h_dma_kernel<aae::X3H_OUT_PLANES, 1>), dim3(nblk), dim3(256), aae::kConvIgemmSmem, stream, a);
+            else if (tag == 2) AAE_LAUNCH((aae::conv_igemm_x3h_dma_kernel<aae::X3H_OUT_PLANES, 2>), dim3(nblk), dim3(256), aae::kConvIgemmSmem, stream, a);
+            else if (tag == 3) AAE_LAUNCH((aae::conv_igemm_x3h_dma_kernel<aae::X3H_OUT_PLANES, 3>), dim3(nblk), dim3(256), aae::kConvIgemmSmem, stream, a);
             else AAE_LAUNCH((aae::conv_igemm_x3h_dma_kernel<aae::X3H_OUT_PLANES>), dim3(nblk), dim3(256), aae::kConvIgemmSmem, stream, a);
         } else {
             if (out_f32) AAE_LAUNCH((aae::conv_igemm_x3h_kernel<aae::X3H_OUT_F32>), dim3(nblk), dim3(256), aae::kConvIgemmSmem, stream, a);
@@ -432,7 +438,7 @@ static int forward_impl(aae_encoder* enc, const void* x, int x_dtype, int B, flo
             snprintf(name, sizeof(name), "conv%zu", li + 1);
             int rc;
             if (li == 0) rc = launch_first(enc, L, cur, cur_u8, B, out, true, stream, tm);
-            else rc = launch_igemm_x3h(enc, L, cur, B * L.Ho * L.Wo, out, false, partial, stream, tm, name);
+            else rc = launch_igemm_x3h(enc, L, cur, B * L.Ho * L.Wo, out, false, partial, stream, tm, name, (int)li);
             if (rc) return rc;
             cur = out;
         }
@@ -446,7 +452,7 @@ static int forward_impl(aae_encoder* enc, const void* x, int x_dtype, int B, flo
         int rc;
         if (li == 0 && L.kind == KIND_FIRST_MFMA) rc = launch_first(enc, L, cur, cur_u8, B, out, false, stream, tm);
         else if (L.kind == KIND_IGEMM && !cur_u8)
-            rc = launch_igemm(enc, L, static_cast<const float*>(cur), B * L.Ho * L.Wo, out, partial, stream, tm, name);
+            rc = launch_igemm(enc, L, static_cast<const float*>(cur), B * L.Ho * L.Wo, out, partial, stream, tm, name, (int)li);
         else rc = launch_generic(enc, L, cur, cur_u8, B, out, stream, tm, name);
         if (rc) return rc;
         cur = out;
@@ -660,12 +666,18 @@ int aae_encoder_create(const aae_encoder_desc* d, const void* const* hw, int n_w
     (void)hipFuncSetAttribute((const void*)aae::conv_igemm_f32_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
     (void)hipFuncSetAttribute((const void*)aae::conv_igemm_f32_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
     (void)hipFuncSetAttribute((const void*)aae::conv_igemm_f32_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
+    (void)hipFuncSetAttribute((const void*)aae::conv_igemm_f32_kernel<false, true, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
+    (void)hipFuncSetAttribute((const void*)aae::conv_igemm_f32_kernel<false, true, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
+    (void)hipFuncSetAttribute((const void*)aae::conv_igemm_f32_kernel<false, true, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
     (void)hipFuncSetAttribute((const void*)aae::conv_igemm_f32_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
     (void)hipFuncSetAttribute((const void*)aae::conv_igemm_x3h_kernel<aae::X3H_OUT_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
     (void)hipFuncSetAttribute((const void*)aae::conv_igemm_x3h_kernel<aae::X3H_OUT_PLANES>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
     (void)hipFuncSetAttribute((const void*)aae::conv_igemm_x3h_kernel<aae::X3H_OUT_PARTIAL>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
     (void)hipFuncSetAttribute((const void*)aae::conv_igemm_x3h_dma_kernel<aae::X3H_OUT_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
     (void)hipFuncSetAttribute((const void*)aae::conv_igemm_x3h_dma_kernel<aae::X3H_OUT_PLANES>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
+    (void)hipFuncSetAttribute((const void*)aae::conv_igemm_x3h_dma_kernel<aae::X3H_OUT_PLANES, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
+    (void)hipFuncSetAttribute((const void*)aae::conv_igemm_x3h_dma_kernel<aae::X3H_OUT_PLANES, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
+    (void)hipFuncSetAttribute((const void*)aae::conv_igemm_x3h_dma_kernel<aae::X3H_OUT_PLANES, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
     (void)hipFuncSetAttribute((const void*)aae::conv_igemm_x3h_dma_kernel<aae::X3H_OUT_PARTIAL>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
     if (enc->layers[0].kind == KIND_FIRST_MFMA) {
         const int sm = enc->layers[0].first_smem;

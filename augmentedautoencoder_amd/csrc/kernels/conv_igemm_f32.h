@@ -53,7 +53,9 @@ constexpr int kConvIgemmSmem = 2 * (kSlabFloatsA + 8 * 128 * 4) * 4;   // 64 KiB
 // of row r fetches logical slot ps ^ ((r>>1)&7).  Slab t+1 is issued under group 0 of slab t
 // into the other buffer (free since the barrier of slab t-1) and is waited for (vmcnt) by
 // every wave right before the barrier of slab t.  Same MFMA sequence, bit-identical results.
-template <bool SPLITK, bool DMA = false, bool SCATTER = false>
+// TAG only makes the symbol unique: the host instantiates the un-split DMA kernel once per encoder layer
+// (TAG = layer index) so that rocprofv3 --stats reports conv2 / conv3 / conv4 as separate rows.
+template <bool SPLITK, bool DMA = false, bool SCATTER = false, int TAG = 0>
 __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvIgemmArgs p) {
     AAE_DYN_SMEM(smem_raw);
     float* As = reinterpret_cast<float*>(smem_raw);            // [2][128*32]

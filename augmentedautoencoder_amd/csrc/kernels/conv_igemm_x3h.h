@@ -268,7 +268,7 @@ __global__ __launch_bounds__(256) void conv_igemm_x3h_kernel(const ConvIgemmX3hA
 //     read the fragments of slab it+1 from P^1 (all ds_reads first: nothing the compiler could
 //     order behind a DMA), then issue the 8 DMA pieces of slab it+2 into buffer P, all under
 //     step 1 (12 MFMAs on f1[P]).
-template <int OUT>
+template <int OUT, int TAG = 0>       // TAG: unique symbol per encoder layer for rocprofv3 --stats (see conv_igemm_f32.h)
 __global__ __launch_bounds__(256) void conv_igemm_x3h_dma_kernel(const ConvIgemmX3hArgs p) {
     AAE_DYN_SMEM(smem_raw);
     float* As = reinterpret_cast<float*>(smem_raw);            // [2][128 rows][32 dwords]
