@@ -100,6 +100,7 @@ struct aae_encoder {
     int first_target_blocks = 1024;        // conv1 grid size aimed at (x N tiles); 2 blocks fit a CU
     int first_max_tiles_per_block = 8;     // conv1: consecutive 128-pixel tiles one block walks with its weights in registers
     int igemm_dma = 1;                     // fp32 igemm operand slabs by LDS-DMA (buffer_load ... lds); 0 = register-staged variant
+    int x3h_wide_min_blocks = 0;           // > 0: f32x3h conv layers use 256x128 tiles (8 waves) when that still yields this many blocks; measured neutral (+-1.5 %), off by default
     int x3h_dma = 1;                       // f32x3h operand slabs by LDS-DMA (buffer_load ... lds); 0 = register-staged variant
     int x3h_act_shift = 4;                 // activations travel as halves of x*2^shift in f32x3h mode (|x| < 4094 exact range)
     int igemm_stagger = 0;                 // kcycles of start delay for every 2nd block generation of the igemm (0 = off)
@@ -321,6 +322,23 @@ static int launch_igemm_x3h(aae_encoder* enc, const Layer& L, const void* x, int
     const bool dma = enc->x3h_dma != 0;
     const char* kname = dma ? "conv_igemm_x3h_dma" : "conv_igemm_x3h";
     char label[96];
+    // 256 x 128 tiles (8 waves, one block per CU) when they still give every CU a block
+    if (dma && !out_f32 && tag >= 1 && tag <= 3 && enc->x3h_wide_min_blocks > 0 &&
+        ceil_div(M, 256) * a.num_nt >= enc->x3h_wide_min_blocks) {
+        a.num_mt = ceil_div(M, 256);
+        a.splits = 1;
+        a.slabs_per_split = a.slabs_total;
+        a.out = out;
+        const int wide_blocks = a.num_mt * a.num_nt;
+        constexpr int smem = aae::x3h_dma_smem<4>();
+        if (tag == 1) AAE_LAUNCH((aae::conv_igemm_x3h_dma_kernel<aae::X3H_OUT_PLANES, 1, 4>), dim3(wide_blocks), dim3(512), smem, stream, a);
+        else if (tag == 2) AAE_LAUNCH((aae::conv_igemm_x3h_dma_kernel<aae::X3H_OUT_PLANES, 2, 4>), dim3(wide_blocks), dim3(512), smem, stream, a);
+        else AAE_LAUNCH((aae::conv_igemm_x3h_dma_kernel<aae::X3H_OUT_PLANES, 3, 4>), dim3(wide_blocks), dim3(512), smem, stream, a);
+        snprintf(label, sizeof(label), "%s:conv_igemm_x3h_dma256 M=%d N=%d K=%lld", name, M, L.Cout, L.K());
+        enc->records.push_back({label, flops});
+        AAE_HIP_TRY(hipGetLastError());
+        return tm.mark();
+    }
     if (a.splits == 1) {
         a.out = out;
         if (dma) {
@@ -675,6 +693,9 @@ int aae_encoder_create(const aae_encoder_desc* d, const void* const* hw, int n_w
     (void)hipFuncSetAttribute((const void*)aae::conv_igemm_x3h_kernel<aae::X3H_OUT_PARTIAL>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
     (void)hipFuncSetAttribute((const void*)aae::conv_igemm_x3h_dma_kernel<aae::X3H_OUT_F32>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
     (void)hipFuncSetAttribute((const void*)aae::conv_igemm_x3h_dma_kernel<aae::X3H_OUT_PLANES>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
+    (void)hipFuncSetAttribute((const void*)aae::conv_igemm_x3h_dma_kernel<aae::X3H_OUT_PLANES, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::x3h_dma_smem<4>());
+    (void)hipFuncSetAttribute((const void*)aae::conv_igemm_x3h_dma_kernel<aae::X3H_OUT_PLANES, 2, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::x3h_dma_smem<4>());
+    (void)hipFuncSetAttribute((const void*)aae::conv_igemm_x3h_dma_kernel<aae::X3H_OUT_PLANES, 3, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::x3h_dma_smem<4>());
     (void)hipFuncSetAttribute((const void*)aae::conv_igemm_x3h_dma_kernel<aae::X3H_OUT_PLANES, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
     (void)hipFuncSetAttribute((const void*)aae::conv_igemm_x3h_dma_kernel<aae::X3H_OUT_PLANES, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
     (void)hipFuncSetAttribute((const void*)aae::conv_igemm_x3h_dma_kernel<aae::X3H_OUT_PLANES, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
@@ -707,6 +728,7 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
     else if (!strcmp(name, "splitk_target_blocks")) enc->splitk_target_blocks = value;
     else if (!strcmp(name, "igemm_stagger")) enc->igemm_stagger = value;
     else if (!strcmp(name, "x3h_dma")) enc->x3h_dma = value ? 1 : 0;
+    else if (!strcmp(name, "x3h_wide_min_blocks")) enc->x3h_wide_min_blocks = value < 0 ? 0 : value;
     else if (!strcmp(name, "igemm_dma")) enc->igemm_dma = value ? 1 : 0;
     else if (!strcmp(name, "first_target_blocks")) enc->first_target_blocks = value < 1 ? 1 : value;
     else if (!strcmp(name, "first_max_tiles_per_block")) enc->first_max_tiles_per_block = value < 1 ? 1 : value;

@@ -78,7 +78,7 @@ __device__ __forceinline__ void x3h_mfma_tile(const X3hFrag& f, int q, f32x16 (&
 // bias / ReLU / folded BN and the store of a wave's 64x64 accumulator tile in the layout OUT names
 template <int OUT>
 __device__ __forceinline__ void x3h_epilogue(const ConvIgemmX3hArgs& p, const f32x16 (&acc)[2][2], int mt, int nt, int split,
-                                             int wm, int wn, int lane) {
+                                             int wm, int wn, int lane, int bm = kBM) {
     const int i = lane & 31;
 #pragma unroll
     for (int ni = 0; ni < 2; ++ni) {
@@ -93,7 +93,7 @@ __device__ __forceinline__ void x3h_epilogue(const ConvIgemmX3hArgs& p, const f3
         for (int mi = 0; mi < 2; ++mi) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = mt * kBM + wm * 64 + mi * 32 + acc_row(r, lane);
+                const int m = mt * bm + wm * 64 + mi * 32 + acc_row(r, lane);
                 if (m >= p.M) continue;
                 float v = acc[mi][ni][r] * p.inv_scale;
                 if (OUT == X3H_OUT_PARTIAL) {
@@ -268,11 +268,27 @@ __global__ __launch_bounds__(256) void conv_igemm_x3h_kernel(const ConvIgemmX3hA
 //     read the fragments of slab it+1 from P^1 (all ds_reads first: nothing the compiler could
 //     order behind a DMA), then issue the 8 DMA pieces of slab it+2 into buffer P, all under
 //     step 1 (12 MFMAs on f1[P]).
-template <int OUT, int TAG = 0>       // TAG: unique symbol per encoder layer for rocprofv3 --stats (see conv_igemm_f32.h)
-__global__ __launch_bounds__(256) void conv_igemm_x3h_dma_kernel(const ConvIgemmX3hArgs p) {
+//
+// WM = wave rows of the block: 2 -> 4 waves, 128 x 128 tile, 64 KB of LDS (two blocks per CU);
+//                              4 -> 8 waves, 256 x 128 tile, 96 KB (one block per CU, still two waves per
+// SIMD).  The wide tile moves 25 % fewer operand bytes per MFMA (32 KB per 96 MFMAs -> 48 KB per 192) and
+// issues 6 instead of 8 DMA instructions per wave and slab.  Measured at B = 256: neutral (conv2 358 vs 363,
+// conv3 388 vs 381, conv4 390 vs 390 TF-equivalent), bit-identical; host option x3h_wide_min_blocks, off by
+// default.  (Also measured and dropped: term-major MFMA order, single-MFMA interleave of reads/DMA, an L2
+// prefetch two slabs beyond the DMA -- the latter cost 20 %: the DMA/texture-address issue path, at ~100+
+// cycles of wave time per 1-KiB piece, is what bounds this kernel near 47 % of the fp16 matrix peak.)
+// TAG only makes the symbol unique per encoder layer for rocprofv3 --stats (see conv_igemm_f32.h).
+template <int WM> constexpr int x3h_dma_smem() { return 2 * (64 * WM * kBK + 8 * 128 * 4) * 4; }
+
+template <int OUT, int TAG = 0, int WM = 2>
+__global__ __launch_bounds__(128 * WM) void conv_igemm_x3h_dma_kernel(const ConvIgemmX3hArgs p) {
+    constexpr int T = 128 * WM;                                // threads
+    constexpr int BM = 64 * WM;                                // tile rows
+    constexpr int kStageA = BM * kBK;                          // floats of one A slab image
+    constexpr int NB = 1024 / T;                               // 16-B weight pieces per thread and slab
     AAE_DYN_SMEM(smem_raw);
-    float* As = reinterpret_cast<float*>(smem_raw);            // [2][128 rows][32 dwords]
-    float* Bs = As + 2 * kSlabFloatsA;                         // [2][8 slots][128 cols][4 dwords]
+    float* As = reinterpret_cast<float*>(smem_raw);            // [2][BM rows][32 dwords]
+    float* Bs = As + 2 * kStageA;                              // [2][8 slots][128 cols][4 dwords]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
@@ -286,8 +302,8 @@ __global__ __launch_bounds__(256) void conv_igemm_x3h_dma_kernel(const ConvIgemm
     const int slab1 = min(slab0 + p.slabs_per_split, p.slabs_total);
     const int nslab = slab1 - slab0;
 
-    // ---- A pieces: piece q of wave w fills rows 32q + 8w .. +7 (8 lanes per row) --------------------
-    const int a_row = tid >> 3;                                    // + 32 q
+    // ---- A pieces: piece q of wave w fills rows (T/8) q + 8w .. +7 (8 lanes per row) -----------------
+    const int a_row = tid >> 3;                                    // + (T/8) q
     const int a_slot = (tid & 7) ^ ((a_row >> 1) & 7);             // logical slot for this LDS position
     const buffer_rsrc xbuf = make_buffer(p.x, p.x_bytes);
     const buffer_rsrc wbuf = make_buffer(p.wp, p.wp_bytes);
@@ -296,7 +312,7 @@ __global__ __launch_bounds__(256) void conv_igemm_x3h_dma_kernel(const ConvIgemm
     bool a_ok[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
-        const int m = mt * kBM + a_row + 32 * q;
+        const int m = mt * BM + a_row + (T / 8) * q;
         a_ok[q] = m < p.M;
         const int mm = a_ok[q] ? m : 0;
         const int b = mm / (p.Ho * p.Wo);
@@ -307,9 +323,9 @@ __global__ __launch_bounds__(256) void conv_igemm_x3h_dma_kernel(const ConvIgemm
         a_off[q] = (unsigned)((((long long)b * p.H + a_ih0[q]) * p.W + a_iw0[q]) * (long long)p.Cin * 2) +
                    (unsigned)(a_slot & 3) * 16u + (unsigned)(a_slot >> 2) * p.plane_bytes;
     }
-    // ---- B pieces: idx = tid + 256 q -> slot = idx>>7, col = idx&127, LDS position idx ------------
+    // ---- B pieces: idx = tid + T q -> slot = idx>>7, col = idx&127, LDS position idx (q < NB) --------
     const unsigned b_off0 = (unsigned)(((tid >> 7) * p.CoutPad + nt * 128 + (tid & 127)) * 16);
-    const unsigned b_piece_stride = (unsigned)(2 * p.CoutPad * 16);   // two slot rows per piece
+    const unsigned b_piece_stride = (unsigned)((T / 128) * p.CoutPad * 16);   // T/128 slot rows per piece
 
     const int taps = p.KS * p.KS;
     int cc = slab0 / taps;
@@ -320,8 +336,9 @@ __global__ __launch_bounds__(256) void conv_igemm_x3h_dma_kernel(const ConvIgemm
     auto dma_piece = [&](int slab, int buf, int q) {
         if (q == 0) tap_off = (unsigned)(((kh * p.W + kw) * p.Cin + cc * 32) * 2);
         const bool ok = a_ok[q] && (unsigned)(a_ih0[q] + kh) < (unsigned)p.H && (unsigned)(a_iw0[q] + kw) < (unsigned)p.W;
-        lds_dma16(xbuf, ok ? a_off[q] + tap_off : kOobOffset, As + buf * kSlabFloatsA + (32 * q + 8 * wave) * kBK);
-        lds_dma16(wbuf, b_off0 + (unsigned)(slab * 4 + q) * b_piece_stride, Bs + buf * (8 * 128 * 4) + (256 * q + 64 * wave) * 4);
+        lds_dma16(xbuf, ok ? a_off[q] + tap_off : kOobOffset, As + buf * kStageA + ((T / 8) * q + 8 * wave) * kBK);
+        if (q < NB)
+            lds_dma16(wbuf, b_off0 + (unsigned)(slab * NB + q) * b_piece_stride, Bs + buf * (8 * 128 * 4) + (T * q + 64 * wave) * 4);
         if (q == 3) {
             if (++kw == p.KS) { kw = 0; if (++kh == p.KS) { kh = 0; ++cc; } }
         }
@@ -354,7 +371,7 @@ __global__ __launch_bounds__(256) void conv_igemm_x3h_dma_kernel(const ConvIgemm
         auto iteration = [&](auto PAR, int it) {
             constexpr int P = decltype(PAR)::value;
             const bool has1 = it + 1 < nslab, has2 = it + 2 < nslab;
-            const float* An = As + (P ^ 1) * kSlabFloatsA;
+            const float* An = As + (P ^ 1) * kStageA;
             const float* Btn = Bs + (P ^ 1) * (8 * 128 * 4);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -390,7 +407,7 @@ __global__ __launch_bounds__(256) void conv_igemm_x3h_dma_kernel(const ConvIgemm
         }
         if (it < nslab) iteration(P0{}, it);
     }
-    x3h_epilogue<OUT>(p, acc, mt, nt, split, wm, wn, lane);
+    x3h_epilogue<OUT>(p, acc, mt, nt, split, wm, wn, lane, BM);
 }
 
 }  // namespace aae

@@ -181,3 +181,21 @@ def test_topk_two_level_selection_across_chunks():
     ik, _ = cb.nn(z, topk=7)
     assert list(ik[0, :3]) == [5, 2047, 2048]
     cb.close()
+
+
+def test_f32x3h_wide_tile_variant_is_bit_identical():
+    """conv_igemm_x3h_dma_kernel<.., WM=4>: 256 x 128 tiles / 8 waves (host option x3h_wide_min_blocks) must
+    reproduce the 128 x 128 kernel bit for bit, including a partial second M tile."""
+    cfg = EncoderConfig((32, 32, 3), [32, 64], [2, 2], 5, 128)
+    w = synth.make_weights(seed=5, shape=cfg.shape, num_filter=cfg.num_filter, strides=cfg.strides, latent=128)
+    x = synth.make_crops(5, seed=6, shape=cfg.shape)                     # conv2: M = 320 = one full + one partial 256-row tile
+    enc = eb.EmuEncoder(w, cfg)
+    enc.set_option('precision', 1)
+    enc.set_option('splitk_min_base_blocks', 0)
+    z0, a0 = enc.forward(x), None
+    a0 = enc.activation(1)
+    enc.set_option('x3h_wide_min_blocks', 1)
+    z1 = enc.forward(x)
+    assert any('x3h_dma256' in l for l in enc.labels())
+    assert np.array_equal(z0, z1) and np.array_equal(a0, enc.activation(1))
+    enc.close()

@@ -181,6 +181,21 @@ def main():
         print(json.dumps({'what': 'stream', 'batches': nb, 'batch': 256, 'overlapped_crops_per_s': round(nb * 256 / dt, 1),
                           'overlapped_ms_per_batch': round(dt / nb * 1e3, 4), 'serial_crops_per_s': round(nb * 256 / dt_serial, 1),
                           'serial_ms_per_batch': round(dt_serial / nb * 1e3, 4), 'identical_to_resident': bool(ok)}))
+    if 'wide' in what:
+        # f32x3h conv layers: 128x128 tiles (4 waves, 2 blocks/CU) vs 256x128 tiles (8 waves, 1 block/CU)
+        x = torch.from_numpy(synth.make_crops(256, seed=1)).cuda()
+        enc.set_option('precision', 1)
+        z0 = None
+        for wide in (0, 256, 0, 256):
+            enc.set_option('x3h_wide_min_blocks', wide)
+            ms = timeit(lambda: enc.encode(x), 10)
+            z, recs = enc.encode_timed(x)
+            z0 = z if z0 is None else z0
+            print(json.dumps({'what': 'wide', 'x3h_wide_min_blocks': wide, 'encode_ms': round(ms, 4), 'crops_per_s': round(256 / ms * 1e3, 1),
+                              'identical': bool(torch.equal(z, z0)),
+                              'kernels': [(l.split(' ')[0], round(t, 4), round(f / t / 1e9, 1)) for l, t, f in recs[:4]]}))
+        enc.set_option('x3h_wide_min_blocks', 0)
+        enc.set_option('precision', 0)
     if 'config5' in what:
         # 368928 x 128 bf16 codebook (94.4 MB), batched queries, arg-max and top-5
         E5 = synth.make_codebook(368928, 128, seed=11)
