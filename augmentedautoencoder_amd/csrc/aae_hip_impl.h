@@ -99,6 +99,8 @@ struct aae_encoder {
     int precision = 0;                     // 0: exact fp32 MFMA; 1: f32x3h split-precision igemm (explicit opt-in)
     int first_target_blocks = 1024;        // conv1 grid size aimed at (x N tiles); 2 blocks fit a CU
     int first_max_tiles_per_block = 8;     // conv1: consecutive 128-pixel tiles one block walks with its weights in registers
+    int igemm_breg_min_blocks = 768;       // ... with the 32 KB footprint only for grids of at least this many blocks
+    int igemm_breg = 1;                    // conv layers: weight fragments straight from global memory to registers (A-only LDS-DMA, 32 KB LDS)
     int igemm_dma = 1;                     // fp32 igemm operand slabs by LDS-DMA (buffer_load ... lds); 0 = register-staged variant
     int x3h_wide_min_blocks = 0;           // > 0: f32x3h conv layers use 256x128 tiles (8 waves) when that still yields this many blocks; measured neutral (+-1.5 %), off by default
     int x3h_dma = 1;                       // f32x3h operand slabs by LDS-DMA (buffer_load ... lds); 0 = register-staged variant
@@ -268,7 +270,15 @@ static int launch_igemm(aae_encoder* enc, const Layer& L, const float* x, int M,
     char label[96];
     if (a.splits == 1) {
         a.out = out;
-        if (dma && tag == 1) AAE_LAUNCH((aae::conv_igemm_f32_kernel<false, true, false, 1>), dim3(nblk), dim3(256), aae::kConvIgemmSmem, stream, a);
+        // A buffers only (32 KB: three blocks per CU); grids too small to give every CU three blocks keep the
+        // 64 KB footprint so that the blocks spread two per CU instead of 3/2/1
+        const int kBregSmem = nblk >= enc->igemm_breg_min_blocks ? 2 * aae::kSlabFloatsA * 4 : aae::kConvIgemmSmem;
+        const bool breg = dma && enc->igemm_breg && tag >= 1 && tag <= 3;
+        if (breg) kname = "conv_igemm_f32_dma_breg";
+        if (breg && tag == 1) AAE_LAUNCH((aae::conv_igemm_f32_kernel<false, true, false, 1, true>), dim3(nblk), dim3(256), kBregSmem, stream, a);
+        else if (breg && tag == 2) AAE_LAUNCH((aae::conv_igemm_f32_kernel<false, true, false, 2, true>), dim3(nblk), dim3(256), kBregSmem, stream, a);
+        else if (breg && tag == 3) AAE_LAUNCH((aae::conv_igemm_f32_kernel<false, true, false, 3, true>), dim3(nblk), dim3(256), kBregSmem, stream, a);
+        else if (dma && tag == 1) AAE_LAUNCH((aae::conv_igemm_f32_kernel<false, true, false, 1>), dim3(nblk), dim3(256), aae::kConvIgemmSmem, stream, a);
         else if (dma && tag == 2) AAE_LAUNCH((aae::conv_igemm_f32_kernel<false, true, false, 2>), dim3(nblk), dim3(256), aae::kConvIgemmSmem, stream, a);
         else if (dma && tag == 3) AAE_LAUNCH((aae::conv_igemm_f32_kernel<false, true, false, 3>), dim3(nblk), dim3(256), aae::kConvIgemmSmem, stream, a);
         else if (dma) AAE_LAUNCH((aae::conv_igemm_f32_kernel<false, true>), dim3(nblk), dim3(256), aae::kConvIgemmSmem, stream, a);
@@ -684,6 +694,9 @@ int aae_encoder_create(const aae_encoder_desc* d, const void* const* hw, int n_w
     (void)hipFuncSetAttribute((const void*)aae::conv_igemm_f32_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
     (void)hipFuncSetAttribute((const void*)aae::conv_igemm_f32_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
     (void)hipFuncSetAttribute((const void*)aae::conv_igemm_f32_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
+    (void)hipFuncSetAttribute((const void*)aae::conv_igemm_f32_kernel<false, true, false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
+    (void)hipFuncSetAttribute((const void*)aae::conv_igemm_f32_kernel<false, true, false, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
+    (void)hipFuncSetAttribute((const void*)aae::conv_igemm_f32_kernel<false, true, false, 3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
     (void)hipFuncSetAttribute((const void*)aae::conv_igemm_f32_kernel<false, true, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
     (void)hipFuncSetAttribute((const void*)aae::conv_igemm_f32_kernel<false, true, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
     (void)hipFuncSetAttribute((const void*)aae::conv_igemm_f32_kernel<false, true, false, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
@@ -730,6 +743,8 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
     else if (!strcmp(name, "x3h_dma")) enc->x3h_dma = value ? 1 : 0;
     else if (!strcmp(name, "x3h_wide_min_blocks")) enc->x3h_wide_min_blocks = value < 0 ? 0 : value;
     else if (!strcmp(name, "igemm_dma")) enc->igemm_dma = value ? 1 : 0;
+    else if (!strcmp(name, "igemm_breg")) enc->igemm_breg = value ? 1 : 0;
+    else if (!strcmp(name, "igemm_breg_min_blocks")) enc->igemm_breg_min_blocks = value;
     else if (!strcmp(name, "first_target_blocks")) enc->first_target_blocks = value < 1 ? 1 : value;
     else if (!strcmp(name, "first_max_tiles_per_block")) enc->first_max_tiles_per_block = value < 1 ? 1 : value;
     else if (!strcmp(name, "x3h_act_shift")) {

@@ -76,6 +76,11 @@ __device__ __forceinline__ void lds_dma16(buffer_rsrc r, uint32_t byte_off, floa
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds_wave_base, 16, (int)byte_off, 0, 0, 0);
 }
 __device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+// ... leaving the N youngest VMEM operations in flight (vmcnt retires loads in issue order)
+template <int N>
+__device__ __forceinline__ void wait_dma_keep_and_lds() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
+// bare s_barrier: unlike __syncthreads() it carries no fence, so it does not drain loads that are meant to stay in flight
+__device__ __forceinline__ void block_barrier() { __builtin_amdgcn_s_barrier(); }
 __device__ __forceinline__ void wait_dma_and_lds() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
 
 // Cross-lane add through the DPP path (no LDS crossbar).  Lanes whose source is outside

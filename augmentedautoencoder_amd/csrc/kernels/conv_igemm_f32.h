@@ -55,7 +55,15 @@ constexpr int kConvIgemmSmem = 2 * (kSlabFloatsA + 8 * 128 * 4) * 4;   // 64 KiB
 // every wave right before the barrier of slab t.  Same MFMA sequence, bit-identical results.
 // TAG only makes the symbol unique: the host instantiates the un-split DMA kernel once per encoder layer
 // (TAG = layer index) so that rocprofv3 --stats reports conv2 / conv3 / conv4 as separate rows.
-template <bool SPLITK, bool DMA = false, bool SCATTER = false, int TAG = 0>
+//
+// BREG = true (needs DMA): the weight operand skips LDS altogether.  The packed weights [K/4][CoutPad][4] are
+// already in MFMA B-fragment order, so lane (i, h) of a wave loads its two 16-B fragments of k-group c
+// straight from global memory (L2-resident: every M tile re-reads them) into registers, one slab ahead, right
+// after the MFMAs of group c have consumed the previous ones.  Per wave and slab that is 4 DMA pieces (A only)
+// + 8 plain loads instead of 8 DMA pieces + 8 LDS fragment reads; an LDS-DMA piece costs the issuing wave
+// well over 100 cycles, a plain load a fraction of that.  LDS shrinks to the two A buffers (32 KB).
+// The slab barrier is a bare s_barrier behind a counted vmcnt that covers the DMA pieces only.
+template <bool SPLITK, bool DMA = false, bool SCATTER = false, int TAG = 0, bool BREG = false>
 __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvIgemmArgs p) {
     AAE_DYN_SMEM(smem_raw);
     float* As = reinterpret_cast<float*>(smem_raw);            // [2][128*32]
@@ -149,7 +157,78 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvIgemmArgs
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    if (slab0 < slab1) {
+    if (BREG && slab0 < slab1) {
+        const int i = lane & 31, h = lane >> 5;
+        const unsigned bw_off = (unsigned)(((h * p.CoutPad) + nt * 128 + wn * 64 + i) * 16);
+        f32x4 bw[4][2];                          // B fragments of the 4 k-groups of one slab
+        auto load_bw = [&](int slab, int c) {
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+                bw[c][ni] = buffer_load4(wbuf, bw_off + (unsigned)(((slab * 8 + 2 * c) * p.CoutPad + 32 * ni) * 16));
+        };
+        auto load_fa = [&](const float* A, int c, f32x4 (&fa)[2]) {
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi) fa[mi] = lds_read4(A + a_slab_off(wm * 64 + 32 * mi + i, 2 * c + h));
+        };
+        auto dma_a = [&](int q, int buf) {
+            if (q == 0) tap_off = (unsigned)(((kh * p.W + kw) * p.Cin + cc * 32) * 4);
+            const bool ok = a_ok[q] && (unsigned)(a_ih0[q] + kh) < (unsigned)p.H && (unsigned)(a_iw0[q] + kw) < (unsigned)p.W;
+            lds_dma16(xbuf, ok ? a_off[q] + tap_off : kOobOffset, As + buf * kSlabFloatsA + (32 * q + 8 * wave) * kBK);
+            if (q == 3) {
+                if (++kw == p.KS) { kw = 0; if (++kh == p.KS) { kh = 0; ++cc; } }
+            }
+        };
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dma_a(q, 0);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) load_bw(slab0, c);
+        wait_dma_and_lds();
+        block_barrier();
+        int buf = 0;
+        f32x4 fa0[2], fa1[2];
+        load_fa(As, 0, fa0);
+        load_fa(As, 1, fa1);
+        for (int t = slab0; t < slab1; ++t) {
+            const bool more = (t + 1) < slab1;
+            const float* A = As + buf * kSlabFloatsA;
+            const float* An = As + (buf ^ 1) * kSlabFloatsA;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {        // group 0: the A pieces of slab t+1 ride in its MFMA shadows
+                sched_fence();
+                frag_mfma_q<2, 2>(fa0, bw[0], q, acc);
+                sched_fence();
+                if (more) dma_a(q, buf ^ 1);
+            }
+            sched_fence();
+            if (more) load_bw(t + 1, 0);         // bw[0] has been consumed
+            load_fa(A, 2, fa0);
+            sched_fence();
+            frag_mfma<2, 2>(fa1, bw[1], acc);    // group 1
+            sched_fence();
+            if (more) load_bw(t + 1, 1);
+            load_fa(A, 3, fa1);
+            sched_fence();
+            frag_mfma<2, 2>(fa0, bw[2], acc);    // group 2
+            sched_fence();
+            if (more) {
+                load_bw(t + 1, 2);
+                wait_dma_keep_and_lds<6>();      // the 4 DMA pieces have landed; the 6 weight loads issued after them stay in flight
+            } else {
+                wait_dma_and_lds();
+            }
+            block_barrier();
+            sched_fence();
+            if (more) load_fa(An, 0, fa0);
+            sched_fence();
+            frag_mfma<2, 2>(fa1, bw[3], acc);    // group 3
+            sched_fence();
+            if (more) {
+                load_bw(t + 1, 3);
+                load_fa(An, 1, fa1);
+            }
+            buf ^= 1;
+        }
+    } else if (slab0 < slab1) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) fetch_piece(slab0, q, 0);
 #pragma unroll

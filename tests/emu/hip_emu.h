@@ -75,6 +75,9 @@ inline void lds_dma16(buffer_rsrc r, uint32_t byte_off, float* lds_wave_base) {
     const f32x4 v = buffer_load4(r, byte_off);
     memcpy(reinterpret_cast<unsigned char*>(lds_wave_base) + 16 * lane_id(), &v, 16);
 }
+template <int N>
+inline void wait_dma_keep_and_lds() {}
+inline void block_barrier() { __syncthreads(); }
 inline void wait_dma_and_lds() {}
 inline int wave_uniform(int v) { return v; }
 

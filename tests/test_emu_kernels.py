@@ -12,7 +12,7 @@ from oracle import reference_cpu as ref
 from oracle import synth
 
 
-def _run(cfg, B, seed, f32_in=False, nosplit=False, dma=0):
+def _run(cfg, B, seed, f32_in=False, nosplit=False, dma=0, breg=0):
     w = synth.make_weights(seed=seed, shape=cfg.shape, num_filter=cfg.num_filter, strides=cfg.strides,
                            latent=cfg.latent_space_size, batch_norm=cfg.batch_norm, kernel_size=cfg.kernel_size)
     x = synth.make_crops(B, seed=seed + 1, shape=cfg.shape)
@@ -21,6 +21,7 @@ def _run(cfg, B, seed, f32_in=False, nosplit=False, dma=0):
     if nosplit:
         enc.set_option('splitk_min_base_blocks', 0)
     enc.set_option('igemm_dma', dma)           # operand slabs by LDS-DMA instead of register staging
+    enc.set_option('igemm_breg', breg)         # weights straight from global memory into the MFMA B fragments
     z = enc.forward(xin)
     z64, acts = ref.encoder_forward_np(ref.input_to_float(x), w, cfg.strides, cfg.batch_norm, return_activations=True)
     for i, a in enumerate(acts):
@@ -39,10 +40,16 @@ def test_first_layer_mfma_igemm_splitk_and_dense(dma):
     assert ('f32_dma' in labels[1]) == bool(dma)
 
 
-@pytest.mark.parametrize('dma', [0, 1])
-def test_unsplit_igemm_epilogue_with_batchnorm(dma):
-    labels = _run(EncoderConfig((16, 16, 3), [32, 64], [2, 2], 5, 128, True), 2, 41, nosplit=True, dma=dma)
+@pytest.mark.parametrize('dma,breg', [(0, 0), (1, 0), (1, 1)])
+def test_unsplit_igemm_epilogue_with_batchnorm(dma, breg):
+    labels = _run(EncoderConfig((16, 16, 3), [32, 64], [2, 2], 5, 128, True), 2, 41, nosplit=True, dma=dma, breg=breg)
     assert all('splitk' not in l for l in labels)
+    assert any('dma_breg' in l for l in labels) == bool(breg)
+
+
+def test_weights_to_registers_variant_partial_tiles_and_several_slabs():
+    # conv2: M = 5*8*8 = 320 rows (two full 128-row tiles + a partial one), K = 25 taps x 32 channels = 25 slabs
+    _run(EncoderConfig((32, 32, 3), [32, 64], [2, 2], 5, 128), 5, 61, nosplit=True, dma=1, breg=1)
 
 
 def test_partial_tiles_row_straddling_and_odd_channel_counts():

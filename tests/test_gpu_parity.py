@@ -236,9 +236,11 @@ def test_update_embedding_rebuilds_codebook():
 
 
 def test_fp32_igemm_lds_dma_variant_is_bit_identical():
-    """igemm_dma=1 moves the operand slabs global -> LDS by DMA (no staging registers); the MFMA
-    sequence is unchanged, so every output bit must match the register-staged kernel.  Repeats
-    catch landing-order races (a slab read before its DMA arrived)."""
+    """igemm_dma=1 moves the operand slabs global -> LDS by DMA (no staging registers); igemm_breg=1
+    (the default) additionally takes the weights straight from global memory into the MFMA B
+    fragments, with a counted vmcnt + bare s_barrier per slab.  The MFMA sequence is unchanged, so
+    every output bit must match the register-staged kernel.  Repeats catch landing-order races
+    (a slab read before its DMA arrived, a fragment used before its load returned)."""
     from augmentedautoencoder_amd.engine import EncoderEngine
     from augmentedautoencoder_amd.weights import EncoderConfig
     weights = synth.make_weights(seed=2024)
@@ -249,8 +251,12 @@ def test_fp32_igemm_lds_dma_variant_is_bit_identical():
         z0 = enc.encode(crops).cpu().numpy()
         acts0 = [enc.activation(i).cpu().numpy() for i in range(4)] if B == 5 else []
         enc.set_option('igemm_dma', 1)
-        for _ in range(25):
-            assert np.array_equal(enc.encode(crops).cpu().numpy(), z0)
+        for breg in (0, 1):
+            enc.set_option('igemm_breg', breg)
+            for _ in range(20):
+                assert np.array_equal(enc.encode(crops).cpu().numpy(), z0), 'igemm_breg %d' % breg
+            if B == 256:                               # (small batches split K and run the LDS-operand kernel)
+                assert all(('dma_breg' in l) == bool(breg) for l, _, _ in enc.encode_timed(crops)[1] if l.startswith('conv2'))
         if B == 256:
             # ... and again while a second stream saturates HBM with copies (stretches the DMA landing times)
             import torch
@@ -264,12 +270,15 @@ def test_fp32_igemm_lds_dma_variant_is_bit_identical():
                 z_quiet = enc.encode(crops).cpu().numpy()
                 enc.set_option('igemm_dma', 1)
                 enc.set_option('x3h_dma', 1)
-                with torch.cuda.stream(side):
-                    for _ in range(60):
-                        big_a.copy_(big_b)
-                for _ in range(12):
-                    assert np.array_equal(enc.encode(crops).cpu().numpy(), z_quiet), 'precision %d under memory load' % precision
-                torch.cuda.synchronize()
+                for breg in ((0, 1) if precision == 0 else (1,)):
+                    enc.set_option('igemm_breg', breg)
+                    with torch.cuda.stream(side):
+                        for _ in range(60):
+                            big_a.copy_(big_b)
+                    for _ in range(12):
+                        assert np.array_equal(enc.encode(crops).cpu().numpy(), z_quiet), \
+                            'precision %d breg %d under memory load' % (precision, breg)
+                    torch.cuda.synchronize()
             enc.set_option('precision', 0)
         for i, a in enumerate(acts0):
             assert np.array_equal(enc.activation(i).cpu().numpy(), a), 'layer %d' % i

@@ -196,6 +196,19 @@ def main():
                               'kernels': [(l.split(' ')[0], round(t, 4), round(f / t / 1e9, 1)) for l, t, f in recs[:4]]}))
         enc.set_option('x3h_wide_min_blocks', 0)
         enc.set_option('precision', 0)
+    if 'breg' in what:
+        # fp32 igemm: weights through LDS (0) vs straight from global memory into the MFMA B fragments (1)
+        x = torch.from_numpy(synth.make_crops(256, seed=1)).cuda()
+        z0 = None
+        for v in (0, 1, 0, 1):
+            enc.set_option('igemm_breg', v)
+            ms = timeit(lambda: enc.encode(x), 10)
+            z, recs = enc.encode_timed(x)
+            z0 = z if z0 is None else z0
+            print(json.dumps({'what': 'breg', 'igemm_breg': v, 'encode_ms': round(ms, 4), 'crops_per_s': round(256 / ms * 1e3, 1),
+                              'identical': bool(torch.equal(z, z0)),
+                              'kernels': [(l.split(' ')[0], round(t, 4), round(f / t / 1e9, 1)) for l, t, f in recs[:4]]}))
+        enc.set_option('igemm_breg', 0)
     if 'config5' in what:
         # 368928 x 128 bf16 codebook (94.4 MB), batched queries, arg-max and top-5
         E5 = synth.make_codebook(368928, 128, seed=11)
