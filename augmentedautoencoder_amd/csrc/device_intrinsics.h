@@ -80,7 +80,11 @@ __device__ __forceinline__ int wave_uniform(int v) { return __builtin_amdgcn_rea
 template <int N>
 __device__ __forceinline__ void wait_dma_keep_and_lds() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N) : "memory"); }
 // bare s_barrier: unlike __syncthreads() it carries no fence, so it does not drain loads that are meant to stay in flight
-__device__ __forceinline__ void block_barrier() { __builtin_amdgcn_s_barrier(); }
+__device__ __forceinline__ void block_barrier() {
+    asm volatile("" ::: "memory");       // compiler-level fence on both sides: no LDS access may be moved across the barrier
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
 __device__ __forceinline__ void wait_dma_and_lds() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); }
 
 // Cross-lane add through the DPP path (no LDS crossbar).  Lanes whose source is outside
