@@ -209,6 +209,56 @@ def main():
                               'identical': bool(torch.equal(z, z0)),
                               'kernels': [(l.split(' ')[0], round(t, 4), round(f / t / 1e9, 1)) for l, t, f in recs[:4]]}))
         enc.set_option('igemm_breg', 0)
+    if 'estimator' in what:
+        # next row N1: AePoseEstimator.process on a 1080p frame -- all detections of a class as one batch vs the
+        # reference's flow (one crop + one B=1 query per detection)
+        import configparser
+        from augmentedautoencoder_amd import session as S
+        from augmentedautoencoder_amd.codebook import Codebook
+        from augmentedautoencoder_amd.dataset import Dataset
+        from augmentedautoencoder_amd.encoder import Encoder
+        from augmentedautoencoder_amd.pose_estimator import AePoseEstimator, BoundingBox
+        targs = configparser.ConfigParser()
+        targs.read_string("[Dataset]\nH: 128\nW: 128\nC: 3\nRADIUS: 700\nPAD_FACTOR: 1.2\nK: [1075.65, 0, 720/2, 0, 1073.90, 540/2, 0, 0, 1]\n"
+                          "[Embedding]\nEMBED_BB: True\nMIN_N_VIEWS: 2562\nNUM_CYCLO: 36\n")
+        S.reset_default_graph()
+        books = {}
+        for k, name in enumerate(['obj_a', 'obj_b']):
+            ds = Dataset('', h=128, w=128, c=3, min_n_views=2562, radius=700, num_cyclo=36)
+            with S.variable_scope(name):
+                e = Encoder(S.Placeholder((128, 128, 3)), 128, [128, 256, 512, 512], 5, [2, 2, 2, 2], False)
+                c = Codebook(e, ds, True)
+            e.load_weights(synth.make_weights(seed=50 + k))
+            c.assign_embedding(synth.make_codebook(92232, 128, seed=60 + k))
+            r = np.random.default_rng(70 + k)
+            c.assign_obj_bbs(np.stack([r.integers(250, 350, 92232), r.integers(180, 260, 92232), r.integers(80, 200, 92232), r.integers(80, 200, 92232)], 1))
+            books[name] = c
+        est = AePoseEstimator(codebooks=books, train_args={'obj_a': targs, 'obj_b': targs})
+        rng = np.random.default_rng(0)
+        img = rng.integers(0, 256, (1080, 1920, 3), dtype=np.uint8)
+        camK = np.array([[1075.65, 0, 960.0], [0, 1073.9, 540.0], [0, 0, 1]])
+        for D in (1, 4, 16, 64):
+            dets = []
+            for i in range(D):
+                x, y, w, h = rng.uniform(0, 1500), rng.uniform(0, 800), rng.uniform(60, 400), rng.uniform(60, 270)
+                dets.append(BoundingBox(xmin=x / 1920, xmax=(x + w) / 1920, ymin=y / 1080, ymax=(y + h) / 1080, classes={'obj_a' if i % 3 else 'obj_b': 1.0}))
+            for _ in range(3):
+                est.process(dets, img, camK)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            reps = 10
+            for _ in range(reps):
+                est.process(dets, img, camK)
+            torch.cuda.synchronize()
+            dt_batched = (time.perf_counter() - t0) / reps
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                for d in dets:
+                    est.process([d], img, camK)
+            torch.cuda.synchronize()
+            dt_loop = (time.perf_counter() - t0) / reps
+            print(json.dumps({'what': 'estimator', 'detections': D, 'image': '1080x1920', 'batched_ms': round(dt_batched * 1e3, 3),
+                              'per_detection_loop_ms': round(dt_loop * 1e3, 3), 'detections_per_s_batched': round(D / dt_batched, 1)}))
     if 'config5' in what:
         # 368928 x 128 bf16 codebook (94.4 MB), batched queries, arg-max and top-5
         E5 = synth.make_codebook(368928, 128, seed=11)
