@@ -396,3 +396,32 @@ def test_captured_graph_and_streaming_pipelines_equal_the_eager_calls():
     assert list(sp.run([])) == []
     enc.close()
     cb.close()
+
+
+@pytest.mark.parametrize('kw', [
+    dict(shape=(64, 64, 3), num_filter=[64, 128, 256], strides=[2, 2, 2], latent=64, batch_norm=True, B=70),
+    dict(shape=(96, 160, 3), num_filter=[32, 96, 160], strides=[2, 2, 1], latent=128, batch_norm=False, B=33),
+    dict(shape=(128, 128, 1), num_filter=[128, 256, 512, 512], strides=[2, 2, 2, 2], latent=128, batch_norm=False, B=9),
+])
+def test_non_default_network_shapes_on_the_matrix_core_kernels(kw):
+    """Other [Network] settings than train_template.cfg: narrower / non-128-multiple channel counts (padded N
+    tiles), batch norm, a stride-1 layer, non-square and grayscale inputs, ragged batch sizes -- every layer
+    output against the fp64 oracle."""
+    from augmentedautoencoder_amd.engine import EncoderEngine
+    from augmentedautoencoder_amd.weights import EncoderConfig
+    cfg = EncoderConfig(kw['shape'], kw['num_filter'], kw['strides'], 5, kw['latent'], kw['batch_norm'])
+    w = synth.make_weights(seed=77, shape=cfg.shape, num_filter=cfg.num_filter, strides=cfg.strides, latent=cfg.latent_space_size,
+                           batch_norm=cfg.batch_norm)
+    x = synth.make_crops(kw['B'], seed=78, shape=cfg.shape)
+    enc = EncoderEngine(cfg, w)
+    z, recs = enc.encode_timed(x)
+    z64, acts = ref.encoder_forward_torch(ref.input_to_float(x), w, cfg.strides, cfg.batch_norm, 'float64', return_activations=True)
+    for i, a in enumerate(acts):
+        g = enc.activation(i).cpu().numpy()
+        assert np.abs(g - a).max() / np.abs(a).max() < 2e-5, 'layer %d (%s)' % (i, [l for l, _, _ in recs])
+    assert np.abs(z.cpu().numpy() - z64).max() / np.abs(z64).max() < 2e-5
+    assert all('generic' not in l for l, _, _ in recs)                 # all on the MFMA kernels
+    enc.set_option('precision', 1)
+    z3 = enc.encode(x).cpu().numpy()
+    assert np.abs(z3 - z64).max() / np.abs(z64).max() < 2e-5
+    enc.close()
