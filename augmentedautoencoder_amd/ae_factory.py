@@ -1,10 +1,14 @@
-"""Builders with the signatures of /root/reference/auto_pose/ae/ae_factory.py
-for the inference path (dataset, encoder, codebook, decoder, build_codebook_from_name,
-restore_checkpoint).  Training builders (ae, train_op, queue) are out of scope and raise
-NotImplementedError."""
+"""Builder functions with the names and signatures of the reference's factory module
+(/root/reference/auto_pose/ae/ae_factory.py) for everything the inference path needs: dataset,
+encoder, decoder, codebook, ``build_codebook_from_name`` and ``restore_checkpoint``.
+
+The cfg keys are parsed once, by ``EncoderConfig.from_cfg`` / ``DecoderConfig.from_cfg``
+(weights.py); the builders below only hand the parsed shapes to the API classes.  Builders of
+the training graph (queue, autoencoder loss, train op) raise ``NotImplementedError``: training
+is outside the scope of this package.  Configuration errors raise instead of ``exit()``-ing.
+"""
 from __future__ import annotations
 
-import ast
 import configparser
 import os
 
@@ -14,103 +18,98 @@ from .codebook import Codebook
 from .dataset import Dataset
 from .decoder import Decoder
 from .encoder import Encoder
+from .weights import DecoderConfig, EncoderConfig
 
-
-def _section_items(args, name):
-    return args.items(name) if args.has_section(name) else []
+_DATASET_SECTIONS = ('Dataset', 'Paths', 'Augmentation', 'Queue', 'Embedding')
 
 
 def build_dataset(dataset_path, args):
-    dataset_args = {k: v for k, v in
-                    _section_items(args, 'Dataset') + _section_items(args, 'Paths') +
-                    _section_items(args, 'Augmentation') + _section_items(args, 'Queue') +
-                    _section_items(args, 'Embedding')}
-    return Dataset(dataset_path, **dataset_args)
+    """ae_factory.py:5-15 -- every key of the dataset-related cfg sections becomes a keyword."""
+    merged = {}
+    for section in _DATASET_SECTIONS:
+        if args.has_section(section):
+            merged.update(args.items(section))
+    return Dataset(dataset_path, **merged)
 
 
 def build_encoder(x, args, is_training=False):
-    LATENT_SPACE_SIZE = args.getint('Network', 'LATENT_SPACE_SIZE')
-    NUM_FILTER = ast.literal_eval(args.get('Network', 'NUM_FILTER'))
-    KERNEL_SIZE_ENCODER = args.getint('Network', 'KERNEL_SIZE_ENCODER')
-    STRIDES = ast.literal_eval(args.get('Network', 'STRIDES'))
-    BATCH_NORM = args.getboolean('Network', 'BATCH_NORMALIZATION')
-    return Encoder(x, LATENT_SPACE_SIZE, NUM_FILTER, KERNEL_SIZE_ENCODER, STRIDES, BATCH_NORM, is_training=is_training)
-
-
-def build_codebook(encoder, dataset, args):
-    embed_bb = args.getboolean('Embedding', 'EMBED_BB')
-    return Codebook(encoder, dataset, embed_bb)
-
-
-def _out_of_scope(name):
-    def fn(*a, **k):
-        raise NotImplementedError('%s builds the training graph, which is out of scope of this package' % name)
-    fn.__name__ = name
-    return fn
-
-
-build_queue = _out_of_scope('build_queue')
+    """ae_factory.py:33-48."""
+    net = EncoderConfig.from_cfg(args)
+    return Encoder(x, net.latent_space_size, net.num_filter, net.kernel_size, net.strides, net.batch_norm,
+                   is_training=is_training)
 
 
 def build_decoder(reconstruction_target, encoder, args, is_training=False):
-    """ae_factory.py:50-70, inference form: reversed NUM_FILTER / STRIDES, KERNEL_SIZE_DECODER;
-    the variational sampling branch only exists while training."""
-    NUM_FILTER = ast.literal_eval(args.get('Network', 'NUM_FILTER'))
-    KERNEL_SIZE_DECODER = args.getint('Network', 'KERNEL_SIZE_DECODER')
-    STRIDES = ast.literal_eval(args.get('Network', 'STRIDES'))
-    LOSS = args.get('Network', 'LOSS', fallback='L2')
-    BOOTSTRAP_RATIO = args.getint('Network', 'BOOTSTRAP_RATIO', fallback=1)
-    AUXILIARY_MASK = args.getboolean('Network', 'AUXILIARY_MASK', fallback=False)
-    BATCH_NORM = args.getboolean('Network', 'BATCH_NORMALIZATION')
-    return Decoder(reconstruction_target, encoder.z, list(reversed(NUM_FILTER)), KERNEL_SIZE_DECODER,
-                   list(reversed(STRIDES)), LOSS, BOOTSTRAP_RATIO, AUXILIARY_MASK, BATCH_NORM,
+    """ae_factory.py:50-70, inference form (the variational sampling branch exists only while training):
+    the decoder receives NUM_FILTER / STRIDES reversed and KERNEL_SIZE_DECODER."""
+    net = DecoderConfig.from_cfg(args)
+    return Decoder(reconstruction_target, encoder.z, net.num_filters, net.kernel_size, net.strides,
+                   loss=args.get('Network', 'LOSS', fallback='L2'),
+                   bootstrap_ratio=args.getint('Network', 'BOOTSTRAP_RATIO', fallback=1),
+                   auxiliary_mask=net.auxiliary_mask, batch_norm=net.batch_norm,
                    is_training=is_training, encoder=encoder)
 
 
-build_ae = _out_of_scope('build_ae')
-build_train_op = _out_of_scope('build_train_op')
+def build_codebook(encoder, dataset, args):
+    """ae_factory.py:97-100."""
+    return Codebook(encoder, dataset, args.getboolean('Embedding', 'EMBED_BB'))
+
+
+def _training_only(name):
+    def refuse(*unused_args, **unused_kw):
+        raise NotImplementedError('%s builds the training graph, which is out of scope of this package' % name)
+    refuse.__name__ = name
+    return refuse
+
+
+build_queue = _training_only('build_queue')
+build_ae = _training_only('build_ae')
+build_train_op = _training_only('build_train_op')
+
+
+def _experiment_args(experiment_name, experiment_group):
+    """(train cfg of the experiment, dataset path) below $AE_WORKSPACE_PATH."""
+    workspace = os.environ.get('AE_WORKSPACE_PATH')
+    if workspace is None:
+        raise RuntimeError('Please define a workspace path: export AE_WORKSPACE_PATH=/path/to/workspace')
+    log_dir = u.get_log_dir(workspace, experiment_name, experiment_group)
+    cfg_path = u.get_train_config_exp_file_path(log_dir, experiment_name)
+    if not os.path.exists(cfg_path):
+        raise FileNotFoundError('Config File not found: %s' % cfg_path)
+    args = configparser.ConfigParser()
+    args.read(cfg_path)
+    return args, u.get_dataset_path(workspace)
 
 
 def build_codebook_from_name(experiment_name, experiment_group='', return_dataset=False, return_decoder=False):
-    """Encoder + codebook of a trained experiment under $AE_WORKSPACE_PATH
-    (ae_factory.py:102-146).  Raises instead of exit()ing on missing paths."""
-    workspace_path = os.environ.get('AE_WORKSPACE_PATH')
-    if workspace_path is None:
-        raise RuntimeError('Please define a workspace path: export AE_WORKSPACE_PATH=/path/to/workspace')
-    log_dir = u.get_log_dir(workspace_path, experiment_name, experiment_group)
-    cfg_file_path = u.get_train_config_exp_file_path(log_dir, experiment_name)
-    dataset_path = u.get_dataset_path(workspace_path)
-    if not os.path.exists(cfg_file_path):
-        raise FileNotFoundError('Config File not found: %s' % cfg_file_path)
-    args = configparser.ConfigParser()
-    args.read(cfg_file_path)
-
+    """Dataset + encoder + codebook (+ decoder) of a trained experiment, built under the experiment's
+    variable scope (ae_factory.py:102-146).  Return shape as in the reference: codebook,
+    (codebook, dataset) or (codebook, dataset, decoder)."""
+    args, dataset_path = _experiment_args(experiment_name, experiment_group)
+    decoder = None
     with S.variable_scope(experiment_name):
         dataset = build_dataset(dataset_path, args)
-        x = S.Placeholder(dataset.shape, 'x')
-        encoder = build_encoder(x, args)
+        encoder = build_encoder(S.Placeholder(dataset.shape, 'x'), args)
         codebook = build_codebook(encoder, dataset, args)
-        decoder = build_decoder(S.Placeholder(dataset.shape, 'reconst_target'), encoder, args) if return_decoder else None
-
-    if return_dataset:
         if return_decoder:
-            return codebook, dataset, decoder
-        return codebook, dataset
-    return codebook
+            decoder = build_decoder(S.Placeholder(dataset.shape, 'reconst_target'), encoder, args)
+    if not return_dataset:
+        return codebook
+    return (codebook, dataset, decoder) if return_decoder else (codebook, dataset)
 
 
 def restore_checkpoint(session, saver, ckpt_dir, at_step=None):
-    """Load encoder weights + codebook from ckpt_dir (ae_factory.py:149-172).
-    `saver` may be None (then every module built so far is restored)."""
-    saver = saver if saver is not None else S.Saver()
-    chkpt = S.get_checkpoint_state(ckpt_dir)
-    if chkpt and chkpt.model_checkpoint_path:
-        if at_step is None:
-            saver.restore(session, chkpt.model_checkpoint_path)
-        else:
-            for ckpt_path in chkpt.all_model_checkpoint_paths:
-                if str(at_step) in str(ckpt_path):
-                    saver.restore(session, ckpt_path)
-                    print('restoring', os.path.basename(ckpt_path))
-    else:
+    """Weights + codebook variables from the newest checkpoint in ``ckpt_dir``, or from every
+    checkpoint whose name contains ``at_step`` (ae_factory.py:149-172).  ``saver=None`` restores all
+    modules built so far.  Understands TensorFlow checkpoint-v2 files and the native .npz."""
+    state = S.get_checkpoint_state(ckpt_dir)
+    if not state or not state.model_checkpoint_path:
         raise FileNotFoundError('No checkpoint found. Expected one in: %s' % ckpt_dir)
+    saver = S.Saver() if saver is None else saver
+    if at_step is None:
+        saver.restore(session, state.model_checkpoint_path)
+        return
+    for path in state.all_model_checkpoint_paths:
+        if str(at_step) in str(path):
+            saver.restore(session, path)
+            print('restoring', os.path.basename(path))
