@@ -140,7 +140,7 @@ static int launch_stage(aae_decoder* dec, const DecStage& s, const float* x, int
         const int nblk = a.num_mt * a.num_nt * 4;
         AAE_LAUNCH((aae::conv_igemm_f32_kernel<false, true, true>), dim3(nblk), dim3(256), aae::kConvIgemmSmem, stream, a);
         snprintf(label, sizeof(label), "%s:upconv2x_igemm_f32_dma 4 phases x (M=%d N=%d K=%d)", name, a.M, L.Cout, s.U * s.U * L.Cin);
-        ctx->records.push_back({label, flops});
+        note_kernel({label, flops});
         AAE_HIP_TRY(hipGetLastError());
         return tm.mark();
     }
@@ -154,7 +154,7 @@ static int launch_stage(aae_decoder* dec, const DecStage& s, const float* x, int
         (void)hipFuncSetAttribute((const void*)aae::upconv2x_narrow_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
         AAE_LAUNCH((aae::upconv2x_narrow_kernel), dim3((unsigned)(B * a.tiles_y * a.tiles_x)), dim3(256), smem, stream, a);
         snprintf(label, sizeof(label), "%s:upconv2x_narrow px=%lld Cin=%d Cout=%d taps=%dx%d", name, (long long)B * L.H * L.W, L.Cin, L.Cout, s.Un, s.Un);
-        ctx->records.push_back({label, flops});
+        note_kernel({label, flops});
         AAE_HIP_TRY(hipGetLastError());
         return tm.mark();
     }
@@ -166,7 +166,7 @@ static int launch_stage(aae_decoder* dec, const DecStage& s, const float* x, int
     if (blocks > 16384) blocks = 16384;
     AAE_LAUNCH((aae::upconv_direct_kernel), dim3((unsigned)blocks), dim3(256), 0, stream, a);
     snprintf(label, sizeof(label), "%s:upconv_direct", name);
-    ctx->records.push_back({label, flops});
+    note_kernel({label, flops});
     AAE_HIP_TRY(hipGetLastError());
     return tm.mark();
 }
@@ -182,7 +182,7 @@ static int decoder_forward_impl(aae_decoder* dec, const float* z, int B, float* 
     unsigned char* base = static_cast<unsigned char*>(workspace);
     float* partial = reinterpret_cast<float*>(base + ws.partial_off);
     aae_encoder* ctx = &dec->ctx;
-    ctx->records.clear();
+    RecordScope rec(ctx);
     tm.stream = stream;
     if (int rc = tm.mark()) return rc;
 

@@ -14,6 +14,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -93,7 +94,8 @@ struct aae_encoder {
     aae_host::Layer dense;                 // 1x1 "conv" over the flattened activation
     float* lut = nullptr;                  // device [256] float32(v/255.)
     std::vector<void*> allocations;
-    std::vector<aae_host::KernelRecord> records;   // of the most recent forward
+    std::vector<aae_host::KernelRecord> records;   // of the most recent completed forward (swapped in under rec_mu)
+    std::mutex rec_mu;
     int splitk_min_base_blocks = 384;      // split K only when the un-split grid is smaller than this
     int splitk_target_blocks = 512;        // ... and then aim for about this many blocks
     int precision = 0;                     // 0: exact fp32 MFMA; 1: f32x3h split-precision igemm (explicit opt-in)
@@ -118,6 +120,24 @@ struct aae_codebook {
 namespace aae_host {
 
 // ------------------------------------------------------------------ helpers
+// Kernel records (label, algorithmic flops) of a forward call are collected in a call-local list and
+// published to the handle when the call returns, so concurrent forwards on one handle (distinct streams and
+// workspaces) never touch shared state while they launch.
+static thread_local std::vector<KernelRecord>* t_records = nullptr;
+static void note_kernel(KernelRecord r) {
+    if (t_records) t_records->push_back(std::move(r));
+}
+struct RecordScope {
+    aae_encoder* owner;
+    std::vector<KernelRecord> local;
+    explicit RecordScope(aae_encoder* e) : owner(e) { t_records = &local; }
+    ~RecordScope() {
+        t_records = nullptr;
+        std::lock_guard<std::mutex> lk(owner->rec_mu);
+        owner->records.swap(local);
+    }
+};
+
 static int upload(aae_encoder* enc, const float* host, size_t count, float** dev) {
     void* p = nullptr;
     AAE_HIP_TRY(hipMalloc(&p, count * sizeof(float)));
@@ -284,7 +304,7 @@ static int launch_igemm(aae_encoder* enc, const Layer& L, const float* x, int M,
         else if (dma) AAE_LAUNCH((aae::conv_igemm_f32_kernel<false, true>), dim3(nblk), dim3(256), aae::kConvIgemmSmem, stream, a);
         else AAE_LAUNCH((aae::conv_igemm_f32_kernel<false, false>), dim3(nblk), dim3(256), aae::kConvIgemmSmem, stream, a);
         snprintf(label, sizeof(label), "%s:%s M=%d N=%d K=%lld", name, kname, M, L.Cout, L.K());
-        enc->records.push_back({label, flops});
+        note_kernel({label, flops});
         AAE_HIP_TRY(hipGetLastError());
         return tm.mark();
     }
@@ -292,7 +312,7 @@ static int launch_igemm(aae_encoder* enc, const Layer& L, const float* x, int M,
     if (dma) AAE_LAUNCH((aae::conv_igemm_f32_kernel<true, true>), dim3(nblk), dim3(256), aae::kConvIgemmSmem, stream, a);
     else AAE_LAUNCH((aae::conv_igemm_f32_kernel<true, false>), dim3(nblk), dim3(256), aae::kConvIgemmSmem, stream, a);
     snprintf(label, sizeof(label), "%s:%s_splitk%d M=%d N=%d K=%lld", name, kname, a.splits, M, L.Cout, L.K());
-    enc->records.push_back({label, flops});
+    note_kernel({label, flops});
     AAE_HIP_TRY(hipGetLastError());
     if (int rc = tm.mark()) return rc;
     aae::SplitKReduceArgs r;
@@ -303,7 +323,7 @@ static int launch_igemm(aae_encoder* enc, const Layer& L, const float* x, int M,
     if (blocks > 4096) blocks = 4096;
     AAE_LAUNCH((aae::splitk_reduce_kernel), dim3((unsigned)blocks), dim3(512), aae::kReduceGroups * 64 * (int)sizeof(float), stream, r);
     snprintf(label, sizeof(label), "%s:splitk_reduce", name);
-    enc->records.push_back({label, 0.0});
+    note_kernel({label, 0.0});
     AAE_HIP_TRY(hipGetLastError());
     return tm.mark();
 }
@@ -345,7 +365,7 @@ static int launch_igemm_x3h(aae_encoder* enc, const Layer& L, const void* x, int
         else if (tag == 2) AAE_LAUNCH((aae::conv_igemm_x3h_dma_kernel<aae::X3H_OUT_PLANES, 2, 4>), dim3(wide_blocks), dim3(512), smem, stream, a);
         else AAE_LAUNCH((aae::conv_igemm_x3h_dma_kernel<aae::X3H_OUT_PLANES, 3, 4>), dim3(wide_blocks), dim3(512), smem, stream, a);
         snprintf(label, sizeof(label), "%s:conv_igemm_x3h_dma256 M=%d N=%d K=%lld", name, M, L.Cout, L.K());
-        enc->records.push_back({label, flops});
+        note_kernel({label, flops});
         AAE_HIP_TRY(hipGetLastError());
         return tm.mark();
     }
@@ -362,7 +382,7 @@ static int launch_igemm_x3h(aae_encoder* enc, const Layer& L, const void* x, int
             else AAE_LAUNCH((aae::conv_igemm_x3h_kernel<aae::X3H_OUT_PLANES>), dim3(nblk), dim3(256), aae::kConvIgemmSmem, stream, a);
         }
         snprintf(label, sizeof(label), "%s:%s M=%d N=%d K=%lld", name, kname, M, L.Cout, L.K());
-        enc->records.push_back({label, flops});
+        note_kernel({label, flops});
         AAE_HIP_TRY(hipGetLastError());
         return tm.mark();
     }
@@ -370,7 +390,7 @@ static int launch_igemm_x3h(aae_encoder* enc, const Layer& L, const void* x, int
     if (dma) AAE_LAUNCH((aae::conv_igemm_x3h_dma_kernel<aae::X3H_OUT_PARTIAL>), dim3(nblk), dim3(256), aae::kConvIgemmSmem, stream, a);
     else AAE_LAUNCH((aae::conv_igemm_x3h_kernel<aae::X3H_OUT_PARTIAL>), dim3(nblk), dim3(256), aae::kConvIgemmSmem, stream, a);
     snprintf(label, sizeof(label), "%s:%s_splitk%d M=%d N=%d K=%lld", name, kname, a.splits, M, L.Cout, L.K());
-    enc->records.push_back({label, flops});
+    note_kernel({label, flops});
     AAE_HIP_TRY(hipGetLastError());
     if (int rc = tm.mark()) return rc;
     aae::SplitKReduceArgs r;
@@ -381,7 +401,7 @@ static int launch_igemm_x3h(aae_encoder* enc, const Layer& L, const void* x, int
     if (blocks > 4096) blocks = 4096;
     AAE_LAUNCH((aae::splitk_reduce_kernel), dim3((unsigned)blocks), dim3(512), aae::kReduceGroups * 64 * (int)sizeof(float), stream, r);
     snprintf(label, sizeof(label), "%s:splitk_reduce", name);
-    enc->records.push_back({label, 0.0});
+    note_kernel({label, 0.0});
     AAE_HIP_TRY(hipGetLastError());
     return tm.mark();
 }
@@ -415,7 +435,7 @@ static int launch_first(aae_encoder* enc, const Layer& L, const void* x, bool u8
     else launch_first_t<5, 1>(a, u8, planes, grid, L.first_smem, stream);
     char label[96];
     snprintf(label, sizeof(label), "conv1:conv_first_f32 M=%d N=%d K=%lld", B * L.Ho * L.Wo, L.Cout, L.K());
-    enc->records.push_back({label, 2.0 * (double)B * L.Ho * L.Wo * (double)L.K() * L.Cout});
+    note_kernel({label, 2.0 * (double)B * L.Ho * L.Wo * (double)L.K() * L.Cout});
     AAE_HIP_TRY(hipGetLastError());
     return tm.mark();
 }
@@ -433,7 +453,7 @@ static int launch_generic(aae_encoder* enc, const Layer& L, const void* x, bool 
     else AAE_LAUNCH((aae::conv_direct_generic_kernel<false>), dim3((unsigned)blocks), dim3(256), 0, stream, a);
     char label[96];
     snprintf(label, sizeof(label), "%s:conv_direct_generic", name);
-    enc->records.push_back({label, 2.0 * (double)B * L.Ho * L.Wo * (double)L.K() * L.Cout});
+    note_kernel({label, 2.0 * (double)B * L.Ho * L.Wo * (double)L.K() * L.Cout});
     AAE_HIP_TRY(hipGetLastError());
     return tm.mark();
 }
@@ -450,7 +470,7 @@ static int forward_impl(aae_encoder* enc, const void* x, int x_dtype, int B, flo
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
     unsigned char* base = static_cast<unsigned char*>(workspace);
     float* partial = reinterpret_cast<float*>(base + ws.partial_off);
-    enc->records.clear();
+    RecordScope rec(enc);
     tm.stream = stream;
     if (int rc = tm.mark()) return rc;
 

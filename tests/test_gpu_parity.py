@@ -425,3 +425,62 @@ def test_non_default_network_shapes_on_the_matrix_core_kernels(kw):
     z3 = enc.encode(x).cpu().numpy()
     assert np.abs(z3 - z64).max() / np.abs(z64).max() < 2e-5
     enc.close()
+
+
+def test_c_abi_forward_is_reentrant_on_distinct_streams_and_workspaces():
+    """include/aae_hip.h threading contract: one handle, several host threads, each with its own stream,
+    workspace and outputs (ctypes releases the GIL, so the launches really interleave)."""
+    import ctypes
+    import threading
+    import torch
+    from augmentedautoencoder_amd import _lib
+    from augmentedautoencoder_amd.engine import CodebookEngine, EncoderEngine
+    from augmentedautoencoder_amd.weights import EncoderConfig
+    enc = EncoderEngine(EncoderConfig(), synth.make_weights(seed=2024))
+    cb = CodebookEngine(synth.make_codebook(92232, 128, seed=7, planted_duplicates=64))
+    lib = enc.lib
+    jobs = []
+    for t in range(4):
+        B = (3, 17, 64, 5)[t]
+        x = torch.from_numpy(synth.make_crops(B, seed=900 + t)).cuda()
+        want_z = enc.encode(x).clone()
+        want_i, want_s = cb.nn(want_z, 1, 1)
+        jobs.append((B, x, want_z, want_i.clone(), want_s.clone()))
+    torch.cuda.synchronize()
+    errors = []
+
+    def worker(B, x, want_z, want_i, want_s):
+        try:
+            stream = torch.cuda.Stream()
+            sp = ctypes.c_void_p(stream.cuda_stream)
+            n_e = lib.aae_encoder_workspace_bytes(enc.handle, B)
+            n_c = lib.aae_codebook_workspace_bytes(cb.handle, B, 1)
+            with torch.cuda.stream(stream):
+                ws_e = torch.empty(n_e + 256, dtype=torch.uint8, device='cuda')
+                ws_c = torch.empty(n_c + 256, dtype=torch.uint8, device='cuda')
+                z = torch.empty((B, 128), dtype=torch.float32, device='cuda')
+                idx = torch.empty((B, 1), dtype=torch.int64, device='cuda')
+                sc = torch.empty((B, 1), dtype=torch.float32, device='cuda')
+            pe = ws_e.data_ptr() + (-ws_e.data_ptr()) % 256
+            pc = ws_c.data_ptr() + (-ws_c.data_ptr()) % 256
+            stream.synchronize()
+            for _ in range(20):
+                rc = lib.aae_encoder_forward(enc.handle, ctypes.c_void_p(x.data_ptr()), _lib.AAE_DTYPE_U8, B, ctypes.c_void_p(z.data_ptr()),
+                                             ctypes.c_void_p(pe), n_e, sp)
+                assert rc == 0, lib.aae_last_error()
+                rc = lib.aae_codebook_nn(cb.handle, ctypes.c_void_p(z.data_ptr()), B, 1, 1, ctypes.c_void_p(idx.data_ptr()),
+                                         ctypes.c_void_p(sc.data_ptr()), ctypes.c_void_p(pc), n_c, sp)
+                assert rc == 0, lib.aae_last_error()
+                stream.synchronize()
+                assert torch.equal(z, want_z) and torch.equal(idx, want_i) and torch.equal(sc, want_s)
+        except Exception as e:                                    # noqa: BLE001 (reported below)
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=worker, args=j) for j in jobs]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors
+    enc.close()
+    cb.close()
