@@ -526,9 +526,11 @@ static ScanPlan plan_scan(const aae_codebook* cb, int B, int topk) {
     s.gemv = B <= 4 && cb->scan_mode == AAE_SCAN_GEMV;
     s.NT = B <= 32 ? 1 : (B <= 64 ? 2 : 4);
     s.Bpad = (int)align_up((size_t)B, (size_t)(32 * s.NT));
-    if (cb->dtype == AAE_DTYPE_BF16) {           // one kernel for every B: 64 queries per pass, 3 bf16 query terms
-        s.stream = s.gemv = false;
+    if (cb->dtype == AAE_DTYPE_BF16) {           // B <= 4: HBM-streaming kernel (256 rows per block); else 64 queries per MFMA pass
+        s.gemv = false;
+        s.stream = B <= 4 && cb->scan_mode != AAE_SCAN_MFMA;
         s.Bpad = (int)align_up((size_t)B, (size_t)aae::kScanBf16QC);
+        if (s.stream) s.nblk = ceil_div(cb->N, 256);
     }
     s.Bstride = s.Bpad;
     size_t off = 0;
@@ -567,6 +569,29 @@ static int run_scan(aae_codebook* cb, const float* z, int B, int col_stride, flo
                     unsigned char* base, hipStream_t stream) {
     float* q = reinterpret_cast<float*>(base + s.q_off);
     float* qp = reinterpret_cast<float*>(base + s.qp_off);
+    if (cb->dtype == AAE_DTYPE_BF16 && s.stream) {
+        aae::ScanArgs a;
+        a.z = z; a.e_bytes = (unsigned)((size_t)cb->N * cb->J * 2);
+        a.E = cb->E; a.q = nullptr; a.qp = nullptr;
+        a.pval = reinterpret_cast<float*>(base + s.pval_off);
+        a.pidx = reinterpret_cast<int*>(base + s.pidx_off);
+        a.cs = cs_out;
+        a.N = cb->N; a.J = cb->J; a.Jpad = s.Jpad; a.B = B; a.Bpad = s.Bpad; a.Bstride = s.Bstride;
+        a.col_stride = col_stride;
+        const bool up = col_stride > 1;
+        if (B == 1) {
+            if (up) AAE_LAUNCH((aae::scan_stream_bf16_kernel<1, true>), dim3(s.nblk), dim3(256), 64, stream, a);
+            else AAE_LAUNCH((aae::scan_stream_bf16_kernel<1, false>), dim3(s.nblk), dim3(256), 64, stream, a);
+        } else if (B == 2) {
+            if (up) AAE_LAUNCH((aae::scan_stream_bf16_kernel<2, true>), dim3(s.nblk), dim3(256), 128, stream, a);
+            else AAE_LAUNCH((aae::scan_stream_bf16_kernel<2, false>), dim3(s.nblk), dim3(256), 128, stream, a);
+        } else {
+            if (up) AAE_LAUNCH((aae::scan_stream_bf16_kernel<4, true>), dim3(s.nblk), dim3(256), 256, stream, a);
+            else AAE_LAUNCH((aae::scan_stream_bf16_kernel<4, false>), dim3(s.nblk), dim3(256), 256, stream, a);
+        }
+        AAE_HIP_TRY(hipGetLastError());
+        return AAE_OK;
+    }
     if (cb->dtype == AAE_DTYPE_BF16) {
         aae::L2NormBf16Args n;
         n.z = z; n.qp3 = reinterpret_cast<unsigned short*>(qp); n.B = B; n.J = cb->J; n.Jpad = 128; n.Bpad = s.Bpad;

@@ -104,6 +104,15 @@ __device__ __forceinline__ float half_wave_sum(float v) {
     return v;
 }
 
+// Sum over each 16-lane row of the wave (4 DPP adds); every lane of the row ends up with the total.
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_take<0xB1, 0xF>(v);     // quad_perm [1,0,3,2]
+    v += dpp_take<0x4E, 0xF>(v);     // quad_perm [2,3,0,1]
+    v += dpp_take<0x141, 0xF>(v);    // row_half_mirror
+    v += dpp_take<0x140, 0xF>(v);    // row_mirror
+    return v;
+}
+
 // instruction-scheduling fence: nothing is moved across it by the compiler's scheduler
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 

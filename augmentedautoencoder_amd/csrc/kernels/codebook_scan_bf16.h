@@ -140,4 +140,95 @@ __global__ __launch_bounds__(256) void scan_bf16_kernel(const ScanBf16Args p) {
     }
 }
 
+// ---------------------------------------------------------------- scan_stream_bf16
+// B <= 4 against a bf16 codebook: the HBM-streaming form (cf. scan_stream_kernel in codebook_scan_f32.h).
+// A row is 256 B = 16 lanes x 16 B, so one 1-KiB wave load covers 4 rows; a wave owns 64 consecutive rows and
+// puts all 16 loads in flight before it touches any.  The bf16 elements are widened exactly (<< 16), the dot
+// products are fp32 fma chains against the fp32-normalised queries (no query splitting needed off the matrix
+// cores) and finished with 4 DPP adds inside each 16-lane row group.
+template <int NQ, bool UPRIGHT>
+__global__ __launch_bounds__(256) void scan_stream_bf16_kernel(const ScanArgs p) {
+    AAE_DYN_SMEM(smem_raw);
+    float* red_v = reinterpret_cast<float*>(smem_raw);           // [4][NQ]
+    int* red_i = reinterpret_cast<int*>(red_v + 4 * NQ);         // [4][NQ]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rs = lane >> 4, kq = lane & 15;                    // row within the 4-row load, 8-element column group
+    const int row_first = blockIdx.x * 256 + wave * 64;
+
+    const buffer_rsrc ebuf = make_buffer(p.E, p.e_bytes);
+    u32x4 e[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int row = row_first + 4 * u + rs;
+        e[u] = __builtin_bit_cast(u32x4, buffer_load4(ebuf, row < p.N ? (unsigned)(row * 256 + kq * 16) : kOobOffset));
+    }
+
+    // tf.nn.l2_normalize(z, 1) per query, 8 columns per lane, replicated in every 16-lane group
+    float qv[NQ][8];
+#pragma unroll
+    for (int b = 0; b < NQ; ++b) {
+        f32x4 z0 = {0.f, 0.f, 0.f, 0.f}, z1 = z0;
+        if (b < p.B) {
+            z0 = *reinterpret_cast<const f32x4*>(p.z + (long long)b * 128 + kq * 8);
+            z1 = *reinterpret_cast<const f32x4*>(p.z + (long long)b * 128 + kq * 8 + 4);
+        }
+        float ss = z0.x * z0.x;
+        ss = fmaf(z0.y, z0.y, ss); ss = fmaf(z0.z, z0.z, ss); ss = fmaf(z0.w, z0.w, ss);
+        ss = fmaf(z1.x, z1.x, ss); ss = fmaf(z1.y, z1.y, ss); ss = fmaf(z1.z, z1.z, ss); ss = fmaf(z1.w, z1.w, ss);
+#pragma unroll
+        for (int m = 8; m >= 1; m >>= 1) ss += shfl_xor(ss, m);
+        const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
+        qv[b][0] = z0.x * inv; qv[b][1] = z0.y * inv; qv[b][2] = z0.z * inv; qv[b][3] = z0.w * inv;
+        qv[b][4] = z1.x * inv; qv[b][5] = z1.y * inv; qv[b][6] = z1.z * inv; qv[b][7] = z1.w * inv;
+    }
+
+    float best_v[NQ];
+    int best_i[NQ];
+#pragma unroll
+    for (int b = 0; b < NQ; ++b) { best_v[b] = kNegInf; best_i[b] = row_first + rs; }
+
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int row = row_first + 4 * u + rs;
+        bool cand = row < p.N;
+        if (UPRIGHT) cand = cand && (row % p.col_stride == 0);
+        float ev[8];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            ev[2 * w] = __builtin_bit_cast(float, e[u][w] << 16);            // element 2w   (low half)
+            ev[2 * w + 1] = __builtin_bit_cast(float, e[u][w] & 0xFFFF0000u); // element 2w+1 (high half)
+        }
+#pragma unroll
+        for (int b = 0; b < NQ; ++b) {
+            float d = ev[0] * qv[b][0];
+#pragma unroll
+            for (int j = 1; j < 8; ++j) d = fmaf(ev[j], qv[b][j], d);
+            d = row16_sum(d);                     // every lane of the 16-lane group holds the row's dot product
+            if (p.cs && kq == 0 && row < p.N && b < p.B) p.cs[(long long)b * p.N + row] = d;
+            if (cand && d > best_v[b]) { best_v[b] = d; best_i[b] = row; }
+        }
+    }
+    // rows rs = 0..3 live in the four 16-lane groups: fold groups, then the four waves
+#pragma unroll
+    for (int b = 0; b < NQ; ++b) {
+#pragma unroll
+        for (int m = 16; m <= 32; m <<= 1) {
+            const float ov = shfl_xor(best_v[b], m);
+            const int oi = shfl_xor(best_i[b], m);
+            if (better(ov, oi, best_v[b], best_i[b])) { best_v[b] = ov; best_i[b] = oi; }
+        }
+        if (lane == 0) { red_v[wave * NQ + b] = best_v[b]; red_i[wave * NQ + b] = best_i[b]; }
+    }
+    __syncthreads();
+    if (tid < NQ && tid < p.B) {
+        float v = red_v[tid];
+        int ix = red_i[tid];
+        for (int w = 1; w < 4; ++w)
+            if (better(red_v[w * NQ + tid], red_i[w * NQ + tid], v, ix)) { v = red_v[w * NQ + tid]; ix = red_i[w * NQ + tid]; }
+        p.pval[(long long)blockIdx.x * p.Bstride + tid] = v;
+        p.pidx[(long long)blockIdx.x * p.Bstride + tid] = ix;
+    }
+}
+
 }  // namespace aae

@@ -177,6 +177,19 @@ inline T shfl_xor(T v, int mask) {
     return out;
 }
 
+// DPP add tree of device_intrinsics.h::row16_sum, same partner order.
+inline float row16_sum(float v) {
+    const int lane = lane_id();
+    const int partners[4] = {lane ^ 1, lane ^ 2, (lane & ~7) | (7 - (lane & 7)), (lane & ~15) | (15 - (lane & 15))};
+    for (int s = 0; s < 4; ++s) {
+        const aae_emu::lane_slot* all = aae_emu::wave_exchange(&v, 4);
+        float o;
+        memcpy(&o, &all[partners[s]][0], 4);
+        v += o;
+    }
+    return v;
+}
+
 // DPP add tree of device_intrinsics.h::half_wave_sum, same partner order.
 inline float half_wave_sum(float v) {
     const int lane = lane_id();

@@ -143,8 +143,9 @@ def test_split_precision_f32x3h_path(cfg, B, nosplit, dma):
     gen.close()
 
 
-@pytest.mark.parametrize('B', [1, 5, 70])
-def test_bf16_codebook_scan(B):
+@pytest.mark.parametrize('B,mode', [(1, _lib.AAE_SCAN_AUTO), (2, _lib.AAE_SCAN_AUTO), (4, _lib.AAE_SCAN_AUTO), (1, _lib.AAE_SCAN_MFMA),
+                                    (5, _lib.AAE_SCAN_AUTO), (70, _lib.AAE_SCAN_AUTO)])
+def test_bf16_codebook_scan(B, mode):
     """BASELINE config 5 in miniature: bf16 codebook rows, queries as three bf16 terms on the
     bf16 matrix cores; parity against the fp64 oracle evaluated on the bf16-rounded codebook."""
     from augmentedautoencoder_amd.weights import bf16_bits_to_f32, to_bf16_bits
@@ -153,6 +154,7 @@ def test_bf16_codebook_scan(B):
     Eb = bf16_bits_to_f32(to_bf16_bits(E))
     assert np.abs(Eb - E).max() < 2.0 ** -8 and np.array_equal(to_bf16_bits(Eb), to_bf16_bits(E))
     cb = eb.EmuCodebook(E, dtype='bf16')
+    cb.set_mode(mode)                                         # B <= 4: streaming kernel unless the MFMA kernel is forced
     rows = np.random.default_rng(B).integers(0, N, B)
     z = synth.make_queries_near_rows(E, rows, noise=0.3, seed=B)
     z[0] = Eb[36 * 3 + 35] * 3.0                              # exact tie between rows 108 and 143

@@ -364,6 +364,17 @@ def test_config5_large_bf16_codebook_topk():
     assert np.array_equal(idxk[:Bo], ref.topk_canonical(cs, K))   # exact w.r.t. the kernel's own scores
     up, _ = cb.nn(z[:Bo], 1, 36)
     assert np.array_equal(up[:, 0].cpu().numpy(), ref.nearest_indices_reference(cs, 1, upright=True, num_cyclo=36))
+    # B <= 4 takes the HBM-streaming bf16 kernel: same scores to fp32 roundoff, same tie rules, same top-k
+    for Bs in (1, 2, 3, 4):
+        zs = z[4:4 + Bs]
+        cs_s = cb.similarity(zs).cpu().numpy()
+        assert np.abs(cs_s - cs64[4:4 + Bs]).max() <= COS_TOL
+        i_s, s_s = cb.nn(zs, 1, 1)
+        assert np.array_equal(i_s[:, 0].cpu().numpy(), np.argmax(cs_s, axis=1)) and np.array_equal(i_s[:, 0].cpu().numpy(), idx1[4:4 + Bs])
+        ik_s, _ = cb.nn(zs, K, 1)
+        assert np.array_equal(ik_s.cpu().numpy(), ref.topk_canonical(cs_s, K))
+        u_s, _ = cb.nn(zs, 1, 36)
+        assert np.array_equal(u_s[:, 0].cpu().numpy(), ref.nearest_indices_reference(cs_s, 1, upright=True, num_cyclo=36))
     cb.close()
 
 
