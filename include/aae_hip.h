@@ -93,7 +93,13 @@ void aae_encoder_destroy(aae_encoder* enc);
  *   "igemm_dma" (1) / "x3h_dma" (1): operand slabs of the implicit GEMM travel global -> LDS by
  *                        LDS-DMA (buffer_load ... lds); 0 selects the register-staged variant
  *                        (bit-identical results, kept for A/B measurements);
- *   "first_target_blocks" (1024), "first_max_tiles_per_block" (8): conv1 grid shaping. */
+ *   "igemm_breg" (1): un-split fp32 conv layers take their weight fragments straight from global memory
+ *                        into registers (A operand alone goes through LDS-DMA; 32 KB of LDS, three blocks
+ *                        per CU); "igemm_breg_min_blocks" (768): smaller grids keep the 64 KB footprint;
+ *   "x3h_wide_min_blocks" (0): > 0 lets f32x3h conv layers use 256x128 tiles when that still yields this
+ *                        many blocks (measured neutral);
+ *   "first_target_blocks" (1024), "first_max_tiles_per_block" (8): conv1 grid shaping.
+ * All variants selected by these knobs are bit-identical to each other (tests/test_gpu_parity.py). */
 int aae_encoder_set_option(aae_encoder* enc, const char* name, int value);
 
 size_t aae_encoder_workspace_bytes(const aae_encoder* enc, int B);
