@@ -102,6 +102,8 @@ struct aae_encoder {
     int first_target_blocks = 1024;        // conv1 grid size aimed at (x N tiles); 2 blocks fit a CU
     int first_max_tiles_per_block = 8;     // conv1: consecutive 128-pixel tiles one block walks with its weights in registers
     int igemm_breg_min_blocks = 768;       // ... with the 32 KB footprint only for grids of at least this many blocks
+    int igemm_breg_wide = 1;               // BREG conv2/conv3: 128 x 256 block tiles (each wave 64 x 128) when the layer is wide enough (+0.9 %)
+    int igemm_breg_wide_min_blocks = 512;
     int igemm_breg = 1;                    // conv layers: weight fragments straight from global memory to registers (A-only LDS-DMA, 32 KB LDS)
     int igemm_dma = 1;                     // fp32 igemm operand slabs by LDS-DMA (buffer_load ... lds); 0 = register-staged variant
     int x3h_wide_min_blocks = 0;           // > 0: f32x3h conv layers use 256x128 tiles (8 waves) when that still yields this many blocks; measured neutral (+-1.5 %), off by default
@@ -295,6 +297,19 @@ static int launch_igemm(aae_encoder* enc, const Layer& L, const float* x, int M,
         const int kBregSmem = nblk >= enc->igemm_breg_min_blocks ? 2 * aae::kSlabFloatsA * 4 : aae::kConvIgemmSmem;
         const bool breg = dma && enc->igemm_breg && tag >= 1 && tag <= 3;
         if (breg) kname = "conv_igemm_f32_dma_breg";
+        // 128 x 256 block tiles (each wave 64 x 128) where the layer is wide enough and the grid stays large
+        if (breg && enc->igemm_breg_wide && (tag == 1 || tag == 2) && L.CoutPad % 256 == 0 &&
+            a.num_mt * (L.CoutPad / 256) >= enc->igemm_breg_wide_min_blocks) {
+            a.num_nt = L.CoutPad / 256;
+            const int wide_blocks = a.num_mt * a.num_nt;
+            constexpr int smem = 2 * aae::kSlabFloatsA * 4;
+            if (tag == 1) AAE_LAUNCH((aae::conv_igemm_f32_kernel<false, true, false, 1, true, 4>), dim3(wide_blocks), dim3(256), smem, stream, a);
+            else AAE_LAUNCH((aae::conv_igemm_f32_kernel<false, true, false, 2, true, 4>), dim3(wide_blocks), dim3(256), smem, stream, a);
+            snprintf(label, sizeof(label), "%s:conv_igemm_f32_dma_breg_n256 M=%d N=%d K=%lld", name, M, L.Cout, L.K());
+            note_kernel({label, flops});
+            AAE_HIP_TRY(hipGetLastError());
+            return tm.mark();
+        }
         if (breg && tag == 1) AAE_LAUNCH((aae::conv_igemm_f32_kernel<false, true, false, 1, true>), dim3(nblk), dim3(256), kBregSmem, stream, a);
         else if (breg && tag == 2) AAE_LAUNCH((aae::conv_igemm_f32_kernel<false, true, false, 2, true>), dim3(nblk), dim3(256), kBregSmem, stream, a);
         else if (breg && tag == 3) AAE_LAUNCH((aae::conv_igemm_f32_kernel<false, true, false, 3, true>), dim3(nblk), dim3(256), kBregSmem, stream, a);
@@ -789,6 +804,8 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
     else if (!strcmp(name, "x3h_wide_min_blocks")) enc->x3h_wide_min_blocks = value < 0 ? 0 : value;
     else if (!strcmp(name, "igemm_dma")) enc->igemm_dma = value ? 1 : 0;
     else if (!strcmp(name, "igemm_breg")) enc->igemm_breg = value ? 1 : 0;
+    else if (!strcmp(name, "igemm_breg_wide")) enc->igemm_breg_wide = value ? 1 : 0;
+    else if (!strcmp(name, "igemm_breg_wide_min_blocks")) enc->igemm_breg_wide_min_blocks = value;
     else if (!strcmp(name, "igemm_breg_min_blocks")) enc->igemm_breg_min_blocks = value;
     else if (!strcmp(name, "first_target_blocks")) enc->first_target_blocks = value < 1 ? 1 : value;
     else if (!strcmp(name, "first_max_tiles_per_block")) enc->first_max_tiles_per_block = value < 1 ? 1 : value;

@@ -63,8 +63,12 @@ constexpr int kConvIgemmSmem = 2 * (kSlabFloatsA + 8 * 128 * 4) * 4;   // 64 KiB
 // + 8 plain loads instead of 8 DMA pieces + 8 LDS fragment reads; an LDS-DMA piece costs the issuing wave
 // well over 100 cycles, a plain load a fraction of that.  LDS shrinks to the two A buffers (32 KB).
 // The slab barrier is a bare s_barrier behind a counted vmcnt that covers the DMA pieces only.
-template <bool SPLITK, bool DMA = false, bool SCATTER = false, int TAG = 0, bool BREG = false>
-__global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvIgemmArgs p) {
+// NW (BREG only): 32-column MFMA tiles per wave.  2 -> 128 x 128 block tile; 4 -> 128 x 256 (each wave 64 x 128,
+// 8 accumulators): half the A bytes, DMA pieces and LDS fragment reads per MFMA, at two instead of three waves
+// per SIMD.
+template <bool SPLITK, bool DMA = false, bool SCATTER = false, int TAG = 0, bool BREG = false, int NW = 2>
+__global__ __launch_bounds__(256, NW == 4 ? 2 : 1) void conv_igemm_f32_kernel(const ConvIgemmArgs p) {
+    static_assert(NW == 2 || BREG, "wide wave tiles exist for the weights-to-registers variant only");
     AAE_DYN_SMEM(smem_raw);
     float* As = reinterpret_cast<float*>(smem_raw);            // [2][128*32]
     float* Bs = As + 2 * kSlabFloatsA;                         // [2][8*128*4]
@@ -149,21 +153,22 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvIgemmArgs
         lds_write4(Bs + buf * (8 * 128 * 4) + (tid + 256 * q) * 4, rb[q]);
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NW];
 #pragma unroll
     for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni)
+        for (int ni = 0; ni < NW; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
 
-    if (BREG && slab0 < slab1) {
+    if constexpr (BREG) {
+      if (slab0 < slab1) {
         const int i = lane & 31, h = lane >> 5;
-        const unsigned bw_off = (unsigned)(((h * p.CoutPad) + nt * 128 + wn * 64 + i) * 16);
-        f32x4 bw[4][2];                          // B fragments of the 4 k-groups of one slab
+        const unsigned bw_off = (unsigned)(((h * p.CoutPad) + nt * (64 * NW) + wn * (32 * NW) + i) * 16);
+        f32x4 bw[4][NW];                         // B fragments of the 4 k-groups of one slab
         auto load_bw = [&](int slab, int c) {
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni)
+            for (int ni = 0; ni < NW; ++ni)
                 bw[c][ni] = buffer_load4(wbuf, bw_off + (unsigned)(((slab * 8 + 2 * c) * p.CoutPad + 32 * ni) * 16));
         };
         auto load_fa = [&](const float* A, int c, f32x4 (&fa)[2]) {
@@ -195,7 +200,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvIgemmArgs
 #pragma unroll
             for (int q = 0; q < 4; ++q) {        // group 0: the A pieces of slab t+1 ride in its MFMA shadows
                 sched_fence();
-                frag_mfma_q<2, 2>(fa0, bw[0], q, acc);
+                frag_mfma_q<2, NW>(fa0, bw[0], q, acc);
                 sched_fence();
                 if (more) dma_a(q, buf ^ 1);
             }
@@ -203,16 +208,16 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvIgemmArgs
             if (more) load_bw(t + 1, 0);         // bw[0] has been consumed
             load_fa(A, 2, fa0);
             sched_fence();
-            frag_mfma<2, 2>(fa1, bw[1], acc);    // group 1
+            frag_mfma<2, NW>(fa1, bw[1], acc);   // group 1
             sched_fence();
             if (more) load_bw(t + 1, 1);
             load_fa(A, 3, fa1);
             sched_fence();
-            frag_mfma<2, 2>(fa0, bw[2], acc);    // group 2
+            frag_mfma<2, NW>(fa0, bw[2], acc);   // group 2
             sched_fence();
             if (more) {
                 load_bw(t + 1, 2);
-                wait_dma_keep_and_lds<6>();      // the 4 DMA pieces have landed; the 6 weight loads issued after them stay in flight
+                wait_dma_keep_and_lds<3 * NW>(); // the 4 DMA pieces have landed; the 3*NW weight loads issued after them stay in flight
             } else {
                 wait_dma_and_lds();
             }
@@ -220,7 +225,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvIgemmArgs
             sched_fence();
             if (more) load_fa(An, 0, fa0);
             sched_fence();
-            frag_mfma<2, 2>(fa1, bw[3], acc);    // group 3
+            frag_mfma<2, NW>(fa1, bw[3], acc);   // group 3
             sched_fence();
             if (more) {
                 load_bw(t + 1, 3);
@@ -228,6 +233,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvIgemmArgs
             }
             buf ^= 1;
         }
+      }
     } else if (slab0 < slab1) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) fetch_piece(slab0, q, 0);
@@ -290,8 +296,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32_kernel(const ConvIgemmArgs
     // ---- epilogue -----------------------------------------------------------
     const int i = lane & 31;
 #pragma unroll
-    for (int ni = 0; ni < 2; ++ni) {
-        const int n = nt * 128 + wn * 64 + ni * 32 + i;
+    for (int ni = 0; ni < NW; ++ni) {
+        const int n = nt * (64 * NW) + wn * (32 * NW) + ni * 32 + i;
         if (n >= p.Cout) continue;
         float bias = 0.f, sc = 1.f, sh = 0.f;
         if (!SPLITK) {

@@ -208,3 +208,25 @@ def test_f32x3h_wide_tile_variant_is_bit_identical():
     assert any('x3h_dma256' in l for l in enc.labels())
     assert np.array_equal(z0, z1) and np.array_equal(a0, enc.activation(1))
     enc.close()
+
+
+def test_wide_block_tile_of_the_weights_to_registers_variant_is_bit_identical():
+    """conv_igemm_f32_kernel<..., BREG, NW=4>: 128 x 256 block tiles (each wave 64 x 128) for layers whose padded
+    Cout is a multiple of 256 -- same accumulation order per output, so bit-identical to the 128 x 128 tiles."""
+    for shape, B, filters, bn in (((16, 16, 3), 3, [32, 256], False), ((24, 16, 3), 5, [64, 512], True)):
+        cfg = EncoderConfig(shape, filters, [2, 2], 5, 128, bn)
+        w = synth.make_weights(seed=5, shape=cfg.shape, num_filter=cfg.num_filter, strides=cfg.strides, latent=128, batch_norm=bn)
+        x = synth.make_crops(B, seed=6, shape=cfg.shape)
+        enc = eb.EmuEncoder(w, cfg)
+        enc.set_option('splitk_min_base_blocks', 0)
+        enc.set_option('igemm_breg_wide', 0)
+        z0, a0 = enc.forward(x), None
+        a0 = enc.activation(1)
+        enc.set_option('igemm_breg_wide', 1)
+        enc.set_option('igemm_breg_wide_min_blocks', 1)
+        z1 = enc.forward(x)
+        assert any('breg_n256' in l for l in enc.labels())
+        assert np.array_equal(z0, z1) and np.array_equal(a0, enc.activation(1))
+        z64 = ref.encoder_forward_np(ref.input_to_float(x), w, cfg.strides, bn)
+        assert np.abs(z1 - z64).max() / np.abs(z64).max() < 5e-6
+        enc.close()

@@ -251,10 +251,11 @@ def test_fp32_igemm_lds_dma_variant_is_bit_identical():
         z0 = enc.encode(crops).cpu().numpy()
         acts0 = [enc.activation(i).cpu().numpy() for i in range(4)] if B == 5 else []
         enc.set_option('igemm_dma', 1)
-        for breg in (0, 1):
+        for breg, wide in ((0, 0), (1, 0), (1, 1)):
             enc.set_option('igemm_breg', breg)
-            for _ in range(20):
-                assert np.array_equal(enc.encode(crops).cpu().numpy(), z0), 'igemm_breg %d' % breg
+            enc.set_option('igemm_breg_wide', wide)          # 128 x 256 block tiles for conv2 / conv3 at B = 256
+            for _ in range(15):
+                assert np.array_equal(enc.encode(crops).cpu().numpy(), z0), 'igemm_breg %d wide %d' % (breg, wide)
             if B == 256:                               # (small batches split K and run the LDS-operand kernel)
                 assert all(('dma_breg' in l) == bool(breg) for l, _, _ in enc.encode_timed(crops)[1] if l.startswith('conv2'))
         if B == 256:

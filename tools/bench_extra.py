@@ -259,6 +259,18 @@ def main():
             dt_loop = (time.perf_counter() - t0) / reps
             print(json.dumps({'what': 'estimator', 'detections': D, 'image': '1080x1920', 'batched_ms': round(dt_batched * 1e3, 3),
                               'per_detection_loop_ms': round(dt_loop * 1e3, 3), 'detections_per_s_batched': round(D / dt_batched, 1)}))
+    if 'n256' in what:
+        x = torch.from_numpy(synth.make_crops(256, seed=1)).cuda()
+        z0 = None
+        for v in (0, 1, 0, 1):
+            enc.set_option('igemm_breg_wide', v)
+            ms = timeit(lambda: enc.encode(x), 10)
+            z, recs = enc.encode_timed(x)
+            z0 = z if z0 is None else z0
+            print(json.dumps({'what': 'n256', 'igemm_breg_wide': v, 'encode_ms': round(ms, 4), 'crops_per_s': round(256 / ms * 1e3, 1),
+                              'identical': bool(torch.equal(z, z0)),
+                              'kernels': [(l.split(' ')[0], round(t, 4), round(f / t / 1e9, 1)) for l, t, f in recs[:4]]}))
+        enc.set_option('igemm_breg_wide', 0)
     if 'config5' in what:
         # 368928 x 128 bf16 codebook (94.4 MB), batched queries, arg-max and top-5
         E5 = synth.make_codebook(368928, 128, seed=11)
