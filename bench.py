@@ -57,9 +57,17 @@ def cpu_baseline(weights, E, crops, min_seconds=12.0, max_iters=60):
         el = time.perf_counter() - t0
         if el >= min_seconds or done >= max_iters:
             break
+    model = 'unknown'
+    try:
+        with open('/proc/cpuinfo') as f:
+            model = next((l.split(':', 1)[1].strip() for l in f if l.startswith('model name')), 'unknown')
+    except OSError:
+        pass
     return {'value': round(done * len(sample) / el, 2), 'unit': 'crops/s', 'cores': nthreads, 'kind': 'port',
             'sample': '%d x %d crops, fp32 torch-CPU (oneDNN) encoder + numpy fp32 codebook matmul/argmax, %.1f s'
-                      % (done, len(sample), el)}
+                      % (done, len(sample), el),
+            'host': {'cpu_model': model, 'logical_cpus': os.cpu_count(),
+                     'note': 'threads = best point of a sweep (8..256) on this host; more threads are slower'}}
 
 
 def main():
