@@ -24,6 +24,7 @@
 #include "kernels/conv_igemm_x3h.h"
 #include "kernels/conv_first_f32.h"
 #include "kernels/conv_direct_generic.h"
+#include "kernels/dense_gemv_f32.h"
 #include "kernels/codebook_scan_f32.h"
 #include "kernels/codebook_scan_bf16.h"
 #include "kernels/crop_resize_u8.h"
@@ -104,6 +105,7 @@ struct aae_encoder {
     int igemm_breg_min_blocks = 768;       // ... with the 32 KB footprint only for grids of at least this many blocks
     int igemm_breg_wide = 1;               // BREG conv2/conv3: 128 x 256 block tiles (each wave 64 x 128) when the layer is wide enough (+0.9 %)
     int igemm_breg_wide_min_blocks = 512;
+    int dense_gemv = 1;                    // B <= 4: dense layer as a weight-streaming GEMV instead of a split-K MFMA tile
     int igemm_breg = 1;                    // conv layers: weight fragments straight from global memory to registers (A-only LDS-DMA, 32 KB LDS)
     int igemm_dma = 1;                     // fp32 igemm operand slabs by LDS-DMA (buffer_load ... lds); 0 = register-staged variant
     int x3h_wide_min_blocks = 0;           // > 0: f32x3h conv layers use 256x128 tiles (8 waves) when that still yields this many blocks; measured neutral (+-1.5 %), off by default
@@ -248,6 +250,10 @@ static Workspace plan_workspace(const aae_encoder* enc, int B) {
         need_partial(L, B * L.Ho * L.Wo);
     }
     need_partial(enc->dense, B);
+    if (B <= 4 && enc->dense.kind == KIND_IGEMM) {           // the GEMV form of the dense layer: one partial row per 128-k chunk
+        const size_t gemv = (size_t)ceil_div((int)enc->dense.K(), aae::kGemvChunk) * B * enc->dense.Cout * sizeof(float);
+        if (gemv > partial) partial = gemv;
+    }
     ws.partial_off = off;
     ws.partial_bytes = partial;
     off += align_up(partial, 256);
@@ -473,6 +479,35 @@ static int launch_generic(aae_encoder* enc, const Layer& L, const void* x, bool 
     return tm.mark();
 }
 
+// dense layer at B <= 4: weight-streaming GEMV + the fixed-order chunk reduction
+static int launch_dense_gemv(aae_encoder* enc, const Layer& D, const float* x, int B, float* out, float* partial,
+                             hipStream_t stream, Timer& tm) {
+    aae::DenseGemvArgs a;
+    a.x = x; a.wp = D.wp; a.partial = partial; a.B = B; a.K = (int)D.K(); a.Cout = D.Cout; a.CoutPad = D.CoutPad;
+    a.wp_bytes = (unsigned)((unsigned long long)(D.K() / 4) * D.CoutPad * 16ull);
+    const int chunks = ceil_div(a.K, aae::kGemvChunk);
+    const dim3 grid(chunks, D.CoutPad / 128);
+    const int MQ = B <= 1 ? 1 : (B <= 2 ? 2 : 4);
+    const int smem = 2 * MQ * aae::kGemvChunk * (int)sizeof(float);
+    if (MQ == 1) AAE_LAUNCH((aae::dense_gemv_f32_kernel<1>), grid, dim3(256), smem, stream, a);
+    else if (MQ == 2) AAE_LAUNCH((aae::dense_gemv_f32_kernel<2>), grid, dim3(256), smem, stream, a);
+    else AAE_LAUNCH((aae::dense_gemv_f32_kernel<4>), grid, dim3(256), smem, stream, a);
+    char label[96];
+    snprintf(label, sizeof(label), "dense:dense_gemv_f32 chunks=%d M=%d N=%d K=%d", chunks, B, D.Cout, a.K);
+    note_kernel({label, 2.0 * B * (double)D.K() * D.Cout});
+    AAE_HIP_TRY(hipGetLastError());
+    if (int rc = tm.mark()) return rc;
+    aae::SplitKReduceArgs r;
+    r.partial = partial; r.bias = D.bias; r.bn_scale = D.bn_scale; r.bn_shift = D.bn_shift; r.out = out;
+    r.MN = (long long)B * D.Cout; r.Cout = D.Cout; r.splits = chunks; r.relu = D.relu; r.out_planes = 0; r.out_scale = 1.f;
+    long long blocks = (r.MN + 63) / 64;
+    if (blocks > 4096) blocks = 4096;
+    AAE_LAUNCH((aae::splitk_reduce_kernel), dim3((unsigned)blocks), dim3(512), aae::kReduceGroups * 64 * (int)sizeof(float), stream, r);
+    note_kernel({"dense:splitk_reduce", 0.0});
+    AAE_HIP_TRY(hipGetLastError());
+    return tm.mark();
+}
+
 static int forward_impl(aae_encoder* enc, const void* x, int x_dtype, int B, float* z_out, void* workspace,
                         size_t ws_bytes, void* stream_v, Timer& tm) {
     if (!enc || !x || !z_out) return fail(AAE_ERR_INVALID, "aae_encoder_forward: null argument");
@@ -522,6 +557,8 @@ static int forward_impl(aae_encoder* enc, const void* x, int x_dtype, int B, flo
         cur_u8 = false;
     }
     const Layer& D = enc->dense;
+    if (D.kind == KIND_IGEMM && B <= 4 && enc->dense_gemv && D.K() % aae::kGemvChunk == 0)
+        return launch_dense_gemv(enc, D, static_cast<const float*>(cur), B, z_out, partial, stream, tm);
     if (D.kind == KIND_IGEMM) return launch_igemm(enc, D, static_cast<const float*>(cur), B, z_out, partial, stream, tm, "dense");
     return launch_generic(enc, D, cur, false, B, z_out, stream, tm, "dense");
 }
@@ -804,6 +841,7 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
     else if (!strcmp(name, "x3h_wide_min_blocks")) enc->x3h_wide_min_blocks = value < 0 ? 0 : value;
     else if (!strcmp(name, "igemm_dma")) enc->igemm_dma = value ? 1 : 0;
     else if (!strcmp(name, "igemm_breg")) enc->igemm_breg = value ? 1 : 0;
+    else if (!strcmp(name, "dense_gemv")) enc->dense_gemv = value ? 1 : 0;
     else if (!strcmp(name, "igemm_breg_wide")) enc->igemm_breg_wide = value ? 1 : 0;
     else if (!strcmp(name, "igemm_breg_wide_min_blocks")) enc->igemm_breg_wide_min_blocks = value;
     else if (!strcmp(name, "igemm_breg_min_blocks")) enc->igemm_breg_min_blocks = value;

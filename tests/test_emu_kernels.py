@@ -20,6 +20,7 @@ def _run(cfg, B, seed, f32_in=False, nosplit=False, dma=0, breg=0):
     enc = eb.EmuEncoder(w, cfg)
     if nosplit:
         enc.set_option('splitk_min_base_blocks', 0)
+        enc.set_option('dense_gemv', 0)         # keep the dense layer on the (un-split) MFMA tile too
     enc.set_option('igemm_dma', dma)           # operand slabs by LDS-DMA instead of register staging
     enc.set_option('igemm_breg', breg)         # weights straight from global memory into the MFMA B fragments
     z = enc.forward(xin)
@@ -230,3 +231,22 @@ def test_wide_block_tile_of_the_weights_to_registers_variant_is_bit_identical():
         z64 = ref.encoder_forward_np(ref.input_to_float(x), w, cfg.strides, bn)
         assert np.abs(z1 - z64).max() / np.abs(z64).max() < 5e-6
         enc.close()
+
+
+@pytest.mark.parametrize('B', [1, 2, 3, 4, 5])
+def test_dense_layer_as_weight_streaming_gemv_for_tiny_batches(B):
+    """B <= 4: dense_gemv_f32_kernel (+ the fixed-order chunk reduction) instead of a padded MFMA tile; B = 5 stays
+    on the MFMA path.  Both against the fp64 oracle, and against each other within fp32 summation-order noise."""
+    cfg = EncoderConfig((16, 16, 3), [32, 64], [2, 2], 5, 128)
+    w = synth.make_weights(seed=12, shape=cfg.shape, num_filter=cfg.num_filter, strides=cfg.strides, latent=128)
+    x = synth.make_crops(B, seed=13, shape=cfg.shape)
+    enc = eb.EmuEncoder(w, cfg)
+    z = enc.forward(x)
+    assert any('dense_gemv' in l for l in enc.labels()) == (B <= 4)
+    z64 = ref.encoder_forward_np(ref.input_to_float(x), w, cfg.strides, False)
+    assert np.abs(z - z64).max() / np.abs(z64).max() < 5e-6
+    enc.set_option('dense_gemv', 0)
+    z_mfma = enc.forward(x)
+    assert not any('dense_gemv' in l for l in enc.labels())
+    assert np.abs(z - z_mfma).max() / np.abs(z64).max() < 2e-6
+    enc.close()
