@@ -96,6 +96,10 @@ void aae_encoder_destroy(aae_encoder* enc);
  *   "igemm_breg" (1): un-split fp32 conv layers take their weight fragments straight from global memory
  *                        into registers (A operand alone goes through LDS-DMA; 32 KB of LDS, three blocks
  *                        per CU); "igemm_breg_min_blocks" (768): smaller grids keep the 64 KB footprint;
+ *   "igemm_breg_wide" (1): ... with 128x256 block tiles for layers whose padded Cout is a multiple of 256 and
+ *                        whose grid stays >= 512 blocks;
+ *   "dense_gemv" (1): batches of <= 4 run the dense layer as a weight-streaming GEMV instead of a padded
+ *                        matrix-core tile (same value up to fp32 summation order);
  *   "x3h_wide_min_blocks" (0): > 0 lets f32x3h conv layers use 256x128 tiles when that still yields this
  *                        many blocks (measured neutral);
  *   "first_target_blocks" (1024), "first_max_tiles_per_block" (8): conv1 grid shaping.
