@@ -95,3 +95,68 @@ def test_single_process_no_collective():
     r = route([3, 0, 3, 1, 8], 8, 3)
     assert list(r.keys()) == [3] and r[3].tolist() == [0, 2]
     assert route([3, 0, 3, 1, 8], 8, 0)[8].tolist() == [4]
+
+
+# ---- row-sharded codebook: local top-k per rank, one all_gather, k-way merge ----
+def _rows_problem():
+    from oracle import synth
+    N, J, B = 36 * 53 + 7, 32, 19                      # ragged: the last shard is shorter and not a multiple of 36
+    E = synth.make_codebook(N, J, seed=5, planted_duplicates=12)
+    rng = np.random.default_rng(3)
+    z = rng.standard_normal((B, J)).astype(np.float32)
+    z[:6] = E[[0, 35, 36, 71, 36 * 30, N - 1]]         # queries that hit planted duplicates on both sides of the cut
+    return E, z
+
+
+def _local_nn(E, lo, hi):
+    from oracle import reference_cpu as ref
+
+    def fn(z, k, stride):
+        cs = ref.cos_similarity(np.asarray(z), E[lo:hi])
+        cols = np.arange(0, hi - lo, stride)
+        idx = cols[ref.topk_canonical(cs[:, cols], min(k, len(cols)))]
+        return idx, np.take_along_axis(cs, idx, axis=1).astype(np.float32)
+    return fn
+
+
+def _rows_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from augmentedautoencoder_amd.dist import RowShardedCodebook, row_shard_bounds
+    E, z = _rows_problem()
+    lo, hi = row_shard_bounds(len(E), world, align=36)[rank]
+    cb = RowShardedCodebook(_local_nn(E, lo, hi), len(E), align=36)
+    out = {}
+    for name, k, stride in (('top1', 1, 1), ('top5', 5, 1), ('up1', 1, 36), ('up3', 3, 36)):
+        i, s = cb.nn(z, k, stride)
+        out[name + '_i'], out[name + '_s'] = i.numpy(), s.numpy()
+    np.savez(os.path.join(out_dir, 'rows%d.npz' % rank), **out)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize('world', [2, 3])
+def test_row_sharded_codebook_matches_single_scan(tmp_path, world):
+    port = _free_port()
+    mp.spawn(_rows_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    E, z = _rows_problem()
+    whole = _local_nn(E, 0, len(E))
+    for r in range(world):
+        got = np.load(os.path.join(str(tmp_path), 'rows%d.npz' % r))
+        for name, k, stride in (('top1', 1, 1), ('top5', 5, 1), ('up1', 1, 36), ('up3', 3, 36)):
+            wi, ws = whole(z, k, stride)
+            assert np.array_equal(got[name + '_i'], wi), (name, r)      # same rows, same tie order as one scan
+            assert np.array_equal(got[name + '_s'], ws), (name, r)
+
+
+def test_row_shard_bounds_and_merge():
+    sys.path.insert(0, ROOT)
+    from augmentedautoencoder_amd.dist import merge_topk, row_shard_bounds
+    assert row_shard_bounds(92232, 8, 36) == [(i * 11556, min((i + 1) * 11556, 92232)) for i in range(8)]
+    b = row_shard_bounds(100, 3, 36)
+    assert b == [(0, 36), (36, 72), (72, 100)] and row_shard_bounds(10, 4, 36)[1:] == [(10, 10)] * 3
+    s = torch.tensor([[0.5, 0.9, 0.9, float('-inf'), 0.9]])
+    i = torch.tensor([[7, 40, 3, torch.iinfo(torch.int64).max, 12]])
+    mi, ms = merge_topk(s, i, 3)
+    assert mi.tolist() == [[3, 12, 40]] and ms.tolist() == [[pytest.approx(0.9)] * 3]

@@ -496,3 +496,30 @@ def test_c_abi_forward_is_reentrant_on_distinct_streams_and_workspaces():
     assert not errors, errors
     enc.close()
     cb.close()
+
+
+def test_row_sharded_codebook_shards_merge_to_the_single_scan():
+    """SURVEY 8e alternative: rows of one codebook split over 3 'ranks' (emulated in one process, HIP engine per
+    shard); the merged local top-k lists must equal the single-engine scan bit for bit, ties included."""
+    import torch
+    from augmentedautoencoder_amd.dist import RowShardedCodebook, merge_topk
+    from augmentedautoencoder_amd.engine import CodebookEngine
+    N, B = 92232, 40
+    E = synth.make_codebook(N, 128, seed=21, planted_duplicates=64)
+    rng = np.random.default_rng(8)
+    z = rng.standard_normal((B, 128)).astype(np.float32)
+    z[:6] = E[[0, 35, 30744 - 36, 30744 + 35, 61488, N - 1]] * 3.0      # duplicates straddling the shard cuts
+    zt = torch.from_numpy(z).cuda()
+    whole = CodebookEngine(E)
+    shards = [RowShardedCodebook.from_array(E, device=torch.device('cuda'), align=36, world_size=3, rank=r) for r in range(3)]
+    assert [(s.lo, s.hi) for s in shards] == [(0, 30744), (30744, 61488), (61488, 92232)]
+    for k, stride in ((1, 1), (5, 1), (8, 1), (1, 36)):           # the C ABI defines upright for topk == 1 only
+        cand = [s.local_candidates(zt, k, stride) for s in shards]
+        ix = torch.cat([c[0] for c in cand], dim=1)
+        sc = torch.cat([c[1] for c in cand], dim=1)
+        mi, ms = merge_topk(sc, ix, k)
+        wi, ws = whole.nn(zt, k, stride)
+        assert torch.equal(mi, wi) and torch.equal(ms, ws), (k, stride)
+    for s in shards:
+        s.engine.close()
+    whole.close()
