@@ -78,7 +78,9 @@ struct Layer {
     float* bn_scale = nullptr;  // folded inference BN: x*scale + shift
     float* bn_shift = nullptr;
     // first-layer staging geometry
-    int rowlen = 0, first_smem = 0;
+    int rowlen = 0, first_smem = 0;       // conv1 (conv_first_f32.h): staged floats per input row, LDS bytes
+    bool first_packable = true;
+    int rowlen4 = 0, lead4 = 0;           // same for the dword-staged uint8 form (0 = not applicable)
     long long K() const { return (long long)KS * KS * Cin; }
 };
 
@@ -100,8 +102,9 @@ struct aae_encoder {
     int splitk_min_base_blocks = 384;      // split K only when the un-split grid is smaller than this
     int splitk_target_blocks = 512;        // ... and then aim for about this many blocks
     int precision = 0;                     // 0: exact fp32 MFMA; 1: f32x3h split-precision igemm (explicit opt-in)
-    int first_target_blocks = 1024;        // conv1 grid size aimed at (x N tiles); 2 blocks fit a CU
-    int first_max_tiles_per_block = 8;     // conv1: consecutive 128-pixel tiles one block walks with its weights in registers
+    int first_target_blocks = 512;         // conv1 grid size aimed at (x N tiles); 2 blocks fit a CU
+    int first_vec4 = 1;                    // conv1: stage uint8 rows as aligned dwords when W*C % 4 == 0
+    int first_max_tiles_per_block = 16;    // conv1: consecutive 128-pixel tiles one block walks with its weights in registers
     int igemm_breg_min_blocks = 768;       // ... with the 32 KB footprint only for grids of at least this many blocks
     int igemm_breg_wide = 1;               // BREG conv2/conv3: 128 x 256 block tiles (each wave 64 x 128) when the layer is wide enough (+0.9 %)
     int igemm_breg_wide_min_blocks = 512;
@@ -209,7 +212,16 @@ static void plan_first_layer(Layer& L) {
     int max_out_rows = 127 / L.Wo + 2;
     if (max_out_rows > L.Ho) max_out_rows = L.Ho;
     const int max_in_rows = (max_out_rows - 1) * L.S + L.KS;
-    L.first_smem = (256 + max_in_rows * L.rowlen) * (int)sizeof(float);
+    int widest = L.rowlen;
+    L.rowlen4 = L.lead4 = 0;
+    if ((L.W * L.Cin) % 4 == 0) {          // uint8 rows can be staged as aligned dwords
+        L.lead4 = (4 - (L.pl * L.Cin) % 4) % 4;
+        L.rowlen4 = (L.rowlen + L.lead4 + 3) / 4 * 4;
+        widest = L.rowlen4;
+    }
+    L.first_smem = (256 + max_in_rows * widest) * (int)sizeof(float);
+    // the staging units keep (row, offset from the first staged row) packed in 12 + 20 bits
+    L.first_packable = (long long)(max_in_rows + 1) * L.W * L.Cin < (1ll << 20);
 }
 
 // split-K factor: aim for >= ~512 resident-able blocks without splitting finer than one slab
@@ -429,11 +441,14 @@ static int launch_igemm_x3h(aae_encoder* enc, const Layer& L, const void* x, int
 
 template <int KS, int C>
 static void launch_first_t(const aae::ConvFirstArgs& a, bool u8, bool planes, dim3 grid, int smem, hipStream_t stream) {
+    const bool vec4 = u8 && a.vec4;
     if (planes) {
-        if (u8) AAE_LAUNCH((aae::conv_first_f32_kernel<KS, C, true, true>), grid, dim3(256), smem, stream, a);
+        if (vec4) AAE_LAUNCH((aae::conv_first_f32_kernel<KS, C, true, true, true>), grid, dim3(256), smem, stream, a);
+        else if (u8) AAE_LAUNCH((aae::conv_first_f32_kernel<KS, C, true, true>), grid, dim3(256), smem, stream, a);
         else AAE_LAUNCH((aae::conv_first_f32_kernel<KS, C, false, true>), grid, dim3(256), smem, stream, a);
     } else {
-        if (u8) AAE_LAUNCH((aae::conv_first_f32_kernel<KS, C, true, false>), grid, dim3(256), smem, stream, a);
+        if (vec4) AAE_LAUNCH((aae::conv_first_f32_kernel<KS, C, true, false, true>), grid, dim3(256), smem, stream, a);
+        else if (u8) AAE_LAUNCH((aae::conv_first_f32_kernel<KS, C, true, false>), grid, dim3(256), smem, stream, a);
         else AAE_LAUNCH((aae::conv_first_f32_kernel<KS, C, false, false>), grid, dim3(256), smem, stream, a);
     }
 }
@@ -443,7 +458,10 @@ static int launch_first(aae_encoder* enc, const Layer& L, const void* x, bool u8
     aae::ConvFirstArgs a;
     a.x = x; a.lut = enc->lut; a.w = L.w_hwio; a.bias = L.bias; a.bn_scale = L.bn_scale; a.bn_shift = L.bn_shift;
     a.out = out; a.H = L.H; a.W = L.W; a.Ho = L.Ho; a.Wo = L.Wo; a.Cout = L.Cout;
-    a.S = L.S; a.pt = L.pt; a.pl = L.pl; a.rowlen = L.rowlen; a.relu = L.relu;
+    a.S = L.S; a.pt = L.pt; a.pl = L.pl; a.relu = L.relu;
+    a.vec4 = (u8 && L.rowlen4 > 0 && enc->first_vec4) ? 1 : 0;
+    a.rowlen = a.vec4 ? L.rowlen4 : L.rowlen;
+    a.lead = a.vec4 ? L.lead4 : 0;
     a.out_scale = ldexpf(1.f, enc->x3h_act_shift);
     a.tiles_per_image = ceil_div(L.Ho * L.Wo, 128);
     a.total_tiles = B * a.tiles_per_image;
@@ -756,7 +774,7 @@ int aae_encoder_create(const aae_encoder_desc* d, const void* const* hw, int n_w
         }
         if (li == 0 && first_layer_instantiated(L.KS, L.Cin)) {
             plan_first_layer(L);
-            L.kind = (L.first_smem <= 160 * 1024) ? KIND_FIRST_MFMA : KIND_GENERIC;
+            L.kind = (L.first_smem <= 160 * 1024 && L.first_packable) ? KIND_FIRST_MFMA : KIND_GENERIC;
         }
         if (L.kind == KIND_GENERIC && L.Cin % 32 == 0) {
             L.kind = KIND_IGEMM;
@@ -816,6 +834,10 @@ int aae_encoder_create(const aae_encoder_desc* d, const void* const* hw, int n_w
         (void)hipFuncSetAttribute((const void*)aae::conv_first_f32_kernel<5, 3, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
         (void)hipFuncSetAttribute((const void*)aae::conv_first_f32_kernel<5, 1, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
         (void)hipFuncSetAttribute((const void*)aae::conv_first_f32_kernel<5, 1, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
+        (void)hipFuncSetAttribute((const void*)aae::conv_first_f32_kernel<5, 3, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
+        (void)hipFuncSetAttribute((const void*)aae::conv_first_f32_kernel<5, 1, true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
+        (void)hipFuncSetAttribute((const void*)aae::conv_first_f32_kernel<5, 3, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
+        (void)hipFuncSetAttribute((const void*)aae::conv_first_f32_kernel<5, 1, true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
         (void)hipFuncSetAttribute((const void*)aae::conv_first_f32_kernel<5, 3, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
         (void)hipFuncSetAttribute((const void*)aae::conv_first_f32_kernel<5, 3, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
         (void)hipFuncSetAttribute((const void*)aae::conv_first_f32_kernel<5, 1, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, sm);
@@ -845,6 +867,7 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
     else if (!strcmp(name, "igemm_breg_wide")) enc->igemm_breg_wide = value ? 1 : 0;
     else if (!strcmp(name, "igemm_breg_wide_min_blocks")) enc->igemm_breg_wide_min_blocks = value;
     else if (!strcmp(name, "igemm_breg_min_blocks")) enc->igemm_breg_min_blocks = value;
+    else if (!strcmp(name, "first_vec4")) enc->first_vec4 = value ? 1 : 0;
     else if (!strcmp(name, "first_target_blocks")) enc->first_target_blocks = value < 1 ? 1 : value;
     else if (!strcmp(name, "first_max_tiles_per_block")) enc->first_max_tiles_per_block = value < 1 ? 1 : value;
     else if (!strcmp(name, "x3h_act_shift")) {

@@ -102,7 +102,8 @@ void aae_encoder_destroy(aae_encoder* enc);
  *                        matrix-core tile (same value up to fp32 summation order);
  *   "x3h_wide_min_blocks" (0): > 0 lets f32x3h conv layers use 256x128 tiles when that still yields this
  *                        many blocks (measured neutral);
- *   "first_target_blocks" (1024), "first_max_tiles_per_block" (8): conv1 grid shaping.
+ *   "first_target_blocks" (512), "first_max_tiles_per_block" (16): conv1 grid shaping;
+ *   "first_vec4" (1): stage uint8 rows of conv1 as aligned dwords when W*C % 4 == 0.
  * All variants selected by these knobs are bit-identical to each other (tests/test_gpu_parity.py). */
 int aae_encoder_set_option(aae_encoder* enc, const char* name, int value);
 

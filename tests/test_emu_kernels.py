@@ -250,3 +250,29 @@ def test_dense_layer_as_weight_streaming_gemv_for_tiny_batches(B):
     assert not any('dense_gemv' in l for l in enc.labels())
     assert np.abs(z - z_mfma).max() / np.abs(z64).max() < 2e-6
     enc.close()
+
+
+@pytest.mark.parametrize('shape,filters,B', [
+    ((40, 24, 3), [48, 32], 2),      # W*C = 72: dword staging, ragged last tile (240 px), Cout cut by the 32-channel wave tile
+    ((24, 20, 1), [32, 32], 3),      # one input channel, W*C = 20, pl*C = 1 -> three lead floats
+    ((16, 10, 3), [64, 32], 2),      # W*C = 30 is not a multiple of 4: element-wise staging only
+    ((64, 32, 3), [32, 32], 1),      # 512 px: four full tiles walked by one block with its weights in registers
+])
+def test_first_layer_dword_and_elementwise_staging_agree_bitwise(shape, filters, B):
+    """conv1 stages uint8 rows either as aligned dwords (W*C % 4 == 0) or element by element; float input
+    always takes the element path.  All three must give the same bits -- staging only moves data."""
+    cfg = EncoderConfig(shape, filters, [2, 2], 5, 16)
+    w = synth.make_weights(seed=5, shape=cfg.shape, num_filter=filters, strides=cfg.strides, latent=16)
+    x = synth.make_crops(B, seed=6, shape=cfg.shape)
+    acts = []
+    for vec4, f32_in in ((1, False), (0, False), (1, True)):
+        enc = eb.EmuEncoder(w, cfg)
+        enc.set_option('first_vec4', vec4)
+        enc.set_option('first_max_tiles_per_block', 3)
+        enc.forward(ref.input_to_float(x).astype(np.float32) if f32_in else x)
+        assert 'conv_first_f32' in enc.labels()[0]
+        acts.append(enc.activation(0).copy())
+        enc.close()
+    assert np.array_equal(acts[0], acts[1]) and np.array_equal(acts[0], acts[2])
+    _, want = ref.encoder_forward_np(ref.input_to_float(x), w, cfg.strides, False, return_activations=True)
+    assert np.abs(acts[0] - want[0]).max() / np.abs(want[0]).max() < 5e-6

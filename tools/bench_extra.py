@@ -103,7 +103,7 @@ def main():
         enc.set_option('igemm_dma', 0)
     if 'conv1' in what:
         x = torch.from_numpy(synth.make_crops(256, seed=1)).cuda()
-        for tpb, tb in ((8, 1024), (16, 512), (32, 256), (4, 2048), (2, 4096), (8, 1024), (16, 512)):
+        for tpb, tb in ((8, 1024), (16, 512), (32, 256), (11, 768), (12, 768), (6, 1536), (22, 384), (4, 2048), (2, 4096), (8, 1024), (16, 512)):
             enc.set_option('first_max_tiles_per_block', tpb)
             enc.set_option('first_target_blocks', tb)
             ts = []
@@ -111,8 +111,8 @@ def main():
                 _, recs = enc.encode_timed(x)
                 ts.append(recs[0][1])
             print(json.dumps({'what': 'conv1', 'max_tiles_per_block': tpb, 'target_blocks': tb, 'conv1_ms': [round(t, 4) for t in ts]}))
-        enc.set_option('first_max_tiles_per_block', 8)
-        enc.set_option('first_target_blocks', 1024)
+        enc.set_option('first_max_tiles_per_block', 16)
+        enc.set_option('first_target_blocks', 512)
     if 'decoder' in what:
         # next row N4: Decoder.x for batches of latent codes (default shapes), kernel split + torch-CPU reference beside it
         from augmentedautoencoder_amd.engine import DecoderEngine
