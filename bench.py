@@ -87,7 +87,7 @@ def main():
     import torch.distributed as dist
     from augmentedautoencoder_amd.engine import CodebookEngine, EncoderEngine
     from augmentedautoencoder_amd.weights import EncoderConfig
-    from oracle import synth
+    from augmentedautoencoder_amd import synth            # seeded synthetic inputs (no oracle code on the measured path)
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
