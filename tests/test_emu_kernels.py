@@ -118,6 +118,7 @@ def test_small_latent_and_l2_normalize():
     (EncoderConfig((16, 16, 3), [32, 64], [2, 2], 5, 128), 3, False),
     (EncoderConfig((16, 16, 3), [32, 64], [2, 2], 5, 128, True), 2, True),
     (EncoderConfig((12, 12, 1), [160, 32], [1, 2], 5, 128), 1, False),
+    (EncoderConfig((32, 32, 3), [64, 32], [2, 2], 5, 128), 1, False),      # conv1: two full 128-pixel tiles -> lane-pair packed plane stores
 ])
 def test_split_precision_f32x3h_path(cfg, B, nosplit, dma):
     """f32x3h (3 fp16 MFMAs per product on (hi, lo) operand pairs, fp32 accumulate): same
