@@ -113,6 +113,10 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// makes v available HERE (the compiler must finish the load that produces it before this point instead of
+// waiting in front of every later use in its own basic block)
+__device__ __forceinline__ float pin_value(float v) { asm volatile("" : "+v"(v)); return v; }
+
 // instruction-scheduling fence: nothing is moved across it by the compiler's scheduler
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 

@@ -303,6 +303,10 @@ __global__ __launch_bounds__(256, NW == 4 ? 2 : 1) void conv_igemm_f32_kernel(co
         if (!SPLITK) {
             bias = p.bias[n];
             if (p.bn_scale) { sc = p.bn_scale[n]; sh = p.bn_shift[n]; }
+            // wait for these three loads ONCE: every store below sits in its own predicated basic block, and the
+            // compiler otherwise puts s_waitcnt vmcnt(0) in front of each of them -- which also waits for the
+            // previous STORE's acknowledge: 64-128 serialised round trips per wave.
+            bias = pin_value(bias); sc = pin_value(sc); sh = pin_value(sh);
         }
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi) {

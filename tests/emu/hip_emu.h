@@ -58,6 +58,7 @@ namespace aae {
 inline int lane_id() { return threadIdx.x & 63; }
 inline void sleep_kcycles(int) {}
 inline void sched_fence() {}
+inline float pin_value(float v) { return v; }
 
 struct buffer_rsrc { const unsigned char* base; uint32_t bytes; };
 constexpr uint32_t kOobOffset = 0xFFFFFFF0u;
