@@ -459,7 +459,7 @@ static int launch_first(aae_encoder* enc, const Layer& L, const void* x, bool u8
     a.x = x; a.lut = enc->lut; a.w = L.w_hwio; a.bias = L.bias; a.bn_scale = L.bn_scale; a.bn_shift = L.bn_shift;
     a.out = out; a.H = L.H; a.W = L.W; a.Ho = L.Ho; a.Wo = L.Wo; a.Cout = L.Cout;
     a.S = L.S; a.pt = L.pt; a.pl = L.pl; a.relu = L.relu;
-    a.vec4 = (u8 && L.rowlen4 > 0 && enc->first_vec4) ? 1 : 0;
+    a.vec4 = (u8 && L.rowlen4 > 0 && enc->first_vec4 && (reinterpret_cast<uintptr_t>(x) & 3) == 0) ? 1 : 0;   // dword loads want a 4-byte aligned batch
     a.rowlen = a.vec4 ? L.rowlen4 : L.rowlen;
     a.lead = a.vec4 ? L.lead4 : 0;
     a.out_scale = ldexpf(1.f, enc->x3h_act_shift);

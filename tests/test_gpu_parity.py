@@ -523,3 +523,22 @@ def test_row_sharded_codebook_shards_merge_to_the_single_scan():
     for s in shards:
         s.engine.close()
     whole.close()
+
+
+def test_uint8_batch_at_an_odd_address_gives_the_same_bits(default_model):
+    """conv1 stages uint8 rows as aligned dwords; a batch that starts at an odd byte address (a view into a larger
+    buffer) must fall back to element-wise staging and give bit-identical latents."""
+    import torch
+    from augmentedautoencoder_amd.engine import EncoderEngine
+    from augmentedautoencoder_amd.weights import EncoderConfig
+    weights = default_model[0]
+    x = torch.from_numpy(synth.make_crops(9, seed=77)).cuda()
+    enc = EncoderEngine(EncoderConfig(), weights, max_batch=16)
+    z0 = enc.encode(x).clone()
+    big = torch.empty(x.numel() + 3, dtype=torch.uint8, device='cuda')
+    for shift in (1, 2, 3):
+        view = big[shift:shift + x.numel()].view(x.shape)
+        view.copy_(x)
+        assert view.data_ptr() % 4 == shift
+        assert torch.equal(enc.encode(view), z0), shift
+    enc.close()
