@@ -101,6 +101,7 @@ struct aae_encoder {
     std::mutex rec_mu;
     int splitk_min_base_blocks = 384;      // split K only when the un-split grid is smaller than this
     int splitk_target_blocks = 512;        // ... and then aim for about this many blocks
+    int reduce_small = 1;                  // <= 8 splits over >= 16k outputs: barrier-free float4 reduce kernel
     int precision = 0;                     // 0: exact fp32 MFMA; 1: f32x3h split-precision igemm (explicit opt-in)
     int first_target_blocks = 512;         // conv1 grid size aimed at (x N tiles); 2 blocks fit a CU
     int first_vec4 = 1;                    // conv1: stage uint8 rows as aligned dwords when W*C % 4 == 0
@@ -203,6 +204,18 @@ static std::vector<unsigned short> pack_weights_x3h(const float* w, int taps, in
             }
         }
     return out;
+}
+
+// split-K partial sums -> layer output: few splits over a large tile take the barrier-free float4 kernel
+static void launch_splitk_reduce(const aae::SplitKReduceArgs& r, hipStream_t stream, bool allow_small = true) {
+    if (allow_small && r.splits <= aae::kReduceGroups && r.MN % 4 == 0 && r.Cout % 4 == 0 && r.MN >= 16384) {
+        const long long blocks = (r.MN / 4 + 255) / 256;
+        AAE_LAUNCH((aae::splitk_reduce_small_kernel), dim3((unsigned)blocks), dim3(256), 0, stream, r);
+        return;
+    }
+    long long blocks = (r.MN + 63) / 64;
+    if (blocks > 4096) blocks = 4096;
+    AAE_LAUNCH((aae::splitk_reduce_kernel), dim3((unsigned)blocks), dim3(512), aae::kReduceGroups * 64 * (int)sizeof(float), stream, r);
 }
 
 static bool first_layer_instantiated(int KS, int C) { return KS == 5 && (C == 3 || C == 1); }
@@ -352,9 +365,7 @@ static int launch_igemm(aae_encoder* enc, const Layer& L, const float* x, int M,
     r.partial = partial; r.bias = L.bias; r.bn_scale = L.bn_scale; r.bn_shift = L.bn_shift; r.out = out;
     r.MN = (long long)M * L.Cout; r.Cout = L.Cout; r.splits = a.splits; r.relu = L.relu;
     r.out_planes = 0; r.out_scale = 1.f;
-    long long blocks = (r.MN + 63) / 64;
-    if (blocks > 4096) blocks = 4096;
-    AAE_LAUNCH((aae::splitk_reduce_kernel), dim3((unsigned)blocks), dim3(512), aae::kReduceGroups * 64 * (int)sizeof(float), stream, r);
+    launch_splitk_reduce(r, stream, enc->reduce_small != 0);
     snprintf(label, sizeof(label), "%s:splitk_reduce", name);
     note_kernel({label, 0.0});
     AAE_HIP_TRY(hipGetLastError());
@@ -430,9 +441,7 @@ static int launch_igemm_x3h(aae_encoder* enc, const Layer& L, const void* x, int
     r.partial = partial; r.bias = L.bias; r.bn_scale = L.bn_scale; r.bn_shift = L.bn_shift; r.out = static_cast<float*>(out);
     r.MN = (long long)M * L.Cout; r.Cout = L.Cout; r.splits = a.splits; r.relu = L.relu;
     r.out_planes = out_f32 ? 0 : 1; r.out_scale = a.out_scale;
-    long long blocks = (r.MN + 63) / 64;
-    if (blocks > 4096) blocks = 4096;
-    AAE_LAUNCH((aae::splitk_reduce_kernel), dim3((unsigned)blocks), dim3(512), aae::kReduceGroups * 64 * (int)sizeof(float), stream, r);
+    launch_splitk_reduce(r, stream, enc->reduce_small != 0);
     snprintf(label, sizeof(label), "%s:splitk_reduce", name);
     note_kernel({label, 0.0});
     AAE_HIP_TRY(hipGetLastError());
@@ -518,9 +527,7 @@ static int launch_dense_gemv(aae_encoder* enc, const Layer& D, const float* x, i
     aae::SplitKReduceArgs r;
     r.partial = partial; r.bias = D.bias; r.bn_scale = D.bn_scale; r.bn_shift = D.bn_shift; r.out = out;
     r.MN = (long long)B * D.Cout; r.Cout = D.Cout; r.splits = chunks; r.relu = D.relu; r.out_planes = 0; r.out_scale = 1.f;
-    long long blocks = (r.MN + 63) / 64;
-    if (blocks > 4096) blocks = 4096;
-    AAE_LAUNCH((aae::splitk_reduce_kernel), dim3((unsigned)blocks), dim3(512), aae::kReduceGroups * 64 * (int)sizeof(float), stream, r);
+    launch_splitk_reduce(r, stream, enc->reduce_small != 0);
     note_kernel({"dense:splitk_reduce", 0.0});
     AAE_HIP_TRY(hipGetLastError());
     return tm.mark();
@@ -858,6 +865,7 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
     if (!enc || !name) return fail(AAE_ERR_INVALID, "aae_encoder_set_option: null argument");
     if (!strcmp(name, "splitk_min_base_blocks")) enc->splitk_min_base_blocks = value;
     else if (!strcmp(name, "splitk_target_blocks")) enc->splitk_target_blocks = value;
+    else if (!strcmp(name, "reduce_small")) enc->reduce_small = value ? 1 : 0;
     else if (!strcmp(name, "igemm_stagger")) enc->igemm_stagger = value;
     else if (!strcmp(name, "x3h_dma")) enc->x3h_dma = value ? 1 : 0;
     else if (!strcmp(name, "x3h_wide_min_blocks")) enc->x3h_wide_min_blocks = value < 0 ? 0 : value;

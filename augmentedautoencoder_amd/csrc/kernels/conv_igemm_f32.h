@@ -395,4 +395,52 @@ __global__ __launch_bounds__(512) void splitk_reduce_kernel(const SplitKReduceAr
     }
 }
 
+// Few splits (<= kReduceGroups) over a large tile -- the mid-batch case (B = 4 ... 128): four consecutive
+// elements per thread, every split's float4 in flight at once, no LDS, no barriers.  Same summation
+// order as splitk_reduce_kernel (there group g holds split g alone and the groups are added in order),
+// including its "+ 0.f" canonicalisation of each term, so both kernels give the same bits.
+// Requires MN % 4 == 0 and Cout % 4 == 0.
+__global__ __launch_bounds__(256) void splitk_reduce_small_kernel(const SplitKReduceArgs p) {
+    const long long e = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e >= p.MN) return;
+    f32x4 t[kReduceGroups];
+#pragma unroll
+    for (int s = 0; s < kReduceGroups; ++s) {
+        t[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (s < p.splits) t[s] = *reinterpret_cast<const f32x4*>(p.partial + (long long)s * p.MN + e);
+    }
+    const int n = (int)(e % p.Cout);
+    const f32x4 bias = *reinterpret_cast<const f32x4*>(p.bias + n);
+    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    if (p.bn_scale) {
+        sc = *reinterpret_cast<const f32x4*>(p.bn_scale + n);
+        sh = *reinterpret_cast<const f32x4*>(p.bn_shift + n);
+    }
+    f32x4 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        float a = (t[0][j] + 0.f) + (0.f + 0.f);
+#pragma unroll
+        for (int s = 1; s < kReduceGroups; ++s) a += (t[s][j] + 0.f) + (0.f + 0.f);
+        a += bias[j];
+        if (p.relu) a = fmaxf(a, 0.f);
+        if (p.bn_scale) a = a * sc[j] + sh[j];
+        v[j] = a;
+    }
+    if (p.out_planes) {
+        u16x4 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned short h16, l16;
+            split_f16(v[j] * p.out_scale, h16, l16);
+            hi[j] = h16; lo[j] = l16;
+        }
+        unsigned short* op = reinterpret_cast<unsigned short*>(p.out);
+        *reinterpret_cast<u16x4*>(op + e) = hi;
+        *reinterpret_cast<u16x4*>(op + p.MN + e) = lo;
+    } else {
+        *reinterpret_cast<f32x4*>(p.out + e) = v;
+    }
+}
+
 }  // namespace aae

@@ -103,7 +103,8 @@ void aae_encoder_destroy(aae_encoder* enc);
  *   "x3h_wide_min_blocks" (0): > 0 lets f32x3h conv layers use 256x128 tiles when that still yields this
  *                        many blocks (measured neutral);
  *   "first_target_blocks" (512), "first_max_tiles_per_block" (16): conv1 grid shaping;
- *   "first_vec4" (1): stage uint8 rows of conv1 as aligned dwords when W*C % 4 == 0.
+ *   "first_vec4" (1): stage uint8 rows of conv1 as aligned dwords when W*C % 4 == 0;
+ *   "reduce_small" (1): split-K sums of <= 8 splits over >= 16k outputs by the barrier-free float4 kernel.
  * All variants selected by these knobs are bit-identical to each other (tests/test_gpu_parity.py). */
 int aae_encoder_set_option(aae_encoder* enc, const char* name, int value);
 

@@ -277,3 +277,27 @@ def test_first_layer_dword_and_elementwise_staging_agree_bitwise(shape, filters,
     assert np.array_equal(acts[0], acts[1]) and np.array_equal(acts[0], acts[2])
     _, want = ref.encoder_forward_np(ref.input_to_float(x), w, cfg.strides, False, return_activations=True)
     assert np.abs(acts[0] - want[0]).max() / np.abs(want[0]).max() < 5e-6
+
+
+@pytest.mark.parametrize('precision,bn', [(0, False), (0, True), (1, False)])
+def test_few_split_reduce_kernel_matches_the_grouped_one_bitwise(precision, bn):
+    """Mid batches split K into <= 8 parts over a large output tile; those sums take the barrier-free float4
+    reduce kernel (fp32 output, BN epilogue, and the two-plane f32x3h output).  Same bits as the grouped
+    kernel, and both within fp32 roundoff of the oracle."""
+    cfg = EncoderConfig((32, 32, 3), [32, 64], [2, 2], 5, 128, bn)
+    w = synth.make_weights(seed=8, shape=cfg.shape, num_filter=cfg.num_filter, strides=cfg.strides, latent=128, batch_norm=bn)
+    x = synth.make_crops(4, seed=9, shape=cfg.shape)
+    outs = []
+    for small in (1, 0):
+        enc = eb.EmuEncoder(w, cfg)
+        enc.set_option('precision', precision)
+        enc.set_option('splitk_target_blocks', 8)          # conv2: 2 base blocks -> 4 splits over 256 x 64 outputs
+        enc.set_option('reduce_small', small)
+        z = enc.forward(x)
+        assert any('splitk4' in l for l in enc.labels()), enc.labels()
+        outs.append((enc.activation(1).copy(), z.copy()))
+        enc.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    z64, acts = ref.encoder_forward_np(ref.input_to_float(x), w, cfg.strides, bn, return_activations=True)
+    assert np.abs(outs[0][0] - acts[1]).max() / np.abs(acts[1]).max() < 5e-6
+    assert np.abs(outs[0][1] - z64).max() / np.abs(z64).max() < 5e-6
