@@ -242,6 +242,8 @@ class CodebookEngine(object):
         B = z.shape[0]
         idx = torch.empty((B, topk), dtype=torch.int64, device=self.device)
         score = torch.empty((B, topk), dtype=torch.float32, device=self.device)
+        if B == 0:                    # an empty batch is an empty answer (TF/NumPy semantics of the reference), not an error
+            return idx, score
         nbytes = self.lib.aae_codebook_workspace_bytes(self.handle, B, topk)
         _, ws_ptr = self.ws.get(nbytes)
         with torch.cuda.device(self.device):
@@ -257,6 +259,8 @@ class CodebookEngine(object):
         z = self._z(z)
         B = z.shape[0]
         cs = torch.empty((B, self.N), dtype=torch.float32, device=self.device)
+        if B == 0:
+            return cs
         nbytes = self.lib.aae_codebook_workspace_bytes(self.handle, B, 1)
         _, ws_ptr = self.ws.get(nbytes)
         with torch.cuda.device(self.device):
@@ -269,6 +273,8 @@ class CodebookEngine(object):
         torch = _torch()
         z = self._z(z)
         q = torch.empty_like(z)
+        if z.shape[0] == 0:
+            return q
         with torch.cuda.device(self.device):
             rc = self.lib.aae_l2_normalize(ctypes.c_void_p(z.data_ptr()), z.shape[0], z.shape[1], ctypes.c_void_p(q.data_ptr()),
                                            _stream_ptr(torch))

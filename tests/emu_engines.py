@@ -22,6 +22,8 @@ class EmuEncoderEngine(object):
             x = x[None]
         if x.dtype != np.uint8:
             x = x.astype(np.float32)
+        if len(x) == 0:                        # same empty-batch contract as engine.EncoderEngine.encode
+            return torch.empty((0, self.cfg.latent_space_size), dtype=torch.float32)
         return torch.from_numpy(self._e.forward(x))
 
     def activation(self, layer):
@@ -43,15 +45,21 @@ class EmuCodebookEngine(object):
 
     def nn(self, z, topk=1, col_stride=1):
         z = z.numpy() if torch.is_tensor(z) else np.asarray(z)
+        if len(z) == 0:
+            return torch.empty((0, topk), dtype=torch.int64), torch.empty((0, topk), dtype=torch.float32)
         idx, score = self._c.nn(z, topk, col_stride)
         return torch.from_numpy(idx), torch.from_numpy(score)
 
     def similarity(self, z):
         z = z.numpy() if torch.is_tensor(z) else np.asarray(z)
+        if len(z) == 0:
+            return torch.empty((0, self._c.E.shape[0]), dtype=torch.float32)
         return torch.from_numpy(self._c.similarity(z))
 
     def l2_normalize(self, z):
         z = z.numpy() if torch.is_tensor(z) else np.asarray(z)
+        if len(z) == 0:
+            return torch.from_numpy(np.asarray(z, dtype=np.float32))
         return torch.from_numpy(eb.l2_normalize(z))
 
     def close(self):

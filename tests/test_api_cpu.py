@@ -117,6 +117,23 @@ def test_nearest_rotation_shapes_and_values(tiny):
     assert np.abs(cb.test_embedding(sess, crops, normalized=False) - z64).max() < 1e-5
 
 
+def test_empty_batch_is_an_empty_answer(tiny):
+    """TF + NumPy semantics of the reference: session.run on a [0,H,W,C] feed gives a [0,N] similarity, np.argmax
+    over it an empty int64 vector and Rs[idcs].squeeze() a [0,3,3] array -- no exception."""
+    args, ds, enc, cb, w, E = tiny
+    none = np.zeros((0, 16, 16, 3), dtype=np.uint8)
+    idcs = cb.nearest_rotation(None, none, return_idcs=True)
+    assert idcs.dtype == np.int64 and idcs.shape == (0,)
+    assert cb.nearest_rotation(None, none).shape == (0, 3, 3)
+    assert cb.nearest_rotation(None, none, upright=True, return_idcs=True).shape == (0,)
+    assert cb.nearest_rotation_batch(None, none).shape == (0, 3, 3)
+    sess = S.Session()
+    assert sess.run(cb.cos_similarity, {enc.x: none}).shape == (0, len(E))
+    assert cb.test_embedding(sess, none).shape == (0, 128)
+    with pytest.raises(ValueError):
+        cb.nearest_rotation(None, none, top_n=3)               # the reference's squeeze()-based top-n needs exactly one crop
+
+
 def test_auto_pose6d_matches_reference_geometry(tiny):
     args, ds, enc, cb, w, E = tiny
     rng = np.random.default_rng(4)

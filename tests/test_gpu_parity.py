@@ -542,3 +542,15 @@ def test_uint8_batch_at_an_odd_address_gives_the_same_bits(default_model):
         assert view.data_ptr() % 4 == shift
         assert torch.equal(enc.encode(view), z0), shift
     enc.close()
+
+
+def test_empty_batch_returns_empty_results(default_model):
+    """[0,H,W,C] in -> [0] indices / [0,3,3] rotations / [0,N] similarity out, as TF + NumPy give in the reference."""
+    from augmentedautoencoder_amd import session as S
+    _, enc, cb, E, _ = default_model
+    none = np.zeros((0, 128, 128, 3), dtype=np.uint8)
+    idcs = cb.nearest_rotation(None, none, return_idcs=True)
+    assert idcs.dtype == np.int64 and idcs.shape == (0,)
+    assert cb.nearest_rotation(None, none).shape == (0, 3, 3)
+    assert S.Session().run(cb.cos_similarity, {enc.x: none}).shape == (0, len(E))
+    assert cb.test_embedding(None, none).shape == (0, 128)
