@@ -27,6 +27,7 @@
 #include "kernels/dense_gemv_f32.h"
 #include "kernels/codebook_scan_f32.h"
 #include "kernels/codebook_scan_bf16.h"
+#include "kernels/codebook_scan_resident.h"
 #include "kernels/crop_resize_u8.h"
 
 namespace aae_host {
@@ -592,6 +593,8 @@ static int forward_impl(aae_encoder* enc, const void* x, int x_dtype, int B, flo
 struct ScanPlan {
     int nblk, Bpad, Bstride, Jpad, NT;
     bool gemv, stream;
+    bool resident_ok;              // query-resident streaming kernel eligible (top-1, no similarity output, stride 1 decided at run time)
+    int res_tiles_per_block, res_blocks;
     size_t q_off, qp_off, pval_off, pidx_off, cs_off, cand_off, total;
 };
 
@@ -610,6 +613,20 @@ static ScanPlan plan_scan(const aae_codebook* cb, int B, int topk) {
         if (s.stream) s.nblk = ceil_div(cb->N, 256);
     }
     s.Bstride = s.Bpad;
+    // large batches: queries resident in registers, codebook streamed (codebook_scan_resident.h); about one
+    // block (8 waves) per CU: row ranges x 128-query chunks
+    s.resident_ok = false; s.res_tiles_per_block = 0; s.res_blocks = 0;
+    if (cb->scan_mode == AAE_SCAN_AUTO && cb->J == 128 && !s.stream && !s.gemv && B > 32) {
+        const int tile_rows = cb->dtype == AAE_DTYPE_BF16 ? 128 : 64;
+        const int ntiles = ceil_div(cb->N, tile_rows);
+        const int qchunks = ceil_div(s.Bpad, aae::kScanResidentQueries);
+        int row_blocks = 256 / qchunks;
+        if (row_blocks < 1) row_blocks = 1;
+        s.res_tiles_per_block = ceil_div(ntiles, row_blocks);
+        if (s.res_tiles_per_block < 128 / tile_rows) s.res_tiles_per_block = 128 / tile_rows;   // never more row blocks than nblk
+        s.res_blocks = ceil_div(ntiles, s.res_tiles_per_block);
+        s.resident_ok = s.res_blocks <= s.nblk;          // the partial buffers are sized for nblk row blocks
+    }
     size_t off = 0;
     s.q_off = off;    off += align_up((size_t)B * cb->J * sizeof(float), 256);
     s.qp_off = off;   off += align_up((size_t)s.Jpad * s.Bpad * 6, 256);   // fp32 packing: 4 B/elem; bf16: 3 terms x 2 B
@@ -642,10 +659,32 @@ static void launch_scan_stream_t(const aae::ScanArgs& a, bool upright, int nblk,
     else AAE_LAUNCH((aae::scan_stream_kernel<NQ, false>), dim3(nblk), dim3(256), smem, stream, a);
 }
 
+static int launch_scan_resident(const aae_codebook* cb, const void* qp, int B, const ScanPlan& s, unsigned char* base, hipStream_t stream) {
+    aae::ScanResidentArgs a;
+    a.E = cb->E; a.e_bytes = (unsigned)((size_t)cb->N * cb->J * (cb->dtype == AAE_DTYPE_BF16 ? 2 : 4));
+    a.qp = qp;
+    a.pval = reinterpret_cast<float*>(base + s.pval_off);
+    a.pidx = reinterpret_cast<int*>(base + s.pidx_off);
+    a.N = cb->N; a.B = B; a.Bpad = s.Bpad; a.Bstride = s.Bstride; a.tiles_per_block = s.res_tiles_per_block;
+    const dim3 grid(s.res_blocks, ceil_div(s.Bpad, aae::kScanResidentQueries));
+    if (cb->dtype == AAE_DTYPE_BF16) {
+        (void)hipFuncSetAttribute((const void*)aae::scan_resident_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kScanResidentSmem);
+        AAE_LAUNCH((aae::scan_resident_kernel<true>), grid, dim3(aae::kScanResidentThreads), aae::kScanResidentSmem, stream, a);
+    } else {
+        (void)hipFuncSetAttribute((const void*)aae::scan_resident_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kScanResidentSmem);
+        AAE_LAUNCH((aae::scan_resident_kernel<false>), grid, dim3(aae::kScanResidentThreads), aae::kScanResidentSmem, stream, a);
+    }
+    AAE_HIP_TRY(hipGetLastError());
+    return AAE_OK;
+}
+
+// *partial_rows: how many [Bstride]-rows of (pval, pidx) the arg-max reduce has to look at
 static int run_scan(aae_codebook* cb, const float* z, int B, int col_stride, float* cs_out, const ScanPlan& s,
-                    unsigned char* base, hipStream_t stream) {
+                    unsigned char* base, hipStream_t stream, int* partial_rows = nullptr) {
     float* q = reinterpret_cast<float*>(base + s.q_off);
     float* qp = reinterpret_cast<float*>(base + s.qp_off);
+    const bool resident = s.resident_ok && cs_out == nullptr && col_stride == 1;
+    if (partial_rows) *partial_rows = resident ? s.res_blocks : s.nblk;
     if (cb->dtype == AAE_DTYPE_BF16 && s.stream) {
         aae::ScanArgs a;
         a.z = z; a.e_bytes = (unsigned)((size_t)cb->N * cb->J * 2);
@@ -674,6 +713,7 @@ static int run_scan(aae_codebook* cb, const float* z, int B, int col_stride, flo
         n.z = z; n.qp3 = reinterpret_cast<unsigned short*>(qp); n.B = B; n.J = cb->J; n.Jpad = 128; n.Bpad = s.Bpad;
         AAE_LAUNCH((aae::l2norm_pack_bf16x3_kernel), dim3(ceil_div(s.Bpad, 4)), dim3(256), 0, stream, n);
         AAE_HIP_TRY(hipGetLastError());
+        if (resident) return launch_scan_resident(cb, n.qp3, B, s, base, stream);
         aae::ScanBf16Args a;
         a.E = reinterpret_cast<const unsigned short*>(cb->E);
         a.e_bytes = (unsigned)((size_t)cb->N * cb->J * 2);
@@ -698,6 +738,7 @@ static int run_scan(aae_codebook* cb, const float* z, int B, int col_stride, flo
         AAE_LAUNCH((aae::l2norm_pack_kernel), dim3(ceil_div(n.Bpad, 4)), dim3(256), 0, stream, n);
         AAE_HIP_TRY(hipGetLastError());
     }
+    if (resident) return launch_scan_resident(cb, qp, B, s, base, stream);
 
     aae::ScanArgs a;
     a.z = z; a.e_bytes = (unsigned)((size_t)cb->N * cb->J * sizeof(float));
@@ -1015,13 +1056,14 @@ int aae_codebook_nn(aae_codebook* cb, const float* z, int B, int topk, int col_s
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
     unsigned char* base = static_cast<unsigned char*>(workspace);
     float* cs = topk > 1 ? reinterpret_cast<float*>(base + s.cs_off) : nullptr;
-    if (int rc = run_scan(cb, z, B, col_stride, cs, s, base, stream)) return rc;
+    int partial_rows = s.nblk;
+    if (int rc = run_scan(cb, z, B, col_stride, cs, s, base, stream, &partial_rows)) return rc;
     if (topk == 1) {
         aae::ArgmaxReduceArgs r;
         r.pval = reinterpret_cast<float*>(base + s.pval_off);
         r.pidx = reinterpret_cast<int*>(base + s.pidx_off);
         r.idx_out = reinterpret_cast<long long*>(idx_out);
-        r.score_out = score_out; r.nblk = s.nblk; r.B = B; r.Bstride = s.Bstride;
+        r.score_out = score_out; r.nblk = partial_rows; r.B = B; r.Bstride = s.Bstride;
         AAE_LAUNCH((aae::argmax_reduce_kernel), dim3(B), dim3(256), 64, stream, r);
     } else {
         aae::TopKArgs t;

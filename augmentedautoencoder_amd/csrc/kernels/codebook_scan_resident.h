@@ -1,0 +1,170 @@
+// Batched codebook arg-max with the QUERIES resident in registers and the codebook streamed
+// through LDS -- the large-batch form of
+//   tf.matmul(q, E, transpose_b=True) + argmax   (/root/reference/auto_pose/ae/codebook.py:50-51, 63-64)
+// for fp32 rows (exact fp32 MFMA) and bf16 rows (three bf16 MFMA terms per product, fp32 accumulate).
+//
+// scan_mfma_kernel / scan_bf16_kernel keep one 128-row codebook tile in LDS and walk the query
+// chunks through LDS as well: one block per CU (128 KB of LDS), every chunk pays a staging round
+// trip, two barriers and an epilogue, and each MFMA needs more than one 16-byte LDS read.  Here a
+// block of 8 waves owns 128 queries for its whole life: wave (rh, qg) keeps the MFMA B fragments
+// of query group qg (32 queries) in registers (64 VGPRs fp32, 96 bf16) and accumulates rows
+// rh*R .. rh*R+R-1 of every 32-KB row tile (64 fp32 rows / 128 bf16 rows) that streams through a
+// double-buffered LDS image: one barrier and one 16-byte LDS read per 4 (fp32) or 3 (bf16) MFMAs,
+// global loads of tile t+1 in flight under the MFMAs of tile t, a running (best score, first row)
+// pair per lane, and one partial per (row range, query) at the very end.  The per-accumulator MFMA
+// order is the one of the tile-resident kernels, so scores and indices are bit-identical to theirs.
+//
+// Restrictions (the tile-resident kernels remain for the rest): J == 128, top-1, col_stride == 1,
+// no similarity output.
+#pragma once
+
+namespace aae {
+
+struct ScanResidentArgs {
+    const void* E;          // [N][128] fp32 or bf16, row-major
+    unsigned e_bytes;
+    const void* qp;         // fp32: float [32 slots][Bpad][4]; bf16: ushort [3 terms][16 slots][Bpad][8]
+    float* pval;            // [gridDim.x][Bstride] partial best score per row range
+    int* pidx;              // [gridDim.x][Bstride] partial best row
+    int N, B, Bpad, Bstride;
+    int tiles_per_block;    // row tiles one block walks
+};
+
+constexpr int kScanResidentThreads = 512;
+constexpr int kScanResidentQueries = 128;                                   // per block (gridDim.y chunks)
+constexpr int kScanResidentTileFloats = 8192;                               // 32 KB
+constexpr int kScanResidentSmem = 2 * kScanResidentTileFloats * 4 + 2 * 2 * kScanResidentQueries * 4;
+
+template <bool BF16>
+__global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(const ScanResidentArgs p) {
+    constexpr int kTileRows = BF16 ? 128 : 64;
+    constexpr int kMi = BF16 ? 2 : 1;              // 32-row accumulator tiles per wave
+    constexpr int kSlots = BF16 ? 16 : 32;         // 16-byte pieces per codebook row
+    constexpr int kRowBytes = kSlots * 16;
+    AAE_DYN_SMEM(smem_raw);
+    float* Et = reinterpret_cast<float*>(smem_raw);                        // [2][32 KB]
+    float* red_v = Et + 2 * kScanResidentTileFloats;                       // [2 row halves][128 queries]
+    int* red_i = reinterpret_cast<int*>(red_v + 2 * kScanResidentQueries);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int rh = wave & 1, qg = wave >> 1;
+    const int q0 = blockIdx.y * kScanResidentQueries + qg * 32;
+    const bool active = q0 < p.Bpad;               // wave-uniform
+    const int query = q0 + i;
+
+    // this wave's query fragments, for good
+    f32x4 bq[BF16 ? 24 : 16];
+    if (active) {
+        if (BF16) {
+            const unsigned short* qp3 = reinterpret_cast<const unsigned short*>(p.qp);
+            const long long qplane = (long long)16 * p.Bpad * 8;
+#pragma unroll
+            for (int term = 0; term < 3; ++term)
+#pragma unroll
+                for (int s = 0; s < 8; ++s)
+                    bq[term * 8 + s] = *reinterpret_cast<const f32x4*>(qp3 + term * qplane + ((long long)(2 * s + h) * p.Bpad + query) * 8);
+        } else {
+            const float* qp = reinterpret_cast<const float*>(p.qp);
+#pragma unroll
+            for (int c = 0; c < 16; ++c) bq[c] = *reinterpret_cast<const f32x4*>(qp + ((long long)(2 * c + h) * p.Bpad + query) * 4);
+        }
+    }
+
+    const int ntiles = (p.N + kTileRows - 1) / kTileRows;
+    const int tile0 = blockIdx.x * p.tiles_per_block;
+    const int tile1 = min(tile0 + p.tiles_per_block, ntiles);
+
+    // staging: 2048 16-byte pieces per tile, 4 per thread, coalesced along the row
+    const buffer_rsrc ebuf = make_buffer(p.E, p.e_bytes);
+    f32x4 st[4];
+    auto fetch = [&](int t) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = tid + kScanResidentThreads * u;
+            const int r = idx / kSlots, slot = idx % kSlots;
+            const int row = t * kTileRows + r;
+            st[u] = buffer_load4(ebuf, row < p.N ? (unsigned)row * kRowBytes + slot * 16 : kOobOffset);
+        }
+    };
+    auto put = [&](float* dst) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int idx = tid + kScanResidentThreads * u;
+            const int r = idx / kSlots, slot = idx % kSlots;
+            lds_write4(dst + (BF16 ? e16_tile_off(r, slot) : e_tile_off(r, slot)), st[u]);
+        }
+    };
+
+    float bv = kNegInf;
+    int bi = tile0 * kTileRows + rh * 32 * kMi + acc_row(0, lane);
+    if (tile0 < tile1) fetch(tile0);
+    for (int t = tile0; t < tile1; ++t) {
+        float* Eb = Et + ((t - tile0) & 1) * kScanResidentTileFloats;
+        put(Eb);
+        // one barrier per tile: the buffer written here was last read two tiles ago, and every wave has
+        // passed the barrier of the tile in between since
+        __syncthreads();
+        if (t + 1 < tile1) fetch(t + 1);
+        if (active) {
+            f32x16 acc[kMi];
+#pragma unroll
+            for (int mi = 0; mi < kMi; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[mi][r] = 0.f;
+            if (BF16) {
+#pragma unroll
+                for (int s = 0; s < 8; ++s) {
+                    u32x4 a[kMi];
+#pragma unroll
+                    for (int mi = 0; mi < kMi; ++mi)
+                        a[mi] = __builtin_bit_cast(u32x4, lds_read4(Eb + e16_tile_off(rh * 64 + mi * 32 + i, 2 * s + h)));
+#pragma unroll
+                    for (int mi = 0; mi < kMi; ++mi)
+#pragma unroll
+                        for (int term = 2; term >= 0; --term)              // smallest term first
+                            acc[mi] = mfma_32x32x16_bf16(a[mi], __builtin_bit_cast(u32x4, bq[term * 8 + s]), acc[mi]);
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < 16; ++c) {
+                    const f32x4 a = lds_read4(Eb + e_tile_off(rh * 32 + i, 2 * c + h));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc[0] = mfma_32x32x2(a[q], bq[c][q], acc[0]);
+                }
+            }
+            // running (max, first row): rows ascend with mi, r for a fixed lane, tiles ascend with t
+            const int row_base = t * kTileRows + rh * 32 * kMi;
+            const bool inside = (t + 1) * kTileRows <= p.N;
+#pragma unroll
+            for (int mi = 0; mi < kMi; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = row_base + mi * 32 + acc_row(r, lane);
+                    const float v = acc[mi][r];
+                    if ((inside || row < p.N) && v > bv) { bv = v; bi = row; }
+                }
+        }
+    }
+
+    if (active) {
+        const float ov = shfl_xor(bv, 32);
+        const int oi = shfl_xor(bi, 32);
+        if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+        if (h == 0) { red_v[rh * kScanResidentQueries + qg * 32 + i] = bv; red_i[rh * kScanResidentQueries + qg * 32 + i] = bi; }
+    }
+    __syncthreads();
+    const int qout = blockIdx.y * kScanResidentQueries + tid;
+    if (tid < kScanResidentQueries && qout < p.B) {
+        float v = red_v[tid];
+        int ix = red_i[tid];
+        if (better(red_v[kScanResidentQueries + tid], red_i[kScanResidentQueries + tid], v, ix)) {
+            v = red_v[kScanResidentQueries + tid];
+            ix = red_i[kScanResidentQueries + tid];
+        }
+        p.pval[(long long)blockIdx.x * p.Bstride + qout] = v;
+        p.pidx[(long long)blockIdx.x * p.Bstride + qout] = ix;
+    }
+}
+
+}  // namespace aae

@@ -301,3 +301,22 @@ def test_few_split_reduce_kernel_matches_the_grouped_one_bitwise(precision, bn):
     z64, acts = ref.encoder_forward_np(ref.input_to_float(x), w, cfg.strides, bn, return_activations=True)
     assert np.abs(outs[0][0] - acts[1]).max() / np.abs(acts[1]).max() < 5e-6
     assert np.abs(outs[0][1] - z64).max() / np.abs(z64).max() < 5e-6
+
+
+@pytest.mark.parametrize('dtype,N,B', [('f32', 1000, 40), ('f32', 700, 130), ('bf16', 1100, 70), ('bf16', 640, 129)])
+def test_query_resident_scan_equals_the_tile_resident_kernels_bitwise(dtype, N, B):
+    """Large batches (B > 32, top-1, stride 1) keep the queries in registers and stream the codebook through LDS
+    (codebook_scan_resident.h).  Same per-accumulator MFMA order as the tile-resident kernels -> the same bits:
+    indices AND scores, ragged last tile, partially filled query groups, planted duplicates (first index wins)."""
+    E = synth.make_codebook(N, 128, seed=3, planted_duplicates=6)
+    rng = np.random.default_rng(4)
+    z = rng.standard_normal((B, 128)).astype(np.float32) * rng.uniform(0.1, 20, (B, 1)).astype(np.float32)
+    z[:3] = E[[35, 71, N - 1]] * 2.0
+    cb = eb.EmuCodebook(E, dtype=dtype)
+    idx_r, sc_r = cb.nn(z)                                  # AUTO -> query-resident kernel
+    cb.set_mode(_lib.AAE_SCAN_MFMA)                         # forces the tile-resident MFMA kernel
+    idx_t, sc_t = cb.nn(z)
+    assert np.array_equal(idx_r, idx_t) and np.array_equal(sc_r, sc_t)
+    cs = cb.similarity(z)
+    assert np.array_equal(idx_r[:, 0], np.argmax(cs, axis=1)) and np.array_equal(sc_r[:, 0], cs.max(axis=1))
+    cb.close()

@@ -51,10 +51,10 @@ def main():
                               'encode+nn_ms': round(ms_all, 4), 'crops_per_s': round(B / ms_all * 1e3, 1),
                               'kernels': [(l.split(':')[0] + ':' + l.split(':')[1].split()[0], round(ms, 4)) for l, ms, _ in recs]}))
     if 'scan' in what:
-        for B in (1, 2, 4, 8, 32, 64, 256):
+        for B in (1, 2, 4, 8, 32, 48, 64, 128, 256, 512):
             z = torch.randn(B, 128, device='cuda')
-            for mode, name in ((_lib.AAE_SCAN_STREAM, 'stream'), (_lib.AAE_SCAN_GEMV, 'gemv'), (_lib.AAE_SCAN_MFMA, 'mfma')):
-                if mode != _lib.AAE_SCAN_MFMA and B > 4:
+            for mode, name in ((_lib.AAE_SCAN_STREAM, 'stream'), (_lib.AAE_SCAN_GEMV, 'gemv'), (_lib.AAE_SCAN_MFMA, 'mfma'), (_lib.AAE_SCAN_AUTO, 'auto')):
+                if mode in (_lib.AAE_SCAN_STREAM, _lib.AAE_SCAN_GEMV) and B > 4:
                     continue
                 cb.set_scan_mode(mode)
                 ms = timeit(lambda: cb.nn(z, 1, 1), 100)
