@@ -27,6 +27,7 @@ EXPORTED_SYMBOLS = (
     'aae_encoder_forward_timed', 'aae_encoder_kernel_label', 'aae_encoder_kernel_flops',
     'aae_encoder_activation_info',
     'aae_codebook_create', 'aae_codebook_update', 'aae_codebook_destroy', 'aae_codebook_set_scan_mode',
+    'aae_codebook_prepare_upright',
     'aae_codebook_workspace_bytes', 'aae_codebook_nn', 'aae_codebook_similarity', 'aae_l2_normalize',
     'aae_crop_resize_u8',
     'aae_decoder_create', 'aae_decoder_destroy', 'aae_decoder_workspace_bytes', 'aae_decoder_forward',
@@ -95,6 +96,8 @@ def declare(lib):
     lib.aae_codebook_destroy.argtypes = [c_void_p]
     lib.aae_codebook_set_scan_mode.restype = c_int
     lib.aae_codebook_set_scan_mode.argtypes = [c_void_p, c_int]
+    lib.aae_codebook_prepare_upright.restype = c_int
+    lib.aae_codebook_prepare_upright.argtypes = [c_void_p, c_int, c_void_p]
     lib.aae_codebook_workspace_bytes.restype = c_size_t
     lib.aae_codebook_workspace_bytes.argtypes = [c_void_p, c_int, c_int]
     lib.aae_codebook_nn.restype = c_int

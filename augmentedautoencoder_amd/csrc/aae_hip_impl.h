@@ -124,6 +124,10 @@ struct aae_codebook {
     int dtype = AAE_DTYPE_F32;
     int N = 0, J = 0;
     int scan_mode = AAE_SCAN_AUTO;
+    // upright search (col_stride k > 1): a compacted copy of rows 0, k, 2k, ... prepared by
+    // aae_codebook_prepare_upright; the scan then runs over N/k rows and the winning row id is scaled by k
+    aae_codebook* upright = nullptr;
+    int upright_stride = 0;
 };
 
 namespace aae_host {
@@ -1014,17 +1018,54 @@ int aae_codebook_create(const void* E, int N, int J, int dtype, int src_is_devic
     return AAE_OK;
 }
 
+static int gather_upright_rows(const aae_codebook* cb, hipStream_t stream) {
+    using namespace aae_host;
+    aae::GatherRowsArgs g;
+    g.src = cb->E; g.dst = cb->upright->E; g.rows_out = cb->upright->N; g.stride = cb->upright_stride;
+    g.pieces_per_row = cb->J * (cb->dtype == AAE_DTYPE_BF16 ? 2 : 4) / 16;
+    long long blocks = ((long long)g.rows_out * g.pieces_per_row + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    AAE_LAUNCH((aae::gather_rows_kernel), dim3((unsigned)blocks), dim3(256), 0, stream, g);
+    AAE_HIP_TRY(hipGetLastError());
+    return AAE_OK;
+}
+
+int aae_codebook_prepare_upright(aae_codebook* cb, int col_stride, void* stream_v) {
+    using namespace aae_host;
+    if (!cb) return fail(AAE_ERR_INVALID, "aae_codebook_prepare_upright: null handle");
+    if (col_stride < 2) return fail(AAE_ERR_INVALID, "aae_codebook_prepare_upright: col_stride %d < 2", col_stride);
+    if ((cb->J * (cb->dtype == AAE_DTYPE_BF16 ? 2 : 4)) % 16 != 0) return AAE_OK;     // rows are not 16-byte pieces: the masked scan stays in use
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    if (!cb->upright || cb->upright_stride != col_stride) {
+        if (cb->upright) { aae_codebook_destroy(cb->upright); cb->upright = nullptr; cb->upright_stride = 0; }
+        aae_codebook* sub = new (std::nothrow) aae_codebook();
+        if (!sub) return fail(AAE_ERR_RUNTIME, "out of host memory");
+        sub->N = ceil_div(cb->N, col_stride); sub->J = cb->J; sub->dtype = cb->dtype; sub->scan_mode = cb->scan_mode;
+        void* p = nullptr;
+        const hipError_t e = hipMalloc(&p, (size_t)sub->N * sub->J * (sub->dtype == AAE_DTYPE_BF16 ? 2 : 4));
+        if (e != hipSuccess) { delete sub; return fail(AAE_ERR_RUNTIME, "hipMalloc(upright codebook): %s", hipGetErrorString(e)); }
+        sub->E = static_cast<float*>(p);
+        cb->upright = sub; cb->upright_stride = col_stride;
+    }
+    if (int rc = gather_upright_rows(cb, stream)) return rc;
+    AAE_HIP_TRY(hipStreamSynchronize(stream));
+    return AAE_OK;
+}
+
 int aae_codebook_update(aae_codebook* cb, const void* E, int src_is_device, void* stream) {
     using namespace aae_host;
     if (!cb || !E) return fail(AAE_ERR_INVALID, "aae_codebook_update: null argument");
     AAE_HIP_TRY(hipMemcpyAsync(cb->E, E, (size_t)cb->N * cb->J * (cb->dtype == AAE_DTYPE_BF16 ? 2 : 4),
                                src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
+    if (cb->upright)
+        if (int rc = gather_upright_rows(cb, static_cast<hipStream_t>(stream))) return rc;       // keep the compacted copy in step
     AAE_HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
     return AAE_OK;
 }
 
 void aae_codebook_destroy(aae_codebook* cb) {
     if (!cb) return;
+    if (cb->upright) aae_codebook_destroy(cb->upright);
     if (cb->E) (void)hipFree(cb->E);
     delete cb;
 }
@@ -1034,6 +1075,7 @@ int aae_codebook_set_scan_mode(aae_codebook* cb, int mode) {
     if (!cb) return fail(AAE_ERR_INVALID, "aae_codebook_set_scan_mode: null handle");
     if (mode != AAE_SCAN_AUTO && mode != AAE_SCAN_GEMV && mode != AAE_SCAN_MFMA && mode != AAE_SCAN_STREAM) return fail(AAE_ERR_INVALID, "scan mode %d", mode);
     cb->scan_mode = mode;
+    if (cb->upright) cb->upright->scan_mode = mode;
     return AAE_OK;
 }
 
@@ -1050,9 +1092,19 @@ int aae_codebook_nn(aae_codebook* cb, const float* z, int B, int topk, int col_s
     if (col_stride < 1) return fail(AAE_ERR_INVALID, "col_stride %d < 1", col_stride);
     if (topk > 1 && col_stride != 1) return fail(AAE_ERR_INVALID, "upright (col_stride>1) is defined for topk == 1 only (codebook.py:65-66)");
     if (topk > 1 && B > 65535) return fail(AAE_ERR_UNSUPPORTED, "top-k for more than 65535 queries per call (got %d): split the batch", B);
-    const ScanPlan s = plan_scan(cb, B, topk);
-    if (ws_bytes < s.total) return fail(AAE_ERR_WORKSPACE, "workspace %zu B < required %zu B", ws_bytes, s.total);
+    {
+        const ScanPlan full = plan_scan(cb, B, topk);
+        if (ws_bytes < full.total) return fail(AAE_ERR_WORKSPACE, "workspace %zu B < required %zu B", ws_bytes, full.total);
+    }
     if (!workspace || ((uintptr_t)workspace & 255)) return fail(AAE_ERR_WORKSPACE, "workspace must be non-null and 256-B aligned");
+    // upright: scan the prepared every-col_stride-th-row copy (1/col_stride of the work) and scale the row id back
+    int idx_scale = 1;
+    if (col_stride > 1 && cb->upright && cb->upright_stride == col_stride) {
+        idx_scale = col_stride;
+        cb = cb->upright;
+        col_stride = 1;
+    }
+    const ScanPlan s = plan_scan(cb, B, topk);          // never larger than the plan of the full codebook
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
     unsigned char* base = static_cast<unsigned char*>(workspace);
     float* cs = topk > 1 ? reinterpret_cast<float*>(base + s.cs_off) : nullptr;
@@ -1063,7 +1115,7 @@ int aae_codebook_nn(aae_codebook* cb, const float* z, int B, int topk, int col_s
         r.pval = reinterpret_cast<float*>(base + s.pval_off);
         r.pidx = reinterpret_cast<int*>(base + s.pidx_off);
         r.idx_out = reinterpret_cast<long long*>(idx_out);
-        r.score_out = score_out; r.nblk = partial_rows; r.B = B; r.Bstride = s.Bstride;
+        r.score_out = score_out; r.nblk = partial_rows; r.B = B; r.Bstride = s.Bstride; r.idx_scale = idx_scale;
         AAE_LAUNCH((aae::argmax_reduce_kernel), dim3(B), dim3(256), 64, stream, r);
     } else {
         aae::TopKArgs t;

@@ -319,12 +319,28 @@ __global__ __launch_bounds__(256) void scan_mfma_kernel(const ScanArgs p) {
 }
 
 // ------------------------------------------------- final reduction over blocks
+// dst[r][:] = src[r * stride][:], rows of row_bytes (a multiple of 16): the every-stride-th-row copy the upright
+// search (codebook.py:65-66: arg-max over columns 0, k, 2k, ...) scans instead of masking (k-1)/k of a full scan.
+struct GatherRowsArgs {
+    const void* src;
+    void* dst;
+    int rows_out, stride, pieces_per_row;      // 16-byte pieces
+};
+__global__ __launch_bounds__(256) void gather_rows_kernel(const GatherRowsArgs p) {
+    const long long total = (long long)p.rows_out * p.pieces_per_row;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+        const long long r = idx / p.pieces_per_row, c = idx - r * p.pieces_per_row;
+        reinterpret_cast<f32x4*>(p.dst)[idx] = reinterpret_cast<const f32x4*>(p.src)[r * p.stride * p.pieces_per_row + c];
+    }
+}
+
 struct ArgmaxReduceArgs {
     const float* pval;
     const int* pidx;
     long long* idx_out;   // [B] int64 (np.argmax dtype)
     float* score_out;     // [B]
     int nblk, B, Bstride;
+    int idx_scale;        // row ids are multiplied by this (upright search on the compacted every-k-th-row copy)
 };
 
 __global__ __launch_bounds__(256) void argmax_reduce_kernel(const ArgmaxReduceArgs p) {
@@ -360,7 +376,7 @@ __global__ __launch_bounds__(256) void argmax_reduce_kernel(const ArgmaxReduceAr
         for (int w = 1; w < 4; ++w)
             if (better(red_v[w], red_i[w], bv, bi)) { bv = red_v[w]; bi = red_i[w]; }
         if (bi == 0x7fffffff) bi = 0;          // all-NaN scores: np.argmax would also answer 0
-        p.idx_out[b] = bi;
+        p.idx_out[b] = (long long)bi * p.idx_scale;
         p.score_out[b] = bv;
     }
 }

@@ -199,6 +199,7 @@ class CodebookEngine(object):
         _lib.check(self.lib, rc, 'aae_codebook_create')
         self.handle = handle
         self.ws = _Workspace(self.device)
+        self._upright_stride = 0          # stride the compacted upright copy was prepared for (0 = none yet)
 
     def close(self):
         if getattr(self, 'handle', None):
@@ -244,6 +245,13 @@ class CodebookEngine(object):
         score = torch.empty((B, topk), dtype=torch.float32, device=self.device)
         if B == 0:                    # an empty batch is an empty answer (TF/NumPy semantics of the reference), not an error
             return idx, score
+        if col_stride > 1 and topk == 1 and self._upright_stride != int(col_stride):
+            # first upright query with this stride: build the every-k-th-row copy the scan then runs over (allocates once;
+            # a CapturedNearestNeighbour reaches this in its eager warm-up call, before the capture starts)
+            with torch.cuda.device(self.device):
+                rc = self.lib.aae_codebook_prepare_upright(self.handle, int(col_stride), _stream_ptr(torch))
+            _lib.check(self.lib, rc, 'aae_codebook_prepare_upright')
+            self._upright_stride = int(col_stride)
         nbytes = self.lib.aae_codebook_workspace_bytes(self.handle, B, topk)
         _, ws_ptr = self.ws.get(nbytes)
         with torch.cuda.device(self.device):

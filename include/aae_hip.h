@@ -141,6 +141,11 @@ int aae_codebook_create(const void* E, int N, int J, int dtype, int src_is_devic
 int aae_codebook_update(aae_codebook* cb, const void* E, int src_is_device, void* stream);  /* embedding_assign_op */
 void aae_codebook_destroy(aae_codebook* cb);
 int aae_codebook_set_scan_mode(aae_codebook* cb, int mode);     /* AAE_SCAN_* (tuning / tests) */
+/* Upright search (codebook.py:65-66: arg-max over columns 0, k, 2k, ... of the similarity, k = num_cyclo): builds /
+ * refreshes a compacted device copy of every col_stride-th row, so that aae_codebook_nn(col_stride = k) scans N/k
+ * rows instead of masking a full scan (same scores, same tie rule).  Allocates; call it once outside timed /
+ * graph-captured regions.  aae_codebook_update keeps the copy in step.  Without it nn falls back to the masked scan. */
+int aae_codebook_prepare_upright(aae_codebook* cb, int col_stride, void* stream);
 
 size_t aae_codebook_workspace_bytes(const aae_codebook* cb, int B, int topk);
 

@@ -101,6 +101,9 @@ class EmuCodebook(object):
     def set_mode(self, mode):
         _lib.check(self.L, self.L.aae_codebook_set_scan_mode(self.h, mode), 'set_scan_mode')
 
+    def prepare_upright(self, col_stride):
+        _lib.check(self.L, self.L.aae_codebook_prepare_upright(self.h, int(col_stride), None), 'prepare_upright')
+
     def nn(self, z, topk=1, col_stride=1):
         z = np.ascontiguousarray(z, dtype=np.float32)
         B = z.shape[0]

@@ -320,3 +320,26 @@ def test_query_resident_scan_equals_the_tile_resident_kernels_bitwise(dtype, N, 
     cs = cb.similarity(z)
     assert np.array_equal(idx_r[:, 0], np.argmax(cs, axis=1)) and np.array_equal(sc_r[:, 0], cs.max(axis=1))
     cb.close()
+
+
+@pytest.mark.parametrize('dtype,N,B', [('f32', 36 * 21 + 5, 3), ('f32', 36 * 40, 40), ('bf16', 36 * 30 + 17, 2), ('bf16', 36 * 35, 70)])
+def test_upright_search_on_the_compacted_copy_equals_the_masked_scan(dtype, N, B):
+    """col_stride = 36: after aae_codebook_prepare_upright the scan runs over the every-36th-row copy (N/36 rows) and the
+    row id is scaled back; before it, the full scan masks 35/36 of its candidates.  Same rows, same arithmetic, same
+    tie rule -> same bits; aae_codebook_update refreshes the copy."""
+    E = synth.make_codebook(N, 128, seed=13, planted_duplicates=4)
+    E[72] = E[0]                                            # duplicate among the upright rows: the lower one must win
+    rng = np.random.default_rng(14)
+    z = rng.standard_normal((B, 128)).astype(np.float32)
+    z[0] = E[72] * 3.0
+    cb = eb.EmuCodebook(E, dtype=dtype)
+    idx_m, sc_m = cb.nn(z, 1, 36)                           # masked full scan
+    cb.prepare_upright(36)
+    idx_c, sc_c = cb.nn(z, 1, 36)                           # compacted copy
+    assert np.array_equal(idx_m, idx_c) and np.array_equal(sc_m, sc_c)
+    assert idx_c[0, 0] == 0 and np.all(idx_c % 36 == 0)
+    cs = cb.similarity(z)
+    assert np.array_equal(idx_c[:, 0], ref.nearest_indices_reference(cs, 1, upright=True, num_cyclo=36))
+    idx_p, _ = cb.nn(z, 1, 1)                               # the plain search is untouched
+    assert np.array_equal(idx_p[:, 0], np.argmax(cs, axis=1))
+    cb.close()

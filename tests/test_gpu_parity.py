@@ -554,3 +554,27 @@ def test_empty_batch_returns_empty_results(default_model):
     assert cb.nearest_rotation(None, none).shape == (0, 3, 3)
     assert S.Session().run(cb.cos_similarity, {enc.x: none}).shape == (0, len(E))
     assert cb.test_embedding(None, none).shape == (0, 128)
+
+
+def test_upright_search_uses_the_compacted_copy_and_follows_updates():
+    """nn(col_stride=36) scans the every-36th-row copy prepared on first use; a codebook update must refresh it."""
+    import torch
+    from augmentedautoencoder_amd.engine import CodebookEngine
+    N = 92232
+    E1 = synth.make_codebook(N, 128, seed=31, planted_duplicates=32)
+    E2 = synth.make_codebook(N, 128, seed=32, planted_duplicates=32)
+    rng = np.random.default_rng(33)
+    for dtype in ('f32', 'bf16'):
+        cb = CodebookEngine(E1, dtype=dtype)
+        for B in (1, 3, 40, 256):
+            z = torch.from_numpy(rng.standard_normal((B, 128)).astype(np.float32)).cuda()
+            for E in (E1, E2):
+                cb.update(E)
+                cs = cb.similarity(z).cpu().numpy()
+                up, sc = cb.nn(z, 1, 36)
+                want = ref.nearest_indices_reference(cs, 1, upright=True, num_cyclo=36)
+                assert np.array_equal(up[:, 0].cpu().numpy(), want), (dtype, B)
+                assert np.array_equal(sc[:, 0].cpu().numpy(), cs[np.arange(B), want])
+                plain, _ = cb.nn(z, 1, 1)
+                assert np.array_equal(plain[:, 0].cpu().numpy(), np.argmax(cs, axis=1))
+        cb.close()
