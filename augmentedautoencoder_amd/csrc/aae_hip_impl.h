@@ -617,10 +617,11 @@ static ScanPlan plan_scan(const aae_codebook* cb, int B, int topk) {
         if (s.stream) s.nblk = ceil_div(cb->N, 256);
     }
     s.Bstride = s.Bpad;
-    // large batches: queries resident in registers, codebook streamed (codebook_scan_resident.h); about one
-    // block (8 waves) per CU: row ranges x 128-query chunks
+    // B > 4: queries resident in registers, codebook streamed (codebook_scan_resident.h); about one block (8 waves)
+    // per CU: row ranges x 128-query chunks.  Measured against the tile-resident kernels (whole nn call): B=8 0.035 ->
+    // 0.024 ms, B=32 0.036 -> 0.024, B=256 0.106 -> 0.063; bf16 4x codebook B=32 0.083 -> 0.034, B=256 0.25 -> 0.078
     s.resident_ok = false; s.res_tiles_per_block = 0; s.res_blocks = 0;
-    if (cb->scan_mode == AAE_SCAN_AUTO && cb->J == 128 && !s.stream && !s.gemv && B > 32) {
+    if (cb->scan_mode == AAE_SCAN_AUTO && cb->J == 128 && !s.stream && !s.gemv && B > 4) {
         const int tile_rows = cb->dtype == AAE_DTYPE_BF16 ? 128 : 64;
         const int ntiles = ceil_div(cb->N, tile_rows);
         const int qchunks = ceil_div(s.Bpad, aae::kScanResidentQueries);

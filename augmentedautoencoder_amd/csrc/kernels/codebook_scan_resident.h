@@ -1,5 +1,5 @@
 // Batched codebook arg-max with the QUERIES resident in registers and the codebook streamed
-// through LDS -- the large-batch form of
+// through LDS -- the batched (B > 4) form of
 //   tf.matmul(q, E, transpose_b=True) + argmax   (/root/reference/auto_pose/ae/codebook.py:50-51, 63-64)
 // for fp32 rows (exact fp32 MFMA) and bf16 rows (three bf16 MFMA terms per product, fp32 accumulate).
 //

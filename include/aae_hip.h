@@ -42,7 +42,7 @@ extern "C" {
 
 #define AAE_MAX_LAYERS 8
 
-#define AAE_SCAN_AUTO 0           /* B <= 4: streaming kernel; B > 32, top-1, stride 1: query-resident MFMA kernel;
+#define AAE_SCAN_AUTO 0           /* B <= 4: streaming kernel; B > 4, top-1, stride 1: query-resident MFMA kernel;
                                     * else the tile-resident MFMA kernels                                           */
 #define AAE_SCAN_GEMV 1           /* vector-ALU, shuffle reductions, B <= 4 (first version, kept for A/B) */
 #define AAE_SCAN_MFMA 2           /* tile-resident matrix-core kernels, any B       */
