@@ -150,8 +150,16 @@ class Codebook(object):
         top_n = len(idcs)
         Rs_est = self._dataset.viewsphere_for_embedding[idcs]      # fancy index -> copy
 
-        K_train = np.array(_parse_K(train_args.get('Dataset', 'K'))).reshape(3, 3)
-        render_radius = train_args.getfloat('Dataset', 'RADIUS')
+        # [Dataset] K / RADIUS are parsed once per distinct config text (the per-detection estimator flow
+        # calls this for every box; the parse was 40 % of the call)
+        key = (train_args.get('Dataset', 'K'), train_args.get('Dataset', 'RADIUS'))
+        cached = self._train_geometry.get(key) if hasattr(self, '_train_geometry') else None
+        if cached is None:
+            cached = (np.array(_parse_K(key[0])).reshape(3, 3), float(key[1]))
+            if not hasattr(self, '_train_geometry'):
+                self._train_geometry = {}
+            self._train_geometry[key] = cached
+        K_train, render_radius = cached
         K_diag_ratio = np.sqrt(K_test[0, 0] ** 2 + K_test[1, 1] ** 2) / np.sqrt(K_train[0, 0] ** 2 + K_train[1, 1] ** 2)
 
         if self.embed_obj_bbs_values is None:
