@@ -154,6 +154,46 @@ def test_process_batched_equals_per_detection_oracle_cpu():
         AePoseEstimator(codebooks=est.all_codebooks, train_args=est.all_train_args, topk=2)
 
 
+def test_process_uploads_only_the_union_of_the_boxes_with_identical_results():
+    """process() sends the union rectangle of the boxes (shifted boxes) instead of the frame when that is < 60 % of it:
+    the black-border crop reads nothing outside its box, so every pose must be EXACTLY the one of the full-frame path --
+    boxes in a corner, one hanging over the right / bottom image border, one of a single pixel column."""
+    import emu_backend as eb
+    from emu_engines import EmuCodebookEngine, EmuEncoderEngine
+    import torch
+    seen = []
+
+    def inject(enc, cb, w, E):
+        enc._engine = EmuEncoderEngine(enc.config, w)
+        cb._engine = EmuCodebookEngine(E)
+
+    def crop_fn(scene_img, boxes_xywh, pad_factor, resize=(128, 128)):
+        img = scene_img.numpy() if torch.is_tensor(scene_img) else scene_img
+        seen.append(img.shape[:2])
+        return torch.from_numpy(eb.crop_resize(img, AePoseEstimator.box_rows(boxes_xywh, pad_factor), (resize[1], resize[0])))
+
+    est, weights, embeds = _tiny_estimator(inject, crop_fn)
+    img = _scene(4)
+    H, W = img.shape[:2]
+    camK = np.array([[572.4, 0, 160.0], [0, 573.6, 120.0], [0, 0, 1]])
+    names = sorted(weights)
+
+    def box(x, y, w, h, c):
+        return BoundingBox(xmin=x / W, xmax=(x + w) / W, ymin=y / H, ymax=(y + h) / H, classes={c: 1.0})
+    dets = [box(W - 70.3, H - 60.8, 50.2, 40.9, names[0]), box(W - 40.5, H - 30.2, 60.0, 50.0, names[-1]),      # second one crosses both borders
+            box(W - 90.0, H - 80.0, 1.0, 33.0, names[0]), box(W - 65.7, H - 75.1, 22.6, 21.4, names[-1])]
+    est.upload_union_only = False
+    full = est.process(dets, img, camK, mm=True)
+    shapes_full = list(seen)
+    del seen[:]
+    est.upload_union_only = True
+    part = est.process(dets, img, camK, mm=True)
+    assert all(s == (H, W) for s in shapes_full) and all(s[0] < H and s[1] < W for s in seen)     # the union path really ran
+    assert len(full) == len(part) == 4
+    for a, b in zip(full, part):
+        assert a.name == b.name and np.array_equal(a.trafo, b.trafo)
+
+
 @pytest.mark.gpu
 def test_crop_kernel_bit_exact_on_gpu():
     from augmentedautoencoder_amd.engine import crop_resize
