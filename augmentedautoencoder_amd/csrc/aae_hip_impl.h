@@ -250,9 +250,10 @@ static void choose_splits(const aae_encoder* enc, int base_blocks, int slabs, in
         if (s < 1) s = 1;
         if (s > slabs) s = slabs;
     }
-    const int per = ceil_div(slabs, s);
-    *per_split = per;
-    *splits = ceil_div(slabs, per);
+    // the kernels give split i the slabs [i*slabs/s, (i+1)*slabs/s): every requested split exists and the sizes
+    // differ by at most one slab (uniform ceil-sized splits left e.g. 400 of 512 requested blocks at B=1)
+    *per_split = ceil_div(slabs, s);
+    *splits = s;
 }
 
 struct Workspace {

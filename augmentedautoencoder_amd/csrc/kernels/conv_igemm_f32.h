@@ -81,8 +81,9 @@ __global__ __launch_bounds__(256, NW == 4 ? 2 : 1) void conv_igemm_f32_kernel(co
     const int nt = L % p.num_nt;
     const int mt = (L / p.num_nt) % p.num_mt;
     const int split = L / (p.num_nt * p.num_mt);
-    const int slab0 = SCATTER ? 0 : split * p.slabs_per_split;
-    const int slab1 = SCATTER ? p.slabs_total : min(slab0 + p.slabs_per_split, p.slabs_total);
+    // split-K: split s walks slabs [s*total/splits, (s+1)*total/splits) -- sizes differ by at most one slab
+    const int slab0 = SCATTER ? 0 : (int)((long long)split * p.slabs_total / p.splits);
+    const int slab1 = SCATTER ? p.slabs_total : (int)((long long)(split + 1) * p.slabs_total / p.splits);
     const int pt = SCATTER ? p.ph_pt[split >> 1] : p.pt;
     const int pl = SCATTER ? p.ph_pl[split & 1] : p.pl;
     const float* wp = SCATTER ? p.wp + split * p.wp_phase_floats : p.wp;

@@ -131,8 +131,8 @@ __global__ __launch_bounds__(256) void conv_igemm_x3h_kernel(const ConvIgemmX3hA
     const int nt = L % p.num_nt;
     const int mt = (L / p.num_nt) % p.num_mt;
     const int split = L / (p.num_nt * p.num_mt);
-    const int slab0 = split * p.slabs_per_split;
-    const int slab1 = min(slab0 + p.slabs_per_split, p.slabs_total);
+    const int slab0 = (int)((long long)split * p.slabs_total / p.splits);        // balanced split-K ranges (sizes differ by <= 1 slab)
+    const int slab1 = (int)((long long)(split + 1) * p.slabs_total / p.splits);
     const int nslab = slab1 - slab0;
 
     // ---- A loader: thread -> 4 (row, chunk) pairs; chunk = plane*4 + kgroup8 = LDS slot --------
@@ -298,8 +298,8 @@ __global__ __launch_bounds__(128 * WM) void conv_igemm_x3h_dma_kernel(const Conv
     const int nt = L % p.num_nt;
     const int mt = (L / p.num_nt) % p.num_mt;
     const int split = L / (p.num_nt * p.num_mt);
-    const int slab0 = split * p.slabs_per_split;
-    const int slab1 = min(slab0 + p.slabs_per_split, p.slabs_total);
+    const int slab0 = (int)((long long)split * p.slabs_total / p.splits);        // balanced split-K ranges (sizes differ by <= 1 slab)
+    const int slab1 = (int)((long long)(split + 1) * p.slabs_total / p.splits);
     const int nslab = slab1 - slab0;
 
     // ---- A pieces: piece q of wave w fills rows (T/8) q + 8w .. +7 (8 lanes per row) -----------------
