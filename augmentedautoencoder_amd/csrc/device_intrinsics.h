@@ -117,6 +117,10 @@ __device__ __forceinline__ float row16_sum(float v) {
 // waiting in front of every later use in its own basic block)
 __device__ __forceinline__ float pin_value(float v) { asm volatile("" : "+v"(v)); return v; }
 
+// s_setprio: issue priority of this wave among the waves of its SIMD (0 = default ... 3)
+template <int P>
+__device__ __forceinline__ void wave_priority() { __builtin_amdgcn_s_setprio(P); }
+
 // instruction-scheduling fence: nothing is moved across it by the compiler's scheduler
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
 

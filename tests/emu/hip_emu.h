@@ -58,6 +58,8 @@ namespace aae {
 inline int lane_id() { return threadIdx.x & 63; }
 inline void sleep_kcycles(int) {}
 inline void sched_fence() {}
+template <int P>
+inline void wave_priority() {}
 inline float pin_value(float v) { return v; }
 
 struct buffer_rsrc { const unsigned char* base; uint32_t bytes; };
