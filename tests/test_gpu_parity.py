@@ -76,19 +76,72 @@ def test_nearest_rotation_matches_oracle(default_model, B):
     from augmentedautoencoder_amd import session as S
     idcs = cb.nearest_rotation(None, crops, return_idcs=True)
     assert idcs.dtype == np.int64 and idcs.shape == (B,)
-    Bo = min(B, 32)                                   # oracle on the first 32 crops (fp64 CPU conv)
-    z64 = ref.encoder_forward_torch(ref.input_to_float(crops[:Bo]), weights, STRIDES, False, 'float64')
+    # every crop of the batch against the fp64 oracle; the similarity comes from the SAME batch size, i.e. from the
+    # latents of the kernel variants this B plans (B=256: the un-split weights-to-registers igemm of the bench)
+    z64 = ref.encoder_forward_torch(ref.input_to_float(crops), weights, STRIDES, False, 'float64')
     cs64 = ref.cos_similarity(z64, E)
-    cs = S.Session().run(cb.cos_similarity, {enc.x: crops[:Bo]})
-    assert cs.shape == (Bo, dataset.embedding_size)
+    cs = S.Session().run(cb.cos_similarity, {enc.x: crops})
+    assert cs.shape == (B, dataset.embedding_size)
     assert np.abs(cs - cs64).max() <= COS_TOL, 'cosine error %.3e' % np.abs(cs - cs64).max()
-    _check_indices(idcs[:Bo], cs64)
+    _check_indices(idcs, cs64)
     # the fused arg-max must agree with an arg-max over the kernel's own similarity
-    if B <= 32:
-        assert np.array_equal(idcs, np.argmax(cs, axis=1))
+    assert np.array_equal(idcs, np.argmax(cs, axis=1))
     R = cb.nearest_rotation(None, crops)
     assert R.shape == ((3, 3) if B == 1 else (B, 3, 3))
     assert np.array_equal(R.reshape(-1, 3, 3), dataset.viewsphere_for_embedding[idcs])
+
+
+@pytest.fixture(scope='module')
+def bench_inputs_and_oracle():
+    """bench.py's own inputs (rank 0) and their fp64 oracle outputs, computed once for both precisions."""
+    B = 256
+    weights = synth.make_weights(seed=2024)
+    crops = synth.make_crops(B, seed=1234)
+    E = synth.make_codebook(92232, 128, seed=7)
+    z64, acts = ref.encoder_forward_torch(ref.input_to_float(crops), weights, STRIDES, False, 'float64', return_activations=True)
+    return weights, crops, E, z64, acts, ref.cos_similarity(z64, E)
+
+
+@pytest.mark.parametrize('precision', [0, 1])
+def test_headline_kernels_on_the_bench_inputs_match_fp64_oracle(bench_inputs_and_oracle, precision):
+    """The exact launches bench.py times (its seeds: weights 2024, crops 1234, codebook 7; B = 256, one chunk):
+    kernel labels as in the bench line, then ALL four layer activations, all 256 latents, the similarity of all
+    256 crops and all 256 indices against the fp64 oracle (encoder.py:37-68, codebook.py:27,50,64-68) -- in
+    exact fp32 (precision 0, the headline) and in the opt-in f32x3h mode (precision 1)."""
+    from augmentedautoencoder_amd.engine import CodebookEngine, EncoderEngine
+    from augmentedautoencoder_amd.weights import EncoderConfig
+    weights, crops, E, z64, acts, cs64 = bench_inputs_and_oracle
+    B = len(crops)
+    enc = EncoderEngine(EncoderConfig(), weights, max_batch=B)
+    cb = CodebookEngine(E)
+    enc.set_option('precision', precision)
+    z, recs = enc.encode_timed(crops)
+    labels = [l for l, _, _ in recs]
+    if precision == 0:
+        want = ['conv1:conv_first_f32', 'conv2:conv_igemm_f32_dma_breg_n256', 'conv3:conv_igemm_f32_dma_breg_n256',
+                'conv4:conv_igemm_f32_dma_breg ', 'dense:conv_igemm_f32_dma_splitk', 'dense:splitk_reduce']
+    else:
+        want = ['conv1:conv_first_f32', 'conv2:conv_igemm_x3h_dma', 'conv3:conv_igemm_x3h_dma', 'conv4:conv_igemm_x3h_dma',
+                'dense:conv_igemm_x3h_dma_splitk', 'dense:splitk_reduce']
+    assert len(labels) == len(want) and all(l.startswith(w) for l, w in zip(labels, want)), labels
+    for i, a in enumerate(acts):
+        g = enc.activation(i).cpu().numpy()
+        assert g.shape == a.shape
+        err = np.abs(g - a).max() / np.abs(a).max()
+        assert err < 2e-5, 'layer %d rel err %.3e' % (i, err)
+        del g
+    zh = z.cpu().numpy()
+    assert zh.shape == (B, 128)
+    assert np.abs(zh - z64).max() / np.abs(z64).max() < 2e-5
+    cs = cb.similarity(z).cpu().numpy()
+    assert np.abs(cs - cs64).max() <= COS_TOL, 'cosine error %.3e' % np.abs(cs - cs64).max()
+    idx, score = cb.nn(z, 1, 1)
+    idx, score = idx[:, 0].cpu().numpy(), score[:, 0].cpu().numpy()
+    _check_indices(idx, cs64)
+    assert np.array_equal(idx, np.argmax(cs, axis=1))
+    assert np.abs(score - cs64.max(axis=1)).max() <= COS_TOL
+    enc.close()
+    cb.close()
 
 
 def test_scan_kernels_agree_and_ties_take_lowest_index(default_model):
