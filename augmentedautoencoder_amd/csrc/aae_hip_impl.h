@@ -14,6 +14,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -21,6 +22,7 @@
 #include "../../include/aae_hip.h"
 #include "kernels/tile_f32.h"
 #include "kernels/conv_igemm_f32.h"
+#include "kernels/conv_wavek_f32.h"
 #include "kernels/conv_igemm_x3h.h"
 #include "kernels/conv_first_f32.h"
 #include "kernels/conv_direct_generic.h"
@@ -117,6 +119,14 @@ struct aae_encoder {
     int x3h_dma = 1;                       // f32x3h operand slabs by LDS-DMA (buffer_load ... lds); 0 = register-staged variant
     int x3h_act_shift = 4;                 // activations travel as halves of x*2^shift in f32x3h mode (|x| < 4094 exact range)
     int igemm_stagger = 0;                 // kcycles of start delay for every 2nd block generation of the igemm (0 = off)
+    // small batches (the reference's one-crop-per-detection usage): wave-split-K igemm with the in-launch ticketed reduce
+    int wavek = 1;                         // 0: always the 128 x 128 split-K igemm + reduce launch
+    int wavek_max_tiles = 256;             // used while the layer has at most this many 64 x 64 output tiles (one per CU)
+    int wavek_waves = 4;                   // waves per block (4 | 8), each with its own K range
+    int wavek_depth = 3;                   // slabs of fragments in flight per wave (2 | 3)
+    int wavek_narrow_max_tiles = 16;       // <= this many 64 x 64 tiles: 64 x 32 wave tiles (twice the tiles, half the splits to add up)
+    int gemv_ticket = 1;                   // dense GEMV (B <= 4): chunk sums finished by the last block instead of a reduce launch
+    int wavek_dense = 1;                   // dense layer (B > 4) on the wave-split-K kernel instead of split-K igemm + reduce launch
 };
 
 struct aae_codebook {
@@ -128,6 +138,7 @@ struct aae_codebook {
     // aae_codebook_prepare_upright; the scan then runs over N/k rows and the winning row id is scaled by k
     aae_codebook* upright = nullptr;
     int upright_stride = 0;
+    int scan_ticket = 1;   // B <= 4 top-1: arg-max over the block partials inside the scan launch (0: separate argmax_reduce launch)
 };
 
 namespace aae_host {
@@ -256,18 +267,66 @@ static void choose_splits(const aae_encoder* enc, int base_blocks, int slabs, in
     *splits = s;
 }
 
+// block_ticket_arrive() nonces: unique per launch within the process, never 0
+static unsigned next_nonce() {
+    static std::atomic<unsigned> counter{1};
+    unsigned n = counter.fetch_add(1, std::memory_order_relaxed);
+    while (n == 0) n = counter.fetch_add(1, std::memory_order_relaxed);
+    return n;
+}
+
+constexpr size_t kTicketBytes = 4096;      // 512 ticket words at the front of every workspace (layers reuse them: launches are stream-ordered)
+
+// Launch plan of the wave-split-K igemm (conv_wavek_f32.h) for a layer at M rows, or use == false.
+struct WaveKPlan {
+    bool use = false;
+    int MT = 2, NT = 2, waves = 4, depth = 3;
+    int num_mt = 0, num_nt = 0, gsplits = 1;
+    size_t partial_bytes = 0;
+};
+
+static WaveKPlan plan_wavek(const aae_encoder* enc, const Layer& L, long long M) {
+    WaveKPlan w;
+    if (!enc->wavek || enc->precision != 0 || L.kind != KIND_IGEMM) return w;
+    const long long tiles22 = ((M + 63) / 64) * (L.CoutPad / 64);
+    if (tiles22 > enc->wavek_max_tiles || tiles22 > 512) return w;
+    const unsigned long long x_bytes = (unsigned long long)(M / (L.Ho * L.Wo)) * L.H * L.W * L.Cin * sizeof(float);
+    if (x_bytes >= 0xFFFFFF00ull) return w;
+    w.use = true;
+    w.waves = enc->wavek_waves == 8 ? 8 : 4;
+    w.depth = (enc->wavek_depth == 2 || w.waves == 8) ? 2 : 3;    // 8 waves share the register file two per SIMD: two slabs in flight each
+    w.NT = tiles22 <= enc->wavek_narrow_max_tiles ? 1 : 2;
+    w.num_mt = (int)((M + 63) / 64);
+    w.num_nt = L.CoutPad / (32 * w.NT);
+    const int tiles = w.num_mt * w.num_nt;
+    const int slabs = (int)(L.K() / 32);
+    int g = 256 / tiles;                                   // one block per CU; never a second round of blocks
+    const int gmax = slabs / (2 * w.waves);                // every wave keeps at least two slabs
+    if (g > gmax) g = gmax;
+    if (g < 1) g = 1;
+    w.gsplits = g;
+    if (g > 1) w.partial_bytes = (size_t)tiles * g * (w.MT * w.NT * 16) * 64 * sizeof(float);
+    return w;
+}
+
 struct Workspace {
     std::vector<size_t> act_off;   // per conv layer
+    size_t ticket_off = 0;
     size_t partial_off = 0, partial_bytes = 0;
     size_t total = 0;
 };
 
 static Workspace plan_workspace(const aae_encoder* enc, int B) {
     Workspace ws;
-    size_t off = 0;
+    size_t off = kTicketBytes;                               // ticket words first (offset 0 of the workspace)
     size_t partial = 0;
     auto need_partial = [&](const Layer& L, int M) {
         if (L.kind != KIND_IGEMM) return;
+        const WaveKPlan wk = plan_wavek(enc, L, M);
+        if (wk.use) {
+            if (wk.partial_bytes > partial) partial = wk.partial_bytes;
+            return;
+        }
         int splits, per;
         choose_splits(enc, ceil_div(M, 128) * (L.CoutPad / 128), (int)(L.K() / 32), &splits, &per);
         if (splits > 1) {
@@ -280,7 +339,13 @@ static Workspace plan_workspace(const aae_encoder* enc, int B) {
         off += align_up((size_t)B * L.Ho * L.Wo * L.Cout * sizeof(float), 256);
         need_partial(L, B * L.Ho * L.Wo);
     }
-    need_partial(enc->dense, B);
+    need_partial(enc->dense, B);                             // (sized for either dense variant)
+    if (enc->dense.kind == KIND_IGEMM && !enc->wavek_dense) {   // ... including the split-K igemm when the wave-split-K form is switched off
+        int splits, per;
+        choose_splits(enc, ceil_div(B, 128) * (enc->dense.CoutPad / 128), (int)(enc->dense.K() / 32), &splits, &per);
+        const size_t bytes = splits > 1 ? (size_t)splits * B * enc->dense.Cout * sizeof(float) : 0;
+        if (bytes > partial) partial = bytes;
+    }
     if (B <= 4 && enc->dense.kind == KIND_IGEMM) {           // the GEMV form of the dense layer: one partial row per 128-k chunk
         const size_t gemv = (size_t)ceil_div((int)enc->dense.K(), aae::kGemvChunk) * B * enc->dense.Cout * sizeof(float);
         if (gemv > partial) partial = gemv;
@@ -374,6 +439,56 @@ static int launch_igemm(aae_encoder* enc, const Layer& L, const float* x, int M,
     launch_splitk_reduce(r, stream, enc->reduce_small != 0);
     snprintf(label, sizeof(label), "%s:splitk_reduce", name);
     note_kernel({label, 0.0});
+    AAE_HIP_TRY(hipGetLastError());
+    return tm.mark();
+}
+
+// wave-split-K igemm (conv_wavek_f32.h): small M -- the per-detection batches
+template <int MT, int NT, int WAVES, int DEPTH>
+static void launch_wavek_t(const aae::ConvWaveKArgs& a, int tag, int nblk, hipStream_t stream) {
+    constexpr int smem = aae::conv_wavek_smem<MT, NT, WAVES>();
+    // TAG only makes the symbol unique per encoder layer (separate rows in rocprofv3 --stats)
+    if (tag == 1) {
+        (void)hipFuncSetAttribute((const void*)aae::conv_wavek_f32_kernel<MT, NT, WAVES, DEPTH, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        AAE_LAUNCH((aae::conv_wavek_f32_kernel<MT, NT, WAVES, DEPTH, 1>), dim3(nblk), dim3(64 * WAVES), smem, stream, a);
+    } else if (tag == 2) {
+        (void)hipFuncSetAttribute((const void*)aae::conv_wavek_f32_kernel<MT, NT, WAVES, DEPTH, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        AAE_LAUNCH((aae::conv_wavek_f32_kernel<MT, NT, WAVES, DEPTH, 2>), dim3(nblk), dim3(64 * WAVES), smem, stream, a);
+    } else if (tag == 3) {
+        (void)hipFuncSetAttribute((const void*)aae::conv_wavek_f32_kernel<MT, NT, WAVES, DEPTH, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        AAE_LAUNCH((aae::conv_wavek_f32_kernel<MT, NT, WAVES, DEPTH, 3>), dim3(nblk), dim3(64 * WAVES), smem, stream, a);
+    } else {
+        (void)hipFuncSetAttribute((const void*)aae::conv_wavek_f32_kernel<MT, NT, WAVES, DEPTH, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        AAE_LAUNCH((aae::conv_wavek_f32_kernel<MT, NT, WAVES, DEPTH, 0>), dim3(nblk), dim3(64 * WAVES), smem, stream, a);
+    }
+}
+
+static int launch_wavek(aae_encoder* enc, const Layer& L, const WaveKPlan& w, const float* x, int M, float* out, float* partial,
+                        unsigned long long* tickets, hipStream_t stream, Timer& tm, const char* name, int tag) {
+    aae::ConvWaveKArgs a;
+    a.x = x; a.wp = L.wp; a.bias = L.bias; a.bn_scale = L.bn_scale; a.bn_shift = L.bn_shift; a.out = out;
+    a.partial = partial; a.tickets = tickets; a.nonce = next_nonce();
+    a.H = L.H; a.W = L.W; a.Cin = L.Cin; a.Ho = L.Ho; a.Wo = L.Wo; a.Cout = L.Cout; a.CoutPad = L.CoutPad;
+    a.KS = L.KS; a.S = L.S; a.pt = L.pt; a.pl = L.pl; a.M = M; a.relu = L.relu;
+    a.x_bytes = (unsigned)((unsigned long long)(M / (L.Ho * L.Wo)) * L.H * L.W * L.Cin * sizeof(float));
+    a.slabs_total = (int)(L.K() / 32);
+    a.wp_bytes = (unsigned)((unsigned long long)a.slabs_total * 8ull * L.CoutPad * 16ull);
+    a.num_mt = w.num_mt; a.num_nt = w.num_nt; a.gsplits = w.gsplits;
+    const int nblk = w.num_mt * w.num_nt * w.gsplits;
+    const int key = w.NT * 100 + w.waves * 10 + w.depth;
+    switch (key) {
+        case 243: launch_wavek_t<2, 2, 4, 3>(a, tag, nblk, stream); break;
+        case 242: launch_wavek_t<2, 2, 4, 2>(a, tag, nblk, stream); break;
+        case 282: launch_wavek_t<2, 2, 8, 2>(a, tag, nblk, stream); break;
+        case 143: launch_wavek_t<2, 1, 4, 3>(a, tag, nblk, stream); break;
+        case 142: launch_wavek_t<2, 1, 4, 2>(a, tag, nblk, stream); break;
+        case 182: launch_wavek_t<2, 1, 8, 2>(a, tag, nblk, stream); break;
+        default: return fail(AAE_ERR_RUNTIME, "%s: no wave-split-K instantiation for NT=%d waves=%d depth=%d", name, w.NT, w.waves, w.depth);
+    }
+    char label[112];
+    snprintf(label, sizeof(label), "%s:conv_wavek_f32_%dx%d_w%d_d%d_g%d M=%d N=%d K=%lld", name, 32 * w.MT, 32 * w.NT, w.waves, w.depth,
+             w.gsplits, M, L.Cout, L.K());
+    note_kernel({label, 2.0 * (double)M * (double)L.K() * (double)L.Cout});
     AAE_HIP_TRY(hipGetLastError());
     return tm.mark();
 }
@@ -514,18 +629,32 @@ static int launch_generic(aae_encoder* enc, const Layer& L, const void* x, bool 
 
 // dense layer at B <= 4: weight-streaming GEMV + the fixed-order chunk reduction
 static int launch_dense_gemv(aae_encoder* enc, const Layer& D, const float* x, int B, float* out, float* partial,
-                             hipStream_t stream, Timer& tm) {
+                             unsigned long long* tickets, hipStream_t stream, Timer& tm) {
     aae::DenseGemvArgs a;
     a.x = x; a.wp = D.wp; a.partial = partial; a.B = B; a.K = (int)D.K(); a.Cout = D.Cout; a.CoutPad = D.CoutPad;
     a.wp_bytes = (unsigned)((unsigned long long)(D.K() / 4) * D.CoutPad * 16ull);
     const int chunks = ceil_div(a.K, aae::kGemvChunk);
     const dim3 grid(chunks, D.CoutPad / 128);
     const int MQ = B <= 1 ? 1 : (B <= 2 ? 2 : 4);
-    const int smem = 2 * MQ * aae::kGemvChunk * (int)sizeof(float);
+    int smem = 2 * MQ * aae::kGemvChunk * (int)sizeof(float);
+    const bool ticket = enc->gemv_ticket && tickets && D.Cout % 4 == 0;
+    char label[96];
+    if (ticket) {
+        a.bias = D.bias; a.bn_scale = D.bn_scale; a.bn_shift = D.bn_shift; a.out = out; a.tickets = tickets;
+        a.nonce = next_nonce(); a.relu = D.relu;
+        if (smem < aae::kGemvTicketSmem) smem = aae::kGemvTicketSmem;
+        if (MQ == 1) AAE_LAUNCH((aae::dense_gemv_f32_kernel<1, true>), grid, dim3(256), smem, stream, a);
+        else if (MQ == 2) AAE_LAUNCH((aae::dense_gemv_f32_kernel<2, true>), grid, dim3(256), smem, stream, a);
+        else AAE_LAUNCH((aae::dense_gemv_f32_kernel<4, true>), grid, dim3(256), smem, stream, a);
+        snprintf(label, sizeof(label), "dense:dense_gemv_f32_ticket chunks=%d M=%d N=%d K=%d", chunks, B, D.Cout, a.K);
+        note_kernel({label, 2.0 * B * (double)D.K() * D.Cout});
+        AAE_HIP_TRY(hipGetLastError());
+        return tm.mark();
+    }
+    a.bias = nullptr; a.bn_scale = nullptr; a.bn_shift = nullptr; a.out = nullptr; a.tickets = nullptr; a.nonce = 0; a.relu = 0;
     if (MQ == 1) AAE_LAUNCH((aae::dense_gemv_f32_kernel<1>), grid, dim3(256), smem, stream, a);
     else if (MQ == 2) AAE_LAUNCH((aae::dense_gemv_f32_kernel<2>), grid, dim3(256), smem, stream, a);
     else AAE_LAUNCH((aae::dense_gemv_f32_kernel<4>), grid, dim3(256), smem, stream, a);
-    char label[96];
     snprintf(label, sizeof(label), "dense:dense_gemv_f32 chunks=%d M=%d N=%d K=%d", chunks, B, D.Cout, a.K);
     note_kernel({label, 2.0 * B * (double)D.K() * D.Cout});
     AAE_HIP_TRY(hipGetLastError());
@@ -551,6 +680,7 @@ static int forward_impl(aae_encoder* enc, const void* x, int x_dtype, int B, flo
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
     unsigned char* base = static_cast<unsigned char*>(workspace);
     float* partial = reinterpret_cast<float*>(base + ws.partial_off);
+    unsigned long long* tickets = reinterpret_cast<unsigned long long*>(base + ws.ticket_off);
     RecordScope rec(enc);
     tm.stream = stream;
     if (int rc = tm.mark()) return rc;
@@ -580,16 +710,22 @@ static int forward_impl(aae_encoder* enc, const void* x, int x_dtype, int B, flo
         snprintf(name, sizeof(name), "conv%zu", li + 1);
         int rc;
         if (li == 0 && L.kind == KIND_FIRST_MFMA) rc = launch_first(enc, L, cur, cur_u8, B, out, false, stream, tm);
-        else if (L.kind == KIND_IGEMM && !cur_u8)
-            rc = launch_igemm(enc, L, static_cast<const float*>(cur), B * L.Ho * L.Wo, out, partial, stream, tm, name, (int)li);
-        else rc = launch_generic(enc, L, cur, cur_u8, B, out, stream, tm, name);
+        else if (L.kind == KIND_IGEMM && !cur_u8) {
+            const WaveKPlan wk = plan_wavek(enc, L, (long long)B * L.Ho * L.Wo);
+            if (wk.use) rc = launch_wavek(enc, L, wk, static_cast<const float*>(cur), B * L.Ho * L.Wo, out, partial, tickets, stream, tm, name, (int)li);
+            else rc = launch_igemm(enc, L, static_cast<const float*>(cur), B * L.Ho * L.Wo, out, partial, stream, tm, name, (int)li);
+        } else rc = launch_generic(enc, L, cur, cur_u8, B, out, stream, tm, name);
         if (rc) return rc;
         cur = out;
         cur_u8 = false;
     }
     const Layer& D = enc->dense;
     if (D.kind == KIND_IGEMM && B <= 4 && enc->dense_gemv && D.K() % aae::kGemvChunk == 0)
-        return launch_dense_gemv(enc, D, static_cast<const float*>(cur), B, z_out, partial, stream, tm);
+        return launch_dense_gemv(enc, D, static_cast<const float*>(cur), B, z_out, partial, tickets, stream, tm);
+    if (D.kind == KIND_IGEMM && enc->wavek_dense) {
+        const WaveKPlan wk = plan_wavek(enc, D, B);
+        if (wk.use) return launch_wavek(enc, D, wk, static_cast<const float*>(cur), B, z_out, partial, tickets, stream, tm, "dense", 0);
+    }
     if (D.kind == KIND_IGEMM) return launch_igemm(enc, D, static_cast<const float*>(cur), B, z_out, partial, stream, tm, "dense");
     return launch_generic(enc, D, cur, false, B, z_out, stream, tm, "dense");
 }
@@ -600,7 +736,14 @@ struct ScanPlan {
     bool gemv, stream;
     bool resident_ok;              // query-resident streaming kernel eligible (top-1, no similarity output, stride 1 decided at run time)
     int res_tiles_per_block, res_blocks;
-    size_t q_off, qp_off, pval_off, pidx_off, cs_off, cand_off, total;
+    size_t ticket_off, q_off, qp_off, pval_off, pidx_off, cs_off, cand_off, total;
+};
+
+// answers of a top-1 stream scan that finishes inside its own launch (scan_ticket_finish)
+struct ScanTicketOut {
+    int64_t* idx_out = nullptr;
+    float* score_out = nullptr;
+    int idx_scale = 1;
 };
 
 static ScanPlan plan_scan(const aae_codebook* cb, int B, int topk) {
@@ -634,6 +777,7 @@ static ScanPlan plan_scan(const aae_codebook* cb, int B, int topk) {
         s.resident_ok = s.res_blocks <= s.nblk;          // the partial buffers are sized for nblk row blocks
     }
     size_t off = 0;
+    s.ticket_off = off; off += 256;                        // block_ticket_arrive word of the single-launch stream scan
     s.q_off = off;    off += align_up((size_t)B * cb->J * sizeof(float), 256);
     s.qp_off = off;   off += align_up((size_t)s.Jpad * s.Bpad * 6, 256);   // fp32 packing: 4 B/elem; bf16: 3 terms x 2 B
     s.pval_off = off; off += align_up((size_t)s.nblk * s.Bstride * sizeof(float), 256);
@@ -660,7 +804,7 @@ static void launch_scan_mfma_t(const aae::ScanArgs& a, bool upright, int nblk, h
 
 template <int NQ>
 static void launch_scan_stream_t(const aae::ScanArgs& a, bool upright, int nblk, hipStream_t stream) {
-    const int smem = 2 * 4 * NQ * (int)sizeof(float);
+    const int smem = std::max(2 * 4 * NQ * (int)sizeof(float), aae::kScanTicketSmem);
     if (upright) AAE_LAUNCH((aae::scan_stream_kernel<NQ, true>), dim3(nblk), dim3(256), smem, stream, a);
     else AAE_LAUNCH((aae::scan_stream_kernel<NQ, false>), dim3(nblk), dim3(256), smem, stream, a);
 }
@@ -686,7 +830,7 @@ static int launch_scan_resident(const aae_codebook* cb, const void* qp, int B, c
 
 // *partial_rows: how many [Bstride]-rows of (pval, pidx) the arg-max reduce has to look at
 static int run_scan(aae_codebook* cb, const float* z, int B, int col_stride, float* cs_out, const ScanPlan& s,
-                    unsigned char* base, hipStream_t stream, int* partial_rows = nullptr) {
+                    unsigned char* base, hipStream_t stream, int* partial_rows = nullptr, const ScanTicketOut* fin = nullptr) {
     float* q = reinterpret_cast<float*>(base + s.q_off);
     float* qp = reinterpret_cast<float*>(base + s.qp_off);
     const bool resident = s.resident_ok && cs_out == nullptr && col_stride == 1;
@@ -700,6 +844,10 @@ static int run_scan(aae_codebook* cb, const float* z, int B, int col_stride, flo
         a.cs = cs_out;
         a.N = cb->N; a.J = cb->J; a.Jpad = s.Jpad; a.B = B; a.Bpad = s.Bpad; a.Bstride = s.Bstride;
         a.col_stride = col_stride;
+        if (fin) {
+            a.tickets = reinterpret_cast<unsigned long long*>(base + s.ticket_off); a.nonce = next_nonce();
+            a.idx_out = reinterpret_cast<long long*>(fin->idx_out); a.score_out = fin->score_out; a.idx_scale = fin->idx_scale;
+        }
         const bool up = col_stride > 1;
         if (B == 1) {
             if (up) AAE_LAUNCH((aae::scan_stream_bf16_kernel<1, true>), dim3(s.nblk), dim3(256), 64, stream, a);
@@ -754,6 +902,10 @@ static int run_scan(aae_codebook* cb, const float* z, int B, int col_stride, flo
     a.cs = cs_out;
     a.N = cb->N; a.J = cb->J; a.Jpad = s.Jpad; a.B = B; a.Bpad = s.Bpad; a.Bstride = s.Bstride;
     a.col_stride = col_stride;
+    if (fin && s.stream) {
+        a.tickets = reinterpret_cast<unsigned long long*>(base + s.ticket_off); a.nonce = next_nonce();
+        a.idx_out = reinterpret_cast<long long*>(fin->idx_out); a.score_out = fin->score_out; a.idx_scale = fin->idx_scale;
+    }
     const bool upright = col_stride > 1;
     if (s.stream) {
         if (B == 1) launch_scan_stream_t<1>(a, upright, s.nblk, stream);
@@ -919,6 +1071,18 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
     else if (!strcmp(name, "igemm_dma")) enc->igemm_dma = value ? 1 : 0;
     else if (!strcmp(name, "igemm_breg")) enc->igemm_breg = value ? 1 : 0;
     else if (!strcmp(name, "dense_gemv")) enc->dense_gemv = value ? 1 : 0;
+    else if (!strcmp(name, "gemv_ticket")) enc->gemv_ticket = value ? 1 : 0;
+    else if (!strcmp(name, "wavek")) enc->wavek = value ? 1 : 0;
+    else if (!strcmp(name, "wavek_dense")) enc->wavek_dense = value ? 1 : 0;
+    else if (!strcmp(name, "wavek_max_tiles")) enc->wavek_max_tiles = value < 0 ? 0 : (value > 512 ? 512 : value);
+    else if (!strcmp(name, "wavek_narrow_max_tiles")) enc->wavek_narrow_max_tiles = value < 0 ? 0 : value;
+    else if (!strcmp(name, "wavek_waves")) {
+        if (value != 4 && value != 8) return fail(AAE_ERR_INVALID, "wavek_waves %d: 4 or 8", value);
+        enc->wavek_waves = value;
+    } else if (!strcmp(name, "wavek_depth")) {
+        if (value != 2 && value != 3) return fail(AAE_ERR_INVALID, "wavek_depth %d: 2 or 3", value);
+        enc->wavek_depth = value;
+    }
     else if (!strcmp(name, "igemm_breg_wide")) enc->igemm_breg_wide = value ? 1 : 0;
     else if (!strcmp(name, "igemm_breg_wide_min_blocks")) enc->igemm_breg_wide_min_blocks = value;
     else if (!strcmp(name, "igemm_breg_min_blocks")) enc->igemm_breg_min_blocks = value;
@@ -1042,7 +1206,7 @@ int aae_codebook_prepare_upright(aae_codebook* cb, int col_stride, void* stream_
         if (cb->upright) { aae_codebook_destroy(cb->upright); cb->upright = nullptr; cb->upright_stride = 0; }
         aae_codebook* sub = new (std::nothrow) aae_codebook();
         if (!sub) return fail(AAE_ERR_RUNTIME, "out of host memory");
-        sub->N = ceil_div(cb->N, col_stride); sub->J = cb->J; sub->dtype = cb->dtype; sub->scan_mode = cb->scan_mode;
+        sub->N = ceil_div(cb->N, col_stride); sub->J = cb->J; sub->dtype = cb->dtype; sub->scan_mode = cb->scan_mode; sub->scan_ticket = cb->scan_ticket;
         void* p = nullptr;
         const hipError_t e = hipMalloc(&p, (size_t)sub->N * sub->J * (sub->dtype == AAE_DTYPE_BF16 ? 2 : 4));
         if (e != hipSuccess) { delete sub; return fail(AAE_ERR_RUNTIME, "hipMalloc(upright codebook): %s", hipGetErrorString(e)); }
@@ -1075,9 +1239,11 @@ void aae_codebook_destroy(aae_codebook* cb) {
 int aae_codebook_set_scan_mode(aae_codebook* cb, int mode) {
     using namespace aae_host;
     if (!cb) return fail(AAE_ERR_INVALID, "aae_codebook_set_scan_mode: null handle");
-    if (mode != AAE_SCAN_AUTO && mode != AAE_SCAN_GEMV && mode != AAE_SCAN_MFMA && mode != AAE_SCAN_STREAM) return fail(AAE_ERR_INVALID, "scan mode %d", mode);
-    cb->scan_mode = mode;
-    if (cb->upright) cb->upright->scan_mode = mode;
+    if (mode != AAE_SCAN_AUTO && mode != AAE_SCAN_GEMV && mode != AAE_SCAN_MFMA && mode != AAE_SCAN_STREAM && mode != AAE_SCAN_STREAM_2L)
+        return fail(AAE_ERR_INVALID, "scan mode %d", mode);
+    cb->scan_ticket = mode == AAE_SCAN_STREAM_2L ? 0 : 1;
+    cb->scan_mode = mode == AAE_SCAN_STREAM_2L ? AAE_SCAN_STREAM : mode;
+    if (cb->upright) { cb->upright->scan_mode = cb->scan_mode; cb->upright->scan_ticket = cb->scan_ticket; }
     return AAE_OK;
 }
 
@@ -1111,7 +1277,12 @@ int aae_codebook_nn(aae_codebook* cb, const float* z, int B, int topk, int col_s
     unsigned char* base = static_cast<unsigned char*>(workspace);
     float* cs = topk > 1 ? reinterpret_cast<float*>(base + s.cs_off) : nullptr;
     int partial_rows = s.nblk;
-    if (int rc = run_scan(cb, z, B, col_stride, cs, s, base, stream, &partial_rows)) return rc;
+    // B <= 4, top-1 on a stream kernel: the last block to arrive merges the block partials -- the query is one launch
+    ScanTicketOut fin;
+    fin.idx_out = idx_out; fin.score_out = score_out; fin.idx_scale = idx_scale;
+    const bool one_launch = topk == 1 && s.stream && cb->scan_ticket;
+    if (int rc = run_scan(cb, z, B, col_stride, cs, s, base, stream, &partial_rows, one_launch ? &fin : nullptr)) return rc;
+    if (one_launch) return AAE_OK;
     if (topk == 1) {
         aae::ArgmaxReduceArgs r;
         r.pval = reinterpret_cast<float*>(base + s.pval_off);

@@ -129,6 +129,38 @@ __device__ __forceinline__ void sleep_kcycles(int n) {
     for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);
 }
 
+// "The last block to arrive finishes the job": cross-block hand-off inside ONE launch, so that a split reduction
+// needs no second kernel.  Every thread of the block calls this after its global stores of the block's partial
+// result; it returns true -- in every thread -- for exactly one block: the last of `total` arrivals at `word`
+// in the launch identified by `nonce` (unique per launch, never 0).  That block may then read all partials.
+//   word = nonce << 32 | arrivals so far.  A word that carries another nonce (a launch that died half-way,
+//   memory that was never initialised) counts as empty, and the last arriver leaves the word at 0, so a
+//   workspace is ready for the next launch without any memset between kernels.
+// Memory model: each thread's __threadfence() (agent-scope release: stores complete + L2 write-back) precedes the
+// block barrier, which precedes thread 0's atomic; the winner's threads fence again (acquire: cache invalidate)
+// before they touch the other blocks' partials.
+__device__ __forceinline__ bool block_ticket_arrive(unsigned long long* word, unsigned nonce, unsigned total, int* lds_flag) {
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long seen = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool last;
+        for (;;) {
+            const unsigned count = ((unsigned)(seen >> 32) == nonce) ? (unsigned)seen : 0u;
+            last = count + 1 == total;
+            const unsigned long long want = last ? 0ull : (((unsigned long long)nonce << 32) | (count + 1));
+            const unsigned long long prev = atomicCAS(word, seen, want);
+            if (prev == seen) break;
+            seen = prev;
+        }
+        *lds_flag = last ? 1 : 0;
+    }
+    __syncthreads();
+    const bool last = *lds_flag != 0;
+    if (last) __threadfence();
+    return last;
+}
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 
 __device__ __forceinline__ float shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }

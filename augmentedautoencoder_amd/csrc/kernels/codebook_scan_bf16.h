@@ -229,6 +229,7 @@ __global__ __launch_bounds__(256) void scan_stream_bf16_kernel(const ScanArgs p)
         p.pval[(long long)blockIdx.x * p.Bstride + tid] = v;
         p.pidx[(long long)blockIdx.x * p.Bstride + tid] = ix;
     }
+    if (p.tickets) scan_ticket_finish(p, red_v);
 }
 
 }  // namespace aae

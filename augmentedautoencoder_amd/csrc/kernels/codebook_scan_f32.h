@@ -66,7 +66,58 @@ struct ScanArgs {
     int col_stride;     // 1, or num_cyclo for the reference's `upright` mode
     const float* z;     // [B][J] raw latents                    (stream: normalisation fused)
     unsigned e_bytes;   // N*J*4                                 (stream: bounds-checked view of E)
+    // stream kernels, top-1: when tickets != nullptr the last block to arrive merges the block partials itself
+    // (scan_ticket_finish) and writes the answers -- the whole nearest-neighbour query is ONE launch
+    unsigned long long* tickets = nullptr;
+    unsigned nonce = 0;
+    long long* idx_out = nullptr;   // [B] int64
+    float* score_out = nullptr;     // [B]
+    int idx_scale = 1;              // row ids are multiplied by this (upright search on the compacted copy)
 };
+
+// block-wide (value, index) arg-best in np.argmax order; result broadcast to every thread.  red: 10 dwords of LDS.
+__device__ __forceinline__ void block_best(float& bv, int& bi, float* red) {
+    int* red_i = reinterpret_cast<int*>(red + 4);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const float ov = shfl_xor(bv, m);
+        const int oi = shfl_xor(bi, m);
+        if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
+    }
+    if (lane == 0) { red[wave] = bv; red_i[wave] = bi; }
+    __syncthreads();
+    bv = red[0]; bi = red_i[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w)
+        if (better(red[w], red_i[w], bv, bi)) { bv = red[w]; bi = red_i[w]; }
+    __syncthreads();
+}
+
+// Called by every thread of a stream-scan block after its block partial is written.  The last of the gridDim.x
+// blocks merges all partials (the arg-max reduce of argmax_reduce_kernel: same order, lowest row wins ties) and
+// writes (index, score) per query.  red: >= 12 dwords of LDS.
+constexpr int kScanTicketSmem = 64;
+__device__ __forceinline__ void scan_ticket_finish(const ScanArgs& p, float* red) {
+    int* flag = reinterpret_cast<int*>(red) + 10;
+    if (!block_ticket_arrive(p.tickets, p.nonce, gridDim.x, flag)) return;
+    const int tid = threadIdx.x, nblk = (int)gridDim.x;
+    for (int b = 0; b < p.B; ++b) {
+        float bv = kNegInf;
+        int bi = 0x7fffffff;
+        for (int k = tid; k < nblk; k += 256) {
+            const float v = p.pval[(long long)k * p.Bstride + b];
+            const int ix = p.pidx[(long long)k * p.Bstride + b];
+            if (better(v, ix, bv, bi)) { bv = v; bi = ix; }
+        }
+        block_best(bv, bi, red);
+        if (tid == 0) {
+            if (bi == 0x7fffffff) bi = 0;          // all-NaN scores: np.argmax would also answer 0
+            p.idx_out[b] = (long long)bi * p.idx_scale;
+            p.score_out[b] = bv;
+        }
+    }
+}
 
 // ----------------------------------------------------------------- scan_stream
 // B <= 4, the reference's real usage (one crop per detection).  One launch does the
@@ -154,6 +205,7 @@ __global__ __launch_bounds__(256) void scan_stream_kernel(const ScanArgs p) {
         p.pval[(long long)blockIdx.x * p.Bstride + tid] = v;
         p.pidx[(long long)blockIdx.x * p.Bstride + tid] = ix;
     }
+    if (p.tickets) scan_ticket_finish(p, red_v);
 }
 
 // ------------------------------------------------------------------- scan_gemv
@@ -402,25 +454,6 @@ struct TopKArgs {
 };
 
 constexpr int kTopKChunk = 2048;
-
-// block-wide (value, index) arg-best; result broadcast to every thread.  red: 10 dwords of LDS.
-__device__ __forceinline__ void block_best(float& bv, int& bi, float* red) {
-    int* red_i = reinterpret_cast<int*>(red + 4);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        const float ov = shfl_xor(bv, m);
-        const int oi = shfl_xor(bi, m);
-        if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }
-    }
-    if (lane == 0) { red[wave] = bv; red_i[wave] = bi; }
-    __syncthreads();
-    bv = red[0]; bi = red_i[0];
-#pragma unroll
-    for (int w = 1; w < 4; ++w)
-        if (better(red[w], red_i[w], bv, bi)) { bv = red[w]; bi = red_i[w]; }
-    __syncthreads();
-}
 
 __global__ __launch_bounds__(256) void topk_chunks_kernel(const TopKArgs p) {
     AAE_DYN_SMEM(smem_raw);

@@ -1,0 +1,213 @@
+// Small-batch implicit GEMM on the fp32 matrix cores: K split across the WAVES of a block (and, when the
+// layer has fewer output tiles than the chip has CUs, across blocks), operands straight from global memory
+// into MFMA fragments -- no LDS staging, no slab barriers -- and the cross-block sum finished inside the same
+// launch by the last block to arrive.
+//
+// Replaces tf.layers.conv2d(k, stride, 'same', relu) [+ inference batch-norm] of
+// /root/reference/auto_pose/ae/encoder.py:41-52 for the reference's REAL usage: one crop per detection
+// (m3_interface/ae_pose_estimator.py:143-170, one session.run per box), i.e. M = B*Ho*Wo of 64 ... 4096 rows.
+//
+// Why a second kernel.  conv_igemm_f32.h tiles 128 x 128 outputs per block and shares each staged slab among
+// four waves.  At B = 1 a layer has 8 ... 64 such tiles for 256 CUs, so K has to be cut 32 ... 64 ways: every
+// block then runs 3-4 slabs behind a full pipeline prologue, writes a whole fp32 partial tile to HBM (33 MB per
+// layer at B = 1) and a second launch adds the partials up: 25 us per layer against 11 us of MFMA time.
+// Here the unit of work is ONE WAVE with a (32*MT) x (32*NT) accumulator tile and its own K range:
+//   * both operands arrive in fragment order by plain 16-B buffer loads: packed weights [K/4][CoutPad][4] are the
+//     MFMA B fragments as they lie in memory; an A fragment is 16 B (4 channels) of one input pixel, read through
+//     the bounds-checked view (TF 'SAME' padding = out-of-range offset = zeros, no branches);
+//   * DEPTH slabs of fragments are in flight per wave (static register ring), the MFMAs of slab t run under the
+//     loads of slabs t+1 ... t+DEPTH-1; nothing is shared between waves, so there is no barrier in the K loop;
+//   * the WAVES partial tiles of a block meet in LDS and are added in wave order; with gsplits > 1 each block
+//     writes its tile partial (lane-linear, coalesced) and takes a ticket: the last of the gsplits blocks re-reads
+//     all partials in split order, applies bias / ReLU / BN and stores the outputs.  Fixed orders everywhere ->
+//     run-to-run bit-identical results; 8x fewer partial bytes than the 128 x 128 split-K and no second launch.
+// K order inside a slab and the (c, q) MFMA pairing are those of tile_f32.h, so each wave's partial is the same
+// k-ordered fma chain the large kernel would compute over that K range.
+#pragma once
+
+namespace aae {
+
+struct ConvWaveKArgs {
+    const float* x;              // [B, H, W, Cin] NHWC
+    unsigned x_bytes;            // < 0xFFFFFF00
+    const float* wp;             // [K/4][CoutPad][4]
+    unsigned wp_bytes;
+    const float* bias;           // [Cout]
+    const float* bn_scale;       // [Cout] or nullptr
+    const float* bn_shift;
+    float* out;                  // [M][Cout]
+    float* partial;              // [tiles][gsplits][MT*NT*16][64]       (gsplits > 1)
+    unsigned long long* tickets; // [tiles]                              (gsplits > 1)
+    unsigned nonce;              // unique per launch, never 0
+    int H, W, Cin, Ho, Wo, Cout, CoutPad;
+    int KS, S, pt, pl;
+    int M;                       // B*Ho*Wo
+    int slabs_total;             // KS*KS*Cin/32
+    int num_mt, num_nt, gsplits;
+    int relu;
+};
+
+// Out-of-range byte offset that stays out of range after the +96 a fragment's k-group adds.
+constexpr uint32_t kOobBase = 0xFFFFFF00u;
+
+template <int MT, int NT, int WAVES>
+constexpr int conv_wavek_smem() { return WAVES * MT * NT * 16 * 64 * 4 + 16; }
+
+template <int MT, int NT, int WAVES, int DEPTH, int TAG = 0>
+__global__ __launch_bounds__(64 * WAVES) void conv_wavek_f32_kernel(const ConvWaveKArgs p) {
+    constexpr int COMBOS = MT * NT * 16;                       // accumulator registers per lane
+    static_assert(COMBOS % WAVES == 0, "the cross-wave sum gives every wave COMBOS / WAVES register rows");
+    AAE_DYN_SMEM(smem_raw);
+    float* red = reinterpret_cast<float*>(smem_raw);           // [WAVES][COMBOS][64]
+    int* flag = reinterpret_cast<int*>(red + WAVES * COMBOS * 64);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
+    const int i = lane & 31, h = lane >> 5;
+
+    const int tiles = p.num_mt * p.num_nt;
+    const int L = xcd_remap(blockIdx.x, tiles * p.gsplits);
+    const int tm = L % p.num_mt;                               // M tiles of one (N tile, K split) are neighbours: they share its weights in L2
+    const int tn = (L / p.num_mt) % p.num_nt;
+    const int g = L / tiles;
+    const int tile = tn * p.num_mt + tm;
+    // K ranges: block g of the tile walks slabs [b0, b1), its wave w the w-th part of that; sizes differ by at most one slab
+    const int b0 = (int)((long long)g * p.slabs_total / p.gsplits);
+    const int b1 = (int)((long long)(g + 1) * p.slabs_total / p.gsplits);
+    const int s0 = b0 + wave * (b1 - b0) / WAVES;
+    const int s1 = b0 + (wave + 1) * (b1 - b0) / WAVES;
+
+    // ---- A fragments: lane (i, h) of M sub-tile mi owns output row m and reads 4 channels (slot 2c + h) per k-group c
+    const buffer_rsrc xbuf = make_buffer(p.x, p.x_bytes);
+    unsigned a_off[MT];
+    int a_ih0[MT], a_iw0[MT];
+    bool a_ok[MT];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+        const int m = tm * (32 * MT) + 32 * mi + i;
+        a_ok[mi] = m < p.M;
+        const int mm = a_ok[mi] ? m : 0;
+        const int b = mm / (p.Ho * p.Wo);
+        const int rem = mm - b * (p.Ho * p.Wo);
+        const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+        a_ih0[mi] = oh * p.S - p.pt;
+        a_iw0[mi] = ow * p.S - p.pl;
+        a_off[mi] = (unsigned)(((((long long)b * p.H + a_ih0[mi]) * p.W + a_iw0[mi]) * (long long)p.Cin + h * 4) * 4);
+    }
+    // ---- B fragments: lane (i, h) reads column n0 + 32*ni + i of slot row slab*8 + 2c + h
+    const buffer_rsrc wbuf = make_buffer(p.wp, p.wp_bytes);
+    const unsigned bw_off = (unsigned)((h * p.CoutPad + tn * (32 * NT) + i) * 16);
+    const unsigned bw_slab = (unsigned)(8 * p.CoutPad * 16);
+    const unsigned bw_group = (unsigned)(2 * p.CoutPad * 16);
+
+    // (cc, kh, kw) of the next slab to load; K order = 32-channel chunk, kh, kw (pack_weights)
+    const int taps = p.KS * p.KS;
+    int cc = s0 / taps;
+    int kh = (s0 - cc * taps) / p.KS;
+    int kw = (s0 - cc * taps) - kh * p.KS;
+    int t_load = s0;
+
+    f32x4 fa[DEPTH][MT][4], fb[DEPTH][NT][4];
+    auto load_stage = [&](int d) {
+        const bool live = t_load < s1;                          // past the wave's range: every load is forced out of range (zeros, no traffic)
+        const unsigned tap_off = (unsigned)(((kh * p.W + kw) * p.Cin + cc * 32) * 4);
+        unsigned ao[MT];
+#pragma unroll
+        for (int mi = 0; mi < MT; ++mi) {
+            const bool ok = live && a_ok[mi] && (unsigned)(a_ih0[mi] + kh) < (unsigned)p.H && (unsigned)(a_iw0[mi] + kw) < (unsigned)p.W;
+            ao[mi] = ok ? a_off[mi] + tap_off : kOobBase;
+        }
+        const unsigned bo = live ? bw_off + (unsigned)t_load * bw_slab : kOobBase;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {                           // k-group order = consumption order
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi) fa[d][mi][c] = buffer_load4(xbuf, ao[mi] + 32u * c);
+#pragma unroll
+            for (int ni = 0; ni < NT; ++ni) fb[d][ni][c] = buffer_load4(wbuf, live ? bo + c * bw_group + 512u * ni : kOobBase);
+        }
+        ++t_load;
+        if (++kw == p.KS) { kw = 0; if (++kh == p.KS) { kh = 0; ++cc; } }
+    };
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    auto mfma_stage = [&](int d) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = mfma_32x32x2(fa[d][mi][c][q], fb[d][ni][c][q], acc[mi][ni]);
+    };
+
+#pragma unroll
+    for (int d = 0; d < DEPTH - 1; ++d) load_stage(d);
+    for (int t = s0; t < s1; t += DEPTH) {
+#pragma unroll
+        for (int d = 0; d < DEPTH; ++d) {
+            if (t + d < s1) {                                   // wave-uniform
+                sched_fence();
+                load_stage((d + DEPTH - 1) % DEPTH);            // slab t + d + DEPTH - 1 (dead loads once past s1)
+                sched_fence();
+                mfma_stage(d);
+            }
+        }
+    }
+
+    // ---- the WAVES partial tiles meet in LDS, lane-linear (conflict-free), and are added in wave order ----------
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < NT; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) red[(wave * COMBOS + (mi * NT + ni) * 16 + r) * 64 + lane] = acc[mi][ni][r];
+    __syncthreads();
+    constexpr int PER = COMBOS / WAVES;                         // register rows this thread finishes: combo = wave + WAVES*j
+    float v[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int combo = wave + WAVES * j;
+        float s = red[combo * 64 + lane];
+#pragma unroll
+        for (int w = 1; w < WAVES; ++w) s += red[(w * COMBOS + combo) * 64 + lane];
+        v[j] = s;
+    }
+
+    if (p.gsplits > 1) {
+        float* mine = p.partial + ((long long)tile * p.gsplits + g) * (COMBOS * 64);
+#pragma unroll
+        for (int j = 0; j < PER; ++j) mine[(wave + WAVES * j) * 64 + lane] = v[j];
+        const bool last = block_ticket_arrive(p.tickets + tile, p.nonce, (unsigned)p.gsplits, flag);
+        if (!last) return;
+        const float* all = p.partial + (long long)tile * p.gsplits * (COMBOS * 64);
+#pragma unroll
+        for (int j = 0; j < PER; ++j) v[j] = 0.f;
+        for (int s = 0; s < p.gsplits; ++s) {                   // split order: the same sum whichever block arrives last
+#pragma unroll
+            for (int j = 0; j < PER; ++j) v[j] += all[((long long)s * COMBOS + wave + WAVES * j) * 64 + lane];
+        }
+    }
+
+    // ---- epilogue: bias, ReLU, folded BN; register row combo = (mi, ni, r) of lane -> (m, n) ---------------------
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+        const int combo = wave + WAVES * j;
+        const int r = combo & 15, ni = (combo >> 4) % NT, mi = (combo >> 4) / NT;
+        const int m = tm * (32 * MT) + 32 * mi + acc_row(r, lane);
+        const int n = tn * (32 * NT) + 32 * ni + i;
+        if (m >= p.M || n >= p.Cout) continue;
+        float o = v[j] + p.bias[n];
+        if (p.relu) o = fmaxf(o, 0.f);
+        if (p.bn_scale) o = o * p.bn_scale[n] + p.bn_shift[n];
+        p.out[(long long)m * p.Cout + n] = o;
+    }
+}
+
+}  // namespace aae

@@ -3,7 +3,9 @@
 // 97 % padding and the layer is the 16.8 MB read of W: each block streams a 128-k chunk of the packed weights
 // [K/4][CoutPad][4] -- thread n reads 16 B = four consecutive k of ITS output column, 2 KB contiguous per
 // slot row across the block -- against the activation chunk staged in LDS, and writes one partial row per
-// batch element; splitk_reduce_kernel (fixed order) adds the chunks, bias and the optional BN.
+// batch element.  The chunks are added up (fixed order), with bias and the optional BN, either by
+// splitk_reduce_kernel in a second launch or -- TICKET = true, the default -- inside this launch by the last
+// block to arrive (block_ticket_arrive): one launch less on the per-detection path.
 #pragma once
 
 namespace aae {
@@ -14,11 +16,21 @@ struct DenseGemvArgs {
     unsigned wp_bytes;
     float* partial;        // [chunks][B][Cout]
     int B, K, Cout, CoutPad;
+    // TICKET mode: the last block of a column tile finishes z = sum(chunks) + bias [, BN]
+    const float* bias;
+    const float* bn_scale;
+    const float* bn_shift;
+    float* out;                    // [B][Cout]
+    unsigned long long* tickets;   // [CoutPad / 128]
+    unsigned nonce;
+    int relu;
 };
 
 constexpr int kGemvChunk = 128;            // k per block = 32 slot rows: 64 KB of weights at CoutPad = 128
 
-template <int MQ>
+constexpr int kGemvTicketSmem = 8 * 128 * 4 + 16;                // the finishing block's 8 row-group sums + the ticket flag
+
+template <int MQ, bool TICKET = false>
 __global__ __launch_bounds__(256) void dense_gemv_f32_kernel(const DenseGemvArgs p) {
     AAE_DYN_SMEM(smem_raw);
     float* xs = reinterpret_cast<float*>(smem_raw);              // [MQ][128] activation chunk
@@ -62,6 +74,37 @@ __global__ __launch_bounds__(256) void dense_gemv_f32_kernel(const DenseGemvArgs
 #pragma unroll
         for (int m = 0; m < MQ; ++m)
             if (m < p.B) p.partial[((long long)blockIdx.x * p.B + m) * p.Cout + n] = acc[m] + red[m * 128 + (tid & 127)];
+    }
+    if constexpr (TICKET) {
+        // The last of the gridDim.x chunk blocks of this column tile adds the chunk rows: thread (group = tid / 32,
+        // n4 = tid % 32) sums chunks group, group + 8, ... of four neighbouring columns (16-B loads, all of a batch
+        // row's loads in flight), the 8 group sums meet in LDS and are added in group order -- one fixed tree,
+        // whichever block happens to finish last.  (Needs Cout % 4 == 0; the host checks.)
+        float* gsum = reinterpret_cast<float*>(smem_raw);        // [8][128] (xs / red are dead by now)
+        int* flag = reinterpret_cast<int*>(gsum + 8 * 128);
+        __syncthreads();
+        if (!block_ticket_arrive(p.tickets + blockIdx.y, p.nonce, gridDim.x, flag)) return;
+        const int group = tid >> 5, n4 = blockIdx.y * 128 + (tid & 31) * 4;
+        const int chunks = (int)gridDim.x;
+        for (int m = 0; m < p.B; ++m) {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            if (n4 < p.Cout)
+#pragma unroll 8
+                for (int c = group; c < chunks; c += 8) s += *reinterpret_cast<const f32x4*>(p.partial + ((long long)c * p.B + m) * p.Cout + n4);
+            *reinterpret_cast<f32x4*>(gsum + group * 128 + (tid & 31) * 4) = s;
+            __syncthreads();
+            if (tid < 128 && blockIdx.y * 128 + tid < p.Cout) {
+                const int nn = blockIdx.y * 128 + tid;
+                float v = gsum[tid];
+#pragma unroll
+                for (int k = 1; k < 8; ++k) v += gsum[k * 128 + tid];
+                v += p.bias[nn];
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (p.bn_scale) v = v * p.bn_scale[nn] + p.bn_shift[nn];
+                p.out[(long long)m * p.Cout + nn] = v;
+            }
+            __syncthreads();
+        }
     }
 }
 

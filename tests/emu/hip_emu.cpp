@@ -36,6 +36,7 @@ int g_live = 0;
 int g_bar_arrived = 0;
 unsigned g_bar_gen = 0;
 unsigned long g_events = 0;   // arrivals / releases / exits, for deadlock detection
+int g_block_order = 0;        // 0 ascending, 1 descending, 2 scrambled (aae_emu_set_block_order)
 
 void yield_to_scheduler() {
     Fiber* me = g_cur;
@@ -101,10 +102,26 @@ void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()
     }
     g_waves.assign(nthreads / 64, WaveState());
     g_body = &body;
-    for (unsigned bz = 0; bz < grid.z; ++bz)
-      for (unsigned by = 0; by < grid.y; ++by)
-        for (unsigned bx = 0; bx < grid.x; ++bx) {
+    const unsigned long long nblocks = (unsigned long long)grid.x * grid.y * grid.z;
+    for (unsigned long long seq = 0; seq < nblocks; ++seq) {
+        {
+            // block execution order: ascending (default), descending, or a fixed pseudo-random permutation -- kernels
+            // whose blocks hand work to "the last block to arrive" must give the same bits in every order
+            unsigned long long id = seq;
+            if (g_block_order == 1) id = nblocks - 1 - seq;
+            else if (g_block_order == 2) {
+                unsigned long long stride = 1;                 // a stride coprime to nblocks visits every block once
+                for (unsigned long long c = nblocks / 2 + 1; c < nblocks; ++c) {
+                    unsigned long long a = c, b = nblocks;
+                    while (b) { const unsigned long long t = a % b; a = b; b = t; }
+                    if (a == 1) { stride = c; break; }
+                }
+                id = (seq * stride + 7) % nblocks;
+            }
+            const unsigned bx = (unsigned)(id % grid.x), by = (unsigned)((id / grid.x) % grid.y), bz = (unsigned)(id / ((unsigned long long)grid.x * grid.y));
             blockIdx = {bx, by, bz};
+        }
+        {
             // poison LDS between blocks so stale reuse is visible (NaN pattern)
             memset(aae_emu_dyn_smem, 0xFF, smem_bytes);
             g_live = nthreads;
@@ -147,7 +164,10 @@ void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()
                 }
             }
         }
+    }
     g_body = nullptr;
 }
 
 }  // namespace aae_emu
+
+extern "C" void aae_emu_set_block_order(int order) { g_block_order = order; }

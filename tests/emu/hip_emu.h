@@ -171,6 +171,21 @@ inline void split_f16(float v, unsigned short& hi, unsigned short& lo) {
     memcpy(&lo, &l, 2);
 }
 
+// device_intrinsics.h::block_ticket_arrive: the emulator runs the blocks of a grid one after the other, so the
+// word protocol (nonce << 32 | arrivals; foreign nonce = empty; last arriver leaves 0) is modelled without atomics.
+inline bool block_ticket_arrive(unsigned long long* word, unsigned nonce, unsigned total, int* lds_flag) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long seen = *word;
+        const unsigned count = ((unsigned)(seen >> 32) == nonce) ? (unsigned)seen : 0u;
+        const bool last = count + 1 == total;
+        *word = last ? 0ull : (((unsigned long long)nonce << 32) | (count + 1));
+        *lds_flag = last ? 1 : 0;
+    }
+    __syncthreads();
+    return *lds_flag != 0;
+}
+
 template <typename T>
 inline T shfl_xor(T v, int mask) {
     static_assert(sizeof(T) == 4, "32-bit shuffles only");

@@ -22,10 +22,25 @@ def lib():
     return _EMU
 
 
+def set_block_order(order):
+    """0: blocks of a grid run in ascending order, 1: descending, 2: a scrambled permutation (kernels that let the
+    last block to arrive finish a reduction must give the same bits in every order)."""
+    lib().aae_emu_set_block_order(int(order))
+
+
 def _aligned(nbytes, align=256):
-    raw = np.zeros(nbytes + align, dtype=np.uint8)
+    # workspaces arrive with arbitrary contents (the ticket words of block_ticket_arrive included): never zeros
+    raw = np.full(nbytes + align, 0xA5, dtype=np.uint8)
     off = (-raw.ctypes.data) % align
     return raw[off:off + nbytes]
+
+
+def split_k_small_batches(enc):
+    """Switch an encoder to the 128 x 128 split-K igemm + separate reduce launches for small batches too (the kernels
+    the wave-split-K / ticketed path replaced as the default; kept as options, so their tests keep running)."""
+    for name in ('wavek', 'wavek_dense', 'gemv_ticket'):
+        enc.set_option(name, 0)
+    return enc
 
 
 class EmuEncoder(object):

@@ -12,17 +12,22 @@ from oracle import reference_cpu as ref
 from oracle import synth
 
 
-def _run(cfg, B, seed, f32_in=False, nosplit=False, dma=0, breg=0):
+def _run(cfg, B, seed, f32_in=False, nosplit=False, dma=0, breg=0, wavek=0, options=None):
     w = synth.make_weights(seed=seed, shape=cfg.shape, num_filter=cfg.num_filter, strides=cfg.strides,
                            latent=cfg.latent_space_size, batch_norm=cfg.batch_norm, kernel_size=cfg.kernel_size)
     x = synth.make_crops(B, seed=seed + 1, shape=cfg.shape)
     xin = ref.input_to_float(x).astype(np.float32) if f32_in else x
-    enc = eb.EmuEncoder(w, cfg)
+    enc = eb.split_k_small_batches(eb.EmuEncoder(w, cfg))
     if nosplit:
         enc.set_option('splitk_min_base_blocks', 0)
         enc.set_option('dense_gemv', 0)         # keep the dense layer on the (un-split) MFMA tile too
     enc.set_option('igemm_dma', dma)           # operand slabs by LDS-DMA instead of register staging
     enc.set_option('igemm_breg', breg)         # weights straight from global memory into the MFMA B fragments
+    enc.set_option('wavek', wavek)             # 0: the 128 x 128 split-K igemm + reduce launch also for small batches
+    enc.set_option('wavek_dense', wavek)
+    enc.set_option('gemv_ticket', wavek)
+    for k, v in (options or {}).items():
+        enc.set_option(k, v)
     z = enc.forward(xin)
     z64, acts = ref.encoder_forward_np(ref.input_to_float(x), w, cfg.strides, cfg.batch_norm, return_activations=True)
     for i, a in enumerate(acts):
@@ -126,7 +131,7 @@ def test_split_precision_f32x3h_path(cfg, B, nosplit, dma):
     w = synth.make_weights(seed=5, shape=cfg.shape, num_filter=cfg.num_filter, strides=cfg.strides,
                            latent=cfg.latent_space_size, batch_norm=cfg.batch_norm)
     x = synth.make_crops(B, seed=6, shape=cfg.shape)
-    enc = eb.EmuEncoder(w, cfg)
+    enc = eb.split_k_small_batches(eb.EmuEncoder(w, cfg))
     enc.set_option('precision', 1)
     enc.set_option('x3h_dma', dma)       # operand slabs by LDS-DMA instead of register staging
     if nosplit:
@@ -200,7 +205,7 @@ def test_f32x3h_wide_tile_variant_is_bit_identical():
     cfg = EncoderConfig((32, 32, 3), [32, 64], [2, 2], 5, 128)
     w = synth.make_weights(seed=5, shape=cfg.shape, num_filter=cfg.num_filter, strides=cfg.strides, latent=128)
     x = synth.make_crops(5, seed=6, shape=cfg.shape)                     # conv2: M = 320 = one full + one partial 256-row tile
-    enc = eb.EmuEncoder(w, cfg)
+    enc = eb.split_k_small_batches(eb.EmuEncoder(w, cfg))
     enc.set_option('precision', 1)
     enc.set_option('splitk_min_base_blocks', 0)
     z0, a0 = enc.forward(x), None
@@ -219,7 +224,7 @@ def test_wide_block_tile_of_the_weights_to_registers_variant_is_bit_identical():
         cfg = EncoderConfig(shape, filters, [2, 2], 5, 128, bn)
         w = synth.make_weights(seed=5, shape=cfg.shape, num_filter=cfg.num_filter, strides=cfg.strides, latent=128, batch_norm=bn)
         x = synth.make_crops(B, seed=6, shape=cfg.shape)
-        enc = eb.EmuEncoder(w, cfg)
+        enc = eb.split_k_small_batches(eb.EmuEncoder(w, cfg))
         enc.set_option('splitk_min_base_blocks', 0)
         enc.set_option('igemm_breg_wide', 0)
         z0, a0 = enc.forward(x), None
@@ -241,7 +246,7 @@ def test_dense_layer_as_weight_streaming_gemv_for_tiny_batches(B):
     cfg = EncoderConfig((16, 16, 3), [32, 64], [2, 2], 5, 128)
     w = synth.make_weights(seed=12, shape=cfg.shape, num_filter=cfg.num_filter, strides=cfg.strides, latent=128)
     x = synth.make_crops(B, seed=13, shape=cfg.shape)
-    enc = eb.EmuEncoder(w, cfg)
+    enc = eb.split_k_small_batches(eb.EmuEncoder(w, cfg))
     z = enc.forward(x)
     assert any('dense_gemv' in l for l in enc.labels()) == (B <= 4)
     z64 = ref.encoder_forward_np(ref.input_to_float(x), w, cfg.strides, False)
@@ -267,7 +272,7 @@ def test_first_layer_dword_and_elementwise_staging_agree_bitwise(shape, filters,
     x = synth.make_crops(B, seed=6, shape=cfg.shape)
     acts = []
     for vec4, f32_in in ((1, False), (0, False), (1, True)):
-        enc = eb.EmuEncoder(w, cfg)
+        enc = eb.split_k_small_batches(eb.EmuEncoder(w, cfg))
         enc.set_option('first_vec4', vec4)
         enc.set_option('first_max_tiles_per_block', 3)
         enc.forward(ref.input_to_float(x).astype(np.float32) if f32_in else x)
@@ -289,7 +294,7 @@ def test_few_split_reduce_kernel_matches_the_grouped_one_bitwise(precision, bn):
     x = synth.make_crops(4, seed=9, shape=cfg.shape)
     outs = []
     for small in (1, 0):
-        enc = eb.EmuEncoder(w, cfg)
+        enc = eb.split_k_small_batches(eb.EmuEncoder(w, cfg))
         enc.set_option('precision', precision)
         enc.set_option('splitk_target_blocks', 8)          # conv2: 2 base blocks -> 4 splits over 256 x 64 outputs
         enc.set_option('reduce_small', small)
@@ -343,3 +348,58 @@ def test_upright_search_on_the_compacted_copy_equals_the_masked_scan(dtype, N, B
     idx_p, _ = cb.nn(z, 1, 1)                               # the plain search is untouched
     assert np.array_equal(idx_p[:, 0], np.argmax(cs, axis=1))
     cb.close()
+
+
+# ---- small-batch path: wave-split-K igemm + in-launch ticketed reductions (conv_wavek_f32.h, dense_gemv ticket) ----
+@pytest.mark.parametrize('order', [0, 1, 2])
+@pytest.mark.parametrize('waves,depth', [(4, 3), (4, 2), (8, 2)])
+def test_wave_split_k_igemm_narrow_tiles_and_ticketed_gemv(waves, depth, order):
+    """B = 3 of a 2-layer net: conv2 has M = 48 rows (one partial 64-row tile), 25 slabs over 3 blocks x `waves`
+    waves (some waves get 2 slabs, some 3: ragged ring drain), 64 x 32 wave tiles; the dense layer is the GEMV
+    whose chunk sums are finished by the last block to arrive.  Any block order must give the same bits."""
+    eb.set_block_order(order)
+    try:
+        cfg = EncoderConfig((16, 16, 3), [32, 64], [2, 2], 5, 128)
+        labels = _run(cfg, 3, 1, wavek=1, options={'wavek_waves': waves, 'wavek_depth': depth})
+        assert 'conv_wavek_f32_64x32_w%d_d%d_g%d ' % (waves, depth, 3 if waves == 4 else 1) in labels[1], labels
+        assert labels[-1].startswith('dense:dense_gemv_f32_ticket') and len(labels) == 3, labels
+    finally:
+        eb.set_block_order(0)
+
+
+def test_wave_split_k_results_do_not_depend_on_block_arrival_order():
+    cfg = EncoderConfig((16, 16, 3), [32, 64], [2, 2], 5, 128, True)
+    w = synth.make_weights(seed=3, shape=cfg.shape, num_filter=cfg.num_filter, strides=cfg.strides, latent=128, batch_norm=True)
+    x = synth.make_crops(2, seed=4, shape=cfg.shape)
+    outs = []
+    for order in (0, 1, 2):
+        eb.set_block_order(order)
+        try:
+            enc = eb.EmuEncoder(w, cfg)
+            z = enc.forward(x)
+            outs.append((z.copy(), enc.activation(1)))
+            assert any('wavek' in l for l in enc.labels()) and enc.labels()[-1].startswith('dense:dense_gemv_f32_ticket')
+            enc.close()
+        finally:
+            eb.set_block_order(0)
+    for z, a in outs[1:]:
+        assert np.array_equal(z, outs[0][0]) and np.array_equal(a, outs[0][1])
+
+
+@pytest.mark.parametrize('narrow', [0, 16])
+def test_wave_split_k_igemm_wide_tiles_several_m_tiles_and_dense(narrow):
+    """conv2: M = 5*8*8 = 320 rows = 5 M tiles of 64 (no partial), N = 64, 25 slabs; narrow = 0 forces 64 x 64 wave
+    tiles (5 tiles, K split over 5 blocks x 4 waves -> waves with a single slab), 16 keeps the 64 x 32 form.
+    B = 5 > 4: the dense layer (M = 5, K = 4096 = 128 slabs) also runs on the wave-split-K kernel."""
+    cfg = EncoderConfig((32, 32, 3), [32, 64], [2, 2], 5, 128, True)
+    labels = _run(cfg, 5, 61, wavek=1, options={'wavek_narrow_max_tiles': narrow})
+    assert ('conv_wavek_f32_64x64' if narrow == 0 else 'conv_wavek_f32_64x32') in labels[1], labels
+    assert labels[2].startswith('dense:conv_wavek_f32_64x') and len(labels) == 3, labels
+
+
+def test_wave_split_k_without_cross_block_split_and_with_cout_padding():
+    """96 output channels (CoutPad 128: the second 64-column tile is half padding) and a 3 x 3 kernel: 9 slabs are
+    too few to split across blocks (gsplits == 1) -- the epilogue runs straight from the LDS sum, no tickets."""
+    cfg = EncoderConfig((32, 32, 3), [32, 96], [2, 1], 3, 64)
+    labels = _run(cfg, 2, 71, wavek=1, options={'wavek_narrow_max_tiles': 0})
+    assert 'conv_wavek_f32_64x64' in labels[1] and '_g1 ' in labels[1], labels

@@ -631,3 +631,94 @@ def test_upright_search_uses_the_compacted_copy_and_follows_updates():
                 plain, _ = cb.nn(z, 1, 1)
                 assert np.array_equal(plain[:, 0].cpu().numpy(), np.argmax(cs, axis=1))
         cb.close()
+
+
+# ---- small batches: the reference's one-crop-per-detection usage (m3_interface/ae_pose_estimator.py:143-170) ----
+@pytest.mark.parametrize('B', [1, 2, 3, 4, 7])
+def test_small_batch_wave_split_k_path_matches_fp64_oracle(default_model, B):
+    """B <= 4: conv2..conv4 on the wave-split-K igemm (in-launch ticketed K reduction), dense as the ticketed GEMV:
+    five encoder launches, one scan launch.  Every layer, the latents, the similarity and the indices against the
+    fp64 oracle; B = 7 mixes both kernel families (conv2 on the 128 x 128 split-K path)."""
+    weights, enc, cb, E, _ = default_model
+    crops = synth.make_crops(B, seed=2000 + B)
+    z, recs = enc.engine.encode_timed(crops)
+    labels = [l for l, _, _ in recs]
+    if B <= 4:
+        assert len(labels) == 5 and labels[0].startswith('conv1:conv_first_f32') and labels[4].startswith('dense:dense_gemv_f32_ticket'), labels
+        assert all(':conv_wavek_f32_' in l for l in labels[1:4]), labels
+    else:
+        assert any(':conv_wavek_f32_' in l for l in labels) and any('splitk' in l for l in labels), labels
+    z64, acts = ref.encoder_forward_torch(ref.input_to_float(crops), weights, STRIDES, False, 'float64', return_activations=True)
+    for i, a in enumerate(acts):
+        g = enc.engine.activation(i).cpu().numpy()
+        err = np.abs(g - a).max() / np.abs(a).max()
+        assert err < 2e-5, 'layer %d rel err %.3e (%s)' % (i, err, labels)
+    assert np.abs(z.cpu().numpy() - z64).max() / np.abs(z64).max() < 2e-5
+    cs64 = ref.cos_similarity(z64, E)
+    cs = cb.engine.similarity(z).cpu().numpy()
+    assert np.abs(cs - cs64).max() <= COS_TOL
+    idx, score = cb.engine.nn(z, 1, 1)
+    _check_indices(idx[:, 0].cpu().numpy(), cs64)
+    assert np.array_equal(idx[:, 0].cpu().numpy(), np.argmax(cs, axis=1))
+    assert np.abs(score[:, 0].cpu().numpy() - cs64.max(axis=1)).max() <= COS_TOL
+
+
+def test_in_launch_ticketed_reductions_are_race_free_and_order_independent():
+    """The cross-block hand-offs (block_ticket_arrive: conv_wavek partial tiles, GEMV chunk rows, scan block partials)
+    sum in fixed orders whichever block arrives last, so every repeat must give the same bits -- quiet, with the
+    workspace (ticket words included) overwritten by random bytes between calls, and while a second stream
+    saturates HBM with copies.  The scan's one-launch form must equal the two-launch form (separate arg-max reduce)
+    bit for bit, exact ties included; the encoder must stay within rounding of the split-K kernels."""
+    import torch
+    from augmentedautoencoder_amd import _lib
+    from augmentedautoencoder_amd.engine import CodebookEngine, EncoderEngine
+    from augmentedautoencoder_amd.weights import EncoderConfig
+    enc = EncoderEngine(EncoderConfig(), synth.make_weights(seed=2024))
+    E = synth.make_codebook(92232, 128, seed=7, planted_duplicates=64)
+    cb = CodebookEngine(E)
+    dup = [r for r in range(35, E.shape[0], 36) if np.array_equal(E[r], E[r - 35])][:2]
+    side = torch.cuda.Stream()
+    big_a = torch.empty(512 << 20, dtype=torch.uint8, device='cuda')
+    big_b = torch.zeros(512 << 20, dtype=torch.uint8, device='cuda')
+    gen = torch.Generator(device='cuda')
+    gen.manual_seed(1)
+    for B in (1, 2, 4, 6):
+        x = torch.from_numpy(synth.make_crops(B, seed=2100 + B)).cuda()
+        z0 = enc.encode(x).clone()
+        for name in ('wavek', 'gemv_ticket', 'wavek_dense'):
+            enc.set_option(name, 0)
+        z_old = enc.encode(x).clone()
+        for name in ('wavek', 'gemv_ticket', 'wavek_dense'):
+            enc.set_option(name, 1)
+        assert float((z0 - z_old).abs().max() / z_old.abs().max()) < 1e-5
+        zq = z0.clone()
+        zq[0] = torch.from_numpy(E[dup[0]] * 2.5).cuda()              # exact tie: the lower twin must win in both forms
+        cb.set_scan_mode(_lib.AAE_SCAN_STREAM_2L if B <= 4 else _lib.AAE_SCAN_AUTO)
+        i2, s2 = cb.nn(zq, 1, 1)
+        i2, s2 = i2.clone(), s2.clone()
+        cb.set_scan_mode(_lib.AAE_SCAN_AUTO)
+        assert int(i2[0, 0]) == dup[0] - 35
+        for rep in range(60):
+            if rep % 3 == 1:                                           # garbage in the workspaces, ticket words included
+                for ws in (enc.ws, cb.ws):
+                    ws.buf.copy_(torch.randint(0, 256, ws.buf.shape, dtype=torch.uint8, device='cuda', generator=gen))
+            if rep == 30:
+                with torch.cuda.stream(side):
+                    for _ in range(40):
+                        big_a.copy_(big_b)
+            assert torch.equal(enc.encode(x), z0), (B, rep)
+            i1, s1 = cb.nn(zq, 1, 1)
+            assert torch.equal(i1, i2) and torch.equal(s1, s2), (B, rep)
+        torch.cuda.synchronize()
+    # wave-count / prefetch-depth variants of the kernel: same K ranges per block are summed in a different wave split,
+    # so only rounding-level differences are allowed
+    x = torch.from_numpy(synth.make_crops(3, seed=9)).cuda()
+    z_ref = enc.encode(x).clone()
+    for waves, depth in ((4, 2), (8, 2)):
+        enc.set_option('wavek_waves', waves)
+        enc.set_option('wavek_depth', depth)
+        zv = enc.encode(x)
+        assert float((zv - z_ref).abs().max() / z_ref.abs().max()) < 1e-5, (waves, depth)
+        assert torch.equal(enc.encode(x), zv)
+    enc.close()
+    cb.close()
