@@ -104,7 +104,7 @@ class Codebook(object):
         return self.engine.similarity(self._encode(self._encoder._feed(feed))).cpu().numpy()
 
     def _run_argmax(self, feed):
-        idx, _ = self.engine.nn(self._encode(self._encoder._feed(feed)), 1, 1)
+        _, idx, _ = self._encoder.engine.encode_nn(self.engine, self._prep(self._encoder._feed(feed)), 1)
         return idx[:, 0].cpu().numpy()
 
     def _run_query(self, feed, normalized):
@@ -116,12 +116,13 @@ class Codebook(object):
     # ---- reference API -----------------------------------------------------------
     def nearest_rotation(self, session, x, top_n=1, upright=False, return_idcs=False):
         """R_model2cam of the nearest codebook entries (codebook.py:55-75)."""
-        z = self._encode(x)
         if top_n == 1:
+            # encoder + scan in one C call (aae_encode_nn): per detection that is six launches
             stride = int(self._dataset._kw['num_cyclo']) if upright else 1
-            idx, _ = self.engine.nn(z, 1, stride)
+            _, idx, _ = self._encoder.engine.encode_nn(self.engine, self._prep(x), stride)
             idcs = idx[:, 0].cpu().numpy()
         else:
+            z = self._encode(x)
             if z.shape[0] != 1:
                 # the reference squeezes the [B,N] similarity (codebook.py:70): only B == 1 is meaningful
                 raise ValueError('top_n > 1 needs a single crop (got a batch of %d)' % z.shape[0])

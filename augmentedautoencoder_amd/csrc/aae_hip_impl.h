@@ -125,6 +125,9 @@ struct aae_encoder {
     int wavek_waves = 4;                   // waves per block (4 | 8), each with its own K range
     int wavek_depth = 3;                   // slabs of fragments in flight per wave (2 | 3)
     int wavek_narrow_max_tiles = 16;       // <= this many 64 x 64 tiles: 64 x 32 wave tiles (twice the tiles, half the splits to add up)
+    long long* wavek_timeline = nullptr;   // device [3 layers][512 blocks][8] phase stamps when option wavek_timeline is on (profiling tools)
+    int ticket_prep = 1;                   // conv1 installs the nonces of the later ticketed launches of its forward call (0: every launch installs its own)
+    int wavek_ablate = 0;                  // timing experiments (conv_wavek_f32.h ConvWaveKArgs::ablate); results are wrong when != 0
     int gemv_ticket = 1;                   // dense GEMV (B <= 4): chunk sums finished by the last block instead of a reduce launch
     int wavek_dense = 1;                   // dense layer (B > 4) on the wave-split-K kernel instead of split-K igemm + reduce launch
 };
@@ -138,7 +141,11 @@ struct aae_codebook {
     // aae_codebook_prepare_upright; the scan then runs over N/k rows and the winning row id is scaled by k
     aae_codebook* upright = nullptr;
     int upright_stride = 0;
-    int scan_ticket = 1;   // B <= 4 top-1: arg-max over the block partials inside the scan launch (0: separate argmax_reduce launch)
+    // B <= 4, top-1 on a stream kernel: arg-max over the block partials inside the scan launch (last block to arrive)
+    // instead of a separate argmax_reduce launch.  0: never (AAE_SCAN_STREAM_2L); 1: when the ticket words were prepared
+    // by the encoder's first kernel (aae_encode_nn) -- unprepared, the install path makes the single launch slower
+    // (19 us) than the two launches (15 us); 2: always (AAE_SCAN_STREAM)
+    int scan_ticket = 1;
 };
 
 namespace aae_host {
@@ -275,7 +282,13 @@ static unsigned next_nonce() {
     return n;
 }
 
-constexpr size_t kTicketBytes = 4096;      // 512 ticket words at the front of every workspace (layers reuse them: launches are stream-ordered)
+// Ticket words at the front of every encoder workspace: a range of single words per layer (conv layers 0..7, then
+// the dense layer) for the wave-split-K tiles, then one two-level slot per 128-column tile of the dense GEMV.  Every
+// ticketed launch has its own words, so the first kernel of a forward can prepare all of them (TicketPrep).
+constexpr int kGemvTicketSlots = 8;
+constexpr int kLayerTicketWords = 256;     // per layer: one word per output tile of a split layer (split => at most 128 tiles)
+constexpr size_t kConvTicketBytes = (size_t)(AAE_MAX_LAYERS + 1) * kLayerTicketWords * 8;
+constexpr size_t kTicketBytes = kConvTicketBytes + (size_t)kGemvTicketSlots * aae::kTicketSlotWords * 8;
 
 // Launch plan of the wave-split-K igemm (conv_wavek_f32.h) for a layer at M rows, or use == false.
 struct WaveKPlan {
@@ -303,6 +316,7 @@ static WaveKPlan plan_wavek(const aae_encoder* enc, const Layer& L, long long M)
     int g = 256 / tiles;                                   // one block per CU; never a second round of blocks
     const int gmax = slabs / (2 * w.waves);                // every wave keeps at least two slabs
     if (g > gmax) g = gmax;
+    if (g > (int)aae::kTicketSingleLevelMax) g = (int)aae::kTicketSingleLevelMax;   // one ticket word per tile
     if (g < 1) g = 1;
     w.gsplits = g;
     if (g > 1) w.partial_bytes = (size_t)tiles * g * (w.MT * w.NT * 16) * 64 * sizeof(float);
@@ -464,12 +478,13 @@ static void launch_wavek_t(const aae::ConvWaveKArgs& a, int tag, int nblk, hipSt
 }
 
 static int launch_wavek(aae_encoder* enc, const Layer& L, const WaveKPlan& w, const float* x, int M, float* out, float* partial,
-                        unsigned long long* tickets, hipStream_t stream, Timer& tm, const char* name, int tag) {
+                        unsigned long long* tickets, unsigned nonce, hipStream_t stream, Timer& tm, const char* name, int tag) {
     aae::ConvWaveKArgs a;
     a.x = x; a.wp = L.wp; a.bias = L.bias; a.bn_scale = L.bn_scale; a.bn_shift = L.bn_shift; a.out = out;
-    a.partial = partial; a.tickets = tickets; a.nonce = next_nonce();
+    a.partial = partial; a.partial_bytes = (unsigned)w.partial_bytes; a.tickets = tickets; a.nonce = nonce;
     a.H = L.H; a.W = L.W; a.Cin = L.Cin; a.Ho = L.Ho; a.Wo = L.Wo; a.Cout = L.Cout; a.CoutPad = L.CoutPad;
-    a.KS = L.KS; a.S = L.S; a.pt = L.pt; a.pl = L.pl; a.M = M; a.relu = L.relu;
+    a.KS = L.KS; a.S = L.S; a.pt = L.pt; a.pl = L.pl; a.M = M; a.relu = L.relu; a.ablate = enc->wavek_ablate;
+    a.timeline = (enc->wavek_timeline && tag >= 1 && tag <= 3) ? enc->wavek_timeline + (size_t)(tag - 1) * 512 * 8 : nullptr;
     a.x_bytes = (unsigned)((unsigned long long)(M / (L.Ho * L.Wo)) * L.H * L.W * L.Cin * sizeof(float));
     a.slabs_total = (int)(L.K() / 32);
     a.wp_bytes = (unsigned)((unsigned long long)a.slabs_total * 8ull * L.CoutPad * 16ull);
@@ -584,8 +599,10 @@ static void launch_first_t(const aae::ConvFirstArgs& a, bool u8, bool planes, di
 }
 
 static int launch_first(aae_encoder* enc, const Layer& L, const void* x, bool u8, int B, float* out, bool planes,
-                        hipStream_t stream, Timer& tm) {
+                        hipStream_t stream, Timer& tm, const aae::TicketPrep* prep = nullptr) {
     aae::ConvFirstArgs a;
+    if (prep) a.prep = *prep;
+    else a.prep.n = 0;
     a.x = x; a.lut = enc->lut; a.w = L.w_hwio; a.bias = L.bias; a.bn_scale = L.bn_scale; a.bn_shift = L.bn_shift;
     a.out = out; a.H = L.H; a.W = L.W; a.Ho = L.Ho; a.Wo = L.Wo; a.Cout = L.Cout;
     a.S = L.S; a.pt = L.pt; a.pl = L.pl; a.relu = L.relu;
@@ -599,7 +616,7 @@ static int launch_first(aae_encoder* enc, const Layer& L, const void* x, bool u8
     if (tpb < 1) tpb = 1;
     if (tpb > enc->first_max_tiles_per_block) tpb = enc->first_max_tiles_per_block;
     a.tiles_per_block = tpb;
-    const dim3 grid(ceil_div(a.total_tiles, tpb), ceil_div(L.Cout, 128));
+    const dim3 grid(ceil_div(a.total_tiles, tpb) + (a.prep.n > 0 ? 1 : 0), ceil_div(L.Cout, 128));    // + the ticket-preparation block
     if (L.Cin == 3) launch_first_t<5, 3>(a, u8, planes, grid, L.first_smem, stream);
     else launch_first_t<5, 1>(a, u8, planes, grid, L.first_smem, stream);
     char label[96];
@@ -628,8 +645,12 @@ static int launch_generic(aae_encoder* enc, const Layer& L, const void* x, bool 
 }
 
 // dense layer at B <= 4: weight-streaming GEMV + the fixed-order chunk reduction
+static bool gemv_uses_ticket(const aae_encoder* enc, const Layer& D) {
+    return enc->gemv_ticket && D.Cout % 4 == 0 && D.CoutPad / 128 <= kGemvTicketSlots;
+}
+
 static int launch_dense_gemv(aae_encoder* enc, const Layer& D, const float* x, int B, float* out, float* partial,
-                             unsigned long long* tickets, hipStream_t stream, Timer& tm) {
+                             unsigned long long* tickets, unsigned nonce, hipStream_t stream, Timer& tm) {
     aae::DenseGemvArgs a;
     a.x = x; a.wp = D.wp; a.partial = partial; a.B = B; a.K = (int)D.K(); a.Cout = D.Cout; a.CoutPad = D.CoutPad;
     a.wp_bytes = (unsigned)((unsigned long long)(D.K() / 4) * D.CoutPad * 16ull);
@@ -637,11 +658,13 @@ static int launch_dense_gemv(aae_encoder* enc, const Layer& D, const float* x, i
     const dim3 grid(chunks, D.CoutPad / 128);
     const int MQ = B <= 1 ? 1 : (B <= 2 ? 2 : 4);
     int smem = 2 * MQ * aae::kGemvChunk * (int)sizeof(float);
-    const bool ticket = enc->gemv_ticket && tickets && D.Cout % 4 == 0;
+    const bool ticket = tickets && gemv_uses_ticket(enc, D);
+    a.partial_bytes = (unsigned)((size_t)chunks * B * D.Cout * sizeof(float));
     char label[96];
     if (ticket) {
-        a.bias = D.bias; a.bn_scale = D.bn_scale; a.bn_shift = D.bn_shift; a.out = out; a.tickets = tickets;
-        a.nonce = next_nonce(); a.relu = D.relu;
+        a.bias = D.bias; a.bn_scale = D.bn_scale; a.bn_shift = D.bn_shift; a.out = out;
+        a.tickets = tickets;
+        a.nonce = nonce; a.relu = D.relu;
         if (smem < aae::kGemvTicketSmem) smem = aae::kGemvTicketSmem;
         if (MQ == 1) AAE_LAUNCH((aae::dense_gemv_f32_kernel<1, true>), grid, dim3(256), smem, stream, a);
         else if (MQ == 2) AAE_LAUNCH((aae::dense_gemv_f32_kernel<2, true>), grid, dim3(256), smem, stream, a);
@@ -668,8 +691,17 @@ static int launch_dense_gemv(aae_encoder* enc, const Layer& D, const float* x, i
     return tm.mark();
 }
 
+// One extra ticket range the first kernel of the forward prepares for a launch that FOLLOWS the encoder on the same
+// stream (the single-launch codebook scan of aae_encode_nn).
+struct ExtraTicketPrep {
+    unsigned long long* words = nullptr;
+    int count = 0;
+    unsigned nonce = 0;
+};
+
 static int forward_impl(aae_encoder* enc, const void* x, int x_dtype, int B, float* z_out, void* workspace,
-                        size_t ws_bytes, void* stream_v, Timer& tm) {
+                        size_t ws_bytes, void* stream_v, Timer& tm, const ExtraTicketPrep* extra = nullptr, bool* extra_prepared = nullptr) {
+    if (extra_prepared) *extra_prepared = false;
     if (!enc || !x || !z_out) return fail(AAE_ERR_INVALID, "aae_encoder_forward: null argument");
     if (B < 1) return fail(AAE_ERR_INVALID, "aae_encoder_forward: batch %d < 1", B);
     if (x_dtype != AAE_DTYPE_U8 && x_dtype != AAE_DTYPE_F32)
@@ -681,6 +713,8 @@ static int forward_impl(aae_encoder* enc, const void* x, int x_dtype, int B, flo
     unsigned char* base = static_cast<unsigned char*>(workspace);
     float* partial = reinterpret_cast<float*>(base + ws.partial_off);
     unsigned long long* tickets = reinterpret_cast<unsigned long long*>(base + ws.ticket_off);
+    unsigned long long* gemv_tickets = tickets + kConvTicketBytes / 8;
+    auto layer_tickets = [&](size_t li) { return tickets + li * kLayerTicketWords; };     // li == layers.size(): the dense layer
     RecordScope rec(enc);
     tm.stream = stream;
     if (int rc = tm.mark()) return rc;
@@ -703,29 +737,60 @@ static int forward_impl(aae_encoder* enc, const void* x, int x_dtype, int B, flo
         }
         return launch_igemm_x3h(enc, enc->dense, cur, B, z_out, true, partial, stream, tm, "dense");
     }
-    for (size_t li = 0; li < enc->layers.size(); ++li) {
+
+    // ---- plan every layer first: the ticketed launches get their nonces now, so that the first kernel can install them
+    const size_t nl = enc->layers.size();
+    const Layer& D = enc->dense;
+    std::vector<WaveKPlan> plans(nl + 1);
+    std::vector<unsigned> nonces(nl + 1, 0u);
+    for (size_t li = 0; li < nl; ++li) {
+        const Layer& L = enc->layers[li];
+        const bool first_mfma = li == 0 && L.kind == KIND_FIRST_MFMA;
+        if (!first_mfma && L.kind == KIND_IGEMM && !(li == 0 && cur_u8)) plans[li] = plan_wavek(enc, L, (long long)B * L.Ho * L.Wo);
+    }
+    const bool dense_gemv = D.kind == KIND_IGEMM && B <= 4 && enc->dense_gemv && D.K() % aae::kGemvChunk == 0;
+    const bool gemv_ticket = dense_gemv && gemv_uses_ticket(enc, D);
+    if (!dense_gemv && D.kind == KIND_IGEMM && enc->wavek_dense) plans[nl] = plan_wavek(enc, D, B);
+    aae::TicketPrep prep;
+    prep.n = 0;
+    auto add_prep = [&](unsigned long long* words, int count, unsigned nonce) {
+        if (prep.n < aae::kMaxTicketPrep) { prep.words[prep.n] = words; prep.count[prep.n] = count; prep.nonce[prep.n] = nonce; ++prep.n; }
+    };
+    for (size_t li = 0; li <= nl; ++li)
+        if (plans[li].use && plans[li].gsplits > 1) {
+            nonces[li] = next_nonce();
+            add_prep(layer_tickets(li), plans[li].num_mt * plans[li].num_nt, nonces[li]);
+        }
+    unsigned gemv_nonce = 0;
+    if (gemv_ticket) {
+        gemv_nonce = next_nonce();
+        add_prep(gemv_tickets, (D.CoutPad / 128) * aae::kTicketSlotWords, gemv_nonce);
+    }
+    if (extra && extra->words) add_prep(extra->words, extra->count, extra->nonce);
+    const bool can_prepare = enc->ticket_prep && enc->layers[0].kind == KIND_FIRST_MFMA && prep.n > 0;
+    if (extra_prepared) *extra_prepared = can_prepare && extra && extra->words;
+
+    for (size_t li = 0; li < nl; ++li) {
         const Layer& L = enc->layers[li];
         float* out = reinterpret_cast<float*>(base + ws.act_off[li]);
         char name[16];
         snprintf(name, sizeof(name), "conv%zu", li + 1);
         int rc;
-        if (li == 0 && L.kind == KIND_FIRST_MFMA) rc = launch_first(enc, L, cur, cur_u8, B, out, false, stream, tm);
+        if (li == 0 && L.kind == KIND_FIRST_MFMA) rc = launch_first(enc, L, cur, cur_u8, B, out, false, stream, tm, can_prepare ? &prep : nullptr);
         else if (L.kind == KIND_IGEMM && !cur_u8) {
-            const WaveKPlan wk = plan_wavek(enc, L, (long long)B * L.Ho * L.Wo);
-            if (wk.use) rc = launch_wavek(enc, L, wk, static_cast<const float*>(cur), B * L.Ho * L.Wo, out, partial, tickets, stream, tm, name, (int)li);
+            if (plans[li].use)
+                rc = launch_wavek(enc, L, plans[li], static_cast<const float*>(cur), B * L.Ho * L.Wo, out, partial, layer_tickets(li), nonces[li],
+                                  stream, tm, name, (int)li);
             else rc = launch_igemm(enc, L, static_cast<const float*>(cur), B * L.Ho * L.Wo, out, partial, stream, tm, name, (int)li);
         } else rc = launch_generic(enc, L, cur, cur_u8, B, out, stream, tm, name);
         if (rc) return rc;
         cur = out;
         cur_u8 = false;
     }
-    const Layer& D = enc->dense;
-    if (D.kind == KIND_IGEMM && B <= 4 && enc->dense_gemv && D.K() % aae::kGemvChunk == 0)
-        return launch_dense_gemv(enc, D, static_cast<const float*>(cur), B, z_out, partial, tickets, stream, tm);
-    if (D.kind == KIND_IGEMM && enc->wavek_dense) {
-        const WaveKPlan wk = plan_wavek(enc, D, B);
-        if (wk.use) return launch_wavek(enc, D, wk, static_cast<const float*>(cur), B, z_out, partial, tickets, stream, tm, "dense", 0);
-    }
+    if (dense_gemv)
+        return launch_dense_gemv(enc, D, static_cast<const float*>(cur), B, z_out, partial, gemv_ticket ? gemv_tickets : nullptr, gemv_nonce, stream, tm);
+    if (plans[nl].use)
+        return launch_wavek(enc, D, plans[nl], static_cast<const float*>(cur), B, z_out, partial, layer_tickets(nl), nonces[nl], stream, tm, "dense", 0);
     if (D.kind == KIND_IGEMM) return launch_igemm(enc, D, static_cast<const float*>(cur), B, z_out, partial, stream, tm, "dense");
     return launch_generic(enc, D, cur, false, B, z_out, stream, tm, "dense");
 }
@@ -744,6 +809,7 @@ struct ScanTicketOut {
     int64_t* idx_out = nullptr;
     float* score_out = nullptr;
     int idx_scale = 1;
+    unsigned nonce = 0;            // != 0: the ticket words were prepared with this nonce by an earlier kernel on the stream
 };
 
 static ScanPlan plan_scan(const aae_codebook* cb, int B, int topk) {
@@ -777,7 +843,7 @@ static ScanPlan plan_scan(const aae_codebook* cb, int B, int topk) {
         s.resident_ok = s.res_blocks <= s.nblk;          // the partial buffers are sized for nblk row blocks
     }
     size_t off = 0;
-    s.ticket_off = off; off += 256;                        // block_ticket_arrive word of the single-launch stream scan
+    s.ticket_off = off; off += align_up((size_t)aae::kTicketSlotWords * 8, 256);   // block_ticket_arrive words of the single-launch stream scan
     s.q_off = off;    off += align_up((size_t)B * cb->J * sizeof(float), 256);
     s.qp_off = off;   off += align_up((size_t)s.Jpad * s.Bpad * 6, 256);   // fp32 packing: 4 B/elem; bf16: 3 terms x 2 B
     s.pval_off = off; off += align_up((size_t)s.nblk * s.Bstride * sizeof(float), 256);
@@ -845,7 +911,7 @@ static int run_scan(aae_codebook* cb, const float* z, int B, int col_stride, flo
         a.N = cb->N; a.J = cb->J; a.Jpad = s.Jpad; a.B = B; a.Bpad = s.Bpad; a.Bstride = s.Bstride;
         a.col_stride = col_stride;
         if (fin) {
-            a.tickets = reinterpret_cast<unsigned long long*>(base + s.ticket_off); a.nonce = next_nonce();
+            a.tickets = reinterpret_cast<unsigned long long*>(base + s.ticket_off); a.nonce = fin->nonce ? fin->nonce : next_nonce();
             a.idx_out = reinterpret_cast<long long*>(fin->idx_out); a.score_out = fin->score_out; a.idx_scale = fin->idx_scale;
         }
         const bool up = col_stride > 1;
@@ -903,7 +969,7 @@ static int run_scan(aae_codebook* cb, const float* z, int B, int col_stride, flo
     a.N = cb->N; a.J = cb->J; a.Jpad = s.Jpad; a.B = B; a.Bpad = s.Bpad; a.Bstride = s.Bstride;
     a.col_stride = col_stride;
     if (fin && s.stream) {
-        a.tickets = reinterpret_cast<unsigned long long*>(base + s.ticket_off); a.nonce = next_nonce();
+        a.tickets = reinterpret_cast<unsigned long long*>(base + s.ticket_off); a.nonce = fin->nonce ? fin->nonce : next_nonce();
         a.idx_out = reinterpret_cast<long long*>(fin->idx_out); a.score_out = fin->score_out; a.idx_scale = fin->idx_scale;
     }
     const bool upright = col_stride > 1;
@@ -1074,6 +1140,17 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
     else if (!strcmp(name, "gemv_ticket")) enc->gemv_ticket = value ? 1 : 0;
     else if (!strcmp(name, "wavek")) enc->wavek = value ? 1 : 0;
     else if (!strcmp(name, "wavek_dense")) enc->wavek_dense = value ? 1 : 0;
+    else if (!strcmp(name, "wavek_ablate")) enc->wavek_ablate = value;
+    else if (!strcmp(name, "ticket_prep")) enc->ticket_prep = value ? 1 : 0;
+    else if (!strcmp(name, "wavek_timeline")) {
+        if (value && !enc->wavek_timeline) {
+            void* p = nullptr;
+            AAE_HIP_TRY(hipMalloc(&p, 3 * 512 * 8 * sizeof(long long)));
+            enc->allocations.push_back(p);
+            enc->wavek_timeline = static_cast<long long*>(p);
+        }
+        if (!value) enc->wavek_timeline = nullptr;     // (the buffer stays in `allocations` until the handle goes)
+    }
     else if (!strcmp(name, "wavek_max_tiles")) enc->wavek_max_tiles = value < 0 ? 0 : (value > 512 ? 512 : value);
     else if (!strcmp(name, "wavek_narrow_max_tiles")) enc->wavek_narrow_max_tiles = value < 0 ? 0 : value;
     else if (!strcmp(name, "wavek_waves")) {
@@ -1149,6 +1226,15 @@ const char* aae_encoder_kernel_label(const aae_encoder* enc, int i) {
 double aae_encoder_kernel_flops(const aae_encoder* enc, int i) {
     if (!enc || i < 0 || i >= (int)enc->records.size()) return 0.0;
     return enc->records[i].flops;
+}
+
+int aae_encoder_debug_timeline(aae_encoder* enc, long long* host_out) {
+    using namespace aae_host;
+    if (!enc || !host_out) return fail(AAE_ERR_INVALID, "aae_encoder_debug_timeline: null argument");
+    if (!enc->wavek_timeline) return fail(AAE_ERR_INVALID, "aae_encoder_debug_timeline: option wavek_timeline is off");
+    AAE_HIP_TRY(hipDeviceSynchronize());
+    AAE_HIP_TRY(hipMemcpy(host_out, enc->wavek_timeline, 3 * 512 * 8 * sizeof(long long), hipMemcpyDeviceToHost));
+    return AAE_OK;
 }
 
 int aae_encoder_activation_info(const aae_encoder* enc, int B, int layer, size_t* offset_bytes, size_t* count) {
@@ -1241,7 +1327,7 @@ int aae_codebook_set_scan_mode(aae_codebook* cb, int mode) {
     if (!cb) return fail(AAE_ERR_INVALID, "aae_codebook_set_scan_mode: null handle");
     if (mode != AAE_SCAN_AUTO && mode != AAE_SCAN_GEMV && mode != AAE_SCAN_MFMA && mode != AAE_SCAN_STREAM && mode != AAE_SCAN_STREAM_2L)
         return fail(AAE_ERR_INVALID, "scan mode %d", mode);
-    cb->scan_ticket = mode == AAE_SCAN_STREAM_2L ? 0 : 1;
+    cb->scan_ticket = mode == AAE_SCAN_STREAM_2L ? 0 : (mode == AAE_SCAN_STREAM ? 2 : 1);
     cb->scan_mode = mode == AAE_SCAN_STREAM_2L ? AAE_SCAN_STREAM : mode;
     if (cb->upright) { cb->upright->scan_mode = cb->scan_mode; cb->upright->scan_ticket = cb->scan_ticket; }
     return AAE_OK;
@@ -1252,8 +1338,9 @@ size_t aae_codebook_workspace_bytes(const aae_codebook* cb, int B, int topk) {
     return aae_host::plan_scan(cb, B, topk).total;
 }
 
-int aae_codebook_nn(aae_codebook* cb, const float* z, int B, int topk, int col_stride, int64_t* idx_out,
-                    float* score_out, void* workspace, size_t ws_bytes, void* stream_v) {
+// prepared_nonce != 0: the scan's ticket words (front of `workspace`) carry this nonce already
+static int nn_impl(aae_codebook* cb, const float* z, int B, int topk, int col_stride, int64_t* idx_out,
+                   float* score_out, void* workspace, size_t ws_bytes, void* stream_v, unsigned prepared_nonce) {
     using namespace aae_host;
     if (!cb || !z || !idx_out || !score_out) return fail(AAE_ERR_INVALID, "aae_codebook_nn: null argument");
     if (B < 1 || topk < 1 || topk > cb->N) return fail(AAE_ERR_INVALID, "aae_codebook_nn: B=%d topk=%d N=%d", B, topk, cb->N);
@@ -1279,8 +1366,8 @@ int aae_codebook_nn(aae_codebook* cb, const float* z, int B, int topk, int col_s
     int partial_rows = s.nblk;
     // B <= 4, top-1 on a stream kernel: the last block to arrive merges the block partials -- the query is one launch
     ScanTicketOut fin;
-    fin.idx_out = idx_out; fin.score_out = score_out; fin.idx_scale = idx_scale;
-    const bool one_launch = topk == 1 && s.stream && cb->scan_ticket;
+    fin.idx_out = idx_out; fin.score_out = score_out; fin.idx_scale = idx_scale; fin.nonce = prepared_nonce;
+    const bool one_launch = topk == 1 && s.stream && (cb->scan_ticket == 2 || (cb->scan_ticket == 1 && prepared_nonce != 0));
     if (int rc = run_scan(cb, z, B, col_stride, cs, s, base, stream, &partial_rows, one_launch ? &fin : nullptr)) return rc;
     if (one_launch) return AAE_OK;
     if (topk == 1) {
@@ -1301,6 +1388,34 @@ int aae_codebook_nn(aae_codebook* cb, const float* z, int B, int topk, int col_s
     }
     AAE_HIP_TRY(hipGetLastError());
     return AAE_OK;
+}
+
+int aae_codebook_nn(aae_codebook* cb, const float* z, int B, int topk, int col_stride, int64_t* idx_out,
+                    float* score_out, void* workspace, size_t ws_bytes, void* stream) {
+    return nn_impl(cb, z, B, topk, col_stride, idx_out, score_out, workspace, ws_bytes, stream, 0u);
+}
+
+int aae_encode_nn(aae_encoder* enc, aae_codebook* cb, const void* x, int x_dtype, int B, int col_stride, float* z_out,
+                  int64_t* idx_out, float* score_out, void* enc_workspace, size_t enc_ws_bytes, void* cb_workspace,
+                  size_t cb_ws_bytes, void* stream) {
+    using namespace aae_host;
+    if (!enc || !cb) return fail(AAE_ERR_INVALID, "aae_encode_nn: null handle");
+    if (col_stride < 1) return fail(AAE_ERR_INVALID, "col_stride %d < 1", col_stride);
+    if (!cb_workspace || ((uintptr_t)cb_workspace & 255)) return fail(AAE_ERR_WORKSPACE, "workspace must be non-null and 256-B aligned");
+    if (B >= 1 && cb_ws_bytes < plan_scan(cb, B, 1).total) return fail(AAE_ERR_WORKSPACE, "codebook workspace %zu B too small", cb_ws_bytes);
+    // B <= 4: the scan finishes inside its own launch; its ticket words sit at the front of the codebook workspace and
+    // are prepared by the encoder's first kernel, several launches ahead on the same stream
+    const aae_codebook* eff = (col_stride > 1 && cb->upright && cb->upright_stride == col_stride) ? cb->upright : cb;
+    ExtraTicketPrep extra;
+    if (B >= 1 && eff->scan_ticket >= 1 && plan_scan(eff, B, 1).stream) {
+        extra.words = reinterpret_cast<unsigned long long*>(static_cast<unsigned char*>(cb_workspace) + plan_scan(eff, B, 1).ticket_off);
+        extra.count = aae::kTicketSlotWords;
+        extra.nonce = next_nonce();
+    }
+    bool prepared = false;
+    Timer tm;
+    if (int rc = forward_impl(enc, x, x_dtype, B, z_out, enc_workspace, enc_ws_bytes, stream, tm, extra.words ? &extra : nullptr, &prepared)) return rc;
+    return nn_impl(cb, z_out, B, 1, col_stride, idx_out, score_out, cb_workspace, cb_ws_bytes, stream, prepared ? extra.nonce : 0u);
 }
 
 int aae_codebook_similarity(aae_codebook* cb, const float* z, int B, float* cs_out, void* workspace, size_t ws_bytes,

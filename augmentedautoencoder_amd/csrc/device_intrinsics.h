@@ -129,39 +129,103 @@ __device__ __forceinline__ void sleep_kcycles(int n) {
     for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(16);
 }
 
-// "The last block to arrive finishes the job": cross-block hand-off inside ONE launch, so that a split reduction
-// needs no second kernel.  Every thread of the block calls this after its global stores of the block's partial
-// result; it returns true -- in every thread -- for exactly one block: the last of `total` arrivals at `word`
-// in the launch identified by `nonce` (unique per launch, never 0).  That block may then read all partials.
-//   word = nonce << 32 | arrivals so far.  A word that carries another nonce (a launch that died half-way,
-//   memory that was never initialised) counts as empty, and the last arriver leaves the word at 0, so a
-//   workspace is ready for the next launch without any memset between kernels.
-// Memory model: each thread's __threadfence() (agent-scope release: stores complete + L2 write-back) precedes the
-// block barrier, which precedes thread 0's atomic; the winner's threads fence again (acquire: cache invalidate)
-// before they touch the other blocks' partials.
-__device__ __forceinline__ bool block_ticket_arrive(unsigned long long* word, unsigned nonce, unsigned total, int* lds_flag) {
-    __threadfence();
+// ---- cross-block hand-off inside ONE launch ("the last block to arrive finishes the job") -------------------------
+// A split reduction then needs no second kernel.  Measured on MI355X (tools/ubench/sync_cost.hip, 721 blocks, one
+// launch 3.3 us): agent-scope __threadfence() in every thread +44 us (an L2 write-back per block, serialised); a CAS
+// loop on one word 1.7 ms; sc1 stores + fetch-add on one word +7 us; sc1 stores + two-level fetch-add +0.0 us.  So:
+//   * partials that cross blocks are written with sc1 (device-scope, write-through) stores and read back with sc1
+//     loads -- the instructions the compiler emits for agent-scope relaxed atomics, here in their 4/16-B buffer form,
+//     which unlike atomic loads can be kept in flight by the dozen.  No L2 write-back or invalidate is ever issued;
+//   * a block arrives with ONE fetch-add; above 32 arrivals the blocks first meet in 16 group words (128 B apart:
+//     different channels) and the last of each group arrives at the top word.
+// Ticket word = nonce << 32 | arrivals.  The nonce is unique per launch (never 0).  An arrival whose fetch-add
+// returns another nonce met a foreign state -- a clean word (0), memory that was never initialised, the remains of
+// a launch that died -- and installs (nonce, 1) by compare-and-swap (or, if another arrival got there first, adds
+// again); adds that landed on a foreign state are discarded with it and each of those arrivals counts itself once
+// more, so every block is counted exactly once.
+// The last arriver leaves the word at 0.  A workspace therefore needs no memset, neither at first use nor between
+// launches.
+constexpr int kCoherent = 16;            // cache-policy bit sc1 (gfx940+): device scope
+__device__ __forceinline__ void coherent_store4(buffer_rsrc r, uint32_t byte_off, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)byte_off, 0, kCoherent);
+}
+__device__ __forceinline__ f32x4 coherent_load4(buffer_rsrc r, uint32_t byte_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, kCoherent));
+}
+__device__ __forceinline__ void coherent_store1(buffer_rsrc r, uint32_t byte_off, uint32_t v) {
+    __builtin_amdgcn_raw_buffer_store_b32(v, r, (int)byte_off, 0, kCoherent);
+}
+__device__ __forceinline__ uint32_t coherent_load1(buffer_rsrc r, uint32_t byte_off) {
+    return __builtin_amdgcn_raw_buffer_load_b32(r, (int)byte_off, 0, kCoherent);
+}
+
+constexpr int kTicketGroups = 16;
+constexpr int kTicketGroupStride = 16;                         // 64-bit words between group words: 128 B
+constexpr int kTicketSlotWords = (1 + kTicketGroups) * kTicketGroupStride;   // top word + 16 group words
+constexpr unsigned kTicketSingleLevelMax = 32;
+
+// arrivals at `word` in launch `nonce`, this one included
+__device__ __forceinline__ unsigned ticket_count(unsigned long long* word, unsigned nonce) {
+    const unsigned long long old = __hip_atomic_fetch_add(word, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((unsigned)(old >> 32) == nonce) return (unsigned)old + 1u;         // the common case: one atomic
+    // Foreign state.  From here on this arrival never adds to a foreign word again (arrivals that kept adding would
+    // make every compare-and-swap of every other arrival fail: a livelock with ~40 blocks arriving together): it
+    // either installs (nonce, 1) itself -- discarding the adds that landed on the foreign value, its own included --
+    // or, once somebody else has installed the nonce, takes its number with a fetch-add.
+    unsigned long long cur = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int spin = 0;; ++spin) {
+        if ((unsigned)(cur >> 32) == nonce)
+            return (unsigned)__hip_atomic_fetch_add(word, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        if (__hip_atomic_compare_exchange_strong(word, &cur, ((unsigned long long)nonce << 32) | 1ull, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT))
+            return 1u;
+        if (spin > (1 << 16)) __builtin_trap();        // cannot happen (every failed swap means another arrival made progress); never hang the device
+    }
+}
+__device__ __forceinline__ void ticket_clear(unsigned long long* word) {
+    __hip_atomic_store(word, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Every thread of the block calls this after its coherent_store*() of the block's partial result; it returns true
+// -- in every thread -- for exactly one block: the last of `total` arrivals (this block is arrival `id`, any unique
+// number < total, used only to spread the blocks over the group words).  `words`: kTicketSlotWords words when
+// total > kTicketSingleLevelMax, one word otherwise.  The winning block may then coherent_load*() all partials.
+// Ordering: each thread waits for its own stores (vmcnt(0): an sc1 store is acknowledged once it is visible at device
+// scope), then the block barrier, then thread 0's atomic; the winner's loads are issued after the second barrier.
+// first half: this block's coherent stores are complete and every thread knows it
+__device__ __forceinline__ void block_ticket_publish() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+}
+// second half: take the ticket
+__device__ __forceinline__ bool block_ticket_take(unsigned long long* words, unsigned nonce, unsigned total, unsigned id, int* lds_flag) {
     if (threadIdx.x == 0) {
-        unsigned long long seen = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        bool last;
-        for (;;) {
-            const unsigned count = ((unsigned)(seen >> 32) == nonce) ? (unsigned)seen : 0u;
-            last = count + 1 == total;
-            const unsigned long long want = last ? 0ull : (((unsigned long long)nonce << 32) | (count + 1));
-            const unsigned long long prev = atomicCAS(word, seen, want);
-            if (prev == seen) break;
-            seen = prev;
+        bool last = false;
+        if (total <= kTicketSingleLevelMax) {
+            last = ticket_count(words, nonce) == total;
+            if (last) ticket_clear(words);
+        } else {
+            const unsigned g = id % kTicketGroups, members = (total - g + kTicketGroups - 1) / kTicketGroups;
+            unsigned long long* gw = words + (1 + g) * kTicketGroupStride;
+            if (ticket_count(gw, nonce) == members) {
+                ticket_clear(gw);
+                last = ticket_count(words, nonce) == (unsigned)kTicketGroups;
+                if (last) ticket_clear(words);
+            }
         }
         *lds_flag = last ? 1 : 0;
     }
     __syncthreads();
-    const bool last = *lds_flag != 0;
-    if (last) __threadfence();
-    return last;
+    return *lds_flag != 0;
+}
+__device__ __forceinline__ bool block_ticket_arrive(unsigned long long* words, unsigned nonce, unsigned total, unsigned id, int* lds_flag) {
+    block_ticket_publish();
+    return block_ticket_take(words, nonce, total, id, lds_flag);
 }
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+// shader-clock counter (s_memtime): kernel-internal timelines of the profiling tools
+__device__ __forceinline__ long long clock_ticks() { return (long long)__builtin_readcyclecounter(); }
 
 __device__ __forceinline__ float shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ int shfl_xor(int v, int mask) { return __shfl_xor(v, mask, 64); }

@@ -226,8 +226,7 @@ __global__ __launch_bounds__(256) void scan_stream_bf16_kernel(const ScanArgs p)
         int ix = red_i[tid];
         for (int w = 1; w < 4; ++w)
             if (better(red_v[w * NQ + tid], red_i[w * NQ + tid], v, ix)) { v = red_v[w * NQ + tid]; ix = red_i[w * NQ + tid]; }
-        p.pval[(long long)blockIdx.x * p.Bstride + tid] = v;
-        p.pidx[(long long)blockIdx.x * p.Bstride + tid] = ix;
+        scan_store_block_partial(p, tid, v, ix);
     }
     if (p.tickets) scan_ticket_finish(p, red_v);
 }

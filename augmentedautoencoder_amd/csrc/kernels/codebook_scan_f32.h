@@ -68,7 +68,7 @@ struct ScanArgs {
     unsigned e_bytes;   // N*J*4                                 (stream: bounds-checked view of E)
     // stream kernels, top-1: when tickets != nullptr the last block to arrive merges the block partials itself
     // (scan_ticket_finish) and writes the answers -- the whole nearest-neighbour query is ONE launch
-    unsigned long long* tickets = nullptr;
+    unsigned long long* tickets = nullptr;   // kTicketSlotWords words
     unsigned nonce = 0;
     long long* idx_out = nullptr;   // [B] int64
     float* score_out = nullptr;     // [B]
@@ -94,20 +94,34 @@ __device__ __forceinline__ void block_best(float& bv, int& bi, float* red) {
     __syncthreads();
 }
 
+// block partial (best score, best row) of query b: device-coherent when another block of this launch reads it back
+__device__ __forceinline__ void scan_store_block_partial(const ScanArgs& p, int b, float v, int ix) {
+    if (p.tickets) {
+        const unsigned bytes = gridDim.x * (unsigned)p.Bstride * 4u, at = (blockIdx.x * (unsigned)p.Bstride + (unsigned)b) * 4u;
+        coherent_store1(make_buffer(p.pval, bytes), at, __builtin_bit_cast(uint32_t, v));
+        coherent_store1(make_buffer(p.pidx, bytes), at, (uint32_t)ix);
+    } else {
+        p.pval[(long long)blockIdx.x * p.Bstride + b] = v;
+        p.pidx[(long long)blockIdx.x * p.Bstride + b] = ix;
+    }
+}
+
 // Called by every thread of a stream-scan block after its block partial is written.  The last of the gridDim.x
 // blocks merges all partials (the arg-max reduce of argmax_reduce_kernel: same order, lowest row wins ties) and
 // writes (index, score) per query.  red: >= 12 dwords of LDS.
 constexpr int kScanTicketSmem = 64;
 __device__ __forceinline__ void scan_ticket_finish(const ScanArgs& p, float* red) {
     int* flag = reinterpret_cast<int*>(red) + 10;
-    if (!block_ticket_arrive(p.tickets, p.nonce, gridDim.x, flag)) return;
+    if (!block_ticket_arrive(p.tickets, p.nonce, gridDim.x, blockIdx.x, flag)) return;
     const int tid = threadIdx.x, nblk = (int)gridDim.x;
+    const buffer_rsrc vbuf = make_buffer(p.pval, (unsigned)nblk * p.Bstride * 4u);
+    const buffer_rsrc ibuf = make_buffer(p.pidx, (unsigned)nblk * p.Bstride * 4u);
     for (int b = 0; b < p.B; ++b) {
         float bv = kNegInf;
         int bi = 0x7fffffff;
         for (int k = tid; k < nblk; k += 256) {
-            const float v = p.pval[(long long)k * p.Bstride + b];
-            const int ix = p.pidx[(long long)k * p.Bstride + b];
+            const float v = __builtin_bit_cast(float, coherent_load1(vbuf, (unsigned)(k * p.Bstride + b) * 4u));
+            const int ix = (int)coherent_load1(ibuf, (unsigned)(k * p.Bstride + b) * 4u);
             if (better(v, ix, bv, bi)) { bv = v; bi = ix; }
         }
         block_best(bv, bi, red);
@@ -202,8 +216,7 @@ __global__ __launch_bounds__(256) void scan_stream_kernel(const ScanArgs p) {
         int ix = red_i[tid];
         for (int w = 1; w < 4; ++w)
             if (better(red_v[w * NQ + tid], red_i[w * NQ + tid], v, ix)) { v = red_v[w * NQ + tid]; ix = red_i[w * NQ + tid]; }
-        p.pval[(long long)blockIdx.x * p.Bstride + tid] = v;
-        p.pidx[(long long)blockIdx.x * p.Bstride + tid] = ix;
+        scan_store_block_partial(p, tid, v, ix);
     }
     if (p.tickets) scan_ticket_finish(p, red_v);
 }

@@ -55,6 +55,7 @@ struct ConvFirstArgs {
     int tiles_per_block;
     int relu;
     float out_scale;        // OUT_PLANES: 2^act_shift of the f32x3h activation format
+    TicketPrep prep;        // ticket words of the later launches of this forward call (n == 0: none), see conv_wavek_f32.h
 };
 
 constexpr unsigned kFirstRowShift = 20;                 // packed staging unit: row << 20 | offset from the first staged row
@@ -82,6 +83,12 @@ __global__ __launch_bounds__(256) void conv_first_f32_kernel(const ConvFirstArgs
     const bool n_ok = n < p.Cout;
     const bool wave_n_ok = (int)blockIdx.y * 128 + wave * 32 + 32 <= p.Cout;      // wave-uniform
 
+    // ticket preparation for the later launches of this forward: an EXTRA block (the host adds one to the grid) does
+    // nothing else, so no working block is delayed (at B = 1 the 32 working blocks leave most CUs free anyway)
+    if (p.prep.n > 0 && blockIdx.x == gridDim.x - 1) {
+        if (blockIdx.y == 0) ticket_prep_install(p.prep);
+        return;
+    }
     if (IN_U8) lut_s[tid] = p.lut[tid];
 
     // this wave's weights: breg[s] = W[2s+h][n]

@@ -18,9 +18,10 @@
 //   * DEPTH slabs of fragments are in flight per wave (static register ring), the MFMAs of slab t run under the
 //     loads of slabs t+1 ... t+DEPTH-1; nothing is shared between waves, so there is no barrier in the K loop;
 //   * the WAVES partial tiles of a block meet in LDS and are added in wave order; with gsplits > 1 each block
-//     writes its tile partial (lane-linear, coalesced) and takes a ticket: the last of the gsplits blocks re-reads
-//     all partials in split order, applies bias / ReLU / BN and stores the outputs.  Fixed orders everywhere ->
-//     run-to-run bit-identical results; 8x fewer partial bytes than the 128 x 128 split-K and no second launch.
+//     writes its tile partial (lane-linear 16-B device-coherent stores) and takes a ticket (block_ticket_arrive):
+//     the last of the gsplits blocks re-reads all partials in split order, applies bias / ReLU / BN and stores the
+//     outputs.  Fixed orders everywhere -> run-to-run bit-identical results; 8x fewer partial bytes than the
+//     128 x 128 split-K and no second launch.
 // K order inside a slab and the (c, q) MFMA pairing are those of tile_f32.h, so each wave's partial is the same
 // k-ordered fma chain the large kernel would compute over that K range.
 #pragma once
@@ -36,8 +37,9 @@ struct ConvWaveKArgs {
     const float* bn_scale;       // [Cout] or nullptr
     const float* bn_shift;
     float* out;                  // [M][Cout]
-    float* partial;              // [tiles][gsplits][MT*NT*16][64]       (gsplits > 1)
-    unsigned long long* tickets; // [tiles]                              (gsplits > 1)
+    float* partial;              // [tiles][gsplits][PER/4][threads][4]  (gsplits > 1)
+    unsigned partial_bytes;
+    unsigned long long* tickets; // [tiles]                              (gsplits > 1; gsplits <= kTicketSingleLevelMax)
     unsigned nonce;              // unique per launch, never 0
     int H, W, Cin, Ho, Wo, Cout, CoutPad;
     int KS, S, pt, pl;
@@ -45,7 +47,27 @@ struct ConvWaveKArgs {
     int slabs_total;             // KS*KS*Cin/32
     int num_mt, num_nt, gsplits;
     int relu;
+    long long* timeline;         // optional [blocks][8] shader-clock stamps of wave 0 per phase (tools/ablate_wavek.py); nullptr in production
+    int ablate;                  // timing experiments only (results are then wrong): 1 no A loads, 2 no B loads, 4 no MFMAs, 8 no cross-block hand-off
 };
+
+// Ticket preparation.  A launch whose blocks all arrive at a clean ticket word queue up behind the nonce install
+// (measured at B = 1: 4 / 7 / 9 us for 4 / 8 / 16 simultaneous arrivals, against ~1 us when the nonce is already
+// there and every arrival is one fetch-add).  The FIRST kernel of a forward call (conv1, whose launch precedes all
+// ticketed launches in stream order) therefore installs (nonce, 0 arrivals) in the words of every later ticketed
+// launch of that call: block 0 writes them while the other blocks already compute.  Purely an accelerator: words
+// that were not prepared (another first-layer kernel, a stand-alone scan) are handled by the install path.
+constexpr int kMaxTicketPrep = 10;
+struct TicketPrep {
+    unsigned long long* words[kMaxTicketPrep];
+    int count[kMaxTicketPrep];
+    unsigned nonce[kMaxTicketPrep];
+    int n;
+};
+__device__ __forceinline__ void ticket_prep_install(const TicketPrep& t) {
+    for (int e = 0; e < t.n; ++e)
+        for (int i = threadIdx.x; i < t.count[e]; i += blockDim.x) t.words[e][i] = (unsigned long long)t.nonce[e] << 32;
+}
 
 // Out-of-range byte offset that stays out of range after the +96 a fragment's k-group adds.
 constexpr uint32_t kOobBase = 0xFFFFFF00u;
@@ -63,6 +85,10 @@ __global__ __launch_bounds__(64 * WAVES) void conv_wavek_f32_kernel(const ConvWa
 
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
+    auto stamp = [&](int k) {
+        if (p.timeline && tid == 0) p.timeline[(long long)blockIdx.x * 8 + k] = clock_ticks();
+    };
+    stamp(0);
 
     const int tiles = p.num_mt * p.num_nt;
     const int L = xcd_remap(blockIdx.x, tiles * p.gsplits);
@@ -109,20 +135,21 @@ __global__ __launch_bounds__(64 * WAVES) void conv_wavek_f32_kernel(const ConvWa
     f32x4 fa[DEPTH][MT][4], fb[DEPTH][NT][4];
     auto load_stage = [&](int d) {
         const bool live = t_load < s1;                          // past the wave's range: every load is forced out of range (zeros, no traffic)
+        const bool live_a = live && !(p.ablate & 1), live_b = live && !(p.ablate & 2);
         const unsigned tap_off = (unsigned)(((kh * p.W + kw) * p.Cin + cc * 32) * 4);
         unsigned ao[MT];
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi) {
-            const bool ok = live && a_ok[mi] && (unsigned)(a_ih0[mi] + kh) < (unsigned)p.H && (unsigned)(a_iw0[mi] + kw) < (unsigned)p.W;
+            const bool ok = live_a && a_ok[mi] && (unsigned)(a_ih0[mi] + kh) < (unsigned)p.H && (unsigned)(a_iw0[mi] + kw) < (unsigned)p.W;
             ao[mi] = ok ? a_off[mi] + tap_off : kOobBase;
         }
-        const unsigned bo = live ? bw_off + (unsigned)t_load * bw_slab : kOobBase;
+        const unsigned bo = live_b ? bw_off + (unsigned)t_load * bw_slab : kOobBase;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {                           // k-group order = consumption order
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi) fa[d][mi][c] = buffer_load4(xbuf, ao[mi] + 32u * c);
 #pragma unroll
-            for (int ni = 0; ni < NT; ++ni) fb[d][ni][c] = buffer_load4(wbuf, live ? bo + c * bw_group + 512u * ni : kOobBase);
+            for (int ni = 0; ni < NT; ++ni) fb[d][ni][c] = buffer_load4(wbuf, live_b ? bo + c * bw_group + 512u * ni : kOobBase);
         }
         ++t_load;
         if (++kw == p.KS) { kw = 0; if (++kh == p.KS) { kh = 0; ++cc; } }
@@ -147,6 +174,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_wavek_f32_kernel(const ConvWa
                     for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = mfma_32x32x2(fa[d][mi][c][q], fb[d][ni][c][q], acc[mi][ni]);
     };
 
+    stamp(1);                                                   // index arithmetic done
 #pragma unroll
     for (int d = 0; d < DEPTH - 1; ++d) load_stage(d);
     for (int t = s0; t < s1; t += DEPTH) {
@@ -156,11 +184,12 @@ __global__ __launch_bounds__(64 * WAVES) void conv_wavek_f32_kernel(const ConvWa
                 sched_fence();
                 load_stage((d + DEPTH - 1) % DEPTH);            // slab t + d + DEPTH - 1 (dead loads once past s1)
                 sched_fence();
-                mfma_stage(d);
+                if (!(p.ablate & 4)) mfma_stage(d);
             }
         }
     }
 
+    stamp(2);                                                   // K loop done (MFMA results may still be in the pipe)
     // ---- the WAVES partial tiles meet in LDS, lane-linear (conflict-free), and are added in wave order ----------
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi)
@@ -180,21 +209,44 @@ __global__ __launch_bounds__(64 * WAVES) void conv_wavek_f32_kernel(const ConvWa
         v[j] = s;
     }
 
-    if (p.gsplits > 1) {
-        float* mine = p.partial + ((long long)tile * p.gsplits + g) * (COMBOS * 64);
+    stamp(3);                                                   // cross-wave sum done
+    if (p.gsplits > 1 && !(p.ablate & 8)) {
+        // this block's tile partial: four register rows per 16-B coherent store, lane-linear (coalesced)
+        constexpr unsigned kThreads = 64 * WAVES;
+        const buffer_rsrc pbuf = make_buffer(p.partial, p.partial_bytes);
+        const unsigned tile_base = (unsigned)tile * (unsigned)p.gsplits * (PER / 4) * kThreads * 16u;
+        const unsigned mine = tile_base + (unsigned)g * (PER / 4) * kThreads * 16u + (unsigned)tid * 16u;
 #pragma unroll
-        for (int j = 0; j < PER; ++j) mine[(wave + WAVES * j) * 64 + lane] = v[j];
-        const bool last = block_ticket_arrive(p.tickets + tile, p.nonce, (unsigned)p.gsplits, flag);
-        if (!last) return;
-        const float* all = p.partial + (long long)tile * p.gsplits * (COMBOS * 64);
+        for (int j4 = 0; j4 < PER / 4; ++j4)
+            coherent_store4(pbuf, mine + j4 * kThreads * 16u, f32x4{v[4 * j4], v[4 * j4 + 1], v[4 * j4 + 2], v[4 * j4 + 3]});
+        block_ticket_publish();
+        stamp(4);                                               // partial stores complete (device scope)
+        const bool last_block = block_ticket_take(p.tickets + tile, p.nonce, (unsigned)p.gsplits, (unsigned)g, flag);
+        stamp(5);                                               // ticket taken
+        if (!last_block) return;
 #pragma unroll
         for (int j = 0; j < PER; ++j) v[j] = 0.f;
-        for (int s = 0; s < p.gsplits; ++s) {                   // split order: the same sum whichever block arrives last
+        // all partials of up to 8 splits in flight at once (a coherent load is a round trip to the memory side: one at a
+        // time they cost more than the K loop); splits beyond gsplits read out of range = zeros.  Split order: the same
+        // sum whichever block arrives last.
+        constexpr int kBatch = 8;
+        const unsigned split_stride = (PER / 4) * kThreads * 16u;
+        for (int sb = 0; sb < p.gsplits; sb += kBatch) {
+            f32x4 t[kBatch][PER / 4];
 #pragma unroll
-            for (int j = 0; j < PER; ++j) v[j] += all[((long long)s * COMBOS + wave + WAVES * j) * 64 + lane];
+            for (int u = 0; u < kBatch; ++u)
+#pragma unroll
+                for (int j4 = 0; j4 < PER / 4; ++j4)
+                    t[u][j4] = coherent_load4(pbuf, sb + u < p.gsplits ? tile_base + (unsigned)(sb + u) * split_stride + (unsigned)tid * 16u + j4 * kThreads * 16u
+                                                                         : kOobBase);
+#pragma unroll
+            for (int u = 0; u < kBatch; ++u)
+#pragma unroll
+                for (int j = 0; j < PER; ++j) v[j] += t[u][j >> 2][j & 3];
         }
     }
 
+    stamp(6);                                                   // (last block) all partials summed
     // ---- epilogue: bias, ReLU, folded BN; register row combo = (mi, ni, r) of lane -> (m, n) ---------------------
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
@@ -208,6 +260,7 @@ __global__ __launch_bounds__(64 * WAVES) void conv_wavek_f32_kernel(const ConvWa
         if (p.bn_scale) o = o * p.bn_scale[n] + p.bn_shift[n];
         p.out[(long long)m * p.Cout + n] = o;
     }
+    stamp(7);
 }
 
 }  // namespace aae

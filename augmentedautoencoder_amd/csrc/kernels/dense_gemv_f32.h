@@ -15,13 +15,14 @@ struct DenseGemvArgs {
     const float* wp;       // [K/4][CoutPad][4]
     unsigned wp_bytes;
     float* partial;        // [chunks][B][Cout]
+    unsigned partial_bytes;
     int B, K, Cout, CoutPad;
     // TICKET mode: the last block of a column tile finishes z = sum(chunks) + bias [, BN]
     const float* bias;
     const float* bn_scale;
     const float* bn_shift;
     float* out;                    // [B][Cout]
-    unsigned long long* tickets;   // [CoutPad / 128]
+    unsigned long long* tickets;   // [CoutPad / 128][kTicketSlotWords]
     unsigned nonce;
     int relu;
 };
@@ -70,10 +71,16 @@ __global__ __launch_bounds__(256) void dense_gemv_f32_kernel(const DenseGemvArgs
         for (int m = 0; m < MQ; ++m) red[m * 128 + (tid & 127)] = acc[m];
     }
     __syncthreads();
+    const buffer_rsrc pbuf = make_buffer(p.partial, p.partial_bytes);
     if (half == 0 && n < p.Cout) {
 #pragma unroll
         for (int m = 0; m < MQ; ++m)
-            if (m < p.B) p.partial[((long long)blockIdx.x * p.B + m) * p.Cout + n] = acc[m] + red[m * 128 + (tid & 127)];
+            if (m < p.B) {
+                const float sum = acc[m] + red[m * 128 + (tid & 127)];
+                const unsigned at = (unsigned)(((blockIdx.x * p.B + m) * p.Cout + n) * 4);
+                if (TICKET) coherent_store1(pbuf, at, __builtin_bit_cast(uint32_t, sum));      // read back by another block of this launch
+                else p.partial[((long long)blockIdx.x * p.B + m) * p.Cout + n] = sum;
+            }
     }
     if constexpr (TICKET) {
         // The last of the gridDim.x chunk blocks of this column tile adds the chunk rows: thread (group = tid / 32,
@@ -83,14 +90,14 @@ __global__ __launch_bounds__(256) void dense_gemv_f32_kernel(const DenseGemvArgs
         float* gsum = reinterpret_cast<float*>(smem_raw);        // [8][128] (xs / red are dead by now)
         int* flag = reinterpret_cast<int*>(gsum + 8 * 128);
         __syncthreads();
-        if (!block_ticket_arrive(p.tickets + blockIdx.y, p.nonce, gridDim.x, flag)) return;
+        if (!block_ticket_arrive(p.tickets + blockIdx.y * kTicketSlotWords, p.nonce, gridDim.x, blockIdx.x, flag)) return;
         const int group = tid >> 5, n4 = blockIdx.y * 128 + (tid & 31) * 4;
         const int chunks = (int)gridDim.x;
         for (int m = 0; m < p.B; ++m) {
             f32x4 s = {0.f, 0.f, 0.f, 0.f};
             if (n4 < p.Cout)
 #pragma unroll 8
-                for (int c = group; c < chunks; c += 8) s += *reinterpret_cast<const f32x4*>(p.partial + ((long long)c * p.B + m) * p.Cout + n4);
+                for (int c = group; c < chunks; c += 8) s += coherent_load4(pbuf, (unsigned)(((c * p.B + m) * p.Cout + n4) * 4));
             *reinterpret_cast<f32x4*>(gsum + group * 128 + (tid & 31) * 4) = s;
             __syncthreads();
             if (tid < 128 && blockIdx.y * 128 + tid < p.Cout) {

@@ -139,6 +139,37 @@ class EncoderEngine(object):
             self._forward_chunk(t[a:e], z[a:e])
         return z
 
+    def encode_nn(self, codebook_engine, x, col_stride=1):
+        """Encoder.z + the top-1 codebook query of a batch in one C call per chunk (aae_encode_nn): what
+        Codebook.nearest_rotation does per detection.  Returns (z [B,J], idx int64 [B,1], cosine float32 [B,1]) on
+        the device; bit-identical to encode() followed by codebook_engine.nn(z, 1, col_stride)."""
+        torch = _torch()
+        cb = codebook_engine
+        t = self.to_device_batch(x)
+        B = t.shape[0]
+        z = torch.empty((B, self.cfg.latent_space_size), dtype=torch.float32, device=self.device)
+        idx = torch.empty((B, 1), dtype=torch.int64, device=self.device)
+        score = torch.empty((B, 1), dtype=torch.float32, device=self.device)
+        if B == 0:
+            return z, idx, score
+        cb.ensure_upright(col_stride, 1)
+        dt = _lib.AAE_DTYPE_U8 if t.dtype == torch.uint8 else _lib.AAE_DTYPE_F32
+        for a in range(0, B, self.max_batch):
+            e = min(a + self.max_batch, B)
+            n = e - a
+            nb_e = self.lib.aae_encoder_workspace_bytes(self.handle, n)
+            nb_c = self.lib.aae_codebook_workspace_bytes(cb.handle, n, 1)
+            _, ws_e = self.ws.get(nb_e)
+            _, ws_c = cb.ws.get(nb_c)
+            self._last_B = n
+            with torch.cuda.device(self.device):
+                rc = self.lib.aae_encode_nn(self.handle, cb.handle, ctypes.c_void_p(t[a:e].data_ptr()), dt, n, int(col_stride),
+                                            ctypes.c_void_p(z[a:e].data_ptr()), ctypes.c_void_p(idx[a:e].data_ptr()),
+                                            ctypes.c_void_p(score[a:e].data_ptr()), ctypes.c_void_p(ws_e), nb_e,
+                                            ctypes.c_void_p(ws_c), nb_c, _stream_ptr(torch))
+            _lib.check(self.lib, rc, 'aae_encode_nn')
+        return z, idx, score
+
     def encode_timed(self, x):
         """(z, [(kernel label, ms, algorithmic flops)]) for one chunk (B <= max_batch)."""
         torch = _torch()
@@ -236,6 +267,16 @@ class CodebookEngine(object):
             raise ValueError('latents have shape %s, expected [B,%d]' % (tuple(z.shape), self.J))
         return z
 
+    def ensure_upright(self, col_stride, topk=1):
+        """First upright query with this stride: build the every-k-th-row copy the scan then runs over (allocates once;
+        a CapturedNearestNeighbour reaches this in its eager warm-up call, before the capture starts)."""
+        if col_stride > 1 and topk == 1 and self._upright_stride != int(col_stride):
+            torch = _torch()
+            with torch.cuda.device(self.device):
+                rc = self.lib.aae_codebook_prepare_upright(self.handle, int(col_stride), _stream_ptr(torch))
+            _lib.check(self.lib, rc, 'aae_codebook_prepare_upright')
+            self._upright_stride = int(col_stride)
+
     def nn(self, z, topk=1, col_stride=1):
         """(idx int64 [B,topk], cosine float32 [B,topk]) on the device."""
         torch = _torch()
@@ -245,13 +286,7 @@ class CodebookEngine(object):
         score = torch.empty((B, topk), dtype=torch.float32, device=self.device)
         if B == 0:                    # an empty batch is an empty answer (TF/NumPy semantics of the reference), not an error
             return idx, score
-        if col_stride > 1 and topk == 1 and self._upright_stride != int(col_stride):
-            # first upright query with this stride: build the every-k-th-row copy the scan then runs over (allocates once;
-            # a CapturedNearestNeighbour reaches this in its eager warm-up call, before the capture starts)
-            with torch.cuda.device(self.device):
-                rc = self.lib.aae_codebook_prepare_upright(self.handle, int(col_stride), _stream_ptr(torch))
-            _lib.check(self.lib, rc, 'aae_codebook_prepare_upright')
-            self._upright_stride = int(col_stride)
+        self.ensure_upright(col_stride, topk)
         nbytes = self.lib.aae_codebook_workspace_bytes(self.handle, B, topk)
         _, ws_ptr = self.ws.get(nbytes)
         with torch.cuda.device(self.device):
@@ -438,12 +473,18 @@ class CapturedNearestNeighbour(object):
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):                # warm-up: sizes the engines' workspaces outside the capture
                 for _ in range(2):
-                    self.cb.nn(self.enc.encode(self.x), self.topk, self.col_stride)
+                    self._query()
             torch.cuda.current_stream().wait_stream(side)
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
-                self.z = self.enc.encode(self.x)
-                self.idx, self.score = self.cb.nn(self.z, self.topk, self.col_stride)
+                self.z, self.idx, self.score = self._query()
+
+    def _query(self):
+        if self.topk == 1:                               # one C call: conv1 prepares the ticket words of the later launches
+            return self.enc.encode_nn(self.cb, self.x, self.col_stride)
+        z = self.enc.encode(self.x)
+        idx, score = self.cb.nn(z, self.topk, self.col_stride)
+        return z, idx, score
 
     def __call__(self, x):
         """x: [B,H,W,C] (or [H,W,C] when batch == 1) of the dtype given at construction, host or device.
@@ -510,7 +551,10 @@ class StreamingNearestNeighbour(object):
         n = self._upload(slot, nxt)
         while True:
             compute.wait_event(self.copied[slot])
-            idx, score = self.cb.nn(self.enc.encode(self.dev[slot][:n]), self.topk, self.col_stride)
+            if self.topk == 1:
+                _, idx, score = self.enc.encode_nn(self.cb, self.dev[slot][:n], self.col_stride)
+            else:
+                idx, score = self.cb.nn(self.enc.encode(self.dev[slot][:n]), self.topk, self.col_stride)
             self.consumed[slot].record(compute)
             try:
                 nxt = next(it)

@@ -155,18 +155,31 @@ class Saver(object):
         if decoder is not None and decoder.weights is not None:
             weights.update(decoder.weights)
         W.save_npz(path + '.npz', weights, emb, bbs)
+        # The index stays ONE format -- TensorFlow's text CheckpointState -- with the new file as model_checkpoint_path.
+        # (A directory that came with a TensorFlow checkpoint keeps its entries in all_model_checkpoint_paths; were the
+        # new .npz merely appended as a bare line, get_checkpoint_state would keep answering the TF bundle and the
+        # codebook just built by ae_embed would never be restored.)
         ckpt_dir = os.path.dirname(path)
         index = os.path.join(ckpt_dir, 'checkpoint')
-        existing = []
+        every = []
         if os.path.exists(index):
             with open(index) as f:
-                existing = [l.strip() for l in f if l.strip()]
+                text = f.read()
+            from .tf_checkpoint import parse_checkpoint_state
+            latest, every = parse_checkpoint_state(text)
+            if latest is None:                                   # index written by an earlier version: one path per line
+                every = [l.strip() for l in text.splitlines() if l.strip()]
+            elif not every:
+                every = [latest]
         rel = os.path.basename(path) + '.npz'
-        if rel in existing:
-            existing.remove(rel)
-        existing.append(rel)
+        every = [p for p in every if p != rel] + [rel]
+
+        def quoted(p):
+            return '"%s"' % p.replace('\\', '\\\\').replace('"', '\\"')
         with open(index, 'w') as f:
-            f.write('\n'.join(existing) + '\n')
+            f.write('model_checkpoint_path: %s\n' % quoted(rel))
+            for p in every:
+                f.write('all_model_checkpoint_paths: %s\n' % quoted(p))
         return path
 
     def restore(self, session, ckpt_path):

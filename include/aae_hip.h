@@ -131,6 +131,11 @@ double aae_encoder_kernel_flops(const aae_encoder* enc, int i);
 
 /* Byte offset / element count of layer `layer`'s activation [B,Ho,Wo,Cout] inside the
  * workspace after a forward with batch B (parity tests of encoder.py:41-54 per layer). */
+/* Profiling aid (tools/ablate_wavek.py): with option "wavek_timeline" = 1 wave 0 of every block of the small-batch
+ * igemm stamps the shader clock at 8 phase boundaries; this copies the [3 layers][512 blocks][8] stamps of the most
+ * recent forward to host memory (synchronises the device).  Not part of the reference-facing surface. */
+int aae_encoder_debug_timeline(aae_encoder* enc, long long* host_out);
+
 int aae_encoder_activation_info(const aae_encoder* enc, int B, int layer, size_t* offset_bytes,
                                 size_t* count);
 
@@ -159,6 +164,16 @@ size_t aae_codebook_workspace_bytes(const aae_codebook* cb, int B, int topk);
  * index-ascending among equal scores. */
 int aae_codebook_nn(aae_codebook* cb, const float* z, int B, int topk, int col_stride,
                     int64_t* idx_out, float* score_out, void* workspace, size_t ws_bytes, void* stream);
+
+/* aae_encoder_forward followed by aae_codebook_nn(topk = 1) on `stream` in ONE call: what
+ * Codebook.nearest_rotation(session, x) does per detection (auto_pose/ae/codebook.py:55-68,
+ * m3_interface/ae_pose_estimator.py:143-170).  Same results as the two calls, bit for bit.  For B <= 4 the query is
+ * six launches: the encoder's first kernel prepares the ticket words of the later launches (wave-split-K tiles, dense
+ * GEMV chunks, scan block partials), each of which then finishes its own reduction ("last block to arrive").
+ * z_out: device [B, latent] (also returned: Encoder.z).  Workspaces as for the two separate calls. */
+int aae_encode_nn(aae_encoder* enc, aae_codebook* cb, const void* x, int x_dtype, int B, int col_stride, float* z_out,
+                  int64_t* idx_out, float* score_out, void* enc_workspace, size_t enc_ws_bytes, void* cb_workspace,
+                  size_t cb_ws_bytes, void* stream);
 
 /* Full cosine-similarity matrix cs_out [B,N] (device) = session.run(cos_similarity)
  * (codebook.py:63); parity / debugging path, the nn call never materialises it for topk 1. */

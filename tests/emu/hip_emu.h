@@ -56,6 +56,7 @@ void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()
 namespace aae {
 
 inline int lane_id() { return threadIdx.x & 63; }
+inline long long clock_ticks() { return 0; }
 inline void sleep_kcycles(int) {}
 inline void sched_fence() {}
 template <int P>
@@ -171,19 +172,55 @@ inline void split_f16(float v, unsigned short& hi, unsigned short& lo) {
     memcpy(&lo, &l, 2);
 }
 
-// device_intrinsics.h::block_ticket_arrive: the emulator runs the blocks of a grid one after the other, so the
-// word protocol (nonce << 32 | arrivals; foreign nonce = empty; last arriver leaves 0) is modelled without atomics.
-inline bool block_ticket_arrive(unsigned long long* word, unsigned nonce, unsigned total, int* lds_flag) {
-    __syncthreads();
+// device_intrinsics.h cross-block hand-off: the emulator runs the blocks of a grid one after the other (in a
+// selectable order), so the coherent accesses are plain ones and the ticket protocol (nonce << 32 | arrivals;
+// foreign nonce = empty; two levels above 32 arrivals; last arriver leaves 0) is modelled without atomics.
+inline void coherent_store4(buffer_rsrc r, uint32_t byte_off, f32x4 v) {
+    if ((uint64_t)byte_off + 16 <= r.bytes) memcpy(const_cast<unsigned char*>(r.base) + byte_off, &v, 16);
+}
+inline f32x4 coherent_load4(buffer_rsrc r, uint32_t byte_off) { return buffer_load4(r, byte_off); }
+inline void coherent_store1(buffer_rsrc r, uint32_t byte_off, uint32_t v) {
+    if ((uint64_t)byte_off + 4 <= r.bytes) memcpy(const_cast<unsigned char*>(r.base) + byte_off, &v, 4);
+}
+inline uint32_t coherent_load1(buffer_rsrc r, uint32_t byte_off) {
+    uint32_t v = 0;
+    if ((uint64_t)byte_off + 4 <= r.bytes) memcpy(&v, r.base + byte_off, 4);
+    return v;
+}
+constexpr int kTicketGroups = 16;
+constexpr int kTicketGroupStride = 16;
+constexpr int kTicketSlotWords = (1 + kTicketGroups) * kTicketGroupStride;
+constexpr unsigned kTicketSingleLevelMax = 32;
+inline unsigned ticket_count(unsigned long long* word, unsigned nonce) {
+    *word += 1;                                                           // the optimistic add ...
+    if ((unsigned)((*word - 1) >> 32) != nonce) *word = ((unsigned long long)nonce << 32) | 1ull;   // ... met a foreign state: install (nonce, 1)
+    return (unsigned)*word;
+}
+inline void ticket_clear(unsigned long long* word) { *word = 0; }
+inline void block_ticket_publish() { __syncthreads(); }
+inline bool block_ticket_take(unsigned long long* words, unsigned nonce, unsigned total, unsigned id, int* lds_flag) {
     if (threadIdx.x == 0) {
-        const unsigned long long seen = *word;
-        const unsigned count = ((unsigned)(seen >> 32) == nonce) ? (unsigned)seen : 0u;
-        const bool last = count + 1 == total;
-        *word = last ? 0ull : (((unsigned long long)nonce << 32) | (count + 1));
+        bool last = false;
+        if (total <= kTicketSingleLevelMax) {
+            last = ticket_count(words, nonce) == total;
+            if (last) ticket_clear(words);
+        } else {
+            const unsigned g = id % kTicketGroups, members = (total - g + kTicketGroups - 1) / kTicketGroups;
+            unsigned long long* gw = words + (1 + g) * kTicketGroupStride;
+            if (ticket_count(gw, nonce) == members) {
+                ticket_clear(gw);
+                last = ticket_count(words, nonce) == (unsigned)kTicketGroups;
+                if (last) ticket_clear(words);
+            }
+        }
         *lds_flag = last ? 1 : 0;
     }
     __syncthreads();
     return *lds_flag != 0;
+}
+inline bool block_ticket_arrive(unsigned long long* words, unsigned nonce, unsigned total, unsigned id, int* lds_flag) {
+    block_ticket_publish();
+    return block_ticket_take(words, nonce, total, id, lds_flag);
 }
 
 template <typename T>

@@ -147,6 +147,28 @@ class EmuCodebook(object):
             self.h = None
 
 
+def encode_nn(enc, cb, x, col_stride=1):
+    """aae_encode_nn on the emulator: (z, idx [B,1], score [B,1]) -- the fused per-detection call, where the first
+    encoder kernel prepares the ticket words of the later launches (the scan's included)."""
+    L = lib()
+    x = np.ascontiguousarray(x)
+    B = x.shape[0]
+    dt = _lib.AAE_DTYPE_U8 if x.dtype == np.uint8 else _lib.AAE_DTYPE_F32
+    if dt == _lib.AAE_DTYPE_F32:
+        x = x.astype(np.float32)
+    n_e = L.aae_encoder_workspace_bytes(enc.h, B)
+    n_c = L.aae_codebook_workspace_bytes(cb.h, B, 1)
+    enc.ws, ws_c = _aligned(n_e), _aligned(n_c)
+    enc.B = B
+    z = np.zeros((B, enc.cfg.latent_space_size), dtype=np.float32)
+    idx = np.full((B, 1), -7, dtype=np.int64)
+    score = np.zeros((B, 1), dtype=np.float32)
+    rc = L.aae_encode_nn(enc.h, cb.h, x.ctypes.data, dt, B, int(col_stride), z.ctypes.data, idx.ctypes.data, score.ctypes.data,
+                         enc.ws.ctypes.data, n_e, ws_c.ctypes.data, n_c, None)
+    _lib.check(L, rc, 'aae_encode_nn')
+    return z, idx, score
+
+
 def crop_resize(img, boxes_xywh_size, out_hw):
     L = lib()
     img = np.ascontiguousarray(img, dtype=np.uint8)

@@ -26,6 +26,20 @@ class EmuEncoderEngine(object):
             return torch.empty((0, self.cfg.latent_space_size), dtype=torch.float32)
         return torch.from_numpy(self._e.forward(x))
 
+    def encode_nn(self, codebook_engine, x, col_stride=1):
+        if torch.is_tensor(x):
+            x = x.numpy()
+        x = np.asarray(x)
+        if x.ndim == 3:
+            x = x[None]
+        if x.dtype != np.uint8:
+            x = x.astype(np.float32)
+        if len(x) == 0:
+            return (torch.empty((0, self.cfg.latent_space_size), dtype=torch.float32), torch.empty((0, 1), dtype=torch.int64),
+                    torch.empty((0, 1), dtype=torch.float32))
+        z, idx, score = eb.encode_nn(self._e, codebook_engine._c, x, col_stride)
+        return torch.from_numpy(z), torch.from_numpy(idx), torch.from_numpy(score)
+
     def activation(self, layer):
         return torch.from_numpy(self._e.activation(layer))
 

@@ -403,3 +403,39 @@ def test_wave_split_k_without_cross_block_split_and_with_cout_padding():
     cfg = EncoderConfig((32, 32, 3), [32, 96], [2, 1], 3, 64)
     labels = _run(cfg, 2, 71, wavek=1, options={'wavek_narrow_max_tiles': 0})
     assert 'conv_wavek_f32_64x64' in labels[1] and '_g1 ' in labels[1], labels
+
+
+@pytest.mark.parametrize('order', [0, 2])
+@pytest.mark.parametrize('B,stride', [(1, 1), (3, 1), (2, 36), (6, 1)])
+def test_fused_encode_nn_prepares_every_ticket_and_equals_the_two_calls(B, stride, order):
+    """aae_encode_nn: conv1's block 0 installs the nonces of the later ticketed launches (wave-split-K tiles, GEMV
+    chunks, the scan's block partials); the answers must be those of aae_encoder_forward + aae_codebook_nn bit for bit,
+    with prepared tickets, unprepared ones (ticket_prep = 0) and the two-launch scan."""
+    eb.set_block_order(order)
+    try:
+        cfg = EncoderConfig((16, 16, 3), [32, 64], [2, 2], 5, 128)
+        w = synth.make_weights(seed=21, shape=cfg.shape, num_filter=cfg.num_filter, strides=cfg.strides, latent=128)
+        x = synth.make_crops(B, seed=22, shape=cfg.shape)
+        N = 36 * 11 + 5
+        E = synth.make_codebook(N, 128, seed=7, planted_duplicates=11)
+        enc, cb = eb.EmuEncoder(w, cfg), eb.EmuCodebook(E)
+        if stride > 1:
+            cb.prepare_upright(stride)
+        z0 = enc.forward(x)
+        cb.set_mode(_lib.AAE_SCAN_STREAM_2L)
+        i0, s0 = cb.nn(z0, 1, stride)
+        cb.set_mode(_lib.AAE_SCAN_AUTO)
+        for prep in (1, 0):
+            enc.set_option('ticket_prep', prep)
+            z1, i1, s1 = eb.encode_nn(enc, cb, x, stride)
+            assert np.array_equal(z1, z0) and np.array_equal(i1, i0) and np.array_equal(s1, s0), (prep,)
+        cb.set_mode(_lib.AAE_SCAN_STREAM)          # single-launch scan without preparation: the install path
+        i2, s2 = cb.nn(z0, 1, stride)
+        assert np.array_equal(i2, i0) and np.array_equal(s2, s0)
+        cs = cb.similarity(z0)
+        want = ref.nearest_indices_reference(cs, 1, upright=True, num_cyclo=36) if stride > 1 else np.argmax(cs, axis=1)
+        assert np.array_equal(i0[:, 0], want)
+        enc.close()
+        cb.close()
+    finally:
+        eb.set_block_order(0)

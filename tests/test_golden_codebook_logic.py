@@ -98,6 +98,12 @@ class _RowEncoder(object):
         rows = [int(np.flatnonzero((G['crops_u8'] == c).all(axis=(1, 2, 3)))[0]) for c in x]
         return torch.tensor(rows, dtype=torch.float32)[:, None]
 
+    def encode_nn(self, codebook_engine, x, col_stride=1):
+        """the fused per-detection call of the product engine: encode + top-1 scan"""
+        z = self.encode(x)
+        idx, score = codebook_engine.nn(z, 1, col_stride)
+        return z, idx, score
+
 
 class _RecordedScan(object):
     """nn(z, topk, stride): the codebook scan answered from the recorded similarity matrix."""

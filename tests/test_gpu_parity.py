@@ -119,7 +119,7 @@ def test_headline_kernels_on_the_bench_inputs_match_fp64_oracle(bench_inputs_and
     labels = [l for l, _, _ in recs]
     if precision == 0:
         want = ['conv1:conv_first_f32', 'conv2:conv_igemm_f32_dma_breg_n256', 'conv3:conv_igemm_f32_dma_breg_n256',
-                'conv4:conv_igemm_f32_dma_breg ', 'dense:conv_igemm_f32_dma_splitk', 'dense:splitk_reduce']
+                'conv4:conv_igemm_f32_dma_breg ', 'dense:conv_wavek_f32_64x32_w4_d3_g16 ']     # (dense: one launch, ticketed K reduction)
     else:
         want = ['conv1:conv_first_f32', 'conv2:conv_igemm_x3h_dma', 'conv3:conv_igemm_x3h_dma', 'conv4:conv_igemm_x3h_dma',
                 'dense:conv_igemm_x3h_dma_splitk', 'dense:splitk_reduce']
@@ -298,6 +298,8 @@ def test_fp32_igemm_lds_dma_variant_is_bit_identical():
     from augmentedautoencoder_amd.weights import EncoderConfig
     weights = synth.make_weights(seed=2024)
     enc = EncoderEngine(EncoderConfig(), weights)
+    for name in ('wavek', 'wavek_dense', 'gemv_ticket'):    # this test is about the 128 x 128 igemm family at every batch size
+        enc.set_option(name, 0)
     for B in (1, 5, 256):
         crops = synth.make_crops(B, seed=500 + B)
         enc.set_option('igemm_dma', 0)
@@ -666,9 +668,11 @@ def test_small_batch_wave_split_k_path_matches_fp64_oracle(default_model, B):
 def test_in_launch_ticketed_reductions_are_race_free_and_order_independent():
     """The cross-block hand-offs (block_ticket_arrive: conv_wavek partial tiles, GEMV chunk rows, scan block partials)
     sum in fixed orders whichever block arrives last, so every repeat must give the same bits -- quiet, with the
-    workspace (ticket words included) overwritten by random bytes between calls, and while a second stream
-    saturates HBM with copies.  The scan's one-launch form must equal the two-launch form (separate arg-max reduce)
-    bit for bit, exact ties included; the encoder must stay within rounding of the split-K kernels."""
+    workspaces (ticket words included) overwritten by random bytes between calls, and while a second stream saturates
+    HBM with copies.  Four forms of the per-detection query must agree bit for bit, exact ties included: the fused
+    call (aae_encode_nn: conv1 prepares every ticket), the two separate calls (encoder tickets prepared, scan in two
+    launches), the single-launch scan without preparation (install path), and everything unprepared (ticket_prep = 0).
+    The encoder must stay within rounding of the 128 x 128 split-K kernels."""
     import torch
     from augmentedautoencoder_amd import _lib
     from augmentedautoencoder_amd.engine import CodebookEngine, EncoderEngine
@@ -676,12 +680,16 @@ def test_in_launch_ticketed_reductions_are_race_free_and_order_independent():
     enc = EncoderEngine(EncoderConfig(), synth.make_weights(seed=2024))
     E = synth.make_codebook(92232, 128, seed=7, planted_duplicates=64)
     cb = CodebookEngine(E)
-    dup = [r for r in range(35, E.shape[0], 36) if np.array_equal(E[r], E[r - 35])][:2]
     side = torch.cuda.Stream()
     big_a = torch.empty(512 << 20, dtype=torch.uint8, device='cuda')
     big_b = torch.zeros(512 << 20, dtype=torch.uint8, device='cuda')
     gen = torch.Generator(device='cuda')
     gen.manual_seed(1)
+
+    def scribble():
+        for ws in (enc.ws, cb.ws):
+            ws.buf.copy_(torch.randint(0, 256, ws.buf.shape, dtype=torch.uint8, device='cuda', generator=gen))
+
     for B in (1, 2, 4, 6):
         x = torch.from_numpy(synth.make_crops(B, seed=2100 + B)).cuda()
         z0 = enc.encode(x).clone()
@@ -691,25 +699,39 @@ def test_in_launch_ticketed_reductions_are_race_free_and_order_independent():
         for name in ('wavek', 'gemv_ticket', 'wavek_dense'):
             enc.set_option(name, 1)
         assert float((z0 - z_old).abs().max() / z_old.abs().max()) < 1e-5
-        zq = z0.clone()
-        zq[0] = torch.from_numpy(E[dup[0]] * 2.5).cuda()              # exact tie: the lower twin must win in both forms
         cb.set_scan_mode(_lib.AAE_SCAN_STREAM_2L if B <= 4 else _lib.AAE_SCAN_AUTO)
-        i2, s2 = cb.nn(zq, 1, 1)
+        i2, s2 = cb.nn(z0, 1, 1)
         i2, s2 = i2.clone(), s2.clone()
         cb.set_scan_mode(_lib.AAE_SCAN_AUTO)
-        assert int(i2[0, 0]) == dup[0] - 35
         for rep in range(60):
             if rep % 3 == 1:                                           # garbage in the workspaces, ticket words included
-                for ws in (enc.ws, cb.ws):
-                    ws.buf.copy_(torch.randint(0, 256, ws.buf.shape, dtype=torch.uint8, device='cuda', generator=gen))
+                scribble()
             if rep == 30:
                 with torch.cuda.stream(side):
                     for _ in range(40):
                         big_a.copy_(big_b)
+            enc.set_option('ticket_prep', 0 if rep % 4 == 3 else 1)
+            z1, i1, s1 = enc.encode_nn(cb, x, 1)
+            assert torch.equal(z1, z0) and torch.equal(i1, i2) and torch.equal(s1, s2), (B, rep)
             assert torch.equal(enc.encode(x), z0), (B, rep)
-            i1, s1 = cb.nn(zq, 1, 1)
-            assert torch.equal(i1, i2) and torch.equal(s1, s2), (B, rep)
+            if B <= 4 and rep % 5 == 0:
+                cb.set_scan_mode(_lib.AAE_SCAN_STREAM)                 # one launch, nobody prepared the ticket words
+                i3, s3 = cb.nn(z0, 1, 1)
+                cb.set_scan_mode(_lib.AAE_SCAN_AUTO)
+                assert torch.equal(i3, i2) and torch.equal(s3, s2), (B, rep)
+        enc.set_option('ticket_prep', 1)
         torch.cuda.synchronize()
+    # exact ties through the single-launch scan: the lower twin must win in every form
+    dup = [r for r in range(35, E.shape[0], 36) if np.array_equal(E[r], E[r - 35])][:3]
+    zq = torch.from_numpy(np.stack([E[d] * s for d, s in zip(dup, (2.5, 0.7, 9.0))]).astype(np.float32)).cuda()
+    for mode in (_lib.AAE_SCAN_STREAM_2L, _lib.AAE_SCAN_STREAM, _lib.AAE_SCAN_AUTO):
+        cb.set_scan_mode(mode)
+        for rep in range(20):
+            if rep % 2:
+                scribble()
+            it, st = cb.nn(zq, 1, 1)
+            assert it[:, 0].tolist() == [d - 35 for d in dup], (mode, rep)
+    cb.set_scan_mode(_lib.AAE_SCAN_AUTO)
     # wave-count / prefetch-depth variants of the kernel: same K ranges per block are summed in a different wave split,
     # so only rounding-level differences are allowed
     x = torch.from_numpy(synth.make_crops(3, seed=9)).cuda()

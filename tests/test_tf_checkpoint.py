@@ -249,6 +249,57 @@ def test_factory_restore_checkpoint_reads_a_tf_checkpoint(tmp_path):
     S.reset_default_graph()
 
 
+def test_saving_into_a_tensorflow_checkpoint_dir_makes_the_new_file_the_one_restored(tmp_path):
+    """README flow: downloaded TF checkpoint -> ae_embed (restore, rebuild the codebook, saver.save with the same
+    step, ae_embed.py:60-91) -> inference restores the directory.  The rebuilt codebook must be what comes back --
+    from the newest-checkpoint restore and from an at_step restore -- not the embedding stored in the TF bundle."""
+    ckpt_dir = str(tmp_path)
+    prefix, w, emb, bbs = _tf_style_checkpoint(ckpt_dir)
+    args = configparser.ConfigParser()
+    args.read_string(CFG)
+
+    def build():
+        S.reset_default_graph()
+        with S.variable_scope('my_exp'):
+            ds = factory.build_dataset('', args)
+            enc = factory.build_encoder(S.Placeholder(ds.shape), args)
+            return enc, factory.build_codebook(enc, ds, args)
+
+    enc, cb = build()
+    saver = S.Saver()
+    factory.restore_checkpoint(None, saver, ckpt_dir)
+    rng = np.random.default_rng(11)
+    new_emb = rng.standard_normal(emb.shape).astype(np.float32)
+    new_emb /= np.linalg.norm(new_emb, axis=1, keepdims=True)
+    new_bbs = rng.integers(0, 500, bbs.shape).astype(np.int32)
+    cb.assign_embedding(new_emb)
+    cb.assign_obj_bbs(new_bbs)
+    saver.save(None, os.path.join(ckpt_dir, 'chkpt'), global_step=30000)
+    st = S.get_checkpoint_state(ckpt_dir)
+    assert os.path.basename(st.model_checkpoint_path) == 'chkpt-30000.npz'
+    assert [os.path.basename(p) for p in st.all_model_checkpoint_paths] == ['chkpt-20000', 'chkpt-30000', 'chkpt-30000.npz']
+    for at_step in (None, 30000):
+        enc2, cb2 = build()
+        factory.restore_checkpoint(None, S.Saver(), ckpt_dir, at_step=at_step)
+        assert np.array_equal(cb2.embedding_value(), new_emb) and np.array_equal(cb2.embed_obj_bbs_value(), new_bbs), at_step
+        assert all(np.array_equal(enc2.weights[k], w[k]) for k in w)
+    # saving again (same and another step) keeps one index format and one entry per file
+    saver_b = S.Saver()
+    saver_b.save(None, os.path.join(ckpt_dir, 'chkpt'), global_step=30000)
+    saver_b.save(None, os.path.join(ckpt_dir, 'chkpt'), global_step=30001)
+    st = S.get_checkpoint_state(ckpt_dir)
+    assert [os.path.basename(p) for p in st.all_model_checkpoint_paths] == ['chkpt-20000', 'chkpt-30000', 'chkpt-30000.npz', 'chkpt-30001.npz']
+    assert os.path.basename(st.model_checkpoint_path) == 'chkpt-30001.npz'
+    # an index in the old one-path-per-line form is still read and is upgraded by the next save
+    with open(os.path.join(ckpt_dir, 'checkpoint'), 'w') as f:
+        f.write('chkpt-30000.npz\n')
+    assert os.path.basename(S.get_checkpoint_state(ckpt_dir).model_checkpoint_path) == 'chkpt-30000.npz'
+    saver_b.save(None, os.path.join(ckpt_dir, 'chkpt'), global_step=30002)
+    st = S.get_checkpoint_state(ckpt_dir)
+    assert [os.path.basename(p) for p in st.all_model_checkpoint_paths] == ['chkpt-30000.npz', 'chkpt-30002.npz']
+    S.reset_default_graph()
+
+
 def test_cli_convert_and_export(tmp_path, capsys):
     prefix, w, emb, bbs = _tf_style_checkpoint(str(tmp_path))
     npz = str(tmp_path / 'native.npz')

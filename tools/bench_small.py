@@ -65,7 +65,7 @@ def main():
                 z = enc.encode(x)
                 row[tag] = {'encode_us': round(1e3 * timeit(lambda: enc.encode(x), 100), 2),
                             'nn_us': round(1e3 * timeit(lambda: cb.nn(z, 1, 1), 200), 2),
-                            'encode+nn_us': round(1e3 * timeit(lambda: cb.nn(enc.encode(x), 1, 1), 100), 2),
+                            'encode+nn_us': round(1e3 * timeit((lambda: enc.encode_nn(cb, x, 1)) if on else (lambda: cb.nn(enc.encode(x), 1, 1)), 100), 2),
                             'kernels_us': kernel_split(enc, x)}
                 if B <= 4:
                     cap = CapturedNearestNeighbour(enc, cb, B)
