@@ -142,9 +142,7 @@ struct aae_codebook {
     aae_codebook* upright = nullptr;
     int upright_stride = 0;
     // B <= 4, top-1 on a stream kernel: arg-max over the block partials inside the scan launch (last block to arrive)
-    // instead of a separate argmax_reduce launch.  0: never (AAE_SCAN_STREAM_2L); 1: when the ticket words were prepared
-    // by the encoder's first kernel (aae_encode_nn) -- unprepared, the install path makes the single launch slower
-    // (19 us) than the two launches (15 us); 2: always (AAE_SCAN_STREAM)
+    // instead of a separate argmax_reduce launch.  0: never (AAE_SCAN_STREAM_2L); otherwise always
     int scan_ticket = 1;
 };
 
@@ -1327,7 +1325,7 @@ int aae_codebook_set_scan_mode(aae_codebook* cb, int mode) {
     if (!cb) return fail(AAE_ERR_INVALID, "aae_codebook_set_scan_mode: null handle");
     if (mode != AAE_SCAN_AUTO && mode != AAE_SCAN_GEMV && mode != AAE_SCAN_MFMA && mode != AAE_SCAN_STREAM && mode != AAE_SCAN_STREAM_2L)
         return fail(AAE_ERR_INVALID, "scan mode %d", mode);
-    cb->scan_ticket = mode == AAE_SCAN_STREAM_2L ? 0 : (mode == AAE_SCAN_STREAM ? 2 : 1);
+    cb->scan_ticket = mode == AAE_SCAN_STREAM_2L ? 0 : 1;
     cb->scan_mode = mode == AAE_SCAN_STREAM_2L ? AAE_SCAN_STREAM : mode;
     if (cb->upright) { cb->upright->scan_mode = cb->scan_mode; cb->upright->scan_ticket = cb->scan_ticket; }
     return AAE_OK;
@@ -1367,7 +1365,7 @@ static int nn_impl(aae_codebook* cb, const float* z, int B, int topk, int col_st
     // B <= 4, top-1 on a stream kernel: the last block to arrive merges the block partials -- the query is one launch
     ScanTicketOut fin;
     fin.idx_out = idx_out; fin.score_out = score_out; fin.idx_scale = idx_scale; fin.nonce = prepared_nonce;
-    const bool one_launch = topk == 1 && s.stream && (cb->scan_ticket == 2 || (cb->scan_ticket == 1 && prepared_nonce != 0));
+    const bool one_launch = topk == 1 && s.stream && cb->scan_ticket != 0;
     if (int rc = run_scan(cb, z, B, col_stride, cs, s, base, stream, &partial_rows, one_launch ? &fin : nullptr)) return rc;
     if (one_launch) return AAE_OK;
     if (topk == 1) {

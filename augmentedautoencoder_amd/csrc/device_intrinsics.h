@@ -192,6 +192,26 @@ __device__ __forceinline__ void ticket_clear(unsigned long long* word) {
 // total > kTicketSingleLevelMax, one word otherwise.  The winning block may then coherent_load*() all partials.
 // Ordering: each thread waits for its own stores (vmcnt(0): an sc1 store is acknowledged once it is visible at device
 // scope), then the block barrier, then thread 0's atomic; the winner's loads are issued after the second barrier.
+// Early self-preparation.  One thread per ticket word, called by ONE block at the very start of a ticketed kernel:
+// makes the word carry this launch's nonce before the arrivals come (they come microseconds later, after the block's
+// real work), so that they all take the one-atomic path.  Safe in ANY order relative to the arrivals: it only ever
+// replaces a foreign value, by compare-and-swap -- if an arrival installed the nonce first, nothing happens; if its
+// swap discards optimistic adds that landed on the foreign value, those arrivals add again (ticket_count).
+__device__ __forceinline__ void ticket_prepare_word(unsigned long long* word, unsigned nonce) {
+    unsigned long long cur = __hip_atomic_load(word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int spin = 0; (unsigned)(cur >> 32) != nonce; ++spin) {
+        if (__hip_atomic_compare_exchange_strong(word, &cur, (unsigned long long)nonce << 32, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                 __HIP_MEMORY_SCOPE_AGENT))
+            break;
+        if (spin > (1 << 16)) __builtin_trap();
+    }
+}
+// the words of one ticket: a single word (total <= kTicketSingleLevelMax) or the top word + 16 group words
+__device__ __forceinline__ void ticket_prepare_slot(unsigned long long* words, unsigned nonce, unsigned total) {
+    const unsigned n = total <= kTicketSingleLevelMax ? 1u : 1u + kTicketGroups;
+    if (threadIdx.x < n) ticket_prepare_word(words + threadIdx.x * kTicketGroupStride, nonce);
+}
+
 // first half: this block's coherent stores are complete and every thread knows it
 __device__ __forceinline__ void block_ticket_publish() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -164,6 +164,8 @@ __global__ __launch_bounds__(256) void scan_stream_bf16_kernel(const ScanArgs p)
         e[u] = __builtin_bit_cast(u32x4, buffer_load4(ebuf, row < p.N ? (unsigned)(row * 256 + kq * 16) : kOobOffset));
     }
 
+    if (p.tickets && blockIdx.x == 0) ticket_prepare_slot(p.tickets, p.nonce, gridDim.x);   // loads in flight; arrivals come later
+
     // tf.nn.l2_normalize(z, 1) per query, 8 columns per lane, replicated in every 16-lane group
     float qv[NQ][8];
 #pragma unroll

@@ -165,6 +165,8 @@ __global__ __launch_bounds__(256) void scan_stream_kernel(const ScanArgs p) {
         e[u] = buffer_load4(ebuf, ok ? (unsigned)(row * p.J + col) * 4u : kOobOffset);
     }
 
+    if (p.tickets && blockIdx.x == 0) ticket_prepare_slot(p.tickets, p.nonce, gridDim.x);   // the block's loads are in flight; arrivals come microseconds later
+
     // tf.nn.l2_normalize(z, 1) (codebook.py:27), per query, replicated in every lane
     f32x4 qv[NQ];
 #pragma unroll

@@ -177,6 +177,9 @@ __global__ __launch_bounds__(64 * WAVES) void conv_wavek_f32_kernel(const ConvWa
     stamp(1);                                                   // index arithmetic done
 #pragma unroll
     for (int d = 0; d < DEPTH - 1; ++d) load_stage(d);
+    // (block 0, its first loads in flight) the tile words get this launch's nonce long before the first arrival
+    if (p.gsplits > 1 && blockIdx.x == 0)
+        for (int w = tid; w < tiles; w += 64 * WAVES) ticket_prepare_word(p.tickets + w, p.nonce);
     for (int t = s0; t < s1; t += DEPTH) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {

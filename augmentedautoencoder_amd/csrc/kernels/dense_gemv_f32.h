@@ -50,6 +50,7 @@ __global__ __launch_bounds__(256) void dense_gemv_f32_kernel(const DenseGemvArgs
         const int slot = (k0 >> 2) + half * 16 + j;
         w[j] = buffer_load4(wbuf, (slot * 4 < p.K && n < p.CoutPad) ? (unsigned)((slot * p.CoutPad + n) * 16) : kOobOffset);
     }
+    if (TICKET && blockIdx.x == 0) ticket_prepare_slot(p.tickets + blockIdx.y * kTicketSlotWords, p.nonce, gridDim.x);   // loads in flight; arrivals come later
     __syncthreads();
     float acc[MQ];
 #pragma unroll

@@ -102,3 +102,41 @@ def make_queries_near_rows(E, rows, noise=0.05, seed=99):
     z = E[rows].astype(np.float64) * rng.uniform(0.5, 20.0, (len(rows), 1))
     z += noise * rng.standard_normal(z.shape) * np.linalg.norm(z, axis=1, keepdims=True) / np.sqrt(E.shape[1])
     return z.astype(np.float32)
+
+
+def make_decoder_weights_for(cfg, seed=4242):
+    """Synthetic decoder variables for a weights.DecoderConfig (glorot-uniform kernels, small biases, BN statistics)
+    under the TF names cfg.variable_names() gives -- inputs of the decoder line of bench.py."""
+    rng = np.random.default_rng(seed)
+    dense, convs, final, bns = cfg.variable_names()
+    dims = cfg.layer_dimensions()
+    k = cfg.kernel_size
+    w = {}
+
+    def glorot(shape, fan_in, fan_out):
+        lim = np.sqrt(6.0 / (fan_in + fan_out))
+        return rng.uniform(-lim, lim, shape).astype(np.float32)
+
+    def add_bn(name, c):
+        w[name + '/gamma'] = rng.uniform(0.5, 1.5, (c,)).astype(np.float32)
+        w[name + '/beta'] = rng.uniform(-0.1, 0.1, (c,)).astype(np.float32)
+        w[name + '/moving_mean'] = rng.uniform(0.0, 0.2, (c,)).astype(np.float32)
+        w[name + '/moving_variance'] = rng.uniform(0.5, 1.5, (c,)).astype(np.float32)
+
+    units = dims[0][0] * dims[0][1] * cfg.num_filters[0]
+    w[dense + '/kernel'] = glorot((cfg.latent_space_size, units), cfg.latent_space_size, units)
+    w[dense + '/bias'] = rng.uniform(0.0, 0.1, (units,)).astype(np.float32)
+    if cfg.batch_norm:
+        add_bn(bns[0], units)
+    cin = cfg.num_filters[0]
+    for i in range(1, cfg.num_layers):
+        co = cfg.num_filters[i]
+        w[convs[i - 1] + '/kernel'] = glorot((k, k, cin, co), k * k * cin, k * k * co)
+        w[convs[i - 1] + '/bias'] = rng.uniform(-0.05, 0.05, (co,)).astype(np.float32)
+        if cfg.batch_norm:
+            add_bn(bns[i], co)
+        cin = co
+    c = cfg.shape[2]
+    w[final + '/kernel'] = glorot((k, k, cin, c), k * k * cin, k * k * c)
+    w[final + '/bias'] = rng.uniform(-0.05, 0.05, (c,)).astype(np.float32)
+    return w

@@ -15,6 +15,13 @@ line carries a `split_precision` object: the identical step in the opt-in f32x3h
 mode (fp32 in/out, every product as 3 fp16 MFMAs on (hi, lo) operand pairs, fp32
 accumulate; same parity tolerances) -- reported beside
 the headline, never as it.  `--precision f32x3h` makes that mode the measured one.
+
+After the headline (N = 1 only, `--no-extras` skips them) the same line carries the other BASELINE configs and the
+per-detection regime, each measured in this run: `latency` (B = 1, 2, 4 fused encode+nn, eager and as one HIP-graph
+replay), `scan` (the codebook query alone: whole call warm, cold = rotating over 8 codebook copies that exceed the
+256 MB Infinity Cache, fraction of the 8 TB/s HBM peak), `config3` (encode 92232 views: ae_embed), `config5`
+(368928 x 128 bf16 codebook, B = 256, arg-max and top-5), `pcie_inclusive` (host uint8 batches, H2D overlapped)
+and `decoder`.
 """
 from __future__ import annotations
 
@@ -81,6 +88,7 @@ def main():
                     help='arithmetic of the measured step: f32 (default, exact fp32 MFMA) or f32x3h (split precision)')
     ap.add_argument('--no-split-precision', action='store_true', help='skip the extra f32x3h measurement')
     ap.add_argument('--profile-steps', type=int, default=5, help='instrumented per-kernel timing passes after the timed region')
+    ap.add_argument('--no-extras', action='store_true', help='skip the secondary measurements (latency, scan, config3, config5, pcie, decoder)')
     args = ap.parse_args()
 
     import torch
@@ -173,6 +181,8 @@ def main():
             'ms_per_step': round(elapsed / args.steps * 1e3, 4),
             'roofline': {'bound': 'mfma', 'kernel': dom['kernel'], 'achieved': round(achieved, 2), 'peak': round(peak, 1),
                          'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4), 'traffic': traffic,
+                         'traffic_source': 'profiles/traffic.json (rocprofv3 PMC passes of an earlier run of this command: 2*FETCH_SIZE + WRITE_SIZE; '
+                                           'not measured in this run)' if traffic is not None else None,
                          'flops_per_launch': dom_flops, 'avg_ms': dom['ms']},
             'encoder_tflops': round(cfg.flops_per_crop() * B / (sum(k['ms'] for k in kernels) * 1e-3) / 1e12, 2),
             'kernels': kernels,
@@ -184,24 +194,117 @@ def main():
         split_res = measure('f32x3h')
         enc.set_option('precision', 0)
 
-    z = enc.encode(x)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    reps = 20
-    cb.nn(z, 1, 1)
-    ev0.record()
-    for _ in range(reps):
-        cb.nn(z, 1, 1)
-    ev1.record()
-    torch.cuda.synchronize()
-    scan_ms = ev0.elapsed_time(ev1) / reps
-    z1 = z[:1].contiguous()
-    cb.nn(z1, 1, 1)
-    ev0.record()
-    for _ in range(reps):
-        cb.nn(z1, 1, 1)
-    ev1.record()
-    torch.cuda.synchronize()
-    scan1_ms = ev0.elapsed_time(ev1) / reps
+    def time_us(fn, reps, warm=5):
+        """average microseconds per call of fn over `reps` back-to-back calls (HIP events on the launch stream)"""
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e3
+
+    extras = {}
+    if world == 1 and not args.no_extras and args.precision == 'f32':
+        from augmentedautoencoder_amd.engine import CapturedNearestNeighbour, DecoderEngine, StreamingNearestNeighbour
+        from augmentedautoencoder_amd.weights import DecoderConfig
+        import numpy as np
+        cb_bytes = N_ROWS * 128 * 4
+        # ---- per-detection latency: the reference calls session.run once per detected box (ae_pose_estimator.py:143-170)
+        lat = {}
+        for b in (1, 2, 4):
+            xb = x[:b].contiguous()
+            eager = time_us(lambda: enc.encode_nn(cb, xb, 1), 200)
+            cap = CapturedNearestNeighbour(enc, cb, b)
+            graph = time_us(lambda: cap.graph.replay(), 200)
+            _, recs = enc.encode_timed(xb)
+            lat['B%d' % b] = {'encode+nn_us': round(eager, 2), 'graph_replay_us': round(graph, 2), 'crops_per_s': round(b / eager * 1e6, 1),
+                              'launches': len(recs) + 1}
+            del cap
+        lat['note'] = ('fused aae_encode_nn: conv1, three wave-split-K convolutions, dense GEMV, stream scan -- each split reduction finished '
+                       'inside its own launch; floor of this chain = 27 us of fp32 MFMA work (4.28 GFLOP at 157 TF) + 107 MB of weights/codebook')
+        extras['latency'] = lat
+        # ---- the codebook query alone
+        z = enc.encode(x)
+        z1 = z[:1].contiguous()
+        warm1 = time_us(lambda: cb.nn(z1, 1, 1), 300)
+        warm256 = time_us(lambda: cb.nn(z, 1, 1), 100)
+        copies = [cb] + [CodebookEngine(E, device=dev) for _ in range(7)]          # 8 x 47.2 MB = 378 MB > 256 MB Infinity Cache
+        k = [0]
+
+        def cold_call():
+            copies[k[0] % len(copies)].nn(z1, 1, 1)
+            k[0] += 1
+        cold1 = time_us(cold_call, 320, warm=16)
+        for c in copies[1:]:
+            c.close()
+        extras['scan'] = {
+            'codebook_bytes': cb_bytes, 'peak_GBps': PEAK_HBM_GBPS,
+            'B1_whole_call_warm_us': round(warm1, 2), 'B1_warm_GBps': round(cb_bytes / warm1 / 1e3, 1), 'B1_warm_frac': round(cb_bytes / warm1 / 1e3 / PEAK_HBM_GBPS, 3),
+            'B1_whole_call_cold_us': round(cold1, 2), 'B1_cold_GBps': round(cb_bytes / cold1 / 1e3, 1), 'B1_cold_frac': round(cb_bytes / cold1 / 1e3 / PEAK_HBM_GBPS, 3),
+            'B256_whole_call_us': round(warm256, 2),
+            'note': 'whole aae_codebook_nn call, back-to-back calls on one stream (stand-alone: stream scan + arg-max reduce launch; inside '
+                    'aae_encode_nn the scan is one launch).  warm: the 47 MB codebook stays in the 256 MB Infinity Cache between calls '
+                    '(algorithmic bytes, not HBM bytes); cold: 8 codebook copies visited in turn, so every call streams from HBM.  '
+                    'B=256 is MFMA-bound (crossover B~39).  Kernel-only durations: profiles/ (rocprofv3 --kernel-trace --stats)'}
+        # ---- BASELINE config 3: ae_embed -- encode 92232 views (codebook.py:190-219), encoder only, inputs resident
+        c3 = {}
+        for bs in (64, 256):
+            bs = min(bs, B)
+            xb = x[:bs].contiguous()
+            nb = -(-N_ROWS // bs)
+            enc.encode(xb)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(nb):
+                enc.encode(xb)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            c3['batch%d' % bs] = {'seconds': round(dt, 3), 'crops_per_s': round(nb * bs / dt, 1), 'batches': nb}
+        c3['note'] = '92232 synthetic views in batches of 64 (reference batch, train_template.cfg:61) and 256; fp32; the float64 normalise on the host is not timed'
+        extras['config3'] = c3
+        # ---- BASELINE config 5: 4x codebook in bf16, B = 256, arg-max and top-5
+        N5 = 368928
+        E5 = synth.make_codebook(N5, 128, seed=11, planted_duplicates=0)
+        cb5 = CodebookEngine(E5, device=dev, dtype='bf16')
+        z5 = torch.randn(256, 128, device=dev)
+        t_arg = time_us(lambda: cb5.nn(z5, 1, 1), 50)
+        t_top5 = time_us(lambda: cb5.nn(z5, 5, 1), 20)
+        t_b1 = time_us(lambda: cb5.nn(z5[:1], 1, 1), 100)
+        flops5 = 2.0 * 256 * N5 * 128
+        extras['config5'] = {'rows': N5, 'dtype': 'bf16 codebook, fp32-accurate queries (3 bf16 terms)', 'codebook_bytes': N5 * 128 * 2,
+                             'B256_argmax_us': round(t_arg, 2), 'B256_top5_us': round(t_top5, 2), 'B1_argmax_us': round(t_b1, 2),
+                             'B256_argmax_algorithmic_GBps': round(N5 * 256 / t_arg / 1e3, 1),
+                             'B256_argmax_TFLOPs_nominal': round(flops5 / t_arg / 1e6, 1),
+                             'B256_argmax_frac_of_bf16_mfma_peak': round(3 * flops5 / t_arg / 1e6 / 2500.0, 3),
+                             'B1_argmax_GBps': round(N5 * 256 / t_b1 / 1e3, 1), 'B1_frac_of_HBM_peak': round(N5 * 256 / t_b1 / 1e3 / PEAK_HBM_GBPS, 3),
+                             'note': 'frac_of_bf16_mfma_peak counts the 3 MFMAs per product the fp32-accurate query split issues, against 2.5 PFLOP/s dense'}
+        cb5.close()
+        del E5
+        # ---- PCIe-inclusive: host uint8 batches, H2D of batch i+1 overlapped with compute of batch i
+        host = [synth.make_crops(B, seed=100 + i) for i in range(4)]
+        sp = StreamingNearestNeighbour(enc, cb, B)
+        for _ in sp.run(host[:2]):
+            pass
+        torch.cuda.synchronize()
+        nbat = 24
+        t0 = time.perf_counter()
+        for _ in sp.run(host[i % 4] for i in range(nbat)):
+            pass
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        extras['pcie_inclusive'] = {'crops_per_s': round(nbat * B / dt, 1), 'ms_per_batch': round(dt / nbat * 1e3, 3), 'batches': nbat,
+                                    'note': 'host (pageable) uint8 batches of %d, indices copied back; never the headline value' % B}
+        # ---- decoder (eval_plots reconstructions)
+        dcfg = DecoderConfig()
+        dec = DecoderEngine(dcfg, synth.make_decoder_weights_for(dcfg), device=dev, max_batch=256)
+        zd = torch.randn(256, 128, device=dev) * 0.5
+        t_dec = time_us(lambda: dec.decode(zd), 10, warm=2)
+        extras['decoder'] = {'B256_ms': round(t_dec / 1e3, 3), 'images_per_s': round(256 / t_dec * 1e6, 1)}
+        dec.close()
 
     if rank == 0:
         x3h_label = 'f32 in/out, 3xfp16-split MFMA with fp32 accumulate (f32x3h)'
@@ -221,11 +324,8 @@ def main():
             'roofline': main_res['roofline'],
             'encoder_tflops': main_res['encoder_tflops'],
             'kernels': main_res['kernels'],
-            'scan': {'B256_ms': round(scan_ms, 4), 'B1_ms': round(scan1_ms, 4), 'codebook_bytes': N_ROWS * 128 * 4,
-                     'B1_algorithmic_GBps': round(N_ROWS * 128 * 4 / (scan1_ms * 1e-3) / 1e9, 1), 'peak_GBps': PEAK_HBM_GBPS,
-                     'note': 'full aae_codebook_nn call (normalise + scan + reduce).  B=256 is MFMA-bound (crossover B~39); '
-                             'B=1 is the HBM-bound regime: the scan kernel alone runs 10.0 us = 4.7 TB/s (profiles/)'},
         }
+        out.update(extras)
         if split_res is not None:
             out['split_precision'] = {'mode': x3h_label, 'value': split_res['value'], 'unit': 'crops/s',
                                       'ms_per_step': split_res['ms_per_step'], 'roofline': split_res['roofline'],

@@ -47,7 +47,7 @@ extern "C" {
 #define AAE_SCAN_GEMV 1           /* vector-ALU, shuffle reductions, B <= 4 (first version, kept for A/B) */
 #define AAE_SCAN_MFMA 2           /* tile-resident matrix-core kernels, any B       */
 #define AAE_SCAN_STREAM 3         /* fused normalise + HBM stream + DPP reductions, B <= 4 (AUTO picks it); top-1 finishes
-                                     inside the same launch (last block to arrive merges the block partials) */
+                                     inside the same launch (the last block to arrive merges the block partials) */
 #define AAE_SCAN_STREAM_2L 4      /* the same stream kernel followed by a separate arg-max reduce launch (A/B, race screen) */
 
 typedef struct aae_encoder aae_encoder;

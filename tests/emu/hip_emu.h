@@ -197,6 +197,13 @@ inline unsigned ticket_count(unsigned long long* word, unsigned nonce) {
     return (unsigned)*word;
 }
 inline void ticket_clear(unsigned long long* word) { *word = 0; }
+inline void ticket_prepare_word(unsigned long long* word, unsigned nonce) {
+    if ((unsigned)(*word >> 32) != nonce) *word = (unsigned long long)nonce << 32;
+}
+inline void ticket_prepare_slot(unsigned long long* words, unsigned nonce, unsigned total) {
+    const unsigned n = total <= kTicketSingleLevelMax ? 1u : 1u + kTicketGroups;
+    if (threadIdx.x < n) ticket_prepare_word(words + threadIdx.x * kTicketGroupStride, nonce);
+}
 inline void block_ticket_publish() { __syncthreads(); }
 inline bool block_ticket_take(unsigned long long* words, unsigned nonce, unsigned total, unsigned id, int* lds_flag) {
     if (threadIdx.x == 0) {

@@ -24,6 +24,15 @@ static unsigned ticket_count(std::atomic<uint64_t>* word, unsigned nonce) {
     }
 }
 
+// device_intrinsics.h::ticket_prepare_word: the early self-preparation by one block, racing with the arrivals
+static void prepare_word(std::atomic<uint64_t>* word, unsigned nonce) {
+    uint64_t cur = word->load(std::memory_order_relaxed);
+    for (long spin = 0; (unsigned)(cur >> 32) != nonce; ++spin) {
+        if (word->compare_exchange_strong(cur, (uint64_t)nonce << 32, std::memory_order_relaxed)) break;
+        if (spin > (1L << 24)) { fprintf(stderr, "prepare_word: no progress\n"); abort(); }
+    }
+}
+
 static bool arrive(std::atomic<uint64_t>* words, unsigned nonce, unsigned total, unsigned id) {
     if (total <= (unsigned)kSingleMax) {
         const bool last = ticket_count(words, nonce) == total;
@@ -53,9 +62,18 @@ int main(int argc, char** argv) {
         std::atomic<unsigned> arrived{0}, lasts{0}, arrived_when_last{0};
         std::atomic<int> go{0};
         std::vector<std::thread> th;
+        // in half of the rounds "block 0" prepares the words before its own arrival (program order on the device: the
+        // preparation is the first thing block 0 does), at a random moment relative to the OTHER blocks' arrivals
+        const bool with_prepare = (r / 4) % 2 == 1;
+        const unsigned delay = rng() % 4000;
         for (unsigned t = 0; t < total; ++t)
             th.emplace_back([&, t] {
                 while (!go.load(std::memory_order_acquire)) {}
+                if (with_prepare && t == 0) {
+                    for (volatile unsigned d = 0; d < delay; ++d) {}
+                    const int n = total <= (unsigned)kSingleMax ? 1 : 1 + kGroups;
+                    for (int w = 0; w < n; ++w) prepare_word(words.data() + w * kStride, nonce);
+                }
                 arrived.fetch_add(1, std::memory_order_seq_cst);
                 if (arrive(words.data(), nonce, total, t)) {
                     lasts.fetch_add(1);
@@ -69,10 +87,15 @@ int main(int argc, char** argv) {
             return 1;
         }
         // every word the round used is left clean (the other words may still hold the garbage of an earlier round)
+        // (a group word may hold (nonce, 0 arrivals) when block 0's preparation reached it after the group had finished:
+        // an empty state of this launch, foreign -- hence empty -- to every later one)
+        const uint64_t empty_of_this_launch = (uint64_t)nonce << 32;
         if (words[0].load() != 0) { printf("FAIL round %d: top word left dirty\n", r); return 1; }
         if (total > (unsigned)kSingleMax)
-            for (int g = 0; g < kGroups; ++g)
-                if (words[(1 + g) * kStride].load() != 0) { printf("FAIL round %d: group word %d left dirty\n", r, g); return 1; }
+            for (int g = 0; g < kGroups; ++g) {
+                const uint64_t w = words[(1 + g) * kStride].load();
+                if (w != 0 && !(with_prepare && w == empty_of_this_launch)) { printf("FAIL round %d: group word %d left dirty\n", r, g); return 1; }
+            }
     }
     printf("OK %d rounds\n", rounds);
     return 0;
