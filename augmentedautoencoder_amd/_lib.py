@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = (
     'aae_codebook_create', 'aae_codebook_update', 'aae_codebook_destroy', 'aae_codebook_set_scan_mode',
     'aae_codebook_prepare_upright',
     'aae_codebook_workspace_bytes', 'aae_codebook_nn', 'aae_encode_nn', 'aae_codebook_similarity', 'aae_l2_normalize',
-    'aae_crop_resize_u8',
+    'aae_crop_resize_u8', 'aae_pack_pairs',
     'aae_decoder_create', 'aae_decoder_destroy', 'aae_decoder_workspace_bytes', 'aae_decoder_forward',
     'aae_decoder_forward_timed', 'aae_decoder_kernel_label', 'aae_decoder_kernel_flops', 'aae_decoder_activation_info',
 )
@@ -102,6 +102,8 @@ def declare(lib):
     lib.aae_codebook_prepare_upright.argtypes = [c_void_p, c_int, c_void_p]
     lib.aae_codebook_workspace_bytes.restype = c_size_t
     lib.aae_codebook_workspace_bytes.argtypes = [c_void_p, c_int, c_int]
+    lib.aae_pack_pairs.restype = c_int
+    lib.aae_pack_pairs.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]
     lib.aae_encode_nn.restype = c_int
     lib.aae_encode_nn.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                   c_void_p, c_size_t, c_void_p]

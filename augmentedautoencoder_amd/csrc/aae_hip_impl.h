@@ -1437,6 +1437,19 @@ int aae_l2_normalize(const float* z, int B, int J, float* q_out, void* stream_v)
     return AAE_OK;
 }
 
+int aae_pack_pairs(const int64_t* idx, const float* score, const int32_t* pos, int n, int stride, int64_t* packed, void* stream_v) {
+    using namespace aae_host;
+    if (!idx || !score || !packed) return fail(AAE_ERR_INVALID, "aae_pack_pairs: null argument");
+    if (n < 0 || stride < 1) return fail(AAE_ERR_INVALID, "aae_pack_pairs: n=%d stride=%d", n, stride);
+    if (n == 0) return AAE_OK;
+    aae::PackPairsArgs a;
+    a.idx = reinterpret_cast<const long long*>(idx); a.score = score; a.pos = pos; a.packed = reinterpret_cast<long long*>(packed);
+    a.n = n; a.stride = stride;
+    AAE_LAUNCH((aae::pack_pairs_kernel), dim3(ceil_div(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream_v), a);
+    AAE_HIP_TRY(hipGetLastError());
+    return AAE_OK;
+}
+
 int aae_crop_resize_u8(const void* img, int H, int W, int C, const int32_t* boxes, int D, int out_h, int out_w,
                        void* out, void* stream_v) {
     using namespace aae_host;

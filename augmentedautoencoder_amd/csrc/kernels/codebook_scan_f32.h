@@ -401,6 +401,23 @@ __global__ __launch_bounds__(256) void gather_rows_kernel(const GatherRowsArgs p
     }
 }
 
+// (index, score) answers -> the fixed-capacity int64 pair buffer the multi-GPU gather exchanges (dist.py): row pos[i]
+// (or i) of `packed` receives (idx[i], sign-extended float bits of score[i]); rows nobody writes keep their sentinel.
+struct PackPairsArgs {
+    const long long* idx;   // [n * stride]
+    const float* score;     // [n * stride]
+    const int* pos;         // [n] destination rows, or nullptr for 0..n-1
+    long long* packed;      // [capacity][2]
+    int n, stride;          // stride: elements between consecutive answers (top-k buffers: k)
+};
+__global__ __launch_bounds__(256) void pack_pairs_kernel(const PackPairsArgs p) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.n) return;
+    const long long row = p.pos ? p.pos[i] : i;
+    p.packed[2 * row] = p.idx[(long long)i * p.stride];
+    p.packed[2 * row + 1] = (long long)__builtin_bit_cast(int, p.score[(long long)i * p.stride]);
+}
+
 struct ArgmaxReduceArgs {
     const float* pval;
     const int* pidx;

@@ -34,10 +34,13 @@ def route(class_ids, world_size, rank):
 
 
 class ShardedPoseEngine(object):
-    """local_infer(obj_id, crops_subset) -> (idx int64 [n], score float32 [n]); crops_subset is
-    ``crops[positions]`` (numpy array or torch tensor, whatever the caller passed in)."""
+    """local_infer(obj_id, crops_subset) -> (idx int64 [n] or [n,1], score float32 likewise); crops_subset is
+    ``crops[positions]`` (numpy array or torch tensor, whatever the caller passed in).
 
-    def __init__(self, local_infer, world_size=None, rank=None, group=None, device=None):
+    pack_pairs(idx, score, pos int32 tensor, packed): optional one-launch writer of the gather payload (the HIP path
+    passes ``engine.pack_pairs``); without it the pairs are packed with framework tensor ops (CPU / gloo tests)."""
+
+    def __init__(self, local_infer, world_size=None, rank=None, group=None, device=None, pack_pairs=None):
         import torch.distributed as dist
         self.dist = dist
         self.group = group
@@ -46,30 +49,53 @@ class ShardedPoseEngine(object):
         self.rank = int(rank) if rank is not None else (dist.get_rank(group) if self.distributed else 0)
         self.local_infer = local_infer
         self.device = device
+        self.pack_pairs = pack_pairs
+        self._plan_key, self._plan = None, None
+
+    def plan(self, class_ids):
+        """Routing of one batch layout, reusable while the class ids stay the same (a detector's boxes change per frame,
+        a benchmark's do not): this rank's buckets {obj: positions}, their position tensors on the device, and the
+        owner of every batch row for the re-assembly after the gather."""
+        import torch
+        key = tuple(np.asarray(class_ids).tolist())
+        if key != self._plan_key:
+            dev = self.device if self.device is not None else torch.device('cpu')
+            buckets = route(class_ids, self.world_size, self.rank)
+            pos_dev = {o: torch.as_tensor(p, dtype=torch.int32, device=dev) for o, p in buckets.items()}
+            owners = torch.as_tensor([owner_of(o, self.world_size) for o in key], dtype=torch.int64, device=dev)
+            self._plan_key, self._plan = key, (buckets, pos_dev, owners, torch.arange(len(key), device=dev))
+        return self._plan
 
     def infer(self, crops, class_ids):
-        """Every rank passes the same (crops, class_ids); every rank returns the full
-        (idx int64 [B], score float32 [B]) in batch order."""
+        """Every rank passes the same class_ids and either the whole batch ``crops`` (rows of other ranks are never
+        touched) or just its own share as a dict {obj_id: crops of that object, in batch order} -- what a deployment
+        that routes on the host sends to each GPU.  Every rank returns the full (idx int64 [B], score float32 [B]) in
+        batch order."""
         import torch
         B = len(class_ids)
         dev = self.device if self.device is not None else torch.device('cpu')
+        buckets, pos_dev, owners, rows = self.plan(class_ids)
         # fixed-capacity buffers, -1 sentinel for "not mine" (equal sizes for all_gather)
         packed = torch.full((B, 2), -1, dtype=torch.int64, device=dev)
-        for obj, pos in route(class_ids, self.world_size, self.rank).items():
-            sel = crops[torch.as_tensor(pos, device=crops.device)] if torch.is_tensor(crops) else crops[pos]
+        for obj, pos in buckets.items():
+            if isinstance(crops, dict):
+                sel = crops[obj]
+            else:
+                sel = crops[pos_dev[obj].to(crops.device).long()] if torch.is_tensor(crops) else crops[pos]
             idx, score = self.local_infer(obj, sel)
-            idx = torch.as_tensor(idx, dtype=torch.int64, device=dev).reshape(-1)
-            score = torch.as_tensor(score, dtype=torch.float32, device=dev).reshape(-1)
-            p = torch.as_tensor(pos, device=dev)
-            packed[p, 0] = idx
-            packed[p, 1] = score.view(torch.int32).to(torch.int64)
-        if self.world_size > 1:
+            idx = torch.as_tensor(idx, dtype=torch.int64, device=dev)
+            score = torch.as_tensor(score, dtype=torch.float32, device=dev)
+            if self.pack_pairs is not None:
+                self.pack_pairs(idx.reshape(len(pos), -1), score.reshape(len(pos), -1), pos_dev[obj], packed)
+            else:
+                p = pos_dev[obj].long()
+                packed[p, 0] = idx.reshape(-1)
+                packed[p, 1] = score.reshape(-1).view(torch.int32).to(torch.int64)
+        if self.distributed or self.world_size > 1:
+            # the one collective of the path (RCCL over xGMI on the GPUs); a single-rank group runs it too
             gathered = torch.empty((self.world_size * B, 2), dtype=torch.int64, device=dev)
             self.dist.all_gather_into_tensor(gathered, packed, group=self.group)
-            gathered = gathered.view(self.world_size, B, 2)
-            owners = torch.as_tensor([owner_of(o, self.world_size) for o in np.asarray(class_ids).tolist()],
-                                     dtype=torch.int64, device=dev)
-            packed = gathered[owners, torch.arange(B, device=dev)]
+            packed = gathered.view(self.world_size, B, 2)[owners, rows]
         idx = packed[:, 0]
         score = packed[:, 1].to(torch.int32).view(torch.float32)
         return idx, score
@@ -144,7 +170,7 @@ class RowShardedCodebook(object):
         import torch
         ix, sc = self.local_candidates(z, topk, col_stride)
         B = len(z)
-        if self.world_size > 1:
+        if self.distributed or self.world_size > 1:
             packed = torch.stack([ix, sc.view(torch.int32).to(torch.int64)], dim=2).contiguous()        # [B,k,2]
             gathered = torch.empty((self.world_size,) + tuple(packed.shape), dtype=torch.int64, device=ix.device)
             self.dist.all_gather_into_tensor(gathered.view(-1, 2), packed.view(-1, 2), group=self.group)

@@ -325,6 +325,26 @@ class CodebookEngine(object):
         return q
 
 
+def pack_pairs(idx, score, pos, packed):
+    """packed[pos[i]] = (idx[i, 0], float bits of score[i, 0]) in one launch (aae_pack_pairs): the payload of the
+    multi-GPU gather.  idx int64 [n,k], score float32 [n,k], pos int32 [n] device tensor or None (rows 0..n-1),
+    packed int64 [capacity, 2] -- all on one device."""
+    torch = _torch()
+    lib = _lib.load()
+    n = int(idx.shape[0])
+    if n == 0:
+        return packed
+    stride = int(idx.shape[1]) if idx.dim() == 2 else 1
+    if pos is not None and pos.dtype != torch.int32:
+        pos = pos.to(torch.int32)
+    with torch.cuda.device(packed.device):
+        rc = lib.aae_pack_pairs(ctypes.c_void_p(idx.data_ptr()), ctypes.c_void_p(score.data_ptr()),
+                                ctypes.c_void_p(pos.data_ptr()) if pos is not None else None, n, stride,
+                                ctypes.c_void_p(packed.data_ptr()), _stream_ptr(torch))
+    _lib.check(lib, rc, 'aae_pack_pairs')
+    return packed
+
+
 def crop_resize(image, boxes_xywh_size, out_hw, device=None):
     """All detector crops of one image in one launch (extract_square_patch(black_borders=True) +
     cv2.resize(INTER_LINEAR), m3_interface/ae_pose_estimator.py:106-131).

@@ -88,12 +88,14 @@ def main():
                     help='arithmetic of the measured step: f32 (default, exact fp32 MFMA) or f32x3h (split precision)')
     ap.add_argument('--no-split-precision', action='store_true', help='skip the extra f32x3h measurement')
     ap.add_argument('--profile-steps', type=int, default=5, help='instrumented per-kernel timing passes after the timed region')
+    ap.add_argument('--force-dist', action='store_true',
+                    help='initialise the RCCL process group and take the multi-GPU code path (pair packing, all_gather, config4) even at world size 1')
     ap.add_argument('--no-extras', action='store_true', help='skip the secondary measurements (latency, scan, config3, config5, pcie, decoder)')
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from augmentedautoencoder_amd.engine import CodebookEngine, EncoderEngine
+    from augmentedautoencoder_amd.engine import CodebookEngine, EncoderEngine, pack_pairs
     from augmentedautoencoder_amd.weights import EncoderConfig
     from augmentedautoencoder_amd import synth            # seeded synthetic inputs (no oracle code on the measured path)
 
@@ -104,8 +106,12 @@ def main():
         raise SystemExit('--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N > 1)' % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist        # one process per GPU over RCCL; --force-dist runs that path on a single GPU
+    if use_dist:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
+        os.environ.setdefault('RANK', '0')
+        os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group('nccl', device_id=dev)
 
     B = args.batch
@@ -117,19 +123,18 @@ def main():
     cb = CodebookEngine(E, device=dev)
     x = torch.from_numpy(crops).to(dev)                       # inputs resident in HBM before the timed region
     packed = torch.empty((B, 2), dtype=torch.int64, device=dev)
-    gathered = torch.empty((world * B, 2), dtype=torch.int64, device=dev) if world > 1 else None
+    gathered = torch.empty((world * B, 2), dtype=torch.int64, device=dev) if use_dist else None
 
     def step():
         z = enc.encode(x)
         idx, score = cb.nn(z, 1, 1)
-        if world > 1:
-            packed[:, 0] = idx[:, 0]
-            packed[:, 1] = score[:, 0].view(torch.int32).to(torch.int64)
+        if use_dist:
+            pack_pairs(idx, score, None, packed)                  # one launch: (index, score bits) pairs, the gather payload
             dist.all_gather_into_tensor(gathered, packed)
         return idx, score
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -144,11 +149,11 @@ def main():
         for _ in range(args.steps):
             step()
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
-        if world > 1:
+        if use_dist:
             t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
@@ -208,7 +213,37 @@ def main():
         return e0.elapsed_time(e1) / reps * 1e3
 
     extras = {}
-    if world == 1 and not args.no_extras and args.precision == 'f32':
+    if use_dist and not args.no_extras and args.precision == 'f32':
+        # ---- BASELINE config 4 as SURVEY 8d defines it: ONE mixed batch of 256 crops, class labels integers(0, N_obj), N_obj = N
+        # objects sharded one per GPU; every rank runs encode + scan on its bucket (the host routes by class id, as the
+        # reference's per-box loop does, m3_interface/ae_pose_estimator.py:143-170) and one RCCL all_gather of the padded
+        # (index, score) pairs re-assembles the batch.  Strong scaling of a fixed 256-crop batch: per-GPU batches shrink to
+        # 256 / N, so this is a latency-regime number, reported beside the weak-scaling headline.
+        import numpy as np
+        from augmentedautoencoder_amd.dist import ShardedPoseEngine
+        labels = np.random.default_rng(0).integers(0, world, BATCH)
+        all_crops = torch.from_numpy(synth.make_crops(BATCH, seed=4321)).to(dev)     # the same mixed batch on every rank
+        mine = torch.from_numpy(np.flatnonzero(labels == rank)).to(dev)
+        my_bucket = {rank: all_crops[mine].contiguous()}                             # host-side routing, outside the timed region
+        spe = ShardedPoseEngine(lambda obj, c: enc.encode_nn(cb, c, 1)[1:], device=dev, pack_pairs=pack_pairs)
+        for _ in range(max(args.warmup, 3)):
+            spe.infer(my_bucket, labels)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            idx4, _ = spe.infer(my_bucket, labels)
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t4 = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t4, op=dist.ReduceOp.MAX)
+        t4 = float(t4.item())
+        extras['config4'] = {'workload': 'one mixed batch of %d crops, %d objects sharded 1 per GPU, routed by class id, RCCL all_gather of '
+                                         '(idx, score) pairs padded to %d rows per rank' % (BATCH, world, BATCH),
+                             'value': round(BATCH * args.steps / t4, 1), 'unit': 'crops/s', 'ms_per_batch': round(t4 / args.steps * 1e3, 4),
+                             'bucket_sizes': np.bincount(labels, minlength=world).tolist(), 'scaling': 'strong (global batch fixed)',
+                             'answers_complete': bool((idx4 >= 0).all().item())}
+    if not use_dist and not args.no_extras and args.precision == 'f32':
         from augmentedautoencoder_amd.engine import CapturedNearestNeighbour, DecoderEngine, StreamingNearestNeighbour
         from augmentedautoencoder_amd.weights import DecoderConfig
         import numpy as np
@@ -320,7 +355,7 @@ def main():
             'config': {'workload': 'configs[1]: single object per GPU, batch=%d uint8 128x128x3 crops, HIP 4-conv encoder -> 128-d + '
                                    'cosine-NN vs %dx128 fp32 codebook, top-1' % (B, N_ROWS),
                        'batch_per_gpu': B, 'codebook_rows': N_ROWS, 'latent': 128,
-                       'parallelism': 'objects sharded 1 per GPU; all_gather of (idx, score) only' if world > 1 else 'single GPU'},
+                       'parallelism': 'objects sharded 1 per GPU; all_gather of (idx, score) only' if use_dist else 'single GPU'},
             'roofline': main_res['roofline'],
             'encoder_tflops': main_res['encoder_tflops'],
             'kernels': main_res['kernels'],
@@ -331,10 +366,10 @@ def main():
                                       'ms_per_step': split_res['ms_per_step'], 'roofline': split_res['roofline'],
                                       'encoder_tflops_fp32_equivalent': split_res['encoder_tflops'], 'kernels': split_res['kernels'],
                                       'note': 'opt-in mode, same parity tolerances (cosine 1e-5, tie-aware index equality); not the headline'}
-        if world == 1 and not args.no_cpu_baseline:
+        if not use_dist and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(weights, E, crops)
         print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -183,6 +183,13 @@ int aae_codebook_similarity(aae_codebook* cb, const float* z, int B, float* cs_o
 /* normalized_embedding_query (codebook.py:27) for test_embedding(normalized=True) (:135-145). */
 int aae_l2_normalize(const float* z, int B, int J, float* q_out, void* stream);
 
+/* Multi-GPU gather payload (object-sharded inference, one process per GPU): row pos[i] (pos == NULL: row i) of the
+ * fixed-capacity buffer packed[capacity][2] receives (idx[i*stride], float bits of score[i*stride]).  One launch
+ * instead of four framework element-wise ops in the step that ends in the RCCL all_gather; rows that belong to other
+ * ranks keep the -1 sentinel.  Replaces the per-detection bookkeeping of m3_interface/ae_pose_estimator.py:143-170. */
+int aae_pack_pairs(const int64_t* idx, const float* score, const int32_t* pos, int n, int stride, int64_t* packed,
+                   void* stream);
+
 /* ---- Caller side ("next" row N1): detector crops for a whole image in one launch -------------
  * AePoseEstimator.extract_square_patch(black_borders=True) + cv2.resize(INTER_LINEAR)
  * (auto_pose/m3_interface/ae_pose_estimator.py:106-131,157-162).

@@ -57,6 +57,22 @@ def _worker(rank, world, port, out_dir):
 
     eng = ShardedPoseEngine(infer)
     idx, score = eng.infer(z, class_ids)
+    # pre-routed form: this rank is handed only ITS buckets (what a host that routes by class id sends to each GPU),
+    # with a caller-supplied pair writer standing in for engine.pack_pairs
+    from augmentedautoencoder_amd.dist import route
+    mine = {o: z[pos] for o, pos in route(class_ids, world, rank).items()}
+    writes = []
+
+    def pack(ix, sc, pos, packed):
+        writes.append(len(pos))
+        packed[pos.long(), 0] = ix.reshape(-1)
+        packed[pos.long(), 1] = sc.reshape(-1).view(torch.int32).to(torch.int64)
+
+    eng2 = ShardedPoseEngine(infer, pack_pairs=pack)
+    idx2, score2 = eng2.infer(mine, class_ids)
+    assert torch.equal(idx, idx2) and torch.equal(score, score2) and sum(writes) == sum(len(v) for v in mine.values())
+    idx3, _ = eng2.infer(mine, class_ids)                     # the cached routing plan of an unchanged batch layout
+    assert torch.equal(idx3, idx)
     np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), idx=idx.numpy(), score=score.numpy(), calls=np.array(sorted(set(calls))))
     dist.destroy_process_group()
 

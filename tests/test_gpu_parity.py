@@ -744,3 +744,62 @@ def test_in_launch_ticketed_reductions_are_race_free_and_order_independent():
         assert torch.equal(enc.encode(x), zv)
     enc.close()
     cb.close()
+
+
+def test_object_sharded_and_row_sharded_paths_run_through_rccl_at_world_size_one():
+    """The multi-GPU code paths (dist.ShardedPoseEngine: class-routed buckets + all_gather of the packed pairs written
+    by aae_pack_pairs; dist.RowShardedCodebook: all_gather of local top-k + merge) executed with backend 'nccl' (= RCCL)
+    on the one GPU of this box: the collective, the device packing and the re-assembly run as they do on 8 GPUs."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from augmentedautoencoder_amd.dist import RowShardedCodebook, ShardedPoseEngine
+    from augmentedautoencoder_amd.engine import CodebookEngine, EncoderEngine, pack_pairs
+    from augmentedautoencoder_amd.weights import EncoderConfig
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    dev = torch.device('cuda', 0)
+    dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1, device_id=dev)
+    try:
+        objs = {}
+        for o in range(3):                                   # three objects, all owned by rank 0 of 1
+            objs[o] = (EncoderEngine(EncoderConfig(), synth.make_weights(seed=2024 + o)),
+                       CodebookEngine(synth.make_codebook(92232, 128, seed=7 + o, planted_duplicates=8)))
+        labels = np.random.default_rng(0).integers(0, 3, 40)
+        crops = torch.from_numpy(synth.make_crops(40, seed=55)).cuda()
+        spe = ShardedPoseEngine(lambda o, c: objs[o][0].encode_nn(objs[o][1], c, 1)[1:], device=dev, pack_pairs=pack_pairs)
+        assert spe.distributed and spe.world_size == 1
+        idx, score = spe.infer(crops, labels)
+        buckets = {o: crops[torch.from_numpy(np.flatnonzero(labels == o)).cuda()] for o in range(3)}
+        idx_b, score_b = spe.infer(buckets, labels)          # pre-routed buckets: the same answers
+        assert torch.equal(idx, idx_b) and torch.equal(score, score_b)
+        for o in range(3):
+            pos = np.flatnonzero(labels == o)
+            wi, ws = objs[o][1].nn(objs[o][0].encode(crops[torch.from_numpy(pos).cuda()]), 1, 1)
+            assert torch.equal(idx[pos], wi[:, 0]) and torch.equal(score[pos], ws[:, 0]), o
+        # packed-pair writer against the tensor-op packing it replaces
+        packed = torch.full((40, 2), -1, dtype=torch.int64, device=dev)
+        pos = torch.from_numpy(np.flatnonzero(labels == 1).astype(np.int32)).cuda()
+        pack_pairs(idx[pos.long()].reshape(-1, 1).contiguous(), score[pos.long()].reshape(-1, 1).contiguous(), pos, packed)
+        want = torch.full((40, 2), -1, dtype=torch.int64, device=dev)
+        want[pos.long(), 0] = idx[pos.long()]
+        want[pos.long(), 1] = score[pos.long()].view(torch.int32).to(torch.int64)
+        assert torch.equal(packed, want)
+        # row-sharded codebook through the collective
+        E = synth.make_codebook(92232, 128, seed=21, planted_duplicates=16)
+        rs = RowShardedCodebook.from_array(E, device=dev, align=36)
+        assert rs.distributed and (rs.lo, rs.hi) == (0, 92232)
+        z = torch.randn(9, 128, device=dev)
+        whole = CodebookEngine(E)
+        for k, stride in ((1, 1), (5, 1), (1, 36)):
+            mi, ms = rs.nn(z, k, stride)
+            wi, ws = whole.nn(z, k, stride)
+            assert torch.equal(mi, wi) and torch.equal(ms, ws), (k, stride)
+        for e, c in objs.values():
+            e.close()
+            c.close()
+        whole.close()
+        rs.engine.close()
+    finally:
+        dist.destroy_process_group()
