@@ -14,10 +14,24 @@ from . import utils as u
 
 
 def _parse_K(text):
-    """[Dataset] K is written as a Python list with arithmetic (``720/2``,
-    cfg/train_template.cfg:11); the reference eval()s it.  Evaluate the same
-    expression without builtins."""
-    return eval(compile(ast.parse(text.strip(), mode='eval'), '<cfg K>', 'eval'), {'__builtins__': {}}, {})
+    """[Dataset] K is written as a Python list with arithmetic (``720/2``, cfg/train_template.cfg:11); the reference
+    eval()s the text.  Here the expression is parsed and only lists / tuples of numbers combined with + - * / (and
+    unary minus) are evaluated -- nothing else a cfg file could smuggle in is executed."""
+    def ev(node):
+        if isinstance(node, (ast.List, ast.Tuple)):
+            return [ev(e) for e in node.elts]
+        if isinstance(node, ast.Constant) and isinstance(node.value, (int, float)) and not isinstance(node.value, bool):
+            return node.value
+        if isinstance(node, ast.UnaryOp) and isinstance(node.op, (ast.USub, ast.UAdd)):
+            v = ev(node.operand)
+            return -v if isinstance(node.op, ast.USub) else v
+        if isinstance(node, ast.BinOp) and isinstance(node.op, (ast.Add, ast.Sub, ast.Mult, ast.Div)):
+            a, b = ev(node.left), ev(node.right)
+            if isinstance(a, list) or isinstance(b, list):
+                raise ValueError('[Dataset] K: arithmetic on a list')
+            return {ast.Add: a + b, ast.Sub: a - b, ast.Mult: a * b}[type(node.op)] if not isinstance(node.op, ast.Div) else a / b
+        raise ValueError('[Dataset] K: only numbers, + - * / and lists are allowed, found %s' % type(node).__name__)
+    return ev(ast.parse(text.strip(), mode='eval').body)
 
 
 class Codebook(object):

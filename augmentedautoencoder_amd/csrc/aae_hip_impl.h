@@ -139,8 +139,11 @@ struct aae_codebook {
     int scan_mode = AAE_SCAN_AUTO;
     // upright search (col_stride k > 1): a compacted copy of rows 0, k, 2k, ... prepared by
     // aae_codebook_prepare_upright; the scan then runs over N/k rows and the winning row id is scaled by k
-    aae_codebook* upright = nullptr;
+    aae_codebook* upright = nullptr;   // the copy for the stride asked for last (one of upright_copies)
     int upright_stride = 0;
+    // every compacted copy ever prepared, one per stride, kept until the handle is destroyed: a captured HIP graph may
+    // hold the address of a copy made for another stride than the one in use now
+    std::vector<std::pair<int, aae_codebook*>> upright_copies;
     // B <= 4, top-1 on a stream kernel: arg-max over the block partials inside the scan launch (last block to arrive)
     // instead of a separate argmax_reduce launch.  0: never (AAE_SCAN_STREAM_2L); otherwise always
     int scan_ticket = 1;
@@ -1268,10 +1271,10 @@ int aae_codebook_create(const void* E, int N, int J, int dtype, int src_is_devic
     return AAE_OK;
 }
 
-static int gather_upright_rows(const aae_codebook* cb, hipStream_t stream) {
+static int gather_upright_rows(const aae_codebook* cb, const aae_codebook* sub, int stride, hipStream_t stream) {
     using namespace aae_host;
     aae::GatherRowsArgs g;
-    g.src = cb->E; g.dst = cb->upright->E; g.rows_out = cb->upright->N; g.stride = cb->upright_stride;
+    g.src = cb->E; g.dst = sub->E; g.rows_out = sub->N; g.stride = stride;
     g.pieces_per_row = cb->J * (cb->dtype == AAE_DTYPE_BF16 ? 2 : 4) / 16;
     long long blocks = ((long long)g.rows_out * g.pieces_per_row + 255) / 256;
     if (blocks > 2048) blocks = 2048;
@@ -1287,17 +1290,23 @@ int aae_codebook_prepare_upright(aae_codebook* cb, int col_stride, void* stream_
     if ((cb->J * (cb->dtype == AAE_DTYPE_BF16 ? 2 : 4)) % 16 != 0) return AAE_OK;     // rows are not 16-byte pieces: the masked scan stays in use
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
     if (!cb->upright || cb->upright_stride != col_stride) {
-        if (cb->upright) { aae_codebook_destroy(cb->upright); cb->upright = nullptr; cb->upright_stride = 0; }
-        aae_codebook* sub = new (std::nothrow) aae_codebook();
-        if (!sub) return fail(AAE_ERR_RUNTIME, "out of host memory");
-        sub->N = ceil_div(cb->N, col_stride); sub->J = cb->J; sub->dtype = cb->dtype; sub->scan_mode = cb->scan_mode; sub->scan_ticket = cb->scan_ticket;
-        void* p = nullptr;
-        const hipError_t e = hipMalloc(&p, (size_t)sub->N * sub->J * (sub->dtype == AAE_DTYPE_BF16 ? 2 : 4));
-        if (e != hipSuccess) { delete sub; return fail(AAE_ERR_RUNTIME, "hipMalloc(upright codebook): %s", hipGetErrorString(e)); }
-        sub->E = static_cast<float*>(p);
+        aae_codebook* sub = nullptr;
+        for (auto& c : cb->upright_copies)
+            if (c.first == col_stride) sub = c.second;
+        if (!sub) {
+            sub = new (std::nothrow) aae_codebook();
+            if (!sub) return fail(AAE_ERR_RUNTIME, "out of host memory");
+            sub->N = ceil_div(cb->N, col_stride); sub->J = cb->J; sub->dtype = cb->dtype;
+            void* p = nullptr;
+            const hipError_t e = hipMalloc(&p, (size_t)sub->N * sub->J * (sub->dtype == AAE_DTYPE_BF16 ? 2 : 4));
+            if (e != hipSuccess) { delete sub; return fail(AAE_ERR_RUNTIME, "hipMalloc(upright codebook): %s", hipGetErrorString(e)); }
+            sub->E = static_cast<float*>(p);
+            cb->upright_copies.push_back({col_stride, sub});
+        }
+        sub->scan_mode = cb->scan_mode; sub->scan_ticket = cb->scan_ticket;
         cb->upright = sub; cb->upright_stride = col_stride;
     }
-    if (int rc = gather_upright_rows(cb, stream)) return rc;
+    if (int rc = gather_upright_rows(cb, cb->upright, cb->upright_stride, stream)) return rc;
     AAE_HIP_TRY(hipStreamSynchronize(stream));
     return AAE_OK;
 }
@@ -1307,15 +1316,15 @@ int aae_codebook_update(aae_codebook* cb, const void* E, int src_is_device, void
     if (!cb || !E) return fail(AAE_ERR_INVALID, "aae_codebook_update: null argument");
     AAE_HIP_TRY(hipMemcpyAsync(cb->E, E, (size_t)cb->N * cb->J * (cb->dtype == AAE_DTYPE_BF16 ? 2 : 4),
                                src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, static_cast<hipStream_t>(stream)));
-    if (cb->upright)
-        if (int rc = gather_upright_rows(cb, static_cast<hipStream_t>(stream))) return rc;       // keep the compacted copy in step
+    for (auto& c : cb->upright_copies)                                                          // keep every compacted copy in step
+        if (int rc = gather_upright_rows(cb, c.second, c.first, static_cast<hipStream_t>(stream))) return rc;
     AAE_HIP_TRY(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
     return AAE_OK;
 }
 
 void aae_codebook_destroy(aae_codebook* cb) {
     if (!cb) return;
-    if (cb->upright) aae_codebook_destroy(cb->upright);
+    for (auto& c : cb->upright_copies) aae_codebook_destroy(c.second);
     if (cb->E) (void)hipFree(cb->E);
     delete cb;
 }
@@ -1327,7 +1336,7 @@ int aae_codebook_set_scan_mode(aae_codebook* cb, int mode) {
         return fail(AAE_ERR_INVALID, "scan mode %d", mode);
     cb->scan_ticket = mode == AAE_SCAN_STREAM_2L ? 0 : 1;
     cb->scan_mode = mode == AAE_SCAN_STREAM_2L ? AAE_SCAN_STREAM : mode;
-    if (cb->upright) { cb->upright->scan_mode = cb->scan_mode; cb->upright->scan_ticket = cb->scan_ticket; }
+    for (auto& c : cb->upright_copies) { c.second->scan_mode = cb->scan_mode; c.second->scan_ticket = cb->scan_ticket; }
     return AAE_OK;
 }
 

@@ -27,7 +27,9 @@ def _stream_ptr(torch):
 
 
 class _Workspace(object):
-    """One grow-only device scratch buffer per engine (256-B aligned by the allocator)."""
+    """One grow-only device scratch buffer per engine.  The pointer handed out is 256-B aligned and has at least the
+    requested bytes behind it; a fresh buffer starts zeroed (the ticket words of the in-launch reductions are then in
+    their clean state from the first call on -- the kernels tolerate garbage, this only saves the install path)."""
 
     def __init__(self, device):
         self.device = device
@@ -35,11 +37,16 @@ class _Workspace(object):
 
     def get(self, nbytes):
         torch = _torch()
-        if self.buf is None or self.buf.numel() < nbytes:
+        nbytes = int(nbytes)
+        if self.buf is None or self._usable() < nbytes:
             self.buf = None
-            self.buf = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=self.device)
+            self.buf = torch.zeros(nbytes + 256, dtype=torch.uint8, device=self.device)
         off = (-self.buf.data_ptr()) % 256
+        assert self.buf.numel() - off >= nbytes
         return self.buf, self.buf.data_ptr() + off
+
+    def _usable(self):
+        return self.buf.numel() - (-self.buf.data_ptr()) % 256
 
 
 class EncoderEngine(object):
@@ -475,9 +482,10 @@ class DecoderEngine(object):
 
 class CapturedNearestNeighbour(object):
     """encode + codebook nearest-neighbour for one fixed batch shape, recorded once into a HIP
-    graph and replayed: the ~12 kernel launches of a small-batch query (conv1, three implicit
-    GEMMs + split-K reduces, dense, normalise, scan, arg-max) are launch-latency bound at B = 1,
-    the shape the reference's per-detection loop uses (m3_interface/ae_pose_estimator.py:143-170).
+    graph and replayed: the launches of a small-batch query (six for B <= 4: conv1, three wave-split-K
+    convolutions, dense GEMV, scan) without the host-side launch cost -- the shape the reference's
+    per-detection loop uses (m3_interface/ae_pose_estimator.py:143-170).  On the GPU side a replay
+    takes as long as the eager launches (the chain is kernel-bound); the gain is host time.
     Inputs are copied into a static buffer; outputs are static device tensors, valid until the
     next call.  Results are bit-identical to the eager calls (same kernels, same order)."""
 
@@ -488,6 +496,19 @@ class CapturedNearestNeighbour(object):
         dt = torch.uint8 if in_dtype in ('uint8', torch.uint8) else torch.float32
         dev = encoder_engine.device
         self.x = torch.zeros((self.batch,) + tuple(encoder_engine.cfg.shape), dtype=dt, device=dev)
+        # The graph bakes raw device addresses: its scratch memory must outlive it and must never be regrown by somebody
+        # else.  So the capture runs on PRIVATE workspaces owned by this object (the engines' own grow-only buffers are
+        # put back afterwards and may be reallocated by later eager calls with larger batches without touching the graph);
+        # the compacted upright copy is kept per stride by the codebook handle for its whole life.
+        self._ws = (_Workspace(dev), _Workspace(dev))
+        saved = (self.enc.ws, self.cb.ws)
+        self.enc.ws, self.cb.ws = self._ws
+        try:
+            self._capture(torch, dev)
+        finally:
+            self.enc.ws, self.cb.ws = saved
+
+    def _capture(self, torch, dev):
         with torch.cuda.device(dev):
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())

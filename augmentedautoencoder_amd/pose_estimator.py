@@ -53,6 +53,7 @@ class AePoseEstimator(object):
         reference) or explicit ``codebooks`` / ``train_args`` dicts keyed by class name."""
         self._process_requirements = ['color_img', 'camK', 'bboxes']
         self.all_codebooks, self.all_train_args, self.pad_factors, self.patch_sizes = {}, {}, {}, {}
+        self._image_format = {'color_format': 'bgr', 'color_data_type': np.uint8, 'depth_data_type': np.float32}
         self.sess = S.Session()
         if test_config_path is not None:
             test_args = configparser.ConfigParser(inline_comment_prefixes="#")
@@ -61,6 +62,13 @@ class AePoseEstimator(object):
             workspace_path = os.environ.get('AE_WORKSPACE_PATH')
             if workspace_path is None:
                 raise RuntimeError('Please define a workspace path: export AE_WORKSPACE_PATH=/path/to/workspace')
+            # what the estimator asks its caller to deliver (ae_pose_estimator.py:41-43 reads the three keys and eval()s
+            # the type names; here a type name is looked up among the NumPy scalar types instead of being evaluated)
+            fmt = self._image_format
+            fmt['color_format'] = test_args.get('auto_pose', 'color_format', fallback=fmt['color_format'])
+            for key in ('color_data_type', 'depth_data_type'):
+                if test_args.has_option('auto_pose', key):
+                    fmt[key] = self._numpy_type(test_args.get('auto_pose', key))
             camPose = test_args.getboolean('auto_pose', 'camPose')
             upright = test_args.getboolean('auto_pose', 'upright')
             topk = test_args.getint('auto_pose', 'topk')
@@ -100,8 +108,17 @@ class AePoseEstimator(object):
     def query_process_requirements(self):
         return self._process_requirements
 
+    @staticmethod
+    def _numpy_type(text):
+        """'np.uint8' / 'numpy.float32' / 'uint8' -> the NumPy scalar type."""
+        name = text.strip().split('.')[-1]
+        t = getattr(np, name, None)
+        if not (isinstance(t, type) and issubclass(t, np.generic)):
+            raise ValueError('[auto_pose] data type %r is not a NumPy scalar type' % text)
+        return t
+
     def query_image_format(self):
-        return {'color_format': 'bgr', 'color_data_type': np.uint8, 'depth_data_type': np.float32}
+        return dict(self._image_format)
 
     # ------------------------------------------------------------------ crops
     @staticmethod
@@ -123,6 +140,8 @@ class AePoseEstimator(object):
     # ---------------------------------------------------------------- process
     def process(self, bboxes, color_img, camK, depth_img=None, camPose=None, rois3ds=[], mm=False):
         H, W = color_img.shape[:2]
+        if isinstance(color_img, np.ndarray) and color_img.dtype != np.uint8:
+            color_img = color_img.astype(np.uint8)      # the reference assigns the crop into a uint8 canvas (ae_pose_estimator.py:113-126)
         accepted = []                                   # (detection index, class, box_xywh)
         for j, box in enumerate(bboxes):
             pred_clas = max(box.classes, key=box.classes.get)

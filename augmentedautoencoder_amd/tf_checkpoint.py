@@ -21,9 +21,14 @@ Format (restated from TensorFlow's published sources; no TensorFlow code is used
 * ``checkpoint`` (text CheckpointState proto): model_checkpoint_path / all_model_checkpoint_paths.
 
 PARITY NOTE: no TensorFlow-written checkpoint exists in this environment (none ships with the
-reference, no network), so the reader is verified against this module's own writer, CRC-32C /
-varint / snappy known-answer vectors and hand-assembled tables (tests/test_tf_checkpoint.py):
-"parity unpinned" against real TF output until a sample checkpoint is available.
+reference, no network), so the reader is verified against (a) this module's own writer, (b) CRC-32C /
+varint / snappy known-answer vectors, (c) checkpoints assembled in the tests WITHOUT this module's
+writers -- entries serialised by the protobuf runtime from the published tensor_bundle.proto, tables
+laid out by an independent builder (several blocks, snappy-compressed blocks, two data shards) -- and
+(d) a corruption suite (truncation at every structural boundary, flipped bits, unknown enums, sliced
+variables, big-endian header, missing shards: each must raise, none may return arrays)
+(tests/test_tf_checkpoint.py).  "parity unpinned" against real TF output until a sample checkpoint is
+available.
 """
 from __future__ import annotations
 
@@ -422,6 +427,8 @@ class BundleReader(object):
                         self.num_shards = v
                     elif field == 2 and v != 0:
                         raise ValueError('big-endian checkpoints are not supported')
+                if not 1 <= self.num_shards <= 100000:
+                    raise ValueError('%s: implausible shard count %r in the bundle header' % (index, self.num_shards))
             else:
                 self.entries[key.decode('utf-8')] = BundleEntry.parse(value)
 
@@ -444,7 +451,14 @@ class BundleReader(object):
         count = int(np.prod(e.shape, dtype=np.int64)) if e.shape else 1
         if count * dt.itemsize != e.size:
             raise ValueError('%r: %d bytes on disk, shape %s needs %d' % (name, e.size, e.shape, count * dt.itemsize))
-        with open(self._data_path(e.shard_id), 'rb') as f:
+        if not 0 <= e.shard_id < self.num_shards:
+            raise ValueError('%r: shard %d outside the %d data shard(s) the header announces' % (name, e.shard_id, self.num_shards))
+        if e.offset < 0 or e.size < 0:
+            raise ValueError('%r: negative offset/size in its index entry' % name)
+        path = self._data_path(e.shard_id)
+        if not os.path.exists(path):
+            raise FileNotFoundError('%s not found (data shard of %r)' % (path, name))
+        with open(path, 'rb') as f:
             f.seek(e.offset)
             raw = f.read(e.size)
         if len(raw) != e.size:

@@ -214,14 +214,28 @@ class DecoderConfig(object):
             out.append([int(h / p), int(w / p)])
         return out
 
-    def variable_names(self):
+    def variable_names(self, weights=None):
         """(dense, [hidden convs], final conv, [batch norms]) -- TF auto-names in a graph whose
-        encoder was built first (ae_factory.py:134-139)."""
+        encoder was built first (ae_factory.py:134-139).
+
+        The decoder's dense layer is the second tf.layers.dense of the graph ('dense_1') unless the encoder was built
+        with VARIATIONAL > 0: Encoder.q_sigma (encoder.py:70-80) then takes 'dense_1' and the decoder gets 'dense_2'.
+        Given the restored ``weights``, the name is resolved by the kernel shape ([latent, h0*w0*F0] is the decoder's,
+        [flatten, latent] would be q_sigma's)."""
         L = self.num_layers
         convs = ['conv2d_%d' % (L + i) for i in range(L - 1)]
         final = 'conv2d_%d' % (2 * L - 1 + (1 if self.auxiliary_mask else 0))
         bns = ['batch_normalization_%d' % (L + i) for i in range(L)] if self.batch_norm else []
-        return 'dense_1', convs, final, bns
+        dense = 'dense_1'
+        if weights is not None:
+            dims = self.layer_dimensions()
+            want = (self.latent_space_size, dims[0][0] * dims[0][1] * self.num_filters[0])
+            for cand in ('dense_1', 'dense_2'):
+                k = weights.get(cand + '/kernel')
+                if k is not None and tuple(np.shape(k)) == want:
+                    dense = cand
+                    break
+        return dense, convs, final, bns
 
     def flops_per_image(self):
         """Nominal multiply-add count x2 of Decoder.x (upsampled-resolution convolutions)."""
@@ -251,7 +265,7 @@ class DecoderConfig(object):
 def ordered_decoder_weight_arrays(weights, cfg):
     """{name: array} -> the array order aae_decoder_create expects, shapes validated."""
     out = []
-    dense, convs, final, bns = cfg.variable_names()
+    dense, convs, final, bns = cfg.variable_names(weights)
     dims = cfg.layer_dimensions()
     k = cfg.kernel_size
 

@@ -453,6 +453,22 @@ def test_captured_graph_and_streaming_pipelines_equal_the_eager_calls():
             assert torch.equal(i0, i1) and torch.equal(s0, s1)
         with pytest.raises(ValueError):
             cap(synth.make_crops(B + 1, seed=1))
+    # a captured graph owns its scratch memory: later eager calls that regrow the engines' workspaces (bigger batch,
+    # top-k buffers) or ask for the upright copy of another stride must not disturb its replays
+    x1 = synth.make_crops(1, seed=990)
+    cap_up = CapturedNearestNeighbour(enc, cb, 1, col_stride=36)
+    want_i, want_s = cb.nn(enc.encode(x1), 1, 36)
+    want_i, want_s = want_i.clone(), want_s.clone()
+    big = synth.make_crops(96, seed=991)
+    zb = enc.encode(big)                                   # regrows the encoder workspace
+    cb.nn(zb[:3], 7, 1)                                    # similarity + top-k candidate buffers: regrows the codebook workspace
+    cb.nn(zb, 1, 12)                                       # upright copy for another stride
+    cb.nn(zb, 1, 1)
+    junk = [torch.full((1 << 22,), 0x5A, dtype=torch.uint8, device='cuda') for _ in range(8)]     # recycle what was freed
+    for _ in range(3):
+        i1, s1 = cap_up(x1[0])
+        assert torch.equal(i1, want_i) and torch.equal(s1, want_s)
+    del junk
     batches = [synth.make_crops(n, seed=800 + k) for k, n in enumerate((64, 64, 17, 64, 1))]      # ragged tail batches
     sp = StreamingNearestNeighbour(enc, cb, 64)
     got = list(sp.run(batches))

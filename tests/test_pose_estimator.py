@@ -335,3 +335,34 @@ def test_process_bookkeeping_matches_reference_process():
         assert np.array_equal(np.stack([g.trafo for g in got]), PG['%s_trafos' % tag])
         assert sorted(map(tuple, crops_seen)) == sorted(map(tuple, PG['%s_call_boxes' % tag]))     # same boxes reach the crop stage
         assert all(up == bool(PG['%s_call_upright' % tag][0]) for b in books.values() for _, up in b.seen)
+
+
+def test_camera_matrix_expression_is_parsed_not_evaluated():
+    """[Dataset] K (cfg/train_template.cfg:11 writes 720/2): numbers, + - * / and lists only."""
+    assert _parse_K('[1075.65, 0, 720/2, 0, 1073.90, 540/2, 0, 0, 1]') == [1075.65, 0, 360.0, 0, 1073.9, 270.0, 0, 0, 1]
+    assert _parse_K('(-1, +2.5*2, 3-1)') == [-1, 5.0, 2]
+    for bad in ("().__class__.__base__.__subclasses__()", "__import__('os').system('true')", '[1, 2**3]', '[1] * 3', 'K', '[True]'):
+        with pytest.raises((ValueError, SyntaxError)):
+            _parse_K(bad)
+
+
+def test_image_format_comes_from_the_test_config(tmp_path, monkeypatch):
+    """ae_pose_estimator.py:41-43: color_format / color_data_type / depth_data_type of the [auto_pose] section are what
+    query_image_format() hands to the caller; process() casts a non-uint8 image as the reference's uint8 canvas does."""
+    assert AePoseEstimator._numpy_type('np.uint8') is np.uint8 and AePoseEstimator._numpy_type('numpy.float32') is np.float32
+    with pytest.raises(ValueError):
+        AePoseEstimator._numpy_type('os.system')
+    cfg = tmp_path / 'm3.cfg'
+    cfg.write_text('[auto_pose]\ncolor_format: rgb\ncolor_data_type: np.uint8\ndepth_data_type: np.float64\ncamPose: False\n'
+                   'upright: False\ntopk: 1\nclass_2_encoder: {}\n')
+    monkeypatch.setenv('AE_WORKSPACE_PATH', str(tmp_path))
+    est = AePoseEstimator(str(cfg))
+    assert est.query_image_format() == {'color_format': 'rgb', 'color_data_type': np.uint8, 'depth_data_type': np.float64}
+    plain = AePoseEstimator(codebooks={'a': object()}, train_args={'a': _args_for_format_test()})
+    assert plain.query_image_format()['color_format'] == 'bgr'
+
+
+def _args_for_format_test():
+    args = configparser.ConfigParser()
+    args.read_string('[Dataset]\nPAD_FACTOR: 1.2\nW: 128\nH: 128\n')
+    return args

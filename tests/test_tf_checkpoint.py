@@ -78,6 +78,12 @@ def _bundle_proto_classes():
     entry.field.add(name='offset', number=4, type=F.TYPE_INT64, label=F.LABEL_OPTIONAL)
     entry.field.add(name='size', number=5, type=F.TYPE_INT64, label=F.LABEL_OPTIONAL)
     entry.field.add(name='crc32c', number=6, type=F.TYPE_FIXED32, label=F.LABEL_OPTIONAL)
+    sl = fd.message_type.add(name='TensorSliceProto')
+    ext = sl.nested_type.add(name='Extent')
+    ext.field.add(name='start', number=1, type=F.TYPE_INT64, label=F.LABEL_OPTIONAL)
+    ext.field.add(name='length', number=2, type=F.TYPE_INT64, label=F.LABEL_OPTIONAL)
+    sl.field.add(name='extent', number=1, type=F.TYPE_MESSAGE, label=F.LABEL_REPEATED, type_name='.aaetest.TensorSliceProto.Extent')
+    entry.field.add(name='slices', number=7, type=F.TYPE_MESSAGE, label=F.LABEL_REPEATED, type_name='.aaetest.TensorSliceProto')
     header = fd.message_type.add(name='BundleHeaderProto')
     header.field.add(name='num_shards', number=1, type=F.TYPE_INT32, label=F.LABEL_OPTIONAL)
     header.field.add(name='endianness', number=2, type=F.TYPE_INT32, label=F.LABEL_OPTIONAL)
@@ -298,6 +304,224 @@ def test_saving_into_a_tensorflow_checkpoint_dir_makes_the_new_file_the_one_rest
     st = S.get_checkpoint_state(ckpt_dir)
     assert [os.path.basename(p) for p in st.all_model_checkpoint_paths] == ['chkpt-30000.npz', 'chkpt-30002.npz']
     S.reset_default_graph()
+
+
+# ---- checkpoints laid out WITHOUT this module's writers, and the corruption suite ---------------------------------
+def _snappy_literals(raw):
+    """A valid snappy stream made of literal elements only (tag 60: one extra length byte), chunks of <= 200 bytes."""
+    out = bytearray(T.put_varint(len(raw)))
+    for a in range(0, len(raw), 200):
+        chunk = raw[a:a + 200]
+        out += (bytes([(len(chunk) - 1) << 2]) if len(chunk) <= 60 else bytes([60 << 2, len(chunk) - 1])) + chunk
+    return bytes(out)
+
+
+def _independent_table(path, pairs, per_block=3, restart_interval=2, snappy_blocks=()):
+    """LevelDB table format written out from its description: prefix-compressed entries, a restart point every
+    `restart_interval` entries, `per_block` entries per data block, block trailer = type byte + masked CRC-32C,
+    an (empty) metaindex block, an index block keyed by each block's last key, the 48-byte footer."""
+    def varint(v):
+        out = bytearray()
+        while v >= 0x80:
+            out.append((v & 0x7F) | 0x80)
+            v >>= 7
+        out.append(v)
+        return bytes(out)
+
+    def block(entries, interval):
+        out, restarts, last = bytearray(), [], b''
+        for i, (k, v) in enumerate(entries):
+            shared = 0
+            if i % interval == 0:
+                restarts.append(len(out))
+            else:
+                while shared < min(len(k), len(last)) and k[shared] == last[shared]:
+                    shared += 1
+            out += varint(shared) + varint(len(k) - shared) + varint(len(v)) + k[shared:] + v
+            last = k
+        for r in restarts or [0]:
+            out += struct.pack('<I', r)
+        return bytes(out + struct.pack('<I', max(len(restarts), 1)))
+
+    blob, index = bytearray(), []
+
+    def emit(contents, compress):
+        body, ctype = (_snappy_literals(contents), 1) if compress else (contents, 0)
+        off = len(blob)
+        blob.extend(body + bytes([ctype]) + struct.pack('<I', T.mask_crc(T.crc32c(body + bytes([ctype])))))
+        return off, len(body)
+
+    for bi, a in enumerate(range(0, len(pairs), per_block)):
+        chunk = pairs[a:a + per_block]
+        off, size = emit(block(chunk, restart_interval), bi in snappy_blocks)
+        index.append((chunk[-1][0], varint(off) + varint(size)))
+    moff, msize = emit(block([], 1), False)
+    ioff, isize = emit(block(index, 1), False)
+    footer = varint(moff) + varint(msize) + varint(ioff) + varint(isize)
+    blob.extend(footer + b'\x00' * (40 - len(footer)) + struct.pack('<Q', 0xdb4775248b80fb57))
+    open(path, 'wb').write(bytes(blob))
+
+
+_NP_TO_DT = {'float32': 1, 'float64': 2, 'int32': 3, 'int64': 9, 'uint8': 4}
+
+
+def _independent_checkpoint(ckpt_dir, tensors, shards=2, snappy_blocks=(1,), mutate=None, name='ind-7'):
+    """{name: array} -> checkpoint-v2 files built from the protobuf runtime + _independent_table (neither
+    tf_checkpoint.write_bundle, write_table nor BundleEntry.serialize is involved).  Tensors alternate between the
+    data shards and are separated by gaps (tensors are offset-addressed).  mutate(name, entry message) may alter an
+    entry before it is serialised; mutate('', header message) the header."""
+    Entry, Header = _bundle_proto_classes()
+    prefix = os.path.join(ckpt_dir, name)
+    files = [open('%s.data-%05d-of-%05d' % (prefix, i, shards), 'wb') for i in range(shards)]
+    offs, kv = [0] * shards, {}
+    for n, (tname, a) in enumerate(sorted(tensors.items())):
+        a = np.asarray(a)
+        sh = n % shards
+        gap = b'\xEE' * (n % 4)
+        raw = a.tobytes()
+        files[sh].write(gap + raw)
+        m = Entry(dtype=_NP_TO_DT[a.dtype.name], shard_id=sh, offset=offs[sh] + len(gap), size=len(raw), crc32c=T.mask_crc(T.crc32c(raw)))
+        m.shape.SetInParent()
+        for d in a.shape:
+            m.shape.dim.add(size=d)
+        if mutate:
+            mutate(tname, m)
+        kv[tname.encode()] = m.SerializeToString()
+        offs[sh] += len(gap) + len(raw)
+    for f in files:
+        f.close()
+    h = Header(num_shards=shards)
+    if mutate:
+        mutate('', h)
+    kv[b''] = h.SerializeToString()
+    _independent_table(prefix + '.index', sorted(kv.items()), snappy_blocks=snappy_blocks)
+    return prefix
+
+
+def _aae_blob(scope='exp'):
+    w = synth.make_weights(seed=19, shape=(16, 16, 3), num_filter=[32, 64], strides=[2, 2], latent=128, batch_norm=False)
+    rng = np.random.default_rng(5)
+    blob = {scope + '/' + k: v for k, v in w.items()}
+    blob[scope + '/embedding_normalized'] = rng.standard_normal((72, 128)).astype(np.float32)
+    blob[scope + '/embed_obj_bbs_var'] = rng.integers(0, 500, (72, 4)).astype(np.int32)
+    blob['global_step'] = np.int64(7)
+    blob[scope + '/conv2d/kernel/Adam'] = np.zeros_like(w['conv2d/kernel'])
+    return w, blob
+
+
+def test_reader_on_a_checkpoint_built_without_this_modules_writers(tmp_path):
+    """Index entries from the protobuf runtime, table bytes from an independent builder (3 entries per block, restart
+    interval 2, one snappy-compressed block), two data shards with gaps between the tensors."""
+    pytest.importorskip('google.protobuf')
+    w, blob = _aae_blob()
+    prefix = _independent_checkpoint(str(tmp_path), blob)
+    r = T.BundleReader(prefix)
+    assert r.num_shards == 2 and sorted(r.names()) == sorted(blob)
+    for k, v in blob.items():
+        got = r.tensor(k)
+        assert got.dtype == np.asarray(v).dtype and got.shape == np.asarray(v).shape and np.array_equal(got, v), k
+    weights, emb, bbs = T.load_aae_variables(prefix)
+    assert all(np.array_equal(weights[k], w[k]) for k in w) and emb.shape == (72, 128) and bbs.dtype == np.int32
+    assert not any('Adam' in k for k in weights)
+    # the reader's own writer must produce an index the independent expectations agree with, too: same tensors back
+    T.write_bundle(str(tmp_path / 'own-7'), blob)
+    own = T.BundleReader(str(tmp_path / 'own-7'))
+    assert all(np.array_equal(own.tensor(k), r.tensor(k)) for k in blob)
+
+
+def test_corrupt_checkpoints_raise_and_never_return_arrays(tmp_path):
+    """Everything a wrong guess about the on-disk layout, a damaged download or an unsupported feature can present:
+    each case must end in an exception that names the problem -- silently loading garbage weights is the failure
+    mode that matters here (ae_factory.py:149-172 restores whatever the file says)."""
+    pytest.importorskip('google.protobuf')
+    w, blob = _aae_blob()
+    d = str(tmp_path)
+    good = _independent_checkpoint(d, blob)
+    reference = {k: T.BundleReader(good).tensor(k) for k in blob}
+
+    def load_all(prefix):
+        r = T.BundleReader(prefix)
+        return {k: r.tensor(k) for k in r.names()}
+
+    def clone(tag):
+        import shutil
+        for suffix in ('.index', '.data-00000-of-00002', '.data-00001-of-00002'):
+            shutil.copy(good + suffix, os.path.join(d, tag) + suffix)
+        return os.path.join(d, tag)
+
+    # 1. index truncated at every structural neighbourhood (and every 11th byte): never a successful load
+    raw = open(good + '.index', 'rb').read()
+    for cut in sorted(set(list(range(0, len(raw), 11)) + [len(raw) - k for k in (1, 8, 47, 48, 49, 60)])):
+        p = clone('trunc')
+        open(p + '.index', 'wb').write(raw[:cut])
+        with pytest.raises((ValueError, IndexError, struct.error)):
+            load_all(p)
+    # 2. one flipped bit anywhere in the index: an exception, or (footer padding is not covered by a checksum) the same tensors
+    rng = np.random.default_rng(0)
+    for pos in rng.choice(len(raw), 120, replace=False):
+        p = clone('flip')
+        b = bytearray(raw)
+        b[pos] ^= 1 << int(rng.integers(0, 8))
+        open(p + '.index', 'wb').write(bytes(b))
+        try:
+            got = load_all(p)
+        except (ValueError, IndexError, struct.error, KeyError, FileNotFoundError, UnicodeDecodeError):
+            continue
+        assert set(got) == set(reference) and all(np.array_equal(got[k], reference[k]) for k in got), 'bit flip at %d went unnoticed' % pos
+    # 3. data shard damage: flipped byte, truncation, missing file
+    p = clone('data')
+    b = bytearray(open(p + '.data-00001-of-00002', 'rb').read())
+    b[len(b) // 3] ^= 0x10
+    open(p + '.data-00001-of-00002', 'wb').write(bytes(b))
+    with pytest.raises(ValueError, match='checksum'):
+        load_all(p)
+    open(p + '.data-00001-of-00002', 'wb').write(bytes(b[:len(b) // 2]))
+    with pytest.raises(ValueError, match='truncated|checksum'):
+        load_all(p)
+    os.remove(p + '.data-00001-of-00002')
+    with pytest.raises(FileNotFoundError, match='data shard'):
+        load_all(p)
+    # 4. entries the reader does not support or that contradict themselves
+    victim = 'exp/conv2d_1/kernel'
+
+    def case(mut, match, exc=ValueError, shards=2):
+        prefix = _independent_checkpoint(d, blob, shards=shards, mutate=mut, name='bad')
+        with pytest.raises(exc, match=match):
+            load_all(prefix)
+
+    case(lambda n, m: setattr(m, 'dtype', 21) if n == victim else None, 'unsupported dtype enum 21')
+    case(lambda n, m: m.slices.add().extent.add(start=0, length=16) if n == victim else None, 'partitioned')
+    case(lambda n, m: setattr(m, 'endianness', 1) if n == '' else None, 'big-endian')
+    case(lambda n, m: setattr(m, 'shard_id', 5) if n == victim else None, 'shard 5 outside')
+    case(lambda n, m: setattr(m, 'size', m.size - 4) if n == victim else None, 'bytes on disk')
+    case(lambda n, m: setattr(m, 'offset', m.offset + (1 << 40)) if n == victim else None, 'truncated')
+    case(lambda n, m: setattr(m.shape, 'unknown_rank', True) if n == victim else None, 'unknown rank')
+    case(lambda n, m: setattr(m, 'num_shards', -1) if n == '' else None, 'implausible shard count')
+    case(lambda n, m: setattr(m, 'num_shards', 0) if n == '' else None, 'not found', exc=FileNotFoundError)   # proto3 drops the 0: reads as 1 shard
+    case(lambda n, m: setattr(m, 'crc32c', m.crc32c ^ 1) if n == victim else None, 'checksum')
+    # 5. a header that announces more shards than exist
+    case(lambda n, m: setattr(m, 'num_shards', 3) if n == '' else None, 'not found', exc=FileNotFoundError)
+
+
+def test_decoder_dense_name_follows_the_kernel_shape_when_the_encoder_is_variational():
+    """VARIATIONAL > 0 inserts Encoder.q_sigma as 'dense_1' (encoder.py:70-80): the decoder's dense layer is then
+    'dense_2'.  The loader picks the name whose kernel is [latent, h0*w0*F0]."""
+    from augmentedautoencoder_amd.weights import DecoderConfig, ordered_decoder_weight_arrays
+    cfg = DecoderConfig(shape=(16, 16, 3), num_filter=(32, 64), strides=(2, 2), kernel_size=5, latent_space_size=128)
+    from augmentedautoencoder_amd.synth import make_decoder_weights_for
+    plain = make_decoder_weights_for(cfg, seed=3)
+    assert cfg.variable_names(plain)[0] == 'dense_1'
+    arrays_plain = ordered_decoder_weight_arrays(plain, cfg)
+    var = dict(plain)
+    var['dense_2/kernel'], var['dense_2/bias'] = var.pop('dense_1/kernel'), var.pop('dense_1/bias')
+    var['dense_1/kernel'] = np.zeros((4 * 4 * 64, 128), np.float32)            # q_sigma: [flatten, latent]
+    var['dense_1/bias'] = np.zeros((128,), np.float32)
+    assert cfg.variable_names(var)[0] == 'dense_2'
+    arrays_var = ordered_decoder_weight_arrays(var, cfg)
+    assert len(arrays_var) == len(arrays_plain) and all(np.array_equal(a, b) for a, b in zip(arrays_var, arrays_plain))
+    broken = {k: v for k, v in var.items() if not k.startswith('dense_2/')}
+    with pytest.raises(ValueError, match='shape|missing'):
+        ordered_decoder_weight_arrays(broken, cfg)
 
 
 def test_cli_convert_and_export(tmp_path, capsys):
