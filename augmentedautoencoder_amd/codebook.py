@@ -93,6 +93,23 @@ class Codebook(object):
         self.embed_obj_bbs_values = None
         return self._obj_bbs_host
 
+    def close(self, close_encoder=False):
+        """Free the device copy of the codebook now (and, if asked, the encoder's weights) and leave the module
+        registry.  The host arrays stay: a later query rebuilds the device state."""
+        if self._engine is not None:
+            self._engine.close()
+            self._engine = None
+        S.unregister(self)
+        if close_encoder:
+            self._encoder.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
     @property
     def engine(self):
         if self._engine is None:

@@ -126,6 +126,7 @@ struct aae_encoder {
     int wavek_depth = 3;                   // slabs of fragments in flight per wave (2 | 3)
     int wavek_narrow_max_tiles = 16;       // <= this many 64 x 64 tiles: 64 x 32 wave tiles (twice the tiles, half the splits to add up)
     long long* wavek_timeline = nullptr;   // device [3 layers][512 blocks][8] phase stamps when option wavek_timeline is on (profiling tools)
+    int compact_workspace = 0;             // 1: two alternating activation buffers instead of one per layer (layer outputs are then not inspectable)
     int ticket_prep = 1;                   // conv1 installs the nonces of the later ticketed launches of its forward call (0: every launch installs its own)
     int wavek_ablate = 0;                  // timing experiments (conv_wavek_f32.h ConvWaveKArgs::ablate); results are wrong when != 0
     int gemv_ticket = 1;                   // dense GEMV (B <= 4): chunk sums finished by the last block instead of a reduce launch
@@ -349,10 +350,23 @@ static Workspace plan_workspace(const aae_encoder* enc, int B) {
             if (bytes > partial) partial = bytes;
         }
     };
-    for (const Layer& L : enc->layers) {
-        ws.act_off.push_back(off);
-        off += align_up((size_t)B * L.Ho * L.Wo * L.Cout * sizeof(float), 256);
-        need_partial(L, B * L.Ho * L.Wo);
+    if (enc->compact_workspace) {
+        // two alternating activation buffers (layer i writes buffer i % 2 while reading the other): at B = 256 of the default
+        // net 805 MB instead of 973 MB; only the last two layers' outputs survive a forward
+        size_t sz[2] = {0, 0};
+        for (size_t li = 0; li < enc->layers.size(); ++li) {
+            const Layer& L = enc->layers[li];
+            sz[li & 1] = std::max(sz[li & 1], align_up((size_t)B * L.Ho * L.Wo * L.Cout * sizeof(float), 256));
+            need_partial(L, B * L.Ho * L.Wo);
+        }
+        for (size_t li = 0; li < enc->layers.size(); ++li) ws.act_off.push_back(off + ((li & 1) ? sz[0] : 0));
+        off += sz[0] + sz[1];
+    } else {
+        for (const Layer& L : enc->layers) {
+            ws.act_off.push_back(off);
+            off += align_up((size_t)B * L.Ho * L.Wo * L.Cout * sizeof(float), 256);
+            need_partial(L, B * L.Ho * L.Wo);
+        }
     }
     need_partial(enc->dense, B);                             // (sized for either dense variant)
     if (enc->dense.kind == KIND_IGEMM && !enc->wavek_dense) {   // ... including the split-K igemm when the wave-split-K form is switched off
@@ -1143,6 +1157,7 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
     else if (!strcmp(name, "wavek_dense")) enc->wavek_dense = value ? 1 : 0;
     else if (!strcmp(name, "wavek_ablate")) enc->wavek_ablate = value;
     else if (!strcmp(name, "ticket_prep")) enc->ticket_prep = value ? 1 : 0;
+    else if (!strcmp(name, "compact_workspace")) enc->compact_workspace = value ? 1 : 0;
     else if (!strcmp(name, "wavek_timeline")) {
         if (value && !enc->wavek_timeline) {
             void* p = nullptr;
@@ -1242,6 +1257,8 @@ int aae_encoder_activation_info(const aae_encoder* enc, int B, int layer, size_t
     using namespace aae_host;
     if (!enc || !offset_bytes || !count || B < 1) return fail(AAE_ERR_INVALID, "aae_encoder_activation_info: bad argument");
     if (layer < 0 || layer >= (int)enc->layers.size()) return fail(AAE_ERR_INVALID, "layer %d out of range", layer);
+    if (enc->compact_workspace && layer + 2 < (int)enc->layers.size())
+        return fail(AAE_ERR_UNSUPPORTED, "compact_workspace: the output of layer %d has been overwritten by layer %d", layer, layer + 2);
     const Workspace ws = plan_workspace(enc, B);
     const Layer& L = enc->layers[layer];
     *offset_bytes = ws.act_off[layer];

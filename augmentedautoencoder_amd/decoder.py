@@ -64,6 +64,13 @@ class Decoder(object):
             self._engine.close()
             self._engine = None
 
+    def close(self):
+        """Free the device weights now and leave the module registry."""
+        if self._engine is not None:
+            self._engine.close()
+            self._engine = None
+        S.unregister(self)
+
     @property
     def engine(self):
         if self._engine is None:

@@ -69,6 +69,21 @@ class Encoder(object):
             self._engine.close()
             self._engine = None
 
+    def close(self):
+        """Free the device weights now (the TF session of the reference frees them when it is closed) and leave the
+        module registry; the object can be given weights again with load_weights()."""
+        if self._engine is not None:
+            self._engine.close()
+            self._engine = None
+        S.unregister(self)
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
     @property
     def engine(self):
         if self._engine is None:

@@ -102,6 +102,21 @@ class AePoseEstimator(object):
         self.pad_factors[clas_name] = targs.getfloat('Dataset', 'PAD_FACTOR')
         self.patch_sizes[clas_name] = (targs.getint('Dataset', 'W'), targs.getint('Dataset', 'H'))
 
+    def close(self):
+        """Free the device state of every object (N encoders + N codebooks live in one process,
+        ae_pose_estimator.py:61-78); the estimator must not be used afterwards."""
+        for cb in self.all_codebooks.values():
+            if hasattr(cb, 'close'):
+                cb.close(close_encoder=True)
+        self.all_codebooks, self.all_train_args = {}, {}
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+        return False
+
     def set_parameter(self, string_name, string_val):
         pass
 

@@ -16,12 +16,17 @@ weights + the codebook variables) as ``<prefix>-<step>.npz`` next to a
 from __future__ import annotations
 
 import os
+import weakref
 
 import numpy as np
 
 from . import weights as W
 
-_GRAPH = []          # [(scope, encoder, codebook, decoder)] (one of the three set) in construction order
+# [(scope, weakref to an Encoder | Codebook | Decoder, kind)] in construction order.  Weak: the registry exists so
+# that a Saver can find "everything built under scope X" (tf.train.Saver over a variable scope); it must not keep
+# device weights and codebooks of objects alive that their owner has dropped -- a long-running estimator that rebuilds
+# codebooks would otherwise leak device memory until reset_default_graph().
+_GRAPH = []
 _SCOPE = ['']
 
 
@@ -45,10 +50,29 @@ def current_scope():
 
 
 def register(encoder=None, codebook=None, decoder=None):
-    _GRAPH.append((current_scope(), encoder, codebook, decoder))
+    for kind, obj in (('encoder', encoder), ('codebook', codebook), ('decoder', decoder)):
+        if obj is not None:
+            _GRAPH.append((current_scope(), weakref.ref(obj), kind))
+
+
+def unregister(obj):
+    """Forget a module (its close() calls this)."""
+    _GRAPH[:] = [(s, r, k) for (s, r, k) in _GRAPH if r() is not None and r() is not obj]
+
+
+def graph_members(scope=None):
+    """[(scope, encoder, codebook, decoder)] rows (one of the three set) of the live modules, construction order."""
+    out = []
+    for s, r, kind in _GRAPH:
+        obj = r()
+        if obj is None or (scope is not None and s != scope):
+            continue
+        out.append((s, obj if kind == 'encoder' else None, obj if kind == 'codebook' else None, obj if kind == 'decoder' else None))
+    return out
 
 
 def reset_default_graph():
+    """tf.reset_default_graph(): forget every module; engines still referenced elsewhere are untouched."""
     del _GRAPH[:]
 
 
@@ -136,7 +160,7 @@ class Saver(object):
         self.scope = scope
 
     def _members(self):
-        return [(s, e, c, d) for (s, e, c, d) in _GRAPH if self.scope is None or s == self.scope]
+        return graph_members(self.scope)
 
     def save(self, session, save_path, global_step=None):
         path = save_path if global_step is None else '%s-%d' % (save_path, int(global_step))

@@ -266,3 +266,36 @@ def test_decoder_api_reconstruction_calls_of_eval_plots(tmp_path, monkeypatch):
     weights, _, _ = W.load_npz(os.path.join(str(tmp_path), 'native-1.npz'))
     assert 'dense_1/kernel' in weights and 'conv2d/kernel' in weights
     S.reset_default_graph()
+
+
+def test_module_registry_is_weak_and_close_frees_the_engines():
+    """The registry behind Saver(scope=...) must not keep dropped objects (and their device memory) alive; close()
+    releases the engines at once and leaves the registry (m3_interface/ae_pose_estimator.py:61-78 holds N objects in
+    one process for its whole life -- a service that swaps objects needs the memory back)."""
+    import gc
+    S.reset_default_graph()
+    closed = []
+
+    class _Eng(object):
+        def close(self):
+            closed.append(self)
+
+    def build(scope):
+        with S.variable_scope(scope):
+            ds = Dataset('', h=16, w=16, c=3, min_n_views=12, radius=700, num_cyclo=6)
+            enc = Encoder(S.Placeholder((16, 16, 3)), 128, [32, 64], 5, [2, 2], False)
+            return enc, Codebook(enc, ds, True)
+
+    enc_a, cb_a = build('a')
+    enc_b, cb_b = build('b')
+    assert [m[0] for m in S.graph_members()] == ['a', 'a', 'b', 'b'] and len(S.graph_members('b')) == 2
+    enc_b._engine, cb_b._engine = _Eng(), _Eng()
+    with cb_b:                                           # context-manager form of close()
+        pass
+    assert len(closed) == 1 and cb_b._engine is None and [m[0] for m in S.graph_members()] == ['a', 'a', 'b']
+    cb_b.close(close_encoder=True)
+    assert len(closed) == 2 and S.graph_members('b') == []
+    del enc_a, cb_a, enc_b, cb_b
+    gc.collect()
+    assert S.graph_members() == []                       # nothing was kept alive by the registry
+    S.reset_default_graph()

@@ -439,3 +439,21 @@ def test_fused_encode_nn_prepares_every_ticket_and_equals_the_two_calls(B, strid
         cb.close()
     finally:
         eb.set_block_order(0)
+
+
+def test_compact_workspace_alternates_two_activation_buffers():
+    """Option compact_workspace: layer i writes buffer i % 2 -- same latents, smaller workspace, earlier layers not inspectable."""
+    cfg = EncoderConfig((32, 32, 3), [32, 64, 32], [2, 2, 1], 5, 64)
+    w = synth.make_weights(seed=9, shape=cfg.shape, num_filter=cfg.num_filter, strides=cfg.strides, latent=64)
+    x = synth.make_crops(3, seed=10, shape=cfg.shape)
+    enc = eb.EmuEncoder(w, cfg)
+    n_full = enc.L.aae_encoder_workspace_bytes(enc.h, 3)
+    z0 = enc.forward(x)
+    last = enc.activation(2)
+    enc.set_option('compact_workspace', 1)
+    assert enc.L.aae_encoder_workspace_bytes(enc.h, 3) < n_full
+    z1 = enc.forward(x)
+    assert np.array_equal(z0, z1) and np.array_equal(enc.activation(2), last)
+    with pytest.raises(ValueError, match='overwritten'):
+        enc.activation(0)
+    enc.close()
