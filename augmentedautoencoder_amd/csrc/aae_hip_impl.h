@@ -99,6 +99,7 @@ struct aae_encoder {
     std::vector<aae_host::Layer> layers;   // conv layers
     aae_host::Layer dense;                 // 1x1 "conv" over the flattened activation
     float* lut = nullptr;                  // device [256] float32(v/255.)
+    int* x3h_sat = nullptr;                // device flag: an f32x3h activation left the range its fp16 (hi, lo) pair carries exactly
     std::vector<void*> allocations;
     std::vector<aae_host::KernelRecord> records;   // of the most recent completed forward (swapped in under rec_mu)
     std::mutex rec_mu;
@@ -537,6 +538,7 @@ static int launch_igemm_x3h(aae_encoder* enc, const Layer& L, const void* x, int
     a.x_bytes = (unsigned)(2 * plane);
     a.inv_scale = ldexpf(1.f, -(enc->x3h_act_shift + L.w_shift));
     a.out_scale = ldexpf(1.f, enc->x3h_act_shift);
+    a.sat_flag = out_f32 ? nullptr : enc->x3h_sat;
     a.slabs_total = (int)(L.K() / 32);
     a.wp_bytes = (unsigned)((unsigned long long)a.slabs_total * 8ull * L.CoutPad * 16ull);
     a.num_mt = ceil_div(M, 128);
@@ -591,7 +593,7 @@ static int launch_igemm_x3h(aae_encoder* enc, const Layer& L, const void* x, int
     aae::SplitKReduceArgs r;
     r.partial = partial; r.bias = L.bias; r.bn_scale = L.bn_scale; r.bn_shift = L.bn_shift; r.out = static_cast<float*>(out);
     r.MN = (long long)M * L.Cout; r.Cout = L.Cout; r.splits = a.splits; r.relu = L.relu;
-    r.out_planes = out_f32 ? 0 : 1; r.out_scale = a.out_scale;
+    r.out_planes = out_f32 ? 0 : 1; r.out_scale = a.out_scale; r.sat_flag = out_f32 ? nullptr : enc->x3h_sat;
     launch_splitk_reduce(r, stream, enc->reduce_small != 0);
     snprintf(label, sizeof(label), "%s:splitk_reduce", name);
     note_kernel({label, 0.0});
@@ -625,6 +627,7 @@ static int launch_first(aae_encoder* enc, const Layer& L, const void* x, bool u8
     a.rowlen = a.vec4 ? L.rowlen4 : L.rowlen;
     a.lead = a.vec4 ? L.lead4 : 0;
     a.out_scale = ldexpf(1.f, enc->x3h_act_shift);
+    a.sat_flag = planes ? enc->x3h_sat : nullptr;
     a.tiles_per_image = ceil_div(L.Ho * L.Wo, 128);
     a.total_tiles = B * a.tiles_per_image;
     int tpb = ceil_div(a.total_tiles, enc->first_target_blocks);
@@ -1031,6 +1034,12 @@ int aae_encoder_create(const aae_encoder_desc* d, const void* const* hw, int n_w
     float lut[256];
     for (int v = 0; v < 256; ++v) lut[v] = (float)((double)v / 255.0);   // float64 quotient, float32 feed cast
     if (int rc = upload(enc, lut, 256, &enc->lut)) return bail(rc);
+    {
+        const float zero = 0.f;
+        float* flag = nullptr;
+        if (int rc = upload(enc, &zero, 1, &flag)) return bail(rc);
+        enc->x3h_sat = reinterpret_cast<int*>(flag);
+    }
 
     int H = d->in_h, W = d->in_w, C = d->in_c, wi = 0;
     const float eps = d->bn_eps > 0.f ? d->bn_eps : 1e-3f;
@@ -1242,6 +1251,18 @@ const char* aae_encoder_kernel_label(const aae_encoder* enc, int i) {
 double aae_encoder_kernel_flops(const aae_encoder* enc, int i) {
     if (!enc || i < 0 || i >= (int)enc->records.size()) return 0.0;
     return enc->records[i].flops;
+}
+
+int aae_encoder_x3h_saturated(aae_encoder* enc, int* flag_out, void* stream_v) {
+    using namespace aae_host;
+    if (!enc || !flag_out) return fail(AAE_ERR_INVALID, "aae_encoder_x3h_saturated: null argument");
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    int v = 0;
+    AAE_HIP_TRY(hipMemcpyAsync(&v, enc->x3h_sat, sizeof(int), hipMemcpyDeviceToHost, stream));
+    AAE_HIP_TRY(hipStreamSynchronize(stream));
+    if (v) AAE_HIP_TRY(hipMemsetAsync(enc->x3h_sat, 0, sizeof(int), stream));
+    *flag_out = v ? 1 : 0;
+    return AAE_OK;
 }
 
 int aae_encoder_debug_timeline(aae_encoder* enc, long long* host_out) {

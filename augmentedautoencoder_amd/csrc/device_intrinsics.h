@@ -37,6 +37,15 @@ __device__ __forceinline__ void split_f16(float v, unsigned short& hi, unsigned 
     lo = __builtin_bit_cast(unsigned short, (_Float16)r);
 }
 
+// ... and note a value the (hi, lo) pair cannot carry at full accuracy: beyond the fp16 range hi saturates and the
+// remainder lands in lo with the spacing of a large half (accuracy degrades gradually up to 2 x 65504, then the pair
+// clamps).  sat: sticky device flag (nullptr = do not track); every writer stores the same 1, so the race is benign.
+constexpr float kHalfPairLimit = 65504.f;
+__device__ __forceinline__ void split_f16_checked(float v, unsigned short& hi, unsigned short& lo, int* sat) {
+    split_f16(v, hi, lo);
+    if (sat && !(fabsf(v) < kHalfPairLimit)) *sat = 1;         // (NaN counts as out of range too)
+}
+
 // v_mfma_f32_32x32x16_bf16, same fragment maps as the f16 form.
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ f32x16 mfma_32x32x16_bf16(u32x4 a, u32x4 b, f32x16 c) {

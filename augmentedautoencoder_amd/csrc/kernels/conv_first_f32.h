@@ -55,6 +55,7 @@ struct ConvFirstArgs {
     int tiles_per_block;
     int relu;
     float out_scale;        // OUT_PLANES: 2^act_shift of the f32x3h activation format
+    int* sat_flag;          // OUT_PLANES: sticky "a value left the fp16 pair range" flag of the encoder (or nullptr)
     TicketPrep prep;        // ticket words of the later launches of this forward call (n == 0: none), see conv_wavek_f32.h
 };
 
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(256) void conv_first_f32_kernel(const ConvFirstArgs
     auto emit = [&](out_t* at, float v) {
         if constexpr (OUT_PLANES) {
             unsigned short hi, lo;
-            split_f16(v * p.out_scale, hi, lo);
+            split_f16_checked(v * p.out_scale, hi, lo, p.sat_flag);
             at[0] = hi;
             at[plane] = lo;
         } else {

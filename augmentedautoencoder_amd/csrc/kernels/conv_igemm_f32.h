@@ -350,6 +350,7 @@ struct SplitKReduceArgs {
     int Cout, splits, relu;
     int out_planes;         // 1: write two fp16 planes of v*out_scale (f32x3h activation format)
     float out_scale;
+    int* sat_flag = nullptr;  // out_planes: sticky flag "a value left the fp16 pair range" (or nullptr)
 };
 
 // 512 threads = 8 split-groups x 64 consecutive outputs.  Group g sums the partials
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(512) void splitk_reduce_kernel(const SplitKReduceAr
             if (p.bn_scale) v = v * p.bn_scale[n] + p.bn_shift[n];
             if (p.out_planes) {
                 unsigned short hi, lo;
-                split_f16(v * p.out_scale, hi, lo);
+                split_f16_checked(v * p.out_scale, hi, lo, p.sat_flag);
                 unsigned short* op = reinterpret_cast<unsigned short*>(p.out);
                 op[e] = hi;
                 op[p.MN + e] = lo;
@@ -435,7 +436,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_small_kernel(const SplitKRe
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             unsigned short h16, l16;
-            split_f16(v[j] * p.out_scale, h16, l16);
+            split_f16_checked(v[j] * p.out_scale, h16, l16, p.sat_flag);
             hi[j] = h16; lo[j] = l16;
         }
         unsigned short* op = reinterpret_cast<unsigned short*>(p.out);

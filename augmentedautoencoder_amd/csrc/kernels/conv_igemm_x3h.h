@@ -44,6 +44,7 @@ struct ConvIgemmX3hArgs {
     float inv_scale;          // 2^-(act_shift_in + w_shift)
     float out_scale;          // 2^act_shift_out (OUT_PLANES)
     unsigned wp_bytes;        // size of wp (LDS-DMA variant reads it through a buffer view)
+    int* sat_flag;            // OUT_PLANES: sticky flag "an activation left the fp16 pair range" (or nullptr)
 };
 
 enum { X3H_OUT_F32 = 0, X3H_OUT_PLANES = 1, X3H_OUT_PARTIAL = 2 };
@@ -106,7 +107,7 @@ __device__ __forceinline__ void x3h_epilogue(const ConvIgemmX3hArgs& p, const f3
                         reinterpret_cast<float*>(p.out)[(long long)m * p.Cout + n] = v;
                     } else {
                         unsigned short hi, lo;
-                        split_f16(v * p.out_scale, hi, lo);
+                        split_f16_checked(v * p.out_scale, hi, lo, p.sat_flag);
                         unsigned short* o = reinterpret_cast<unsigned short*>(p.out);
                         o[(long long)m * p.Cout + n] = hi;
                         o[(long long)p.M * p.Cout + (long long)m * p.Cout + n] = lo;

@@ -69,6 +69,10 @@ class EncoderEngine(object):
         self.ws = _Workspace(self.device)
         self._last_B = None
         self.options = {}
+        # f32x3h mode ('precision' = 1): activations travel as fp16 (hi, lo) pairs that carry |x| < 4094 exactly.  When a
+        # forward reports a value outside that range (aae_encoder_x3h_saturated), the batch is recomputed in exact fp32.
+        self.x3h_fallback = True
+        self.x3h_fallbacks = 0             # how many chunks were recomputed
 
     def close(self):
         if getattr(self, 'handle', None):
@@ -112,6 +116,24 @@ class EncoderEngine(object):
             raise ValueError('crop batch has shape %s, encoder expects [B,%d,%d,%d]' % ((tuple(t.shape),) + tuple(self.cfg.shape)))
         return t
 
+    def _x3h_left_its_range(self):
+        """True when the f32x3h forwards queued so far met an activation the fp16 pairs cannot carry (waits for the stream)."""
+        torch = _torch()
+        if self.options.get('precision', 0) != 1 or not self.x3h_fallback or torch.cuda.is_current_stream_capturing():
+            return False
+        flag = ctypes.c_int(0)
+        with torch.cuda.device(self.device):
+            _lib.check(self.lib, self.lib.aae_encoder_x3h_saturated(self.handle, ctypes.byref(flag), _stream_ptr(torch)),
+                       'aae_encoder_x3h_saturated')
+        if flag.value:
+            self.x3h_fallbacks += 1
+            if self.x3h_fallbacks == 1:
+                import warnings
+                warnings.warn('f32x3h: an activation exceeded the range of its fp16 (hi, lo) pair (|x| >= 4094 at the default '
+                              'x3h_act_shift); the batch is recomputed in exact fp32 (further occurrences are counted in '
+                              'EncoderEngine.x3h_fallbacks)', RuntimeWarning)
+        return bool(flag.value)
+
     def _forward_chunk(self, t, z_out, timed=False):
         torch = _torch()
         B = t.shape[0]
@@ -125,6 +147,12 @@ class EncoderEngine(object):
                                                   ctypes.c_void_p(z_out.data_ptr()), ctypes.c_void_p(ws_ptr), nbytes,
                                                   _stream_ptr(torch))
                 _lib.check(self.lib, rc, 'aae_encoder_forward')
+                if self._x3h_left_its_range():          # documented failure mode of the split-precision mode: redo in fp32
+                    self.set_option('precision', 0)
+                    try:
+                        self._forward_chunk(t, z_out)
+                    finally:
+                        self.set_option('precision', 1)
                 return None
             ms = (ctypes.c_float * 32)()
             n = ctypes.c_int(0)
@@ -175,6 +203,13 @@ class EncoderEngine(object):
                                             ctypes.c_void_p(score[a:e].data_ptr()), ctypes.c_void_p(ws_e), nb_e,
                                             ctypes.c_void_p(ws_c), nb_c, _stream_ptr(torch))
             _lib.check(self.lib, rc, 'aae_encode_nn')
+            if self._x3h_left_its_range():
+                self.set_option('precision', 0)
+                try:
+                    za, ia, sa = self.encode_nn(cb, t[a:e], col_stride)
+                    z[a:e], idx[a:e], score[a:e] = za, ia, sa
+                finally:
+                    self.set_option('precision', 1)
         return z, idx, score
 
     def encode_timed(self, x):

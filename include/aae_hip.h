@@ -131,6 +131,13 @@ double aae_encoder_kernel_flops(const aae_encoder* enc, int i);
 
 /* Byte offset / element count of layer `layer`'s activation [B,Ho,Wo,Cout] inside the
  * workspace after a forward with batch B (parity tests of encoder.py:41-54 per layer). */
+/* f32x3h range check ("precision" = 1 only).  Activations travel between layers as fp16 (hi, lo) pairs of
+ * x * 2^x3h_act_shift; a pair carries |x * 2^shift| < 65504 (default shift 4: |x| < 4094) at full accuracy.  Every
+ * kernel that writes pairs raises a sticky device flag when a value falls outside; this call waits for `stream`,
+ * returns the flag and clears it.  1 = the latents of the forwards since the last call may be inaccurate: recompute them
+ * with "precision" = 0 (the Python mirror does that automatically).  Exact fp32 mode never sets the flag. */
+int aae_encoder_x3h_saturated(aae_encoder* enc, int* flag_out, void* stream);
+
 /* Profiling aid (tools/ablate_wavek.py): with option "wavek_timeline" = 1 wave 0 of every block of the small-batch
  * igemm stamps the shader clock at 8 phase boundaries; this copies the [3 layers][512 blocks][8] stamps of the most
  * recent forward to host memory (synchronises the device).  Not part of the reference-facing surface. */

@@ -230,6 +230,12 @@ inline bool block_ticket_arrive(unsigned long long* words, unsigned nonce, unsig
     return block_ticket_take(words, nonce, total, id, lds_flag);
 }
 
+constexpr float kHalfPairLimit = 65504.f;
+inline void split_f16_checked(float v, unsigned short& hi, unsigned short& lo, int* sat) {
+    split_f16(v, hi, lo);
+    if (sat && !(fabsf(v) < kHalfPairLimit)) *sat = 1;
+}
+
 template <typename T>
 inline T shfl_xor(T v, int mask) {
     static_assert(sizeof(T) == 4, "32-bit shuffles only");

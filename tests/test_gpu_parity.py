@@ -819,3 +819,90 @@ def test_object_sharded_and_row_sharded_paths_run_through_rccl_at_world_size_one
         rs.engine.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_f32x3h_adversarial_ranges_and_the_saturation_fallback():
+    """Opt-in f32x3h mode outside the comfortable glorot regime (same tolerances as everywhere: layers and latents
+    within 2e-5 of the fp64 oracle relative to the layer's largest value):
+      * weights spanning six decades inside one layer (the per-layer power-of-two scale is set by the largest weight;
+        the small ones live in the low halves / fp16 subnormals: bounded ABSOLUTE error, DESIGN.md section 4);
+      * inference batch-norm with gamma x 1000 (activations of a few hundred);
+      * activations driven to 0.9 x the range limit of the fp16 (hi, lo) pairs (|x| < 4094): still exact, no flag;
+      * activations at 1.5 x the limit: the kernels raise the sticky range flag (C ABI: aae_encoder_x3h_saturated) and the
+        engine recomputes the batch in exact fp32 -- the documented failure mode, never a silently wrong latent."""
+    import ctypes
+    import warnings
+    import torch
+    from augmentedautoencoder_amd.engine import EncoderEngine
+    from augmentedautoencoder_amd.weights import EncoderConfig
+    rng = np.random.default_rng(77)
+    crops = synth.make_crops(4, seed=3100)
+    x64 = ref.input_to_float(crops)
+
+    def check(enc, weights, bn, what):
+        z = enc.encode(crops).cpu().numpy()
+        z64, acts = ref.encoder_forward_torch(x64, weights, STRIDES, bn, 'float64', return_activations=True)
+        for i, a in enumerate(acts):
+            g = enc.activation(i).cpu().numpy()
+            assert np.abs(g - a).max() / np.abs(a).max() < 2e-5, '%s: layer %d rel err %.3e' % (what, i, np.abs(g - a).max() / np.abs(a).max())
+        assert np.abs(z - z64).max() / np.abs(z64).max() < 2e-5, what
+        return z, acts
+
+    def saturated(enc):
+        flag = ctypes.c_int(7)
+        assert enc.lib.aae_encoder_x3h_saturated(enc.handle, ctypes.byref(flag), None) == 0
+        return flag.value
+
+    # ---- six decades of weight magnitudes inside conv2 and conv3 ----
+    w = synth.make_weights(seed=2024)
+    for name in ('conv2d_1/kernel', 'conv2d_2/kernel'):
+        k = w[name].astype(np.float64) * 10.0 ** rng.uniform(-6.0, 0.0, w[name].shape)
+        w[name] = (k * (np.linalg.norm(w[name]) / np.linalg.norm(k))).astype(np.float32)      # same overall gain as before
+        assert np.abs(w[name]).max() / np.abs(w[name][w[name] != 0]).min() > 1e6
+    enc = EncoderEngine(EncoderConfig(), w)
+    enc.set_option('precision', 1)
+    check(enc, w, False, 'wide-range weights')
+    assert enc.x3h_fallbacks == 0 and saturated(enc) == 0
+    enc.close()
+
+    # ---- batch norm with gamma x 1000 in the second layer ----
+    cfg = EncoderConfig((128, 128, 3), synth.DEFAULT_NUM_FILTER, STRIDES, 5, 128, True)
+    wb = synth.make_weights(seed=2025, batch_norm=True)
+    wb['batch_normalization_1/gamma'] = wb['batch_normalization_1/gamma'] * 1000.0
+    wb['conv2d_2/kernel'] = wb['conv2d_2/kernel'] / 1000.0
+    enc = EncoderEngine(cfg, wb)
+    enc.set_option('precision', 1)
+    _, acts = check(enc, wb, True, 'BN gamma x 1000')
+    assert 200 < np.abs(acts[1]).max() < 4094 and enc.x3h_fallbacks == 0
+    enc.close()
+
+    # ---- activations at 0.9 x and 1.5 x the pair range ----
+    w0 = synth.make_weights(seed=2024)
+    _, acts0 = ref.encoder_forward_torch(x64, w0, STRIDES, False, 'float64', return_activations=True)
+    for frac, expect_flag in ((0.9, 0), (1.5, 1)):
+        f = frac * 4094.0 / float(np.abs(acts0[0]).max())
+        ws = dict(w0)
+        ws['conv2d/kernel'], ws['conv2d/bias'] = w0['conv2d/kernel'] * np.float32(f), w0['conv2d/bias'] * np.float32(f)
+        ws['conv2d_1/kernel'] = w0['conv2d_1/kernel'] / np.float32(f)
+        enc = EncoderEngine(EncoderConfig(), ws)
+        z32 = enc.encode(crops).clone()                              # exact fp32 path on the same weights
+        enc.set_option('precision', 1)
+        if not expect_flag:
+            _, acts = check(enc, ws, False, 'activations at %.1f x the range' % frac)
+            assert abs(float(np.abs(acts[0]).max()) / 4094.0 - frac) < 0.01
+            assert enc.x3h_fallbacks == 0 and saturated(enc) == 0
+        else:
+            # raw C ABI (no automatic fallback): the forward completes, the flag is up, and asking again finds it cleared
+            enc.x3h_fallback = False
+            enc.encode(crops)
+            assert saturated(enc) == 1 and saturated(enc) == 0
+            # Python mirror: warns once, recomputes the batch in fp32 -- bit-identical to the fp32 path -- and counts it
+            enc.x3h_fallback = True
+            with warnings.catch_warnings(record=True) as caught:
+                warnings.simplefilter('always')
+                z = enc.encode(crops)
+            assert torch.equal(z, z32) and enc.x3h_fallbacks == 1 and any('f32x3h' in str(c.message) for c in caught)
+            assert enc.options['precision'] == 1                      # the mode itself stays selected
+            z64 = ref.encoder_forward_torch(x64, ws, STRIDES, False, 'float64')
+            assert np.abs(z.cpu().numpy() - z64).max() / np.abs(z64).max() < 2e-5
+        enc.close()
