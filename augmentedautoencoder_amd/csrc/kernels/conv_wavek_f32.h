@@ -177,6 +177,17 @@ __global__ __launch_bounds__(64 * WAVES) void conv_wavek_f32_kernel(const ConvWa
     stamp(1);                                                   // index arithmetic done
 #pragma unroll
     for (int d = 0; d < DEPTH - 1; ++d) load_stage(d);
+    // epilogue constants of this lane's columns, fetched now: the block that finishes the tile must not start its
+    // epilogue with a round trip to L2 (2.5 -> 0.5 us on the critical path of every split layer)
+    float ep_bias[NT], ep_sc[NT], ep_sh[NT];
+#pragma unroll
+    for (int ni = 0; ni < NT; ++ni) {
+        const int n = tn * (32 * NT) + 32 * ni + i;
+        const bool ok = n < p.Cout;
+        ep_bias[ni] = ok ? p.bias[n] : 0.f;
+        ep_sc[ni] = (ok && p.bn_scale) ? p.bn_scale[n] : 1.f;
+        ep_sh[ni] = (ok && p.bn_scale) ? p.bn_shift[n] : 0.f;
+    }
     // (block 0, its first loads in flight) the tile words get this launch's nonce long before the first arrival
     if (p.gsplits > 1 && blockIdx.x == 0)
         for (int w = tid; w < tiles; w += 64 * WAVES) ticket_prepare_word(p.tickets + w, p.nonce);
@@ -258,9 +269,9 @@ __global__ __launch_bounds__(64 * WAVES) void conv_wavek_f32_kernel(const ConvWa
         const int m = tm * (32 * MT) + 32 * mi + acc_row(r, lane);
         const int n = tn * (32 * NT) + 32 * ni + i;
         if (m >= p.M || n >= p.Cout) continue;
-        float o = v[j] + p.bias[n];
+        float o = v[j] + (NT > 1 && ni ? ep_bias[NT - 1] : ep_bias[0]);
         if (p.relu) o = fmaxf(o, 0.f);
-        if (p.bn_scale) o = o * p.bn_scale[n] + p.bn_shift[n];
+        if (p.bn_scale) o = o * (NT > 1 && ni ? ep_sc[NT - 1] : ep_sc[0]) + (NT > 1 && ni ? ep_sh[NT - 1] : ep_sh[0]);
         p.out[(long long)m * p.Cout + n] = o;
     }
     stamp(7);

@@ -94,6 +94,10 @@ __global__ __launch_bounds__(256) void dense_gemv_f32_kernel(const DenseGemvArgs
         if (!block_ticket_arrive(p.tickets + blockIdx.y * kTicketSlotWords, p.nonce, gridDim.x, blockIdx.x, flag)) return;
         const int group = tid >> 5, n4 = blockIdx.y * 128 + (tid & 31) * 4;
         const int chunks = (int)gridDim.x;
+        const int nn_e = blockIdx.y * 128 + (tid & 127);        // epilogue constants first: their latency hides under the partial loads
+        const bool nn_ok = tid < 128 && nn_e < p.Cout;
+        const float e_bias = nn_ok ? p.bias[nn_e] : 0.f;
+        const float e_sc = (nn_ok && p.bn_scale) ? p.bn_scale[nn_e] : 1.f, e_sh = (nn_ok && p.bn_scale) ? p.bn_shift[nn_e] : 0.f;
         for (int m = 0; m < p.B; ++m) {
             f32x4 s = {0.f, 0.f, 0.f, 0.f};
             if (n4 < p.Cout)
@@ -106,9 +110,9 @@ __global__ __launch_bounds__(256) void dense_gemv_f32_kernel(const DenseGemvArgs
                 float v = gsum[tid];
 #pragma unroll
                 for (int k = 1; k < 8; ++k) v += gsum[k * 128 + tid];
-                v += p.bias[nn];
+                v += e_bias;
                 if (p.relu) v = fmaxf(v, 0.f);
-                if (p.bn_scale) v = v * p.bn_scale[nn] + p.bn_shift[nn];
+                if (p.bn_scale) v = v * e_sc + e_sh;
                 p.out[(long long)m * p.Cout + nn] = v;
             }
             __syncthreads();
