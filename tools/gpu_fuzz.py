@@ -39,7 +39,13 @@ def main():
         w = synth.make_weights(seed=case, shape=cfg.shape, num_filter=filters, strides=strides, latent=latent, batch_norm=bn)
         x = synth.make_crops(B, seed=1000 + case, shape=cfg.shape)
         enc = EncoderEngine(cfg, w, max_batch=max(B, 1))
-        opts = {k: int(rng.integers(0, 2)) for k in ('igemm_dma', 'igemm_breg', 'igemm_breg_wide', 'dense_gemv', 'x3h_dma')}
+        opts = {k: int(rng.integers(0, 2)) for k in ('igemm_dma', 'igemm_breg', 'igemm_breg_wide', 'dense_gemv', 'x3h_dma',
+                                                     'wavek', 'wavek_dense', 'gemv_ticket', 'ticket_prep', 'compact_workspace')}
+        # the small-batch igemm family: wave count / prefetch depth / tile shape switch / how far up in batch size it is used
+        opts['wavek_waves'] = int(rng.choice([4, 8]))
+        opts['wavek_depth'] = int(rng.choice([2, 3]))
+        opts['wavek_narrow_max_tiles'] = int(rng.choice([0, 16, 64]))
+        opts['wavek_max_tiles'] = int(rng.choice([64, 256, 512]))
         for k, v in opts.items():
             enc.set_option(k, v)
         precision = int(rng.integers(0, 2)) if cfg.shape[2] in (1, 3) and all(f % 32 == 0 for f in filters) else 0
@@ -51,6 +57,8 @@ def main():
         z64, acts = ref.encoder_forward_torch(ref.input_to_float(x), w, strides, bn, 'float64', return_activations=True)
         tol = 2e-5
         for i, a in enumerate(acts):
+            if opts['compact_workspace'] and i + 2 < len(acts):
+                continue                                   # overwritten by layer i + 2 (two alternating activation buffers)
             g = enc.activation(i).cpu().numpy()
             err = float(np.abs(g - a).max() / max(np.abs(a).max(), 1e-9))
             worst['layer'] = max(worst['layer'], err)
@@ -72,6 +80,11 @@ def main():
             assert errc < 1e-5, (case, 'cos', errc, N, dtype, B)
             idx, sc = cb.nn(z, 1, 1)
             assert np.array_equal(idx[:, 0].cpu().numpy(), np.argmax(cs, axis=1)), (case, 'argmax', N, dtype, B)
+            # the fused call (encoder + top-1 scan, tickets prepared by the first kernel where it can) gives the same bits
+            stride = int(rng.choice([1, 36]))
+            zf, i_f, s_f = enc.encode_nn(cb, x, stride)
+            i_s, s_s = cb.nn(z, 1, stride)
+            assert torch.equal(zf, z) and torch.equal(i_f, i_s) and torch.equal(s_f, s_s), (case, 'fused', stride, N, dtype, B, opts)
             up, _ = cb.nn(z, 1, 36)
             assert np.array_equal(up[:, 0].cpu().numpy(), ref.nearest_indices_reference(cs, 1, upright=True, num_cyclo=36)), (case, 'upright')
             k = int(rng.integers(2, 9))
