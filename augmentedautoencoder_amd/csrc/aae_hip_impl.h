@@ -123,9 +123,13 @@ struct aae_encoder {
     // small batches (the reference's one-crop-per-detection usage): wave-split-K igemm with the in-launch ticketed reduce
     int wavek = 1;                         // 0: always the 128 x 128 split-K igemm + reduce launch
     int wavek_max_tiles = 256;             // used while the layer has at most this many 64 x 64 output tiles (one per CU)
+    int wavek_target_blocks = 256;         // blocks a split layer is cut into (tiles x K splits): one per CU
     int wavek_waves = 4;                   // waves per block (4 | 8), each with its own K range
-    int wavek_depth = 3;                   // slabs of fragments in flight per wave (2 | 3)
-    int wavek_narrow_max_tiles = 16;       // <= this many 64 x 64 tiles: 64 x 32 wave tiles (twice the tiles, half the splits to add up)
+    // measured per layer with rocprofv3 at B = 1 ... 8 (profiles/r09_small/variants_*.txt): depth 2 beats 3 by 0.5-1 us per launch
+    // (208 instead of 272 registers, the second slab in flight is enough); 64 x 32 wave tiles win up to 128 tiles of 64 x 64 --
+    // fewer blocks per tile to hand over, smaller partials -- and lose beyond (conv2 at B = 4: 68.6 vs 61.5 us)
+    int wavek_depth = 2;                   // slabs of fragments in flight per wave (2 | 3)
+    int wavek_narrow_max_tiles = 128;      // <= this many 64 x 64 tiles: 64 x 32 wave tiles (twice the tiles, half the splits to add up)
     long long* wavek_timeline = nullptr;   // device [3 layers][512 blocks][8] phase stamps when option wavek_timeline is on (profiling tools)
     int compact_workspace = 0;             // 1: two alternating activation buffers instead of one per layer (layer outputs are then not inspectable)
     int ticket_prep = 1;                   // conv1 installs the nonces of the later ticketed launches of its forward call (0: every launch installs its own)
@@ -316,7 +320,7 @@ static WaveKPlan plan_wavek(const aae_encoder* enc, const Layer& L, long long M)
     w.num_nt = L.CoutPad / (32 * w.NT);
     const int tiles = w.num_mt * w.num_nt;
     const int slabs = (int)(L.K() / 32);
-    int g = 256 / tiles;                                   // one block per CU; never a second round of blocks
+    int g = enc->wavek_target_blocks / tiles;              // one block per CU; never a second round of blocks
     const int gmax = slabs / (2 * w.waves);                // every wave keeps at least two slabs
     if (g > gmax) g = gmax;
     if (g > (int)aae::kTicketSingleLevelMax) g = (int)aae::kTicketSingleLevelMax;   // one ticket word per tile
@@ -1178,6 +1182,7 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
     }
     else if (!strcmp(name, "wavek_max_tiles")) enc->wavek_max_tiles = value < 0 ? 0 : (value > 512 ? 512 : value);
     else if (!strcmp(name, "wavek_narrow_max_tiles")) enc->wavek_narrow_max_tiles = value < 0 ? 0 : value;
+    else if (!strcmp(name, "wavek_target_blocks")) enc->wavek_target_blocks = value < 1 ? 1 : value;
     else if (!strcmp(name, "wavek_waves")) {
         if (value != 4 && value != 8) return fail(AAE_ERR_INVALID, "wavek_waves %d: 4 or 8", value);
         enc->wavek_waves = value;

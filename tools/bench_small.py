@@ -86,8 +86,8 @@ def main():
                                   'encode_us': round(1e3 * timeit(lambda: enc.encode(x), 100), 2),
                                   'kernels_us': kernel_split(enc, x)}), flush=True)
             enc.set_option('wavek_waves', 4)
-            enc.set_option('wavek_depth', 3)
-            enc.set_option('wavek_narrow_max_tiles', 16)
+            enc.set_option('wavek_depth', 2)
+            enc.set_option('wavek_narrow_max_tiles', 128)
     if 'thresholds' in what:
         # where does the wave-split-K kernel stop paying?  per layer, B = 4 ... 64, both kernel families
         for B in (4, 6, 8, 12, 16, 24, 32, 48, 64, 128, 256):

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """encode + nn at a small batch size, for `rocprofv3 --kernel-trace --stats` (per-kernel GPU durations without
-the event-timing launch gaps).  Usage: python tools/prof_small.py [B] [reps] [new|old|noprep]"""
+the event-timing launch gaps).  Usage: python tools/prof_small.py [B] [reps] [new|old|noprep] [opt=value,...]"""
 import os
 import sys
 
@@ -23,6 +23,9 @@ if mode == 'old':          # the 128 x 128 split-K igemm + separate reduce launc
         cb.set_scan_mode(_lib.AAE_SCAN_STREAM_2L)
 if mode == 'noprep':       # every ticketed launch installs its own nonce (the arrivals queue up behind the install)
     enc.set_option('ticket_prep', 0)
+for kv in (sys.argv[4].split(',') if len(sys.argv) > 4 else []):       # extra encoder options: name=value,name=value
+    name, value = kv.split('=')
+    enc.set_option(name, int(value))
 x = torch.from_numpy(synth.make_crops(B, seed=3)).cuda()
 for _ in range(reps):
     if mode == 'old':
