@@ -123,6 +123,8 @@ struct aae_encoder {
     // small batches (the reference's one-crop-per-detection usage): wave-split-K igemm with the in-launch ticketed reduce
     int wavek = 1;                         // 0: always the 128 x 128 split-K igemm + reduce launch
     int wavek_max_tiles = 256;             // used while the layer has at most this many 64 x 64 output tiles (one per CU)
+    int wavek_tiny_max_tiles = 64;         // <= this many 64 x 64 tiles: 32 x 32 wave tiles (four times the tiles: K is split across fewer blocks or none);
+                                           // measured: wins up to 64 tiles (B=1: 94 -> 87 us), loses from 128 on (twice the operand loads per MFMA)
     int wavek_target_blocks = 256;         // blocks a split layer is cut into (tiles x K splits): one per CU
     int wavek_waves = 4;                   // waves per block (4 | 8), each with its own K range
     // measured per layer with rocprofv3 at B = 1 ... 8 (profiles/r09_small/variants_*.txt): depth 2 beats 3 by 0.5-1 us per launch
@@ -316,7 +318,9 @@ static WaveKPlan plan_wavek(const aae_encoder* enc, const Layer& L, long long M)
     w.waves = enc->wavek_waves == 8 ? 8 : 4;
     w.depth = (enc->wavek_depth == 2 || w.waves == 8) ? 2 : 3;    // 8 waves share the register file two per SIMD: two slabs in flight each
     w.NT = tiles22 <= enc->wavek_narrow_max_tiles ? 1 : 2;
-    w.num_mt = (int)((M + 63) / 64);
+    w.MT = (tiles22 <= enc->wavek_tiny_max_tiles && w.waves == 4) ? 1 : 2;       // 32 x 32 wave tiles (NT = 1 then: the narrow threshold is the larger one)
+    if (w.MT == 1) w.NT = 1;
+    w.num_mt = (int)((M + 32 * w.MT - 1) / (32 * w.MT));
     w.num_nt = L.CoutPad / (32 * w.NT);
     const int tiles = w.num_mt * w.num_nt;
     const int slabs = (int)(L.K() / 32);
@@ -510,13 +514,15 @@ static int launch_wavek(aae_encoder* enc, const Layer& L, const WaveKPlan& w, co
     a.wp_bytes = (unsigned)((unsigned long long)a.slabs_total * 8ull * L.CoutPad * 16ull);
     a.num_mt = w.num_mt; a.num_nt = w.num_nt; a.gsplits = w.gsplits;
     const int nblk = w.num_mt * w.num_nt * w.gsplits;
-    const int key = w.NT * 100 + w.waves * 10 + w.depth;
+    const int key = (w.MT == 1 ? 1000 : 0) + w.NT * 100 + w.waves * 10 + w.depth;
     switch (key) {
         case 243: launch_wavek_t<2, 2, 4, 3>(a, tag, nblk, stream); break;
         case 242: launch_wavek_t<2, 2, 4, 2>(a, tag, nblk, stream); break;
         case 282: launch_wavek_t<2, 2, 8, 2>(a, tag, nblk, stream); break;
         case 143: launch_wavek_t<2, 1, 4, 3>(a, tag, nblk, stream); break;
         case 142: launch_wavek_t<2, 1, 4, 2>(a, tag, nblk, stream); break;
+        case 1142: launch_wavek_t<1, 1, 4, 2>(a, tag, nblk, stream); break;
+        case 1143: launch_wavek_t<1, 1, 4, 3>(a, tag, nblk, stream); break;
         case 182: launch_wavek_t<2, 1, 8, 2>(a, tag, nblk, stream); break;
         default: return fail(AAE_ERR_RUNTIME, "%s: no wave-split-K instantiation for NT=%d waves=%d depth=%d", name, w.NT, w.waves, w.depth);
     }
@@ -1183,6 +1189,7 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
     else if (!strcmp(name, "wavek_max_tiles")) enc->wavek_max_tiles = value < 0 ? 0 : (value > 512 ? 512 : value);
     else if (!strcmp(name, "wavek_narrow_max_tiles")) enc->wavek_narrow_max_tiles = value < 0 ? 0 : value;
     else if (!strcmp(name, "wavek_target_blocks")) enc->wavek_target_blocks = value < 1 ? 1 : value;
+    else if (!strcmp(name, "wavek_tiny_max_tiles")) enc->wavek_tiny_max_tiles = value < 0 ? 0 : value;
     else if (!strcmp(name, "wavek_waves")) {
         if (value != 4 && value != 8) return fail(AAE_ERR_INVALID, "wavek_waves %d: 4 or 8", value);
         enc->wavek_waves = value;

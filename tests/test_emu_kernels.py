@@ -360,7 +360,7 @@ def test_wave_split_k_igemm_narrow_tiles_and_ticketed_gemv(waves, depth, order):
     eb.set_block_order(order)
     try:
         cfg = EncoderConfig((16, 16, 3), [32, 64], [2, 2], 5, 128)
-        labels = _run(cfg, 3, 1, wavek=1, options={'wavek_waves': waves, 'wavek_depth': depth})
+        labels = _run(cfg, 3, 1, wavek=1, options={'wavek_waves': waves, 'wavek_depth': depth, 'wavek_tiny_max_tiles': 0})
         assert 'conv_wavek_f32_64x32_w%d_d%d_g%d ' % (waves, depth, 3 if waves == 4 else 1) in labels[1], labels
         assert labels[-1].startswith('dense:dense_gemv_f32_ticket') and len(labels) == 3, labels
     finally:
@@ -392,7 +392,7 @@ def test_wave_split_k_igemm_wide_tiles_several_m_tiles_and_dense(narrow):
     tiles (5 tiles, K split over 5 blocks x 4 waves -> waves with a single slab), 16 keeps the 64 x 32 form.
     B = 5 > 4: the dense layer (M = 5, K = 4096 = 128 slabs) also runs on the wave-split-K kernel."""
     cfg = EncoderConfig((32, 32, 3), [32, 64], [2, 2], 5, 128, True)
-    labels = _run(cfg, 5, 61, wavek=1, options={'wavek_narrow_max_tiles': narrow})
+    labels = _run(cfg, 5, 61, wavek=1, options={'wavek_narrow_max_tiles': narrow, 'wavek_tiny_max_tiles': 0})
     assert ('conv_wavek_f32_64x64' if narrow == 0 else 'conv_wavek_f32_64x32') in labels[1], labels
     assert labels[2].startswith('dense:conv_wavek_f32_64x') and len(labels) == 3, labels
 
@@ -401,7 +401,7 @@ def test_wave_split_k_without_cross_block_split_and_with_cout_padding():
     """96 output channels (CoutPad 128: the second 64-column tile is half padding) and a 3 x 3 kernel: 9 slabs are
     too few to split across blocks (gsplits == 1) -- the epilogue runs straight from the LDS sum, no tickets."""
     cfg = EncoderConfig((32, 32, 3), [32, 96], [2, 1], 3, 64)
-    labels = _run(cfg, 2, 71, wavek=1, options={'wavek_narrow_max_tiles': 0})
+    labels = _run(cfg, 2, 71, wavek=1, options={'wavek_narrow_max_tiles': 0, 'wavek_tiny_max_tiles': 0})
     assert 'conv_wavek_f32_64x64' in labels[1] and '_g1 ' in labels[1], labels
 
 
@@ -457,3 +457,12 @@ def test_compact_workspace_alternates_two_activation_buffers():
     with pytest.raises(ValueError, match='overwritten'):
         enc.activation(0)
     enc.close()
+
+
+@pytest.mark.parametrize('B', [1, 3])
+def test_wave_split_k_igemm_32x32_wave_tiles(B):
+    """Option wavek_tiny_max_tiles: 32 x 32 wave tiles (one accumulator per wave) -- four times the tiles, so K is split across
+    fewer blocks.  conv2 here: M = B*16 rows (a partial 32-row tile at B = 3: 48 rows), Cout 96 -> CoutPad 128 = four column tiles."""
+    cfg = EncoderConfig((16, 16, 3), [32, 96], [2, 2], 5, 128, True)
+    labels = _run(cfg, B, 81, wavek=1, options={'wavek_tiny_max_tiles': 64})
+    assert 'conv_wavek_f32_32x32_w4_d2' in labels[1], labels

@@ -119,7 +119,7 @@ def test_headline_kernels_on_the_bench_inputs_match_fp64_oracle(bench_inputs_and
     labels = [l for l, _, _ in recs]
     if precision == 0:
         want = ['conv1:conv_first_f32', 'conv2:conv_igemm_f32_dma_breg_n256', 'conv3:conv_igemm_f32_dma_breg_n256',
-                'conv4:conv_igemm_f32_dma_breg ', 'dense:conv_wavek_f32_64x32_w4_d2_g16 ']     # (dense: one launch, ticketed K reduction)
+                'conv4:conv_igemm_f32_dma_breg ', 'dense:conv_wavek_f32_32x32_w4_d2_g8 ']     # (dense: one launch, ticketed K reduction)
     else:
         want = ['conv1:conv_first_f32', 'conv2:conv_igemm_x3h_dma', 'conv3:conv_igemm_x3h_dma', 'conv4:conv_igemm_x3h_dma',
                 'dense:conv_igemm_x3h_dma_splitk', 'dense:splitk_reduce']

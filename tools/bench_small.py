@@ -88,6 +88,7 @@ def main():
             enc.set_option('wavek_waves', 4)
             enc.set_option('wavek_depth', 2)
             enc.set_option('wavek_narrow_max_tiles', 128)
+            enc.set_option('wavek_tiny_max_tiles', 64)
     if 'thresholds' in what:
         # where does the wave-split-K kernel stop paying?  per layer, B = 4 ... 64, both kernel families
         for B in (4, 6, 8, 12, 16, 24, 32, 48, 64, 128, 256):
