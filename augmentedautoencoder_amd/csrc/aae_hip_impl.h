@@ -108,6 +108,7 @@ struct aae_encoder {
     int reduce_small = 1;                  // <= 8 splits over >= 16k outputs: barrier-free float4 reduce kernel
     int precision = 0;                     // 0: exact fp32 MFMA; 1: f32x3h split-precision igemm (explicit opt-in)
     int first_target_blocks = 512;         // conv1 grid size aimed at (x N tiles); 2 blocks fit a CU
+    int first_group_split_max_tiles = 128; // conv1: batches of at most this many 128-pixel tiles (B <= 4 of the default net) run one block per 32-pixel group
     int first_vec4 = 1;                    // conv1: stage uint8 rows as aligned dwords when W*C % 4 == 0
     int first_max_tiles_per_block = 16;    // conv1: consecutive 128-pixel tiles one block walks with its weights in registers
     int igemm_breg_min_blocks = 768;       // ... with the 32 KB footprint only for grids of at least this many blocks
@@ -612,8 +613,18 @@ static int launch_igemm_x3h(aae_encoder* enc, const Layer& L, const void* x, int
 }
 
 template <int KS, int C>
-static void launch_first_t(const aae::ConvFirstArgs& a, bool u8, bool planes, dim3 grid, int smem, hipStream_t stream) {
+static void launch_first_t(const aae::ConvFirstArgs& a, bool u8, bool planes, dim3 grid, int smem, hipStream_t stream, bool group_split = false) {
     const bool vec4 = u8 && a.vec4;
+    if (group_split && !planes) {                 // per-detection batches: one block per 32-pixel group (grid.z = 4)
+        const dim3 g4(grid.x, grid.y, 4);
+        (void)hipFuncSetAttribute((const void*)aae::conv_first_f32_kernel<KS, C, true, false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        (void)hipFuncSetAttribute((const void*)aae::conv_first_f32_kernel<KS, C, true, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        (void)hipFuncSetAttribute((const void*)aae::conv_first_f32_kernel<KS, C, false, false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        if (vec4) AAE_LAUNCH((aae::conv_first_f32_kernel<KS, C, true, false, true, true>), g4, dim3(256), smem, stream, a);
+        else if (u8) AAE_LAUNCH((aae::conv_first_f32_kernel<KS, C, true, false, false, true>), g4, dim3(256), smem, stream, a);
+        else AAE_LAUNCH((aae::conv_first_f32_kernel<KS, C, false, false, false, true>), g4, dim3(256), smem, stream, a);
+        return;
+    }
     if (planes) {
         if (vec4) AAE_LAUNCH((aae::conv_first_f32_kernel<KS, C, true, true, true>), grid, dim3(256), smem, stream, a);
         else if (u8) AAE_LAUNCH((aae::conv_first_f32_kernel<KS, C, true, true>), grid, dim3(256), smem, stream, a);
@@ -645,10 +656,12 @@ static int launch_first(aae_encoder* enc, const Layer& L, const void* x, bool u8
     if (tpb > enc->first_max_tiles_per_block) tpb = enc->first_max_tiles_per_block;
     a.tiles_per_block = tpb;
     const dim3 grid(ceil_div(a.total_tiles, tpb) + (a.prep.n > 0 ? 1 : 0), ceil_div(L.Cout, 128));    // + the ticket-preparation block
-    if (L.Cin == 3) launch_first_t<5, 3>(a, u8, planes, grid, L.first_smem, stream);
-    else launch_first_t<5, 1>(a, u8, planes, grid, L.first_smem, stream);
+    // per-detection batches: the four 32-pixel groups of every tile go to four blocks (10.6 -> ? us at B = 1)
+    const bool group_split = !planes && a.total_tiles <= enc->first_group_split_max_tiles;
+    if (L.Cin == 3) launch_first_t<5, 3>(a, u8, planes, grid, L.first_smem, stream, group_split);
+    else launch_first_t<5, 1>(a, u8, planes, grid, L.first_smem, stream, group_split);
     char label[96];
-    snprintf(label, sizeof(label), "conv1:conv_first_f32 M=%d N=%d K=%lld", B * L.Ho * L.Wo, L.Cout, L.K());
+    snprintf(label, sizeof(label), "conv1:conv_first_f32%s M=%d N=%d K=%lld", group_split ? "_g4" : "", B * L.Ho * L.Wo, L.Cout, L.K());
     note_kernel({label, 2.0 * (double)B * L.Ho * L.Wo * (double)L.K() * L.Cout});
     AAE_HIP_TRY(hipGetLastError());
     return tm.mark();
@@ -1201,6 +1214,7 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
     else if (!strcmp(name, "igemm_breg_wide_min_blocks")) enc->igemm_breg_wide_min_blocks = value;
     else if (!strcmp(name, "igemm_breg_min_blocks")) enc->igemm_breg_min_blocks = value;
     else if (!strcmp(name, "first_vec4")) enc->first_vec4 = value ? 1 : 0;
+    else if (!strcmp(name, "first_group_split_max_tiles")) enc->first_group_split_max_tiles = value < 0 ? 0 : value;
     else if (!strcmp(name, "first_target_blocks")) enc->first_target_blocks = value < 1 ? 1 : value;
     else if (!strcmp(name, "first_max_tiles_per_block")) enc->first_max_tiles_per_block = value < 1 ? 1 : value;
     else if (!strcmp(name, "x3h_act_shift")) {

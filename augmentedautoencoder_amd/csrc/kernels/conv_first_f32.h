@@ -67,9 +67,13 @@ constexpr unsigned kFirstNoRow = 0xFFFu;                // "column outside the i
 // implicit GEMM (conv_igemm_x3h.h) instead of fp32.
 // VEC4: uint8 input staged by aligned dwords (host guarantees W*C % 4 == 0, rowlen % 4 == 0,
 // (pl*C + lead) % 4 == 0).
-template <int KS, int C, bool IN_U8, bool OUT_PLANES, bool VEC4 = false>
+// GROUP_SPLIT (per-detection batches): the four 32-pixel groups of a tile go to four blocks (blockIdx.z = group), each staging
+// the tile's patch and running ONE accumulator chain of 38 MFMA steps instead of four -- at B = 1 a tile kernel launch is 32
+// blocks x 152 MFMA steps on a chip of 256 CUs; split, it is 128 blocks x 38.  Same steps in the same order: bit-identical.
+template <int KS, int C, bool IN_U8, bool OUT_PLANES, bool VEC4 = false, bool GROUP_SPLIT = false>
 __global__ __launch_bounds__(256) void conv_first_f32_kernel(const ConvFirstArgs p) {
     static_assert(!VEC4 || IN_U8, "dword staging is the uint8 path");
+    static_assert(!GROUP_SPLIT || !OUT_PLANES, "the group-split form exists for the fp32 per-detection path");
     constexpr int KROW = KS * C;
     constexpr int K = KS * KROW;
     constexpr int NK2 = (K + 1) / 2;
@@ -87,7 +91,7 @@ __global__ __launch_bounds__(256) void conv_first_f32_kernel(const ConvFirstArgs
     // ticket preparation for the later launches of this forward: an EXTRA block (the host adds one to the grid) does
     // nothing else, so no working block is delayed (at B = 1 the 32 working blocks leave most CUs free anyway)
     if (p.prep.n > 0 && blockIdx.x == gridDim.x - 1) {
-        if (blockIdx.y == 0) ticket_prep_install(p.prep);
+        if (blockIdx.y == 0 && blockIdx.z == 0) ticket_prep_install(p.prep);
         return;
     }
     if (IN_U8) lut_s[tid] = p.lut[tid];
@@ -255,7 +259,9 @@ __global__ __launch_bounds__(256) void conv_first_f32_kernel(const ConvFirstArgs
             // form: MFMA phase alone 0.150, stores + staging alone 0.087, everything 0.203 before the
             // VALU diet described in the header -- the in-wave store overlap buys nothing on top of
             // what the SIMD's other wave already hides, so the default keeps four chains.
-            constexpr int kChains = AAE_FIRST_CHAINS;
+            constexpr int kChains = GROUP_SPLIT ? 1 : AAE_FIRST_CHAINS;
+            constexpr int kBatches = GROUP_SPLIT ? 1 : 4 / kChains;             // batches of kChains groups this block runs
+            const int g0 = GROUP_SPLIT ? (int)blockIdx.z : 0;                   // its first (only) group
             constexpr int kRing = 8;
             constexpr int kVals = 16 * kChains;
             static_assert(NK2 >= kRing && 4 % kChains == 0, "ring deeper than the chain");
@@ -265,7 +271,7 @@ __global__ __launch_bounds__(256) void conv_first_f32_kernel(const ConvFirstArgs
                 // Rows leave in tile order (+1, +1, +1, +5 rows from one accumulator register to the next),
                 // so the address is one running pointer: nothing tile-invariant for the compiler to hoist
                 // into 64 register pairs.
-                out_t* sp = reinterpret_cast<out_t*>(p.out) + tile_at + lane_out;
+                out_t* sp = reinterpret_cast<out_t*>(p.out) + tile_at + lane_out + (long long)g0 * 32 * p.Cout;
                 const long long step1 = p.Cout, step5 = 5ll * p.Cout;
                 auto emit_next = [&](int row, float v) {
                     if (FULL || (n_ok && row < lim)) emit(sp, v);
@@ -275,10 +281,10 @@ __global__ __launch_bounds__(256) void conv_first_f32_kernel(const ConvFirstArgs
 #pragma unroll
                 for (int s = 0; s < kRing; ++s)
 #pragma unroll
-                    for (int c = 0; c < kChains; ++c) av[c][s] = patch[abase[c] + a_off(s)];
+                    for (int c = 0; c < kChains; ++c) av[c][s] = patch[abase[g0 + c] + a_off(s)];
                 float outv[kVals];
 #pragma unroll
-                for (int bt = 0; bt < 4 / kChains; ++bt) {
+                for (int bt = 0; bt < kBatches; ++bt) {
                     f32x16 acc[kChains];
 #pragma unroll
                     for (int c = 0; c < kChains; ++c)
@@ -290,8 +296,8 @@ __global__ __launch_bounds__(256) void conv_first_f32_kernel(const ConvFirstArgs
 #pragma unroll
                         for (int c = 0; c < kChains; ++c) {
                             acc[c] = mfma_32x32x2(av[c][slot], breg[s], acc[c]);
-                            if (s + kRing < NK2) av[c][slot] = patch[abase[bt * kChains + c] + a_off(s + kRing)];
-                            else if (bt + 1 < 4 / kChains) av[c][slot] = patch[abase[(bt + 1) * kChains + c] + a_off(s + kRing - NK2)];
+                            if (s + kRing < NK2) av[c][slot] = patch[abase[g0 + bt * kChains + c] + a_off(s + kRing)];
+                            else if (bt + 1 < kBatches) av[c][slot] = patch[abase[(bt + 1) * kChains + c] + a_off(s + kRing - NK2)];
                         }
                         if (bt > 0) {
 #pragma unroll
@@ -314,7 +320,7 @@ __global__ __launch_bounds__(256) void conv_first_f32_kernel(const ConvFirstArgs
 #pragma unroll
                 for (int v = 0; v < kVals; ++v) {
                     const int r = v & 15;
-                    emit_next(128 - kChains * 32 + (v >> 4) * 32 + (r & 3) + 8 * (r >> 2), outv[v]);
+                    emit_next((GROUP_SPLIT ? g0 * 32 : 128 - kChains * 32) + (v >> 4) * 32 + (r & 3) + 8 * (r >> 2), outv[v]);
                 }
             };
             if (pend - p0 == 128 && wave_n_ok) tile_body(std::true_type{});

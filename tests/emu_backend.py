@@ -38,7 +38,7 @@ def _aligned(nbytes, align=256):
 def split_k_small_batches(enc):
     """Switch an encoder to the 128 x 128 split-K igemm + separate reduce launches for small batches too (the kernels
     the wave-split-K / ticketed path replaced as the default; kept as options, so their tests keep running)."""
-    for name in ('wavek', 'wavek_dense', 'gemv_ticket'):
+    for name in ('wavek', 'wavek_dense', 'gemv_ticket', 'first_group_split_max_tiles'):     # (conv1: four pixel groups per block, too)
         enc.set_option(name, 0)
     return enc
 

@@ -280,6 +280,16 @@ def test_first_layer_dword_and_elementwise_staging_agree_bitwise(shape, filters,
         acts.append(enc.activation(0).copy())
         enc.close()
     assert np.array_equal(acts[0], acts[1]) and np.array_equal(acts[0], acts[2])
+    # ... and the per-detection form (one block per 32-pixel group instead of four groups per block; uint8 dword / element
+    # staging and float input) runs the same MFMA steps in the same order: identical bits again
+    for vec4, f32_in in ((1, False), (0, False), (1, True)):
+        enc = eb.EmuEncoder(w, cfg)
+        enc.set_option('first_vec4', vec4)
+        enc.set_option('first_group_split_max_tiles', 1 << 20)
+        enc.forward(ref.input_to_float(x).astype(np.float32) if f32_in else x)
+        assert 'conv_first_f32_g4' in enc.labels()[0]
+        assert np.array_equal(enc.activation(0), acts[0]), (vec4, f32_in)
+        enc.close()
     _, want = ref.encoder_forward_np(ref.input_to_float(x), w, cfg.strides, False, return_activations=True)
     assert np.abs(acts[0] - want[0]).max() / np.abs(want[0]).max() < 5e-6
 

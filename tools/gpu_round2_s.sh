@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 cd /tmp
 i=0
-for cfg in "1 wavek_tiny_max_tiles=64" "1 wavek_tiny_max_tiles=32" "1 wavek_tiny_max_tiles=8" "2 wavek_tiny_max_tiles=128" "2 wavek_tiny_max_tiles=64" "4 wavek_tiny_max_tiles=256" "4 wavek_tiny_max_tiles=128" "1 wavek_tiny_max_tiles=64,wavek_depth=3"; do
+for cfg in "8 first_group_split_max_tiles=4096" "8 first_group_split_max_tiles=0" "16 first_group_split_max_tiles=4096" "16 first_group_split_max_tiles=0" "32 first_group_split_max_tiles=4096" "32 first_group_split_max_tiles=0"; do
   set -- $cfg
   i=$((i+1))
   timeout 150 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pv_$i -o t -- python $R/tools/prof_small.py $1 200 new $2 > $R/gpurun_out/prof_var/log_$i.txt 2>&1
