@@ -906,3 +906,49 @@ def test_f32x3h_adversarial_ranges_and_the_saturation_fallback():
             z64 = ref.encoder_forward_torch(x64, ws, STRIDES, False, 'float64')
             assert np.abs(z.cpu().numpy() - z64).max() / np.abs(z64).max() < 2e-5
         enc.close()
+
+
+def test_ticketed_partials_are_never_read_stale_across_launches():
+    """The last block of a launch reads the other blocks' partials with device-scope (sc1) loads and nobody ever issues an
+    L2 invalidate.  A stale cache line could only hold the partials of an EARLIER launch on the same workspace -- invisible
+    to a test that repeats one input.  Here every query has new crops and a new batch size; engine X keeps one workspace
+    for all of them, engine Y (same weights, same codebook) gets fresh workspace memory for every query: the answers of the two
+    must be the same bits, query after query, also under HBM-saturating background copies."""
+    import torch
+    from augmentedautoencoder_amd.engine import CodebookEngine, EncoderEngine, _Workspace
+    from augmentedautoencoder_amd.weights import EncoderConfig
+    weights = synth.make_weights(seed=2024)
+    E = synth.make_codebook(92232, 128, seed=7, planted_duplicates=16)
+    ex, ey = EncoderEngine(EncoderConfig(), weights), EncoderEngine(EncoderConfig(), weights)
+    cx, cy = CodebookEngine(E), CodebookEngine(E)
+    rng = np.random.default_rng(5)
+    side = torch.cuda.Stream()
+    big_a = torch.empty(256 << 20, dtype=torch.uint8, device='cuda')
+    big_b = torch.zeros(256 << 20, dtype=torch.uint8, device='cuda')
+    pool = synth.make_crops(64, seed=4000)
+    keep = []
+    for it in range(120):
+        B = int(rng.integers(1, 5))
+        x = torch.from_numpy(pool[rng.choice(64, B, replace=False)] ^ np.uint8(rng.integers(0, 256))).cuda()    # new pixels every query
+        if it == 60:
+            with torch.cuda.stream(side):
+                for _ in range(30):
+                    big_a.copy_(big_b)
+        zx, ix, sx = ex.encode_nn(cx, x, 1)
+        keep.append((ey.ws, cy.ws))                                   # hold the old buffers: the allocator must hand out other memory
+        ey.ws, cy.ws = _Workspace(ey.device), _Workspace(cy.device)
+        if len(keep) > 6:
+            keep.pop(0)
+        zy, iy, sy = ey.encode_nn(cy, x, 1)
+        assert torch.equal(zx, zy) and torch.equal(ix, iy) and torch.equal(sx, sy), (it, B)
+        # the scan alone, with latents that change every time, one launch vs two launches
+        z = torch.randn(B, 128, device='cuda', generator=None)
+        i1, s1 = cx.nn(z, 1, 1)
+        from augmentedautoencoder_amd import _lib
+        cx.set_scan_mode(_lib.AAE_SCAN_STREAM_2L)
+        i2, s2 = cx.nn(z, 1, 1)
+        cx.set_scan_mode(_lib.AAE_SCAN_AUTO)
+        assert torch.equal(i1, i2) and torch.equal(s1, s2), (it, B)
+    torch.cuda.synchronize()
+    for e in (ex, ey, cx, cy):
+        e.close()
