@@ -476,3 +476,34 @@ def test_wave_split_k_igemm_32x32_wave_tiles(B):
     cfg = EncoderConfig((16, 16, 3), [32, 96], [2, 2], 5, 128, True)
     labels = _run(cfg, B, 81, wavek=1, options={'wavek_tiny_max_tiles': 64})
     assert 'conv_wavek_f32_32x32_w4_d2' in labels[1], labels
+
+
+def test_f32x3h_range_flag_on_the_emulated_kernels():
+    """aae_encoder_x3h_saturated: every kernel that writes fp16 (hi, lo) activation pairs raises the sticky flag when a value
+    leaves the range the pair carries (|x * 2^4| < 65504); asking returns it and clears it; exact-fp32 mode never raises it."""
+    import ctypes
+    cfg = EncoderConfig((16, 16, 3), [32, 64], [2, 2], 5, 128)
+    w = synth.make_weights(seed=5, shape=cfg.shape, num_filter=cfg.num_filter, strides=cfg.strides, latent=128)
+    x = synth.make_crops(2, seed=6, shape=cfg.shape)
+    _, acts = ref.encoder_forward_np(ref.input_to_float(x), w, cfg.strides, False, return_activations=True)
+
+    def flag(enc):
+        f = ctypes.c_int(7)
+        assert enc.L.aae_encoder_x3h_saturated(enc.h, ctypes.byref(f), None) == 0
+        return f.value
+
+    for layer, name in ((0, 'conv2d'), (1, 'conv2d_1')):            # conv1's plane epilogue, then the x3h igemm's (via its split-K reduce)
+        for frac, want in ((0.9, 0), (1.3, 1)):
+            f = frac * 4094.0 / float(np.abs(acts[layer]).max())
+            ws = dict(w)
+            ws[name + '/kernel'], ws[name + '/bias'] = w[name + '/kernel'] * np.float32(f), w[name + '/bias'] * np.float32(f)
+            enc = eb.EmuEncoder(ws, cfg)
+            enc.forward(x)
+            assert flag(enc) == 0                                    # exact fp32: no pairs, no flag
+            enc.set_option('precision', 1)
+            z = enc.forward(x)
+            assert flag(enc) == want and flag(enc) == 0, (layer, frac)
+            if not want:
+                z64 = ref.encoder_forward_np(ref.input_to_float(x), ws, cfg.strides, False)
+                assert np.abs(z - z64).max() / np.abs(z64).max() < 5e-6
+            enc.close()
