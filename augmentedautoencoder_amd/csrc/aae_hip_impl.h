@@ -118,6 +118,8 @@ struct aae_encoder {
     int igemm_breg = 1;                    // conv layers: weight fragments straight from global memory to registers (A-only LDS-DMA, 32 KB LDS)
     int igemm_dma = 1;                     // fp32 igemm operand slabs by LDS-DMA (buffer_load ... lds); 0 = register-staged variant
     int x3h_wide_min_blocks = 0;           // > 0: f32x3h conv layers use 256x128 tiles (8 waves) when that still yields this many blocks; measured neutral (+-1.5 %), off by default
+    int x3h_wide256 = 1;                   // f32x3h conv layers with Cout % 256 == 0: 256 x 256 tiles, 8 waves of 64 x 128 ...
+    int x3h_wide256_min_blocks = 256;      // ... when that still gives every CU a block
     int x3h_dma = 1;                       // f32x3h operand slabs by LDS-DMA (buffer_load ... lds); 0 = register-staged variant
     int x3h_act_shift = 4;                 // activations travel as halves of x*2^shift in f32x3h mode (|x| < 4094 exact range)
     int igemm_stagger = 0;                 // kcycles of start delay for every 2nd block generation of the igemm (0 = off)
@@ -560,6 +562,31 @@ static int launch_igemm_x3h(aae_encoder* enc, const Layer& L, const void* x, int
     const bool dma = enc->x3h_dma != 0;
     const char* kname = dma ? "conv_igemm_x3h_dma" : "conv_igemm_x3h";
     char label[96];
+    // 256 x 256 tiles, 8 waves of 64 x 128 (LDS traffic per MFMA -33 %): layers with Cout % 256 == 0 whose grid still fills the chip
+    if (dma && !out_f32 && enc->x3h_wide256 && L.CoutPad % 256 == 0 && tag >= 1 && tag <= 3 &&
+        ceil_div(M, 256) * (L.CoutPad / 256) >= enc->x3h_wide256_min_blocks) {
+        a.num_mt = ceil_div(M, 256);
+        a.num_nt = L.CoutPad / 256;
+        a.splits = 1;
+        a.slabs_per_split = a.slabs_total;
+        a.out = out;
+        const int wide_blocks = a.num_mt * a.num_nt;
+        constexpr int smem = aae::kX3hWideSmem;
+        if (tag == 1) {
+            (void)hipFuncSetAttribute((const void*)aae::conv_igemm_x3h_wide_kernel<aae::X3H_OUT_PLANES, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            AAE_LAUNCH((aae::conv_igemm_x3h_wide_kernel<aae::X3H_OUT_PLANES, 1>), dim3(wide_blocks), dim3(512), smem, stream, a);
+        } else if (tag == 2) {
+            (void)hipFuncSetAttribute((const void*)aae::conv_igemm_x3h_wide_kernel<aae::X3H_OUT_PLANES, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            AAE_LAUNCH((aae::conv_igemm_x3h_wide_kernel<aae::X3H_OUT_PLANES, 2>), dim3(wide_blocks), dim3(512), smem, stream, a);
+        } else {
+            (void)hipFuncSetAttribute((const void*)aae::conv_igemm_x3h_wide_kernel<aae::X3H_OUT_PLANES, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+            AAE_LAUNCH((aae::conv_igemm_x3h_wide_kernel<aae::X3H_OUT_PLANES, 3>), dim3(wide_blocks), dim3(512), smem, stream, a);
+        }
+        snprintf(label, sizeof(label), "%s:conv_igemm_x3h_wide256 M=%d N=%d K=%lld", name, M, L.Cout, L.K());
+        note_kernel({label, flops});
+        AAE_HIP_TRY(hipGetLastError());
+        return tm.mark();
+    }
     // 256 x 128 tiles (8 waves, one block per CU) when they still give every CU a block
     if (dma && !out_f32 && tag >= 1 && tag <= 3 && enc->x3h_wide_min_blocks > 0 &&
         ceil_div(M, 256) * a.num_nt >= enc->x3h_wide_min_blocks) {
@@ -1180,6 +1207,8 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
     else if (!strcmp(name, "reduce_small")) enc->reduce_small = value ? 1 : 0;
     else if (!strcmp(name, "igemm_stagger")) enc->igemm_stagger = value;
     else if (!strcmp(name, "x3h_dma")) enc->x3h_dma = value ? 1 : 0;
+    else if (!strcmp(name, "x3h_wide256")) enc->x3h_wide256 = value ? 1 : 0;
+    else if (!strcmp(name, "x3h_wide256_min_blocks")) enc->x3h_wide256_min_blocks = value < 1 ? 1 : value;
     else if (!strcmp(name, "x3h_wide_min_blocks")) enc->x3h_wide_min_blocks = value < 0 ? 0 : value;
     else if (!strcmp(name, "igemm_dma")) enc->igemm_dma = value ? 1 : 0;
     else if (!strcmp(name, "igemm_breg")) enc->igemm_breg = value ? 1 : 0;

@@ -411,4 +411,198 @@ __global__ __launch_bounds__(128 * WM) void conv_igemm_x3h_dma_kernel(const Conv
     x3h_epilogue<OUT>(p, acc, mt, nt, split, wm, wn, lane, BM);
 }
 
+
+// ---- 256 x 256 block tile, 8 waves of 64 x 128 ------------------------------------------------------------------
+// The 128 x 128 kernel above is bound by the LDS port, not by the matrix pipe: per slab a wave issues 24 MFMAs
+// (768 cycles) against 16 KiB of fragment reads and 8 DMA pieces; at two blocks per CU that is 83 B/clk of reads +
+// 42 B/clk of DMA writes = 125 of the 128 B/clk an LDS delivers (0.45 of the fp16 matrix peak, every scheduling
+// variant measured the same).  A 64 x 128 wave tile re-uses each A fragment for four N tiles instead of two: 24 KiB of
+// reads and 8 DMA pieces per 48 MFMAs -> 62 + 21 = 84 B/clk at full MFMA rate.  Eight accumulator tiles leave 128
+// registers for operands at two waves per SIMD, so the fragments are not kept as whole k16-step sets: the A fragments
+// of the next step are double-buffered (2 x 16 registers), the B fragments of N tile ni are refreshed IN PLACE right
+// after the six MFMAs that consumed them (4 x 8 registers) -- by the time the next step reaches that tile again
+// 18 MFMAs have passed.
+//   step j of slab t:  [group ni = 0..3:  6 MFMAs on (a_cur, b[ni]);  b[ni] <- (next step, ni)],  A_nxt loaded under group 0
+//   the ONE barrier of a slab sits in its step 1 after group 0, in front of the first read of slab t+1's buffer:
+//   every wave waits for its own DMA pieces of slab t+1 (vmcnt) before it; behind it every wave has finished reading
+//   buffer t (its step-1 fragments were all fetched during step 0), so the pieces of slab t+2 go into buffer t.
+// Same k-step and product order per accumulator as the 128 x 128 kernels: bit-identical results (tested).
+constexpr int kX3hWideSmem = 2 * (256 * kBK + 8 * 256 * 4) * 4;         // 128 KiB: one block per CU
+
+template <int OUT, int TAG = 0>
+__global__ __launch_bounds__(512) void conv_igemm_x3h_wide_kernel(const ConvIgemmX3hArgs p) {
+    constexpr int T = 512, BM = 256, BN = 256;
+    constexpr int kStageA = BM * kBK;                          // floats of one A slab image
+    constexpr int kStageB = 8 * BN * 4;
+    AAE_DYN_SMEM(smem_raw);
+    float* As = reinterpret_cast<float*>(smem_raw);            // [2][256 rows][32 dwords]
+    float* Bs = As + 2 * kStageA;                              // [2][8 slots][256 cols][4 dwords]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;                   // 4 x 2 waves of 64 x 128
+    const int i = lane & 31, h = lane >> 5;
+
+    const int nblk = p.num_mt * p.num_nt;
+    const int L = xcd_remap(blockIdx.x, nblk);
+    const int nt = L % p.num_nt;
+    const int mt = L / p.num_nt;
+    const int nslab = p.slabs_total;
+
+    // ---- A pieces: piece q of a thread fills row tid/8 + 64 q, physical slot tid%8 (logical slot swizzled on the source side)
+    const int a_row = tid >> 3;
+    const int a_slot = (tid & 7) ^ ((a_row >> 1) & 7);
+    const buffer_rsrc xbuf = make_buffer(p.x, p.x_bytes);
+    const buffer_rsrc wbuf = make_buffer(p.wp, p.wp_bytes);
+    unsigned a_off[4];
+    int a_ihw[4];                                              // (ih0 << 16) | (iw0 & 0xffff): the window origin, may be negative
+    bool a_ok[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int m = mt * BM + a_row + 64 * q;
+        a_ok[q] = m < p.M;
+        const int mm = a_ok[q] ? m : 0;
+        const int b = mm / (p.Ho * p.Wo);
+        const int rem = mm - b * (p.Ho * p.Wo);
+        const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
+        const int ih0 = oh * p.S - p.pt, iw0 = ow * p.S - p.pl;
+        a_ihw[q] = (ih0 << 16) | (iw0 & 0xffff);
+        a_off[q] = (unsigned)((((long long)b * p.H + ih0) * p.W + iw0) * (long long)p.Cin * 2) +
+                   (unsigned)(a_slot & 3) * 16u + (unsigned)(a_slot >> 2) * p.plane_bytes;
+    }
+    // ---- B pieces: idx = tid + 512 q -> slot = idx >> 8, col = idx & 255; LDS position idx
+    const unsigned b_off0 = (unsigned)(((tid >> 8) * p.CoutPad + nt * BN + (tid & 255)) * 16);
+    const unsigned b_piece_stride = (unsigned)(2 * p.CoutPad * 16);               // two slot rows per piece
+
+    const int taps = p.KS * p.KS;
+    int cc = 0, kh = 0, kw = 0;
+    unsigned tap_off = 0;
+    auto dma_piece = [&](int slab, int buf, int q) {
+        if (q == 0) tap_off = (unsigned)(((kh * p.W + kw) * p.Cin + cc * 32) * 2);
+        const int ih = (a_ihw[q] >> 16) + kh, iw = (int)(short)(a_ihw[q] & 0xffff) + kw;
+        const bool ok = a_ok[q] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
+        lds_dma16(xbuf, ok ? a_off[q] + tap_off : kOobOffset, As + buf * kStageA + (64 * q + 8 * wave) * kBK);
+        lds_dma16(wbuf, b_off0 + (unsigned)(slab * 4 + q) * b_piece_stride, Bs + buf * kStageB + (T * q + 64 * wave) * 4);
+        if (q == 3) {
+            if (++kw == p.KS) { kw = 0; if (++kh == p.KS) { kh = 0; ++cc; } }
+        }
+    };
+    (void)taps;
+
+    f32x16 acc[2][4];
+#pragma unroll
+    for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+
+    // fragment registers: A of the step in progress and of the next one, B per N tile (refreshed in place)
+    u32x4 ah[2][2], al[2][2], bh[4], bl[4];
+    auto load_a = [&](const float* A, int s, int set) {
+        const int slot = 2 * s + h;
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            ah[set][mi] = __builtin_bit_cast(u32x4, lds_read4(A + a_slab_off(wm * 64 + 32 * mi + i, slot)));
+            al[set][mi] = __builtin_bit_cast(u32x4, lds_read4(A + a_slab_off(wm * 64 + 32 * mi + i, 4 + slot)));
+        }
+    };
+    auto load_b = [&](const float* B, int s, int ni) {
+        const int slot = 2 * s + h;
+        bh[ni] = __builtin_bit_cast(u32x4, lds_read4(B + (slot * BN + wn * 128 + 32 * ni + i) * 4));
+        bl[ni] = __builtin_bit_cast(u32x4, lds_read4(B + ((4 + slot) * BN + wn * 128 + 32 * ni + i) * 4));
+    };
+    auto mfma_group = [&](int set, int ni) {
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+            acc[mi][ni] = mfma_32x32x16_f16(al[set][mi], bh[ni], acc[mi][ni]);
+            acc[mi][ni] = mfma_32x32x16_f16(ah[set][mi], bl[ni], acc[mi][ni]);
+            acc[mi][ni] = mfma_32x32x16_f16(ah[set][mi], bh[ni], acc[mi][ni]);
+        }
+    };
+
+    if (nslab > 0) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) dma_piece(0, 0, q);
+        wait_dma_and_lds();
+        __syncthreads();
+        load_a(As, 0, 0);
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) load_b(Bs, 0, ni);
+        sched_fence();
+        if (nslab > 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dma_piece(1, 1, q);
+        }
+        for (int t = 0; t < nslab; ++t) {
+            const int buf = t & 1;
+            const float* A = As + buf * kStageA;
+            const float* B = Bs + buf * kStageB;
+            const float* An = As + (buf ^ 1) * kStageA;
+            const float* Bn = Bs + (buf ^ 1) * kStageB;
+            const bool has1 = t + 1 < nslab, has2 = t + 2 < nslab;
+            // ---- step 0 (fragments in set 0); the fragments of step 1 of this slab are fetched under it
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                sched_fence();
+                mfma_group(0, ni);
+                sched_fence();
+                if (ni == 0) load_a(A, 1, 1);
+                load_b(B, 1, ni);
+            }
+            // ---- step 1 (set 1); behind the barrier the fragments of step 0 of slab t+1 come from the other buffer
+            sched_fence();
+            mfma_group(1, 0);
+            sched_fence();
+            if (has1) {
+                wait_dma_and_lds();
+                __syncthreads();
+                sched_fence();
+                load_a(An, 0, 0);
+                load_b(Bn, 0, 0);
+            }
+#pragma unroll
+            for (int ni = 1; ni < 4; ++ni) {
+                sched_fence();
+                mfma_group(1, ni);
+                sched_fence();
+                if (has1) load_b(Bn, 0, ni);
+                if (has2) dma_piece(t + 2, buf, ni - 1);          // buffer t is free: every wave is past its reads of slab t
+            }
+            sched_fence();
+            if (has2) dma_piece(t + 2, buf, 3);
+        }
+    }
+
+    // ---- epilogue: the wave's 64 x 128 tile
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+        const int n = nt * BN + wn * 128 + ni * 32 + i;
+        if (n >= p.Cout) continue;
+        const float bias = p.bias[n];
+        float sc = 1.f, sh = 0.f;
+        if (p.bn_scale) { sc = p.bn_scale[n]; sh = p.bn_shift[n]; }
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mt * BM + wm * 64 + mi * 32 + acc_row(r, lane);
+                if (m >= p.M) continue;
+                float v = acc[mi][ni][r] * p.inv_scale;
+                v += bias;
+                if (p.relu) v = fmaxf(v, 0.f);
+                if (p.bn_scale) v = v * sc + sh;
+                if (OUT == X3H_OUT_F32) {
+                    reinterpret_cast<float*>(p.out)[(long long)m * p.Cout + n] = v;
+                } else {
+                    unsigned short hi, lo;
+                    split_f16_checked(v * p.out_scale, hi, lo, p.sat_flag);
+                    unsigned short* o = reinterpret_cast<unsigned short*>(p.out);
+                    o[(long long)m * p.Cout + n] = hi;
+                    o[(long long)p.M * p.Cout + (long long)m * p.Cout + n] = lo;
+                }
+            }
+        }
+    }
+}
+
 }  // namespace aae

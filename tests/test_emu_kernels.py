@@ -507,3 +507,31 @@ def test_f32x3h_range_flag_on_the_emulated_kernels():
                 z64 = ref.encoder_forward_np(ref.input_to_float(x), ws, cfg.strides, False)
                 assert np.abs(z - z64).max() / np.abs(z64).max() < 5e-6
             enc.close()
+
+
+@pytest.mark.parametrize('shape,B,filters,bn', [((32, 32, 3), 5, [32, 256], False), ((24, 16, 3), 7, [64, 512, 256], True)])
+def test_f32x3h_256x256_tile_kernel_is_bit_identical(shape, B, filters, bn):
+    """conv_igemm_x3h_wide_kernel: 256 x 256 block tiles, 8 waves of 64 x 128, B fragments refreshed in place, A fragments
+    double-buffered, one barrier per slab -- same k-step and product order per accumulator as the 128 x 128 kernel, so the same
+    bits; M = 320 / 168 rows (a full and a partial 256-row tile / one partial tile), Cout 256 and 512 (one and two N tiles),
+    a third layer consuming the planes the wide kernel wrote."""
+    cfg = EncoderConfig(shape, filters, [2] * len(filters), 5, 128, bn)
+    w = synth.make_weights(seed=15, shape=cfg.shape, num_filter=cfg.num_filter, strides=cfg.strides, latent=128, batch_norm=bn)
+    x = synth.make_crops(B, seed=16, shape=cfg.shape)
+    enc = eb.split_k_small_batches(eb.EmuEncoder(w, cfg))
+    enc.set_option('precision', 1)
+    enc.set_option('splitk_min_base_blocks', 0)
+    enc.set_option('x3h_wide256', 0)
+    z0 = enc.forward(x)
+    a0 = [enc.activation(i) for i in range(1, len(filters))]
+    assert not any('wide256' in l for l in enc.labels())
+    enc.set_option('x3h_wide256', 1)
+    enc.set_option('x3h_wide256_min_blocks', 1)
+    z1 = enc.forward(x)
+    assert any('x3h_wide256' in l for l in enc.labels()), enc.labels()
+    for i, a in enumerate(a0):
+        assert np.array_equal(a, enc.activation(i + 1)), 'layer %d' % (i + 1)
+    assert np.array_equal(z0, z1)
+    z64 = ref.encoder_forward_np(ref.input_to_float(x), w, cfg.strides, bn)
+    assert np.abs(z1 - z64).max() / np.abs(z64).max() < 5e-6
+    enc.close()

@@ -121,7 +121,7 @@ def test_headline_kernels_on_the_bench_inputs_match_fp64_oracle(bench_inputs_and
         want = ['conv1:conv_first_f32', 'conv2:conv_igemm_f32_dma_breg_n256', 'conv3:conv_igemm_f32_dma_breg_n256',
                 'conv4:conv_igemm_f32_dma_breg ', 'dense:conv_wavek_f32_32x32_w4_d2_g8 ']     # (dense: one launch, ticketed K reduction)
     else:
-        want = ['conv1:conv_first_f32', 'conv2:conv_igemm_x3h_dma', 'conv3:conv_igemm_x3h_dma', 'conv4:conv_igemm_x3h_dma',
+        want = ['conv1:conv_first_f32', 'conv2:conv_igemm_x3h_wide256', 'conv3:conv_igemm_x3h_wide256', 'conv4:conv_igemm_x3h_dma',
                 'dense:conv_igemm_x3h_dma_splitk', 'dense:splitk_reduce']
     assert len(labels) == len(want) and all(l.startswith(w) for l, w in zip(labels, want)), labels
     for i, a in enumerate(acts):

@@ -48,6 +48,8 @@ def main():
         opts['wavek_max_tiles'] = int(rng.choice([64, 256, 512]))
         opts['wavek_tiny_max_tiles'] = int(rng.choice([0, 64, 512]))            # 32 x 32 wave tiles
         opts['first_group_split_max_tiles'] = int(rng.choice([0, 128, 4096]))   # conv1: one block per 32-pixel group
+        opts['x3h_wide256'] = int(rng.integers(0, 2))                            # f32x3h: 256 x 256 tiles ...
+        opts['x3h_wide256_min_blocks'] = int(rng.choice([1, 256]))               # ... also on grids that do not fill the chip
         for k, v in opts.items():
             enc.set_option(k, v)
         precision = int(rng.integers(0, 2)) if cfg.shape[2] in (1, 3) and all(f % 32 == 0 for f in filters) else 0
