@@ -537,18 +537,17 @@ static int launch_wavek(aae_encoder* enc, const Layer& L, const WaveKPlan& w, co
     return tm.mark();
 }
 
-// f32x3h variant: x and (unless out_f32) out are fp16 hi/lo planes of value * 2^x3h_act_shift.
+// f32x3h variant: x and (unless out_f32) out are fp16 (hi, lo) pairs of value * 2^x3h_act_shift (x3h_pair_index layout).
 static int launch_igemm_x3h(aae_encoder* enc, const Layer& L, const void* x, int M, void* out, bool out_f32, float* partial,
                             hipStream_t stream, Timer& tm, const char* name, int tag = 0) {
     aae::ConvIgemmX3hArgs a;
     a.x = static_cast<const unsigned short*>(x); a.wp = L.wp16; a.bias = L.bias; a.bn_scale = L.bn_scale; a.bn_shift = L.bn_shift;
     a.H = L.H; a.W = L.W; a.Cin = L.Cin; a.Ho = L.Ho; a.Wo = L.Wo; a.Cout = L.Cout; a.CoutPad = L.CoutPad;
     a.KS = L.KS; a.S = L.S; a.pt = L.pt; a.pl = L.pl; a.M = M; a.relu = L.relu;
-    const unsigned long long plane = (unsigned long long)(M / (L.Ho * L.Wo)) * L.H * L.W * L.Cin * 2;
-    if (2 * plane >= 0xFFFFFFF0ull)
-        return fail(AAE_ERR_UNSUPPORTED, "%s: input activation of %llu bytes exceeds the 4 GiB buffer view; use a smaller batch", name, 2 * plane);
-    a.plane_bytes = (unsigned)plane;
-    a.x_bytes = (unsigned)(2 * plane);
+    const unsigned long long in_bytes = (unsigned long long)(M / (L.Ho * L.Wo)) * L.H * L.W * L.Cin * 4;
+    if (in_bytes >= 0xFFFFFFF0ull)
+        return fail(AAE_ERR_UNSUPPORTED, "%s: input activation of %llu bytes exceeds the 4 GiB buffer view; use a smaller batch", name, in_bytes);
+    a.x_bytes = (unsigned)in_bytes;
     a.inv_scale = ldexpf(1.f, -(enc->x3h_act_shift + L.w_shift));
     a.out_scale = ldexpf(1.f, enc->x3h_act_shift);
     a.sat_flag = out_f32 ? nullptr : enc->x3h_sat;

@@ -37,6 +37,14 @@ __device__ __forceinline__ void split_f16(float v, unsigned short& hi, unsigned 
     lo = __builtin_bit_cast(unsigned short, (_Float16)r);
 }
 
+// f32x3h activation format: element e = m*C + n of an [M][C] activation (C % 32 == 0) is the pair of halves at
+// x3h_pair_index(e) (hi) and x3h_pair_index(e) + 32 (lo): every 32-channel chunk is one 128-byte line, 64 B of hi
+// halves followed by the 64 B of their lo halves -- exactly the A rows of one K slab, so an operand row is ONE full
+// L2 line.  (As two separate planes each row was two half lines in different places: the half-filled lines halved the
+// useful L2 capacity and the tap-to-tap re-reads of the convolution window missed: 2.1 GB fetched for conv2 at B = 256.)
+__host__ __device__ __forceinline__ long long x3h_pair_index(long long e) { return ((e >> 5) << 6) + (e & 31); }
+
+
 // ... and note a value the (hi, lo) pair cannot carry at full accuracy: beyond the fp16 range hi saturates and the
 // remainder lands in lo with the spacing of a large half (accuracy degrades gradually up to 2 x 65504, then the pair
 // clamps).  sat: sticky device flag (nullptr = do not track); every writer stores the same 1, so the race is benign.

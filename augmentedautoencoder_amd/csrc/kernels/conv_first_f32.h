@@ -200,17 +200,19 @@ __global__ __launch_bounds__(256) void conv_first_f32_kernel(const ConvFirstArgs
 
     int abase[4] = {0, 0, 0, 0};
     int abase_key = -1;
-    const unsigned lane_out = (unsigned)(4 * h * p.Cout + n);     // element offset of this lane inside a tile's output
-    const long long plane = (long long)(p.total_tiles / p.tiles_per_image) * HoWo * p.Cout;
+    // element offset of this lane inside a tile's output.  f32x3h pairs (x3h_pair_index): a row is 2*Cout halves,
+    // channel chunk n/32 holds 32 hi halves then 32 lo halves
+    constexpr int kRowMul = OUT_PLANES ? 2 : 1;
+    const unsigned lane_out = OUT_PLANES ? (unsigned)(8 * h * p.Cout + ((n >> 5) << 6) + (n & 31)) : (unsigned)(4 * h * p.Cout + n);
 
-    // one finished value; `at` = this lane's element of the tile row (fp32, or the hi plane of the f32x3h format)
+    // one finished value; `at` = this lane's element of the tile row (fp32, or the hi half of the f32x3h pair)
     using out_t = std::conditional_t<OUT_PLANES, unsigned short, float>;
     auto emit = [&](out_t* at, float v) {
         if constexpr (OUT_PLANES) {
             unsigned short hi, lo;
             split_f16_checked(v * p.out_scale, hi, lo, p.sat_flag);
             at[0] = hi;
-            at[plane] = lo;
+            at[32] = lo;
         } else {
             at[0] = v;
         }
@@ -271,8 +273,8 @@ __global__ __launch_bounds__(256) void conv_first_f32_kernel(const ConvFirstArgs
                 // Rows leave in tile order (+1, +1, +1, +5 rows from one accumulator register to the next),
                 // so the address is one running pointer: nothing tile-invariant for the compiler to hoist
                 // into 64 register pairs.
-                out_t* sp = reinterpret_cast<out_t*>(p.out) + tile_at + lane_out + (long long)g0 * 32 * p.Cout;
-                const long long step1 = p.Cout, step5 = 5ll * p.Cout;
+                out_t* sp = reinterpret_cast<out_t*>(p.out) + kRowMul * (tile_at + (long long)g0 * 32 * p.Cout) + lane_out;
+                const long long step1 = kRowMul * p.Cout, step5 = 5ll * kRowMul * p.Cout;
                 auto emit_next = [&](int row, float v) {
                     if (FULL || (n_ok && row < lim)) emit(sp, v);
                     sp += ((row & 7) == 3) ? step5 : step1;

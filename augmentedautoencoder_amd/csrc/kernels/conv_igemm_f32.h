@@ -389,8 +389,8 @@ __global__ __launch_bounds__(512) void splitk_reduce_kernel(const SplitKReduceAr
                 unsigned short hi, lo;
                 split_f16_checked(v * p.out_scale, hi, lo, p.sat_flag);
                 unsigned short* op = reinterpret_cast<unsigned short*>(p.out);
-                op[e] = hi;
-                op[p.MN + e] = lo;
+                op[x3h_pair_index(e)] = hi;
+                op[x3h_pair_index(e) + 32] = lo;
             } else {
                 p.out[e] = v;
             }
@@ -440,8 +440,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_small_kernel(const SplitKRe
             hi[j] = h16; lo[j] = l16;
         }
         unsigned short* op = reinterpret_cast<unsigned short*>(p.out);
-        *reinterpret_cast<u16x4*>(op + e) = hi;
-        *reinterpret_cast<u16x4*>(op + p.MN + e) = lo;
+        *reinterpret_cast<u16x4*>(op + x3h_pair_index(e)) = hi;              // (e % 4 == 0: the four halves stay inside one chunk)
+        *reinterpret_cast<u16x4*>(op + x3h_pair_index(e) + 32) = lo;
     } else {
         *reinterpret_cast<f32x4*>(p.out + e) = v;
     }

@@ -11,9 +11,10 @@
 //
 // Same layer semantics as conv_igemm_f32.h (/root/reference/auto_pose/ae/encoder.py:41-52,62-66).
 // Differences in data layout:
-//   * activations travel between layers as two fp16 planes [M][C] (hi plane, then lo plane,
-//     same bytes as fp32) of x * 2^act_shift, written by the producer's epilogue -- the
-//     consumer's operand loads are straight 16-B copies, no conversion in the K loop;
+//   * activations travel between layers as (hi, lo) pairs of halves of x * 2^act_shift (same bytes as
+//     fp32), written by the producer's epilogue: [M][C/32][hi x 32 | lo x 32] (x3h_pair_index) -- one
+//     128-B line per row of a K slab; the consumer's operand loads are straight 16-B copies, no
+//     conversion in the K loop;
 //   * weights are split on the host after scaling by 2^w_shift and packed per K-slab as
 //     [8 slots][CoutPad][8 halves], slot = plane*4 + kgroup8.
 //   * LDS slab images: A [128 rows][8 slots x 16 B] (hi slots 0-3, lo slots 4-7, XOR swizzle as
@@ -27,14 +28,13 @@
 namespace aae {
 
 struct ConvIgemmX3hArgs {
-    const unsigned short* x;  // activation planes: hi [Min][Cin], lo [Min][Cin] (halves of x*2^act_shift)
-    unsigned x_bytes;         // both planes
-    unsigned plane_bytes;     // one plane = Min*Cin*2
+    const unsigned short* x;  // activation pairs [Min][Cin/32][hi x 32 | lo x 32] (halves of x*2^act_shift)
+    unsigned x_bytes;         // Min*Cin*4
     const unsigned* wp;       // [slabs][8][CoutPad][4 dwords]
     const float* bias;
     const float* bn_scale;
     const float* bn_shift;
-    void* out;                // OUT_PLANES: two half planes [M][Cout]; OUT_F32: float [M][Cout]; split-K: float partials
+    void* out;                // OUT_PLANES: half pairs [M][Cout/32][64]; OUT_F32: float [M][Cout]; split-K: float partials
     int H, W, Cin, Ho, Wo, Cout, CoutPad;
     int KS, S, pt, pl;
     int M;
@@ -109,8 +109,9 @@ __device__ __forceinline__ void x3h_epilogue(const ConvIgemmX3hArgs& p, const f3
                         unsigned short hi, lo;
                         split_f16_checked(v * p.out_scale, hi, lo, p.sat_flag);
                         unsigned short* o = reinterpret_cast<unsigned short*>(p.out);
-                        o[(long long)m * p.Cout + n] = hi;
-                        o[(long long)p.M * p.Cout + (long long)m * p.Cout + n] = lo;
+                        const long long at = x3h_pair_index((long long)m * p.Cout + n);
+                        o[at] = hi;
+                        o[at + 32] = lo;
                     }
                 }
             }
@@ -153,8 +154,8 @@ __global__ __launch_bounds__(256) void conv_igemm_x3h_kernel(const ConvIgemmX3hA
         const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
         a_ih0[q] = oh * p.S - p.pt;
         a_iw0[q] = ow * p.S - p.pl;
-        a_off[q] = (unsigned)((((long long)b * p.H + a_ih0[q]) * p.W + a_iw0[q]) * (long long)p.Cin * 2) +
-                   (unsigned)(a_slot & 3) * 16u + (unsigned)(a_slot >> 2) * p.plane_bytes;
+        a_off[q] = (unsigned)((((long long)b * p.H + a_ih0[q]) * p.W + a_iw0[q]) * (long long)p.Cin * 4) +
+                   (unsigned)a_slot * 16u;          // hi k-groups 0-3, lo k-groups 4-7 of the 128-B chunk
     }
     // ---- B loader: idx = tid + 256*q -> slot = idx>>7, col = idx&127 ------------------------------
     const unsigned* b_ptr = p.wp + ((long long)nt * 128 + (tid & 127)) * 4 + (long long)(tid >> 7) * p.CoutPad * 4;
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(256) void conv_igemm_x3h_kernel(const ConvIgemmX3hA
     unsigned tap_off = 0;
     auto fetch_piece = [&](auto PAR, int slab, int q) {
         constexpr int P = decltype(PAR)::value;
-        if (q == 0) tap_off = (unsigned)(((kh * p.W + kw) * p.Cin + cc * 32) * 2);
+        if (q == 0) tap_off = (unsigned)(((kh * p.W + kw) * p.Cin + cc * 32) * 4);
         const bool ok = a_ok[q] && (unsigned)(a_ih0[q] + kh) < (unsigned)p.H && (unsigned)(a_iw0[q] + kw) < (unsigned)p.W;
         ra[P][q] = __builtin_bit_cast(u32x4, buffer_load4(xbuf, ok ? a_off[q] + tap_off : kOobOffset));
         rb[P][q] = *reinterpret_cast<const u32x4*>(b_ptr + ((long long)slab * 8 + 2 * q) * b_slot_stride);
@@ -321,8 +322,8 @@ __global__ __launch_bounds__(128 * WM) void conv_igemm_x3h_dma_kernel(const Conv
         const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
         a_ih0[q] = oh * p.S - p.pt;
         a_iw0[q] = ow * p.S - p.pl;
-        a_off[q] = (unsigned)((((long long)b * p.H + a_ih0[q]) * p.W + a_iw0[q]) * (long long)p.Cin * 2) +
-                   (unsigned)(a_slot & 3) * 16u + (unsigned)(a_slot >> 2) * p.plane_bytes;
+        a_off[q] = (unsigned)((((long long)b * p.H + a_ih0[q]) * p.W + a_iw0[q]) * (long long)p.Cin * 4) +
+                   (unsigned)a_slot * 16u;          // hi k-groups 0-3, lo k-groups 4-7 of the 128-B chunk
     }
     // ---- B pieces: idx = tid + T q -> slot = idx>>7, col = idx&127, LDS position idx (q < NB) --------
     const unsigned b_off0 = (unsigned)(((tid >> 7) * p.CoutPad + nt * 128 + (tid & 127)) * 16);
@@ -335,7 +336,7 @@ __global__ __launch_bounds__(128 * WM) void conv_igemm_x3h_dma_kernel(const Conv
     unsigned tap_off = 0;
 
     auto dma_piece = [&](int slab, int buf, int q) {
-        if (q == 0) tap_off = (unsigned)(((kh * p.W + kw) * p.Cin + cc * 32) * 2);
+        if (q == 0) tap_off = (unsigned)(((kh * p.W + kw) * p.Cin + cc * 32) * 4);
         const bool ok = a_ok[q] && (unsigned)(a_ih0[q] + kh) < (unsigned)p.H && (unsigned)(a_iw0[q] + kw) < (unsigned)p.W;
         lds_dma16(xbuf, ok ? a_off[q] + tap_off : kOobOffset, As + buf * kStageA + ((T / 8) * q + 8 * wave) * kBK);
         if (q < NB)
@@ -466,8 +467,8 @@ __global__ __launch_bounds__(512) void conv_igemm_x3h_wide_kernel(const ConvIgem
         const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
         const int ih0 = oh * p.S - p.pt, iw0 = ow * p.S - p.pl;
         a_ihw[q] = (ih0 << 16) | (iw0 & 0xffff);
-        a_off[q] = (unsigned)((((long long)b * p.H + ih0) * p.W + iw0) * (long long)p.Cin * 2) +
-                   (unsigned)(a_slot & 3) * 16u + (unsigned)(a_slot >> 2) * p.plane_bytes;
+        a_off[q] = (unsigned)((((long long)b * p.H + ih0) * p.W + iw0) * (long long)p.Cin * 4) +
+                   (unsigned)a_slot * 16u;          // hi k-groups 0-3, lo k-groups 4-7 of the 128-B chunk
     }
     // ---- B pieces: idx = tid + 512 q -> slot = idx >> 8, col = idx & 255; LDS position idx
     const unsigned b_off0 = (unsigned)(((tid >> 8) * p.CoutPad + nt * BN + (tid & 255)) * 16);
@@ -477,7 +478,7 @@ __global__ __launch_bounds__(512) void conv_igemm_x3h_wide_kernel(const ConvIgem
     int cc = 0, kh = 0, kw = 0;
     unsigned tap_off = 0;
     auto dma_piece = [&](int slab, int buf, int q) {
-        if (q == 0) tap_off = (unsigned)(((kh * p.W + kw) * p.Cin + cc * 32) * 2);
+        if (q == 0) tap_off = (unsigned)(((kh * p.W + kw) * p.Cin + cc * 32) * 4);
         const int ih = (a_ihw[q] >> 16) + kh, iw = (int)(short)(a_ihw[q] & 0xffff) + kw;
         const bool ok = a_ok[q] && (unsigned)ih < (unsigned)p.H && (unsigned)iw < (unsigned)p.W;
         lds_dma16(xbuf, ok ? a_off[q] + tap_off : kOobOffset, As + buf * kStageA + (64 * q + 8 * wave) * kBK);
@@ -597,8 +598,9 @@ __global__ __launch_bounds__(512) void conv_igemm_x3h_wide_kernel(const ConvIgem
                     unsigned short hi, lo;
                     split_f16_checked(v * p.out_scale, hi, lo, p.sat_flag);
                     unsigned short* o = reinterpret_cast<unsigned short*>(p.out);
-                    o[(long long)m * p.Cout + n] = hi;
-                    o[(long long)p.M * p.Cout + (long long)m * p.Cout + n] = lo;
+                    const long long at = x3h_pair_index((long long)m * p.Cout + n);
+                    o[at] = hi;
+                    o[at + 32] = lo;
                 }
             }
         }

@@ -93,6 +93,8 @@ def main():
     ap.add_argument('--full-extras', action='store_true',
                     help='also time config3 at the reference batch size 64 (kept out of the default run: those launches share the kernel '
                          'symbols of the headline batch and would blur the rocprofv3 --stats averages of the same command)')
+    ap.add_argument('--enc-opt', action='append', default=[], metavar='NAME=INT',
+                    help='set an encoder option before measuring (kernel-variant A/B under a profiler); recorded in config')
     ap.add_argument('--no-extras', action='store_true', help='skip the secondary measurements (latency, scan, config3, config5, pcie, decoder)')
     args = ap.parse_args()
 
@@ -145,6 +147,8 @@ def main():
         """W warm-up steps, then exactly K timed steps between barrier+synchronize fences, max over
         ranks; then per-kernel durations from HIP events on the launch stream."""
         enc.set_option('precision', 1 if precision == 'f32x3h' else 0)
+        for kv in args.enc_opt:
+            enc.set_option(kv.split('=')[0], int(kv.split('=')[1]))
         for _ in range(args.warmup):
             step()
         fence()
@@ -364,6 +368,8 @@ def main():
             'encoder_tflops': main_res['encoder_tflops'],
             'kernels': main_res['kernels'],
         }
+        if args.enc_opt:
+            out['config']['encoder_options'] = args.enc_opt
         out.update(extras)
         if split_res is not None:
             out['split_precision'] = {'mode': x3h_label, 'value': split_res['value'], 'unit': 'crops/s',

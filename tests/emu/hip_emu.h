@@ -230,6 +230,8 @@ inline bool block_ticket_arrive(unsigned long long* words, unsigned nonce, unsig
     return block_ticket_take(words, nonce, total, id, lds_flag);
 }
 
+// f32x3h activation pairs (device_intrinsics.h): 32-channel chunks of 32 hi halves + 32 lo halves
+inline long long x3h_pair_index(long long e) { return ((e >> 5) << 6) + (e & 31); }
 constexpr float kHalfPairLimit = 65504.f;
 inline void split_f16_checked(float v, unsigned short& hi, unsigned short& lo, int* sat) {
     split_f16(v, hi, lo);
