@@ -86,7 +86,7 @@ void aae_encoder_destroy(aae_encoder* enc);
  *                    1 = "f32x3h": fp32 in/out, every product of conv2..dense evaluated as three
  *                        fp16 MFMAs on (hi, lo) operand pairs with fp32 accumulation (>= 22-bit
  *                        operands).  Explicit opt-in; same parity tolerances; activations then
- *                        live in the workspace as two fp16 planes of x * 2^x3h_act_shift.
+ *                        live in the workspace as fp16 (hi, lo) pairs of x * 2^x3h_act_shift, interleaved per 32-channel chunk.
  *   "x3h_act_shift" (4): power-of-two activation pre-scale of the f32x3h format (|x| < 4094
  *                        keeps full accuracy; larger values saturate gracefully up to 2x).
  *   "splitk_min_base_blocks" (384): split the K loop of a layer only if its un-split grid
@@ -105,6 +105,9 @@ void aae_encoder_destroy(aae_encoder* enc);
  *                        matrix-core tile (same value up to fp32 summation order);
  *   "x3h_wide_min_blocks" (0): > 0 lets f32x3h conv layers use 256x128 tiles when that still yields this
  *                        many blocks (measured neutral);
+ *   "x3h_wide256" (1), "x3h_wide256_min_blocks" (256): f32x3h conv layers with Cout % 256 == 0 whose grid
+ *                        still has that many blocks run 256x256 tiles / 8 waves of 64x128 (bit-identical to
+ *                        the 128x128 kernel, 10-14 % faster at B = 256);
  *   "first_target_blocks" (512), "first_max_tiles_per_block" (16): conv1 grid shaping;
  *   "first_vec4" (1): stage uint8 rows of conv1 as aligned dwords when W*C % 4 == 0;
  *   "reduce_small" (1): split-K sums of <= 8 splits over >= 16k outputs by the barrier-free float4 kernel;
