@@ -233,8 +233,8 @@ class EncoderEngine(object):
         raw = buf[start:start + 4 * cnt.value]
         if self.options.get('precision', 0) == 1:
             # f32x3h keeps activations as fp16 (hi, lo) pairs of value * 2^shift: [pixel][32-channel chunk][hi x 32 | lo x 32]
-            pairs = raw.view(torch.float16).reshape(self._last_B, Ho, Wo, Co // 32, 2, 32).to(torch.float64)
-            return ((pairs[..., 0, :] + pairs[..., 1, :]).reshape(self._last_B, Ho, Wo, Co)
+            pairs = raw.view(torch.float16).reshape(-1, 2, 32).to(torch.float64)      # chunks of the flat [B*Ho*Wo*Co] index
+            return ((pairs[:, 0, :] + pairs[:, 1, :]).reshape(self._last_B, Ho, Wo, Co)
                     / 2.0 ** self.options.get('x3h_act_shift', 4)).to(torch.float32)
         return raw.view(torch.float32).reshape(self._last_B, Ho, Wo, Co).clone()
 

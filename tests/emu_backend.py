@@ -80,8 +80,8 @@ class EmuEncoder(object):
         H, W, Ci, Ho, Wo, Co = self.cfg.layer_shapes()[layer]
         raw = self.ws[off.value:off.value + 4 * cnt.value]
         if self.options.get('precision', 0) == 1:      # f32x3h: fp16 (hi, lo) pairs of value * 2^shift, [pixel][chunk][hi x 32 | lo x 32]
-            pairs = raw.view(np.float16).reshape(self.B, Ho, Wo, Co // 32, 2, 32).astype(np.float64)
-            return ((pairs[..., 0, :] + pairs[..., 1, :]).reshape(self.B, Ho, Wo, Co)
+            pairs = raw.view(np.float16).reshape(-1, 2, 32).astype(np.float64)          # chunks of the flat [B*Ho*Wo*Co] index
+            return ((pairs[:, 0, :] + pairs[:, 1, :]).reshape(self.B, Ho, Wo, Co)
                     / 2.0 ** self.options.get('x3h_act_shift', 4)).astype(np.float32)
         return raw.view(np.float32).reshape(self.B, Ho, Wo, Co).copy()
 
