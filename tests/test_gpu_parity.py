@@ -490,6 +490,7 @@ def test_non_default_network_shapes_on_the_matrix_core_kernels(kw):
     """Other [Network] settings than train_template.cfg: narrower / non-128-multiple channel counts (padded N
     tiles), batch norm, a stride-1 layer, non-square and grayscale inputs, ragged batch sizes -- every layer
     output against the fp64 oracle."""
+    import torch
     from augmentedautoencoder_amd.engine import EncoderEngine
     from augmentedautoencoder_amd.weights import EncoderConfig
     cfg = EncoderConfig(kw['shape'], kw['num_filter'], kw['strides'], 5, kw['latent'], kw['batch_norm'])
@@ -507,6 +508,19 @@ def test_non_default_network_shapes_on_the_matrix_core_kernels(kw):
     enc.set_option('precision', 1)
     z3 = enc.encode(x).cpu().numpy()
     assert np.abs(z3 - z64).max() / np.abs(z64).max() < 2e-5
+    # f32x3h with the 256 x 256 tile kernel forced onto every layer it can serve (ragged last M tile: 70*16*16 and
+    # 33*24*40 rows are no multiples of 256; Cout 96 / 160 padded to one N tile): same bits as the 128 x 128 kernel
+    enc.set_option('splitk_min_base_blocks', 0)        # no split-K on these small grids: both kernels then sum in the same order
+    enc.set_option('x3h_wide256_min_blocks', 1)
+    z3w, recs_w = enc.encode_timed(x)
+    a3w = [enc.activation(i).cpu().numpy() for i in range(len(acts))]
+    assert any('x3h_wide256' in l for l, _, _ in recs_w), [l for l, _, _ in recs_w]
+    enc.set_option('x3h_wide256', 0)
+    z3n = enc.encode(x)
+    assert torch.equal(z3w, z3n)
+    for i, a in enumerate(a3w):
+        assert np.array_equal(a, enc.activation(i).cpu().numpy()), 'layer %d' % i
+        assert np.abs(a - acts[i]).max() / np.abs(acts[i]).max() < 2e-5, 'layer %d' % i
     enc.close()
 
 
