@@ -868,6 +868,8 @@ struct ScanPlan {
     bool gemv, stream;
     bool resident_ok;              // query-resident streaming kernel eligible (top-1, no similarity output, stride 1 decided at run time)
     int res_tiles_per_block, res_blocks;
+    bool topk_fused;               // top-k (2..8) inside the query-resident kernel: no [B][N] similarity matrix
+    int cand_chunks;               // candidate lists per query that topk_merge_kernel merges
     size_t ticket_off, q_off, qp_off, pval_off, pidx_off, cs_off, cand_off, total;
 };
 
@@ -909,6 +911,8 @@ static ScanPlan plan_scan(const aae_codebook* cb, int B, int topk) {
         s.res_blocks = ceil_div(ntiles, s.res_tiles_per_block);
         s.resident_ok = s.res_blocks <= s.nblk;          // the partial buffers are sized for nblk row blocks
     }
+    // top-k (2 <= k <= 8) on the query-resident kernel: per-lane sorted lists instead of the [B][N] similarity matrix
+    s.topk_fused = topk >= 2 && topk <= 8 && s.resident_ok;     // (AAE_SCAN_MFMA keeps the similarity-matrix path for A/B)
     size_t off = 0;
     s.ticket_off = off; off += align_up((size_t)aae::kTicketSlotWords * 8, 256);   // block_ticket_arrive words of the single-launch stream scan
     s.q_off = off;    off += align_up((size_t)B * cb->J * sizeof(float), 256);
@@ -916,9 +920,10 @@ static ScanPlan plan_scan(const aae_codebook* cb, int B, int topk) {
     s.pval_off = off; off += align_up((size_t)s.nblk * s.Bstride * sizeof(float), 256);
     s.pidx_off = off; off += align_up((size_t)s.nblk * s.Bstride * sizeof(int), 256);
     s.cs_off = off;
-    if (topk > 1) off += align_up((size_t)B * cb->N * sizeof(float), 256);
+    if (topk > 1 && !s.topk_fused) off += align_up((size_t)B * cb->N * sizeof(float), 256);
     s.cand_off = off;
-    if (topk > 1) off += 2 * align_up((size_t)B * ceil_div(cb->N, aae::kTopKChunk) * topk * sizeof(float), 256);
+    s.cand_chunks = s.topk_fused ? s.res_blocks : ceil_div(cb->N, aae::kTopKChunk);
+    if (topk > 1) off += 2 * align_up((size_t)B * s.cand_chunks * topk * sizeof(float), 256);
     s.total = off;
     return s;
 }
@@ -942,7 +947,22 @@ static void launch_scan_stream_t(const aae::ScanArgs& a, bool upright, int nblk,
     else AAE_LAUNCH((aae::scan_stream_kernel<NQ, false>), dim3(nblk), dim3(256), smem, stream, a);
 }
 
-static int launch_scan_resident(const aae_codebook* cb, const void* qp, int B, const ScanPlan& s, unsigned char* base, hipStream_t stream) {
+template <bool BF16, int K>
+static void launch_scan_resident_t(const aae::ScanResidentArgs& a, dim3 grid, hipStream_t stream) {
+    (void)hipFuncSetAttribute((const void*)aae::scan_resident_kernel<BF16, K>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kScanResidentSmem);
+    AAE_LAUNCH((aae::scan_resident_kernel<BF16, K>), grid, dim3(aae::kScanResidentThreads), aae::kScanResidentSmem, stream, a);
+}
+template <bool BF16>
+static void launch_scan_resident_topk(const aae::ScanResidentArgs& a, dim3 grid, hipStream_t stream) {
+    if (a.k <= 2) launch_scan_resident_t<BF16, 2>(a, grid, stream);            // list slots: the smallest instantiated K >= k
+    else if (a.k <= 4) launch_scan_resident_t<BF16, 4>(a, grid, stream);
+    else if (a.k == 5) launch_scan_resident_t<BF16, 5>(a, grid, stream);
+    else launch_scan_resident_t<BF16, 8>(a, grid, stream);
+}
+
+// topk == 1: block partials (pval, pidx) for argmax_reduce_kernel; topk 2..8: candidate lists for topk_merge_kernel
+static int launch_scan_resident(const aae_codebook* cb, const void* qp, int B, const ScanPlan& s, unsigned char* base, hipStream_t stream,
+                                int topk = 1) {
     aae::ScanResidentArgs a;
     a.E = cb->E; a.e_bytes = (unsigned)((size_t)cb->N * cb->J * (cb->dtype == AAE_DTYPE_BF16 ? 2 : 4));
     a.qp = qp;
@@ -950,12 +970,16 @@ static int launch_scan_resident(const aae_codebook* cb, const void* qp, int B, c
     a.pidx = reinterpret_cast<int*>(base + s.pidx_off);
     a.N = cb->N; a.B = B; a.Bpad = s.Bpad; a.Bstride = s.Bstride; a.tiles_per_block = s.res_tiles_per_block;
     const dim3 grid(s.res_blocks, ceil_div(s.Bpad, aae::kScanResidentQueries));
-    if (cb->dtype == AAE_DTYPE_BF16) {
-        (void)hipFuncSetAttribute((const void*)aae::scan_resident_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kScanResidentSmem);
-        AAE_LAUNCH((aae::scan_resident_kernel<true>), grid, dim3(aae::kScanResidentThreads), aae::kScanResidentSmem, stream, a);
+    if (topk > 1) {
+        a.k = topk;
+        a.cand_v = reinterpret_cast<float*>(base + s.cand_off);
+        a.cand_i = reinterpret_cast<int*>(base + s.cand_off + align_up((size_t)B * s.cand_chunks * topk * sizeof(float), 256));
+        if (cb->dtype == AAE_DTYPE_BF16) launch_scan_resident_topk<true>(a, grid, stream);
+        else launch_scan_resident_topk<false>(a, grid, stream);
+    } else if (cb->dtype == AAE_DTYPE_BF16) {
+        launch_scan_resident_t<true, 0>(a, grid, stream);
     } else {
-        (void)hipFuncSetAttribute((const void*)aae::scan_resident_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kScanResidentSmem);
-        AAE_LAUNCH((aae::scan_resident_kernel<false>), grid, dim3(aae::kScanResidentThreads), aae::kScanResidentSmem, stream, a);
+        launch_scan_resident_t<false, 0>(a, grid, stream);
     }
     AAE_HIP_TRY(hipGetLastError());
     return AAE_OK;
@@ -963,7 +987,7 @@ static int launch_scan_resident(const aae_codebook* cb, const void* qp, int B, c
 
 // *partial_rows: how many [Bstride]-rows of (pval, pidx) the arg-max reduce has to look at
 static int run_scan(aae_codebook* cb, const float* z, int B, int col_stride, float* cs_out, const ScanPlan& s,
-                    unsigned char* base, hipStream_t stream, int* partial_rows = nullptr, const ScanTicketOut* fin = nullptr) {
+                    unsigned char* base, hipStream_t stream, int* partial_rows = nullptr, const ScanTicketOut* fin = nullptr, int topk = 1) {
     float* q = reinterpret_cast<float*>(base + s.q_off);
     float* qp = reinterpret_cast<float*>(base + s.qp_off);
     const bool resident = s.resident_ok && cs_out == nullptr && col_stride == 1;
@@ -1000,7 +1024,7 @@ static int run_scan(aae_codebook* cb, const float* z, int B, int col_stride, flo
         n.z = z; n.qp3 = reinterpret_cast<unsigned short*>(qp); n.B = B; n.J = cb->J; n.Jpad = 128; n.Bpad = s.Bpad;
         AAE_LAUNCH((aae::l2norm_pack_bf16x3_kernel), dim3(ceil_div(s.Bpad, 4)), dim3(256), 0, stream, n);
         AAE_HIP_TRY(hipGetLastError());
-        if (resident) return launch_scan_resident(cb, n.qp3, B, s, base, stream);
+        if (resident) return launch_scan_resident(cb, n.qp3, B, s, base, stream, topk);
         aae::ScanBf16Args a;
         a.E = reinterpret_cast<const unsigned short*>(cb->E);
         a.e_bytes = (unsigned)((size_t)cb->N * cb->J * 2);
@@ -1025,7 +1049,7 @@ static int run_scan(aae_codebook* cb, const float* z, int B, int col_stride, flo
         AAE_LAUNCH((aae::l2norm_pack_kernel), dim3(ceil_div(n.Bpad, 4)), dim3(256), 0, stream, n);
         AAE_HIP_TRY(hipGetLastError());
     }
-    if (resident) return launch_scan_resident(cb, qp, B, s, base, stream);
+    if (resident) return launch_scan_resident(cb, qp, B, s, base, stream, topk);
 
     aae::ScanArgs a;
     a.z = z; a.e_bytes = (unsigned)((size_t)cb->N * cb->J * sizeof(float));
@@ -1461,13 +1485,13 @@ static int nn_impl(aae_codebook* cb, const float* z, int B, int topk, int col_st
     const ScanPlan s = plan_scan(cb, B, topk);          // never larger than the plan of the full codebook
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
     unsigned char* base = static_cast<unsigned char*>(workspace);
-    float* cs = topk > 1 ? reinterpret_cast<float*>(base + s.cs_off) : nullptr;
+    float* cs = (topk > 1 && !s.topk_fused) ? reinterpret_cast<float*>(base + s.cs_off) : nullptr;
     int partial_rows = s.nblk;
     // B <= 4, top-1 on a stream kernel: the last block to arrive merges the block partials -- the query is one launch
     ScanTicketOut fin;
     fin.idx_out = idx_out; fin.score_out = score_out; fin.idx_scale = idx_scale; fin.nonce = prepared_nonce;
     const bool one_launch = topk == 1 && s.stream && cb->scan_ticket != 0;
-    if (int rc = run_scan(cb, z, B, col_stride, cs, s, base, stream, &partial_rows, one_launch ? &fin : nullptr)) return rc;
+    if (int rc = run_scan(cb, z, B, col_stride, cs, s, base, stream, &partial_rows, one_launch ? &fin : nullptr, s.topk_fused ? topk : 1)) return rc;
     if (one_launch) return AAE_OK;
     if (topk == 1) {
         aae::ArgmaxReduceArgs r;
@@ -1479,10 +1503,10 @@ static int nn_impl(aae_codebook* cb, const float* z, int B, int topk, int col_st
     } else {
         aae::TopKArgs t;
         t.cs = cs; t.idx_out = reinterpret_cast<long long*>(idx_out); t.score_out = score_out; t.N = cb->N; t.k = topk;
-        t.chunks = ceil_div(cb->N, aae::kTopKChunk);
+        t.chunks = s.cand_chunks;
         t.cand_v = reinterpret_cast<float*>(base + s.cand_off);
         t.cand_i = reinterpret_cast<int*>(base + s.cand_off + align_up((size_t)B * t.chunks * topk * sizeof(float), 256));
-        AAE_LAUNCH((aae::topk_chunks_kernel), dim3(t.chunks, B), dim3(256), 64, stream, t);
+        if (!s.topk_fused) AAE_LAUNCH((aae::topk_chunks_kernel), dim3(t.chunks, B), dim3(256), 64, stream, t);   // (fused: the scan wrote the lists)
         AAE_LAUNCH((aae::topk_merge_kernel), dim3(B), dim3(256), 64, stream, t);
     }
     AAE_HIP_TRY(hipGetLastError());

@@ -266,5 +266,7 @@ __device__ __forceinline__ long long clock_ticks() { return (long long)__builtin
 
 __device__ __forceinline__ float shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ int shfl_xor(int v, int mask) { return __shfl_xor(v, mask, 64); }
+// true in every lane when the predicate holds in any lane of the wave (wave-uniform: usable as a scalar branch)
+__device__ __forceinline__ bool wave_any(bool pred) { return __builtin_amdgcn_ballot_w64(pred) != 0; }
 
 }  // namespace aae

@@ -28,6 +28,11 @@ struct ScanResidentArgs {
     int* pidx;              // [gridDim.x][Bstride] partial best row
     int N, B, Bpad, Bstride;
     int tiles_per_block;    // row tiles one block walks
+    // top-k form (K > 0): per (row block, query) the block's best k rows in canonical order (score descending, lower
+    // row first on ties), sentinel row 0x7fffffff where a block has fewer -- the candidate lists topk_merge_kernel takes
+    float* cand_v = nullptr;    // [B][gridDim.x][k]
+    int* cand_i = nullptr;
+    int k = 0;
 };
 
 constexpr int kScanResidentThreads = 512;
@@ -35,7 +40,12 @@ constexpr int kScanResidentQueries = 128;                                   // p
 constexpr int kScanResidentTileFloats = 8192;                               // 32 KB
 constexpr int kScanResidentSmem = 2 * kScanResidentTileFloats * 4 + 2 * 2 * kScanResidentQueries * 4;
 
-template <bool BF16>
+// K == 0: arg-max (one partial per row block and query).  K > 0: top-k for k <= K WITHOUT the [B][N] similarity matrix:
+// every lane keeps the K best (score, row) pairs of the rows it sees, sorted; a new score enters in front of the first
+// entry it beats strictly (rows arrive in ascending order per lane, so equal scores keep their row order); the four
+// lists that share a query (two row halves x two lane halves) are merged at the end.  The insertion is ~5 VALU
+// instructions per list slot and candidate, skipped when no lane of the wave has a score above its K-th best.
+template <bool BF16, int K = 0>
 __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(const ScanResidentArgs p) {
     constexpr int kTileRows = BF16 ? 128 : 64;
     constexpr int kMi = BF16 ? 2 : 1;              // 32-row accumulator tiles per wave
@@ -98,6 +108,11 @@ __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(con
 
     float bv = kNegInf;
     int bi = tile0 * kTileRows + rh * 32 * kMi + acc_row(0, lane);
+    constexpr int KL = K > 0 ? K : 1;
+    float tv[KL];
+    int ti[KL];
+#pragma unroll
+    for (int j = 0; j < KL; ++j) { tv[j] = kNegInf; ti[j] = 0x7fffffff; }
     if (tile0 < tile1) fetch(tile0);
     for (int t = tile0; t < tile1; ++t) {
         float* Eb = Et + ((t - tile0) & 1) * kScanResidentTileFloats;
@@ -142,11 +157,62 @@ __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(con
                 for (int r = 0; r < 16; ++r) {
                     const int row = row_base + mi * 32 + acc_row(r, lane);
                     const float v = acc[mi][r];
-                    if ((inside || row < p.N) && v > bv) { bv = v; bi = row; }
+                    if constexpr (K == 0) {
+                        if ((inside || row < p.N) && v > bv) { bv = v; bi = row; }
+                    } else {
+                        const bool enters = (inside || row < p.N) && v > tv[K - 1];
+                        if (wave_any(enters)) {
+                            float cv = enters ? v : kNegInf;
+                            int ci = row;
+                            bool ins = false;
+#pragma unroll
+                            for (int j = 0; j < K; ++j) {          // from the first entry it beats on, everything moves down one slot
+                                ins = ins || cv > tv[j];
+                                const float ov = tv[j];
+                                const int oi = ti[j];
+                                tv[j] = ins ? cv : ov; ti[j] = ins ? ci : oi;
+                                cv = ins ? ov : cv; ci = ins ? oi : ci;
+                            }
+                        }
+                    }
                 }
         }
     }
 
+    if constexpr (K > 0) {
+        // ---- the four sorted lists of a query (row half rh, lane half h) meet in LDS (the tile buffers are free) and
+        // are merged by one thread per query: k rounds over the four list heads, canonical order
+        __syncthreads();
+        float* lv = Et;                                                       // [4 lists][128 queries][K]
+        int* li = reinterpret_cast<int*>(Et + 4 * kScanResidentQueries * K);
+        if (active) {
+            const int at = ((rh * 2 + h) * kScanResidentQueries + qg * 32 + i) * K;
+#pragma unroll
+            for (int j = 0; j < K; ++j) { lv[at + j] = tv[j]; li[at + j] = ti[j]; }
+        }
+        __syncthreads();
+        const int qo = blockIdx.y * kScanResidentQueries + tid;
+        if (tid < kScanResidentQueries && qo < p.B) {
+            int head[4] = {0, 0, 0, 0};
+            const long long obase = ((long long)qo * gridDim.x + blockIdx.x) * p.k;
+            for (int j = 0; j < p.k; ++j) {
+                float wv = kNegInf;
+                int wi = 0x7fffffff, wl = 0;
+#pragma unroll
+                for (int l = 0; l < 4; ++l) {
+                    const int at = (l * kScanResidentQueries + tid) * K + head[l];
+                    const float v = head[l] < K ? lv[at] : kNegInf;
+                    const int ix = head[l] < K ? li[at] : 0x7fffffff;
+                    if (better(v, ix, wv, wi)) { wv = v; wi = ix; wl = l; }
+                }
+#pragma unroll
+                for (int l = 0; l < 4; ++l) head[l] += (l == wl && wi != 0x7fffffff) ? 1 : 0;
+                p.cand_v[obase + j] = wv;
+                p.cand_i[obase + j] = wi;
+            }
+        }
+        return;
+    }
     if (active) {
         const float ov = shfl_xor(bv, 32);
         const int oi = shfl_xor(bi, 32);

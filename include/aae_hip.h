@@ -183,7 +183,9 @@ size_t aae_codebook_workspace_bytes(const aae_codebook* cb, int B, int topk);
  * top-n (:69-71).  col_stride = 1, or num_cyclo for `upright` (:66; only with topk 1).
  * idx_out: device int64 [B, topk]; score_out: device float32 [B, topk] (cosine).
  * Ties resolve to the lowest index (np.argmax); top-k is score-descending,
- * index-ascending among equal scores. */
+ * index-ascending among equal scores.  topk 2..8 with B > 4 is computed inside the scan
+ * (sorted per-lane lists); other top-k requests materialise the [B,N] similarity in the
+ * workspace first -- aae_codebook_workspace_bytes(cb, B, topk) accounts for either. */
 int aae_codebook_nn(aae_codebook* cb, const float* z, int B, int topk, int col_stride,
                     int64_t* idx_out, float* score_out, void* workspace, size_t ws_bytes, void* stream);
 

@@ -247,6 +247,14 @@ inline T shfl_xor(T v, int mask) {
     return out;
 }
 
+inline bool wave_any(bool pred) {
+    int v = pred ? 1 : 0;
+    const aae_emu::lane_slot* all = aae_emu::wave_exchange(&v, 4);
+    int any = 0;
+    for (int l = 0; l < 64; ++l) { int o; memcpy(&o, &all[l][0], 4); any |= o; }
+    return any != 0;
+}
+
 // DPP add tree of device_intrinsics.h::row16_sum, same partner order.
 inline float row16_sum(float v) {
     const int lane = lane_id();

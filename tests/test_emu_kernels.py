@@ -337,6 +337,31 @@ def test_query_resident_scan_equals_the_tile_resident_kernels_bitwise(dtype, N, 
     cb.close()
 
 
+@pytest.mark.parametrize('dtype,N,B', [('f32', 1000, 40), ('f32', 700, 130), ('f32', 520, 5), ('bf16', 1100, 70), ('bf16', 640, 129), ('bf16', 300, 9)])
+def test_topk_inside_the_query_resident_scan_equals_the_similarity_matrix_path(dtype, N, B):
+    """top-k for 2 <= k <= 8 and B > 4 keeps K sorted (score, row) pairs per lane inside scan_resident_kernel<.., K> and merges
+    the per-block lists (topk_merge_kernel) -- no [B][N] similarity matrix.  Canonical order (score descending, lower row
+    first on ties) = what the matrix path (AAE_SCAN_MFMA: similarity + two-level selection) returns, bit for bit, scores
+    included; planted duplicate rows (exact ties inside and across lanes / blocks), queries equal to rows, ragged last tile,
+    partially filled query groups, every list size that is instantiated (K = 2, 4, 5, 8)."""
+    E = synth.make_codebook(N, 128, seed=3, planted_duplicates=min(8, N // 72))
+    E[N // 2 + 1] = E[N // 2] = E[7]                       # a three-way tie across row halves / blocks
+    rng = np.random.default_rng(4)
+    z = rng.standard_normal((B, 128)).astype(np.float32) * rng.uniform(0.1, 20, (B, 1)).astype(np.float32)
+    z[:4] = E[[35, 71, N - 1, 7]] * 2.0
+    cb = eb.EmuCodebook(E, dtype=dtype)
+    cs = cb.similarity(z)
+    for k in (2, 3, 5, 8):
+        cb.set_mode(_lib.AAE_SCAN_AUTO)
+        ik, sk = cb.nn(z, topk=k)
+        assert np.array_equal(ik, ref.topk_canonical(cs, k)), k
+        assert np.array_equal(sk, np.take_along_axis(cs, ik, axis=1)), k
+        cb.set_mode(_lib.AAE_SCAN_MFMA)
+        im, sm = cb.nn(z, topk=k)
+        assert np.array_equal(ik, im) and np.array_equal(sk, sm), k
+    cb.close()
+
+
 @pytest.mark.parametrize('dtype,N,B', [('f32', 36 * 21 + 5, 3), ('f32', 36 * 40, 40), ('bf16', 36 * 30 + 17, 2), ('bf16', 36 * 35, 70)])
 def test_upright_search_on_the_compacted_copy_equals_the_masked_scan(dtype, N, B):
     """col_stride = 36: after aae_codebook_prepare_upright the scan runs over the every-36th-row copy (N/36 rows) and the
