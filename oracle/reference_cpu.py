@@ -281,7 +281,8 @@ def auto_pose6d_geometry(idcs, Rs_all, embed_obj_bbs, predicted_bb, K_test, K_tr
 #   (auto_pose/m3_interface/ae_pose_estimator.py:106-131,157-162)
 # cv2 is not installed here: the resize below restates OpenCV's uint8 INTER_LINEAR
 # (fixed point, 11-bit coefficients: resize.cpp HResizeLinear / VResizeLinear<uchar>) --
-# UNPINNED against a real cv2 build.
+# UNPINNED against a real cv2 build (the sampling convention is cross-checked against torch's float bilinear
+# interpolation in tests/test_pose_estimator.py: within one grey level; the 11-bit rounding stays unpinned).
 # --------------------------------------------------------------------------
 def _cv_linear_coeffs(src, dst, horizontal=True):
     """Per output coordinate: (index of the first tap, short coefficients [a0, a1]).

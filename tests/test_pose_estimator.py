@@ -54,6 +54,25 @@ def test_cv_resize_restatement_properties():
     assert np.abs(half.astype(np.int64) - (box + 2) // 4).max() <= 1
 
 
+@pytest.mark.parametrize('src_hw,dst_wh', [((90, 70), (128, 128)), ((300, 411), (128, 128)), ((37, 53), (64, 48)), ((200, 200), (17, 23))])
+def test_cv_resize_restatement_against_an_independent_float_bilinear(src_hw, dst_wh):
+    """cv2 is not installed, so the fixed-point INTER_LINEAR restatement cannot be pinned to OpenCV itself.  Its sampling
+    convention can be pinned to an independent implementation: torch's bilinear interpolation with align_corners=False
+    samples at the same half-pixel centres with border clamping (no antialiasing), in float arithmetic.  OpenCV's 11-bit
+    coefficients and its two rounding stages move a grey level by at most one against that -- a wrong convention
+    (align_corners, floor instead of half-pixel, an off-by-one tap) shows up as tens of grey levels on this noise image."""
+    import torch
+    import torch.nn.functional as F
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, src_hw + (3,), dtype=np.uint8)
+    got = ref.cv_resize_linear_u8(img, dst_wh).astype(np.int64)
+    t = torch.from_numpy(img).permute(2, 0, 1)[None].to(torch.float64)
+    want = F.interpolate(t, size=(dst_wh[1], dst_wh[0]), mode='bilinear', align_corners=False, antialias=False)[0].permute(1, 2, 0).numpy()
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() <= 1.0 + 1e-9, np.abs(got - want).max()
+    assert np.abs(got - np.rint(want)).mean() < 0.2          # and almost always the same grey level
+
+
 @pytest.mark.parametrize('out_hw', [(128, 128), (16, 24)])
 def test_crop_kernel_bit_exact_on_emulator(out_hw):
     import emu_backend as eb
