@@ -205,6 +205,19 @@ def test_upright_and_topk(default_model):
         assert Rk.shape == (k, 3, 3)
     with pytest.raises(ValueError):
         cb.nearest_rotation(None, crops, top_n=3)
+    # engine level, a batch (B > 4): top-k inside the query-resident scan (no similarity matrix), canonical order, scores = the
+    # similarity entries bit for bit; the matrix path (AAE_SCAN_MFMA) gives the same
+    from augmentedautoencoder_amd import _lib
+    z = enc.engine.encode(crops)
+    cs_dev = cb.engine.similarity(z).cpu().numpy()
+    for k in (3, 5, 8):
+        ik, sk = cb.engine.nn(z, k, 1)
+        ik, sk = ik.cpu().numpy(), sk.cpu().numpy()
+        assert np.array_equal(ik, ref.topk_canonical(cs_dev, k)) and np.array_equal(sk, np.take_along_axis(cs_dev, ik, axis=1))
+        cb.engine.set_scan_mode(_lib.AAE_SCAN_MFMA)
+        im, sm = cb.engine.nn(z, k, 1)
+        cb.engine.set_scan_mode(_lib.AAE_SCAN_AUTO)
+        assert np.array_equal(im.cpu().numpy(), ik) and np.array_equal(sm.cpu().numpy(), sk)
 
 
 def test_test_embedding_and_ops(default_model):
