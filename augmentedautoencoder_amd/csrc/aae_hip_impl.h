@@ -723,7 +723,7 @@ static int launch_dense_gemv(aae_encoder* enc, const Layer& D, const float* x, i
     a.wp_bytes = (unsigned)((unsigned long long)(D.K() / 4) * D.CoutPad * 16ull);
     const int chunks = ceil_div(a.K, aae::kGemvChunk);
     const dim3 grid(chunks, D.CoutPad / 128);
-    const int MQ = B <= 1 ? 1 : (B <= 2 ? 2 : 4);
+    const int MQ = B <= 2 ? B : (B == 3 ? 3 : 4);
     int smem = 2 * MQ * aae::kGemvChunk * (int)sizeof(float);
     const bool ticket = tickets && gemv_uses_ticket(enc, D);
     a.partial_bytes = (unsigned)((size_t)chunks * B * D.Cout * sizeof(float));
@@ -735,6 +735,7 @@ static int launch_dense_gemv(aae_encoder* enc, const Layer& D, const float* x, i
         if (smem < aae::kGemvTicketSmem) smem = aae::kGemvTicketSmem;
         if (MQ == 1) AAE_LAUNCH((aae::dense_gemv_f32_kernel<1, true>), grid, dim3(256), smem, stream, a);
         else if (MQ == 2) AAE_LAUNCH((aae::dense_gemv_f32_kernel<2, true>), grid, dim3(256), smem, stream, a);
+        else if (MQ == 3) AAE_LAUNCH((aae::dense_gemv_f32_kernel<3, true>), grid, dim3(256), smem, stream, a);
         else AAE_LAUNCH((aae::dense_gemv_f32_kernel<4, true>), grid, dim3(256), smem, stream, a);
         snprintf(label, sizeof(label), "dense:dense_gemv_f32_ticket chunks=%d M=%d N=%d K=%d", chunks, B, D.Cout, a.K);
         note_kernel({label, 2.0 * B * (double)D.K() * D.Cout});
@@ -744,6 +745,7 @@ static int launch_dense_gemv(aae_encoder* enc, const Layer& D, const float* x, i
     a.bias = nullptr; a.bn_scale = nullptr; a.bn_shift = nullptr; a.out = nullptr; a.tickets = nullptr; a.nonce = 0; a.relu = 0;
     if (MQ == 1) AAE_LAUNCH((aae::dense_gemv_f32_kernel<1>), grid, dim3(256), smem, stream, a);
     else if (MQ == 2) AAE_LAUNCH((aae::dense_gemv_f32_kernel<2>), grid, dim3(256), smem, stream, a);
+    else if (MQ == 3) AAE_LAUNCH((aae::dense_gemv_f32_kernel<3>), grid, dim3(256), smem, stream, a);
     else AAE_LAUNCH((aae::dense_gemv_f32_kernel<4>), grid, dim3(256), smem, stream, a);
     snprintf(label, sizeof(label), "dense:dense_gemv_f32 chunks=%d M=%d N=%d K=%d", chunks, B, D.Cout, a.K);
     note_kernel({label, 2.0 * B * (double)D.K() * D.Cout});
@@ -1067,6 +1069,7 @@ static int run_scan(aae_codebook* cb, const float* z, int B, int col_stride, flo
     if (s.stream) {
         if (B == 1) launch_scan_stream_t<1>(a, upright, s.nblk, stream);
         else if (B == 2) launch_scan_stream_t<2>(a, upright, s.nblk, stream);
+        else if (B == 3) launch_scan_stream_t<3>(a, upright, s.nblk, stream);
         else launch_scan_stream_t<4>(a, upright, s.nblk, stream);
     } else if (s.gemv) {
         const int smem = 2 * 4 * 4 * (int)sizeof(float);
