@@ -125,7 +125,7 @@ struct aae_encoder {
     int igemm_stagger = 0;                 // kcycles of start delay for every 2nd block generation of the igemm (0 = off)
     // small batches (the reference's one-crop-per-detection usage): wave-split-K igemm with the in-launch ticketed reduce
     int wavek = 1;                         // 0: always the 128 x 128 split-K igemm + reduce launch
-    int wavek_max_tiles = 256;             // used while the layer has at most this many 64 x 64 output tiles (one per CU)
+    int wavek_max_tiles = 512;             // used while the layer has at most this many 64 x 64 output tiles (two rounds of one block per CU; 256 until the tile shape was balanced: B = 5 ... 12 gain 7-9 %)
     int wavek_tiny_max_tiles = 64;         // <= this many 64 x 64 tiles: 32 x 32 wave tiles (four times the tiles: K is split across fewer blocks or none);
                                            // measured: wins up to 64 tiles (B=1: 94 -> 87 us), loses from 128 on (twice the operand loads per MFMA)
     int wavek_target_blocks = 256;         // blocks a split layer is cut into (tiles x K splits): one per CU
@@ -138,6 +138,7 @@ struct aae_encoder {
     long long* wavek_timeline = nullptr;   // device [3 layers][512 blocks][8] phase stamps when option wavek_timeline is on (profiling tools)
     int compact_workspace = 0;             // 1: two alternating activation buffers instead of one per layer (layer outputs are then not inspectable)
     int ticket_prep = 1;                   // conv1 installs the nonces of the later ticketed launches of its forward call (0: every launch installs its own)
+    int wavek_balance = 1;                 // wave-split-K tile shape: prefer a smaller wave tile when the larger one leaves CUs idle in its last round of blocks (plan_wavek)
     int wavek_ablate = 0;                  // timing experiments (conv_wavek_f32.h ConvWaveKArgs::ablate); results are wrong when != 0
     int gemv_ticket = 1;                   // dense GEMV (B <= 4): chunk sums finished by the last block instead of a reduce launch
     int wavek_dense = 1;                   // dense layer (B > 4) on the wave-split-K kernel instead of split-K igemm + reduce launch
@@ -323,6 +324,21 @@ static WaveKPlan plan_wavek(const aae_encoder* enc, const Layer& L, long long M)
     w.NT = tiles22 <= enc->wavek_narrow_max_tiles ? 1 : 2;
     w.MT = (tiles22 <= enc->wavek_tiny_max_tiles && w.waves == 4) ? 1 : 2;       // 32 x 32 wave tiles (NT = 1 then: the narrow threshold is the larger one)
     if (w.MT == 1) w.NT = 1;
+    // Balance: when the chosen tile shape needs no K split but leaves CUs idle in its last round of blocks (192 blocks of 64 x 64 on
+    // 256 CUs: B = 3 conv2), a smaller wave tile can win although it moves more operand bytes per MFMA.  Blocks that share a CU share
+    // its matrix pipe, so a layer costs about  ceil(tiles / CUs) * (MT * NT) / efficiency  -- efficiencies from the per-layer A/B
+    // runs at B = 2 ... 4 (profiles/r09_small): 64 x 64 1.0, 64 x 32 0.97, 32 x 32 0.88.  (Layers that split K are left alone: there
+    // the hand-off cost decides, and the thresholds above were set by measuring it.)
+    if (enc->wavek_balance && w.waves == 4 && w.MT * w.NT > 1) {
+        const int cus = enc->wavek_target_blocks;
+        auto tiles_of = [&](int mt, int nt) { return ((M + 32 * mt - 1) / (32 * mt)) * (long long)(L.CoutPad / (32 * nt)); };
+        auto cost_of = [&](int mt, int nt, double eff) { return (double)((tiles_of(mt, nt) + cus - 1) / cus) * (mt * nt) / eff; };
+        if (tiles_of(w.MT, w.NT) >= cus / 2) {                    // (fewer tiles than that: the layer splits K)
+            double best = cost_of(w.MT, w.NT, w.NT == 2 ? 1.0 : 0.97);
+            if (w.NT == 2 && cost_of(2, 1, 0.97) < 0.97 * best) { best = cost_of(2, 1, 0.97); w.NT = 1; }
+            if (cost_of(1, 1, 0.88) < 0.97 * best) { w.MT = 1; w.NT = 1; }
+        }
+    }
     w.num_mt = (int)((M + 32 * w.MT - 1) / (32 * w.MT));
     w.num_nt = L.CoutPad / (32 * w.NT);
     const int tiles = w.num_mt * w.num_nt;
@@ -1243,6 +1259,7 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
     else if (!strcmp(name, "wavek")) enc->wavek = value ? 1 : 0;
     else if (!strcmp(name, "wavek_dense")) enc->wavek_dense = value ? 1 : 0;
     else if (!strcmp(name, "wavek_ablate")) enc->wavek_ablate = value;
+    else if (!strcmp(name, "wavek_balance")) enc->wavek_balance = value ? 1 : 0;
     else if (!strcmp(name, "ticket_prep")) enc->ticket_prep = value ? 1 : 0;
     else if (!strcmp(name, "compact_workspace")) enc->compact_workspace = value ? 1 : 0;
     else if (!strcmp(name, "wavek_timeline")) {

@@ -112,12 +112,13 @@ void aae_encoder_destroy(aae_encoder* enc);
  *   "first_vec4" (1): stage uint8 rows of conv1 as aligned dwords when W*C % 4 == 0;
  *   "reduce_small" (1): split-K sums of <= 8 splits over >= 16k outputs by the barrier-free float4 kernel;
  *   small batches (the reference's one crop per detection):
- *   "wavek" (1): layers with at most "wavek_max_tiles" (256) output tiles of 64x64 run the wave-split-K implicit GEMM
+ *   "wavek" (1): layers with at most "wavek_max_tiles" (512) output tiles of 64x64 run the wave-split-K implicit GEMM
  *                        (operands straight into MFMA fragments, K split over the waves of a block and over blocks, the
  *                        cross-block sum finished inside the launch by the last block to arrive); "wavek_dense" (1): the
  *                        dense layer too (every B > 4); wave tile 32x32 up to "wavek_tiny_max_tiles" (64) tiles, 64x32 up to
  *                        "wavek_narrow_max_tiles" (128), 64x64 above; "wavek_waves" (4 | 8), "wavek_depth" (2 | 3 slabs in
- *                        flight), "wavek_target_blocks" (256) -- defaults set from per-layer rocprofv3 sweeps;
+ *                        flight), "wavek_target_blocks" (256), "wavek_balance" (1: a smaller wave tile when the larger one would leave CUs idle
+ *                        in its last round of blocks) -- defaults set from per-layer rocprofv3 sweeps;
  *   "gemv_ticket" (1): dense GEMV (B <= 4) adds its chunk rows in the same launch; "ticket_prep" (1): the first kernel of a
  *                        forward installs the ticket nonces of the later launches; "first_group_split_max_tiles" (128): conv1
  *                        runs one block per 32-pixel group for batches of at most that many 128-pixel tiles;
