@@ -527,7 +527,8 @@ static int launch_wavek(aae_encoder* enc, const Layer& L, const WaveKPlan& w, co
     a.partial = partial; a.partial_bytes = (unsigned)w.partial_bytes; a.tickets = tickets; a.nonce = nonce;
     a.H = L.H; a.W = L.W; a.Cin = L.Cin; a.Ho = L.Ho; a.Wo = L.Wo; a.Cout = L.Cout; a.CoutPad = L.CoutPad;
     a.KS = L.KS; a.S = L.S; a.pt = L.pt; a.pl = L.pl; a.M = M; a.relu = L.relu; a.ablate = enc->wavek_ablate;
-    a.timeline = (enc->wavek_timeline && tag >= 1 && tag <= 3) ? enc->wavek_timeline + (size_t)(tag - 1) * 512 * 8 : nullptr;
+    a.timeline = (enc->wavek_timeline && tag >= 1 && tag <= 3 && w.num_mt * w.num_nt * w.gsplits <= 512)       // (the debug buffer holds 512 blocks per layer)
+                     ? enc->wavek_timeline + (size_t)(tag - 1) * 512 * 8 : nullptr;
     a.x_bytes = (unsigned)((unsigned long long)(M / (L.Ho * L.Wo)) * L.H * L.W * L.Cin * sizeof(float));
     a.slabs_total = (int)(L.K() / 32);
     a.wp_bytes = (unsigned)((unsigned long long)a.slabs_total * 8ull * L.CoutPad * 16ull);
