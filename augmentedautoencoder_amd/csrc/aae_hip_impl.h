@@ -330,7 +330,7 @@ static WaveKPlan plan_wavek(const aae_encoder* enc, const Layer& L, long long M)
     // runs at B = 2 ... 4 (profiles/r09_small): 64 x 64 1.0, 64 x 32 0.97, 32 x 32 0.88.  (Layers that split K are left alone: there
     // the hand-off cost decides, and the thresholds above were set by measuring it.)
     if (enc->wavek_balance && w.waves == 4 && w.MT * w.NT > 1) {
-        const int cus = enc->wavek_target_blocks;
+        const int cus = enc->wavek_target_blocks > 0 ? enc->wavek_target_blocks : 1;
         auto tiles_of = [&](int mt, int nt) { return ((M + 32 * mt - 1) / (32 * mt)) * (long long)(L.CoutPad / (32 * nt)); };
         auto cost_of = [&](int mt, int nt, double eff) { return (double)((tiles_of(mt, nt) + cus - 1) / cus) * (mt * nt) / eff; };
         if (tiles_of(w.MT, w.NT) >= cus / 2) {                    // (fewer tiles than that: the layer splits K)
