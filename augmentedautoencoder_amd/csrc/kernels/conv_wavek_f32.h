@@ -79,7 +79,7 @@ constexpr int conv_wavek_smem() { return WAVES * MT * NT * 16 * 64 * 4 + 16; }
 // 257 ... 512-tile layer overlaps the first: conv2 at B = 7 / 8 118.6 / 120.6 -> 112.9 / 114.6 us; the smaller tiles lose 8 % under the
 // same bound and keep the whole register file)
 template <int MT, int NT, int WAVES, int DEPTH, int TAG = 0>
-__global__ __launch_bounds__(64 * WAVES, (MT * NT == 4 ? 2 : 1)) void conv_wavek_f32_kernel(const ConvWaveKArgs p) {
+__global__ __launch_bounds__(64 * WAVES, (MT * NT == 4 && WAVES == 4 && DEPTH == 2 ? 2 : 1)) void conv_wavek_f32_kernel(const ConvWaveKArgs p) {
     constexpr int COMBOS = MT * NT * 16;                       // accumulator registers per lane
     static_assert(COMBOS % WAVES == 0, "the cross-wave sum gives every wave COMBOS / WAVES register rows");
     AAE_DYN_SMEM(smem_raw);
