@@ -25,7 +25,7 @@ EXPORTED_SYMBOLS = (
     'aae_abi_version', 'aae_last_error',
     'aae_encoder_create', 'aae_encoder_destroy', 'aae_encoder_set_option', 'aae_encoder_workspace_bytes', 'aae_encoder_forward',
     'aae_encoder_forward_timed', 'aae_encoder_kernel_label', 'aae_encoder_kernel_flops',
-    'aae_encoder_activation_info', 'aae_encoder_debug_timeline', 'aae_encoder_x3h_saturated',
+    'aae_encoder_activation_info', 'aae_encoder_debug_timeline', 'aae_encoder_x3h_saturated', 'aae_encoder_split_precision_for_batch',
     'aae_codebook_create', 'aae_codebook_update', 'aae_codebook_destroy', 'aae_codebook_set_scan_mode',
     'aae_codebook_prepare_upright',
     'aae_codebook_workspace_bytes', 'aae_codebook_nn', 'aae_encode_nn', 'aae_codebook_similarity', 'aae_l2_normalize',
@@ -85,6 +85,8 @@ def declare(lib):
     lib.aae_encoder_kernel_label.argtypes = [c_void_p, c_int]
     lib.aae_encoder_kernel_flops.restype = c_double
     lib.aae_encoder_kernel_flops.argtypes = [c_void_p, c_int]
+    lib.aae_encoder_split_precision_for_batch.restype = c_int
+    lib.aae_encoder_split_precision_for_batch.argtypes = [c_void_p, c_int]
     lib.aae_encoder_x3h_saturated.restype = c_int
     lib.aae_encoder_x3h_saturated.argtypes = [c_void_p, POINTER(c_int), c_void_p]
     lib.aae_encoder_debug_timeline.restype = c_int

@@ -120,6 +120,7 @@ struct aae_encoder {
     int x3h_wide_min_blocks = 0;           // > 0: f32x3h conv layers use 256x128 tiles (8 waves) when that still yields this many blocks; measured neutral (+-1.5 %), off by default
     int x3h_wide256 = 1;                   // f32x3h conv layers with Cout % 256 == 0: 256 x 256 tiles, 8 waves of 64 x 128 ...
     int x3h_wide256_min_blocks = 256;      // ... when that still gives every CU a block
+    int x3h_min_tiles = 256;               // precision 2: f32x3h only for batches whose first igemm layer has at least this many 64 x 64 tiles
     int x3h_dma = 1;                       // f32x3h operand slabs by LDS-DMA (buffer_load ... lds); 0 = register-staged variant
     int x3h_act_shift = 4;                 // activations travel as halves of x*2^shift in f32x3h mode (|x| < 4094 exact range)
     int igemm_stagger = 0;                 // kcycles of start delay for every 2nd block generation of the igemm (0 = off)
@@ -311,9 +312,21 @@ struct WaveKPlan {
     size_t partial_bytes = 0;
 };
 
-static WaveKPlan plan_wavek(const aae_encoder* enc, const Layer& L, long long M) {
+// Does a forward of batch B run in f32x3h?  precision 1: always.  precision 2 ("where it is faster"): only when the first
+// implicit-GEMM layer has at least x3h_min_tiles 64 x 64 output tiles -- below that the layers do not fill the chip, the
+// exact-fp32 wave-split-K path with its in-launch reductions is the faster one (B = 1: 82 us against 156 us for the
+// split-precision split-K igemm + reduce launches; break-even at B = 4 of the default net) and it is at least as accurate.
+static bool runs_split(const aae_encoder* enc, int B) {
+    if (enc->precision == 1) return true;
+    if (enc->precision != 2 || enc->layers.size() < 2) return false;
+    const Layer& L = enc->layers[1];
+    const long long M = (long long)B * L.Ho * L.Wo;
+    return ((M + 63) / 64) * (L.CoutPad / 64) >= enc->x3h_min_tiles;
+}
+
+static WaveKPlan plan_wavek(const aae_encoder* enc, const Layer& L, long long M, bool split) {
     WaveKPlan w;
-    if (!enc->wavek || enc->precision != 0 || L.kind != KIND_IGEMM) return w;
+    if (!enc->wavek || split || L.kind != KIND_IGEMM) return w;
     const long long tiles22 = ((M + 63) / 64) * (L.CoutPad / 64);
     if (tiles22 > enc->wavek_max_tiles || tiles22 > 512) return w;
     const unsigned long long x_bytes = (unsigned long long)(M / (L.Ho * L.Wo)) * L.H * L.W * L.Cin * sizeof(float);
@@ -366,7 +379,7 @@ static Workspace plan_workspace(const aae_encoder* enc, int B) {
     size_t partial = 0;
     auto need_partial = [&](const Layer& L, int M) {
         if (L.kind != KIND_IGEMM) return;
-        const WaveKPlan wk = plan_wavek(enc, L, M);
+        const WaveKPlan wk = plan_wavek(enc, L, M, runs_split(enc, B));
         if (wk.use) {
             if (wk.partial_bytes > partial) partial = wk.partial_bytes;
             return;
@@ -807,7 +820,7 @@ static int forward_impl(aae_encoder* enc, const void* x, int x_dtype, int B, flo
 
     const void* cur = x;
     bool cur_u8 = (x_dtype == AAE_DTYPE_U8);
-    if (enc->precision == 1) {
+    if (runs_split(enc, B)) {
         // f32x3h: conv1 (fp32 MFMA, K = 75) emits fp16 hi/lo planes, every later layer runs the
         // split-precision igemm on planes; only the latent z comes back as fp32.
         for (size_t li = 0; li < enc->layers.size(); ++li) {
@@ -832,11 +845,11 @@ static int forward_impl(aae_encoder* enc, const void* x, int x_dtype, int B, flo
     for (size_t li = 0; li < nl; ++li) {
         const Layer& L = enc->layers[li];
         const bool first_mfma = li == 0 && L.kind == KIND_FIRST_MFMA;
-        if (!first_mfma && L.kind == KIND_IGEMM && !(li == 0 && cur_u8)) plans[li] = plan_wavek(enc, L, (long long)B * L.Ho * L.Wo);
+        if (!first_mfma && L.kind == KIND_IGEMM && !(li == 0 && cur_u8)) plans[li] = plan_wavek(enc, L, (long long)B * L.Ho * L.Wo, false);
     }
     const bool dense_gemv = D.kind == KIND_IGEMM && B <= 4 && enc->dense_gemv && D.K() % aae::kGemvChunk == 0;
     const bool gemv_ticket = dense_gemv && gemv_uses_ticket(enc, D);
-    if (!dense_gemv && D.kind == KIND_IGEMM && enc->wavek_dense) plans[nl] = plan_wavek(enc, D, B);
+    if (!dense_gemv && D.kind == KIND_IGEMM && enc->wavek_dense) plans[nl] = plan_wavek(enc, D, B, false);
     aae::TicketPrep prep;
     prep.n = 0;
     auto add_prep = [&](unsigned long long* words, int count, unsigned nonce) {
@@ -1251,6 +1264,7 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
     else if (!strcmp(name, "igemm_stagger")) enc->igemm_stagger = value;
     else if (!strcmp(name, "x3h_dma")) enc->x3h_dma = value ? 1 : 0;
     else if (!strcmp(name, "x3h_wide256")) enc->x3h_wide256 = value ? 1 : 0;
+    else if (!strcmp(name, "x3h_min_tiles")) enc->x3h_min_tiles = value < 0 ? 0 : value;
     else if (!strcmp(name, "x3h_wide256_min_blocks")) enc->x3h_wide256_min_blocks = value < 1 ? 1 : value;
     else if (!strcmp(name, "x3h_wide_min_blocks")) enc->x3h_wide_min_blocks = value < 0 ? 0 : value;
     else if (!strcmp(name, "igemm_dma")) enc->igemm_dma = value ? 1 : 0;
@@ -1294,8 +1308,8 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
         if (value < -8 || value > 12) return fail(AAE_ERR_INVALID, "x3h_act_shift %d outside [-8, 12]", value);
         enc->x3h_act_shift = value;
     } else if (!strcmp(name, "precision")) {
-        if (value != 0 && value != 1) return fail(AAE_ERR_INVALID, "precision %d: 0 = fp32, 1 = f32x3h", value);
-        if (value == 1) {
+        if (value < 0 || value > 2) return fail(AAE_ERR_INVALID, "precision %d: 0 = fp32, 1 = f32x3h, 2 = f32x3h where it is faster", value);
+        if (value != 0) {
             bool ok = enc->layers[0].kind == KIND_FIRST_MFMA && enc->dense.kind == KIND_IGEMM;
             for (size_t i = 1; i < enc->layers.size(); ++i) ok = ok && enc->layers[i].kind == KIND_IGEMM;
             if (!ok) return fail(AAE_ERR_UNSUPPORTED, "f32x3h needs the matrix-core kernels on every layer (first layer 5x5 with C in {1,3}, later Cin %% 32 == 0)");
@@ -1372,6 +1386,8 @@ int aae_encoder_debug_timeline(aae_encoder* enc, long long* host_out) {
     AAE_HIP_TRY(hipMemcpy(host_out, enc->wavek_timeline, 3 * 512 * 8 * sizeof(long long), hipMemcpyDeviceToHost));
     return AAE_OK;
 }
+
+int aae_encoder_split_precision_for_batch(const aae_encoder* enc, int B) { return (enc && B >= 1 && aae_host::runs_split(enc, B)) ? 1 : 0; }
 
 int aae_encoder_activation_info(const aae_encoder* enc, int B, int layer, size_t* offset_bytes, size_t* count) {
     using namespace aae_host;

@@ -88,7 +88,8 @@ class EncoderEngine(object):
     def set_option(self, name, value):
         """Launch-planning / precision knobs of aae_encoder_set_option, e.g.
         ('precision', 1) selects the f32x3h split-precision matrix-core path
-        (fp32 in/out, 3 fp16 MFMAs per product, fp32 accumulate); default 0 = exact fp32."""
+        (fp32 in/out, 3 fp16 MFMAs per product, fp32 accumulate); ('precision', 2) uses it only for batches it is faster on
+        (B >= 4 of the default net; per-detection batches stay on the exact fp32 wave-split-K path); default 0 = exact fp32."""
         _lib.check(self.lib, self.lib.aae_encoder_set_option(self.handle, name.encode(), int(value)), 'aae_encoder_set_option')
         self.options[name] = int(value)
 
@@ -119,7 +120,8 @@ class EncoderEngine(object):
     def _x3h_left_its_range(self):
         """True when the f32x3h forwards queued so far met an activation the fp16 pairs cannot carry (waits for the stream)."""
         torch = _torch()
-        if self.options.get('precision', 0) != 1 or not self.x3h_fallback or torch.cuda.is_current_stream_capturing():
+        if (self.options.get('precision', 0) not in (1, 2) or not self.x3h_fallback or torch.cuda.is_current_stream_capturing()
+                or not self.lib.aae_encoder_split_precision_for_batch(self.handle, int(self._last_B or 1))):
             return False
         flag = ctypes.c_int(0)
         with torch.cuda.device(self.device):
@@ -148,11 +150,12 @@ class EncoderEngine(object):
                                                   _stream_ptr(torch))
                 _lib.check(self.lib, rc, 'aae_encoder_forward')
                 if self._x3h_left_its_range():          # documented failure mode of the split-precision mode: redo in fp32
+                    mode = self.options.get('precision', 0)
                     self.set_option('precision', 0)
                     try:
                         self._forward_chunk(t, z_out)
                     finally:
-                        self.set_option('precision', 1)
+                        self.set_option('precision', mode)
                 return None
             ms = (ctypes.c_float * 32)()
             n = ctypes.c_int(0)
@@ -204,12 +207,13 @@ class EncoderEngine(object):
                                             ctypes.c_void_p(ws_c), nb_c, _stream_ptr(torch))
             _lib.check(self.lib, rc, 'aae_encode_nn')
             if self._x3h_left_its_range():
+                mode = self.options.get('precision', 0)
                 self.set_option('precision', 0)
                 try:
                     za, ia, sa = self.encode_nn(cb, t[a:e], col_stride)
                     z[a:e], idx[a:e], score[a:e] = za, ia, sa
                 finally:
-                    self.set_option('precision', 1)
+                    self.set_option('precision', mode)
         return z, idx, score
 
     def encode_timed(self, x):
@@ -231,7 +235,7 @@ class EncoderEngine(object):
         start = ws_ptr - buf.data_ptr() + off.value
         _, _, _, Ho, Wo, Co = self.cfg.layer_shapes()[layer]
         raw = buf[start:start + 4 * cnt.value]
-        if self.options.get('precision', 0) == 1:
+        if self.lib.aae_encoder_split_precision_for_batch(self.handle, int(self._last_B)):
             # f32x3h keeps activations as fp16 (hi, lo) pairs of value * 2^shift: [pixel][32-channel chunk][hi x 32 | lo x 32]
             pairs = raw.view(torch.float16).reshape(-1, 2, 32).to(torch.float64)      # chunks of the flat [B*Ho*Wo*Co] index
             return ((pairs[:, 0, :] + pairs[:, 1, :]).reshape(self._last_B, Ho, Wo, Co)

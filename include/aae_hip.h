@@ -87,6 +87,9 @@ void aae_encoder_destroy(aae_encoder* enc);
  *                        fp16 MFMAs on (hi, lo) operand pairs with fp32 accumulation (>= 22-bit
  *                        operands).  Explicit opt-in; same parity tolerances; activations then
  *                        live in the workspace as fp16 (hi, lo) pairs of x * 2^x3h_act_shift, interleaved per 32-channel chunk.
+ *                    2 = f32x3h where it is faster: batches whose first implicit-GEMM layer has at least
+ *                        "x3h_min_tiles" (256) 64x64 output tiles (B >= 4 of the default net) run as 1, smaller ones
+ *                        as 0 -- per-detection batches are faster AND exact on the fp32 wave-split-K path.
  *   "x3h_act_shift" (4): power-of-two activation pre-scale of the f32x3h format (|x| < 4094
  *                        keeps full accuracy; larger values saturate gracefully up to 2x).
  *   "splitk_min_base_blocks" (384): split the K loop of a layer only if its un-split grid
@@ -153,6 +156,10 @@ double aae_encoder_kernel_flops(const aae_encoder* enc, int i);
  * returns the flag and clears it.  1 = the latents of the forwards since the last call may be inaccurate: recompute them
  * with "precision" = 0 (the Python mirror does that automatically).  Exact fp32 mode never sets the flag. */
 int aae_encoder_x3h_saturated(aae_encoder* enc, int* flag_out, void* stream);
+
+/* 1 when a forward of batch B on this handle runs in f32x3h (precision 1, or precision 2 and a large enough batch):
+ * the layer outputs in the workspace are then fp16 (hi, lo) pairs instead of fp32 (aae_encoder_activation_info). */
+int aae_encoder_split_precision_for_batch(const aae_encoder* enc, int B);
 
 /* Profiling aid (tools/ablate_wavek.py): with option "wavek_timeline" = 1 wave 0 of every block of the small-batch
  * igemm stamps the shader clock at 8 phase boundaries; this copies the [3 layers][512 blocks][8] stamps of the most

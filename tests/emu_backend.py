@@ -79,7 +79,7 @@ class EmuEncoder(object):
         _lib.check(self.L, self.L.aae_encoder_activation_info(self.h, self.B, layer, ctypes.byref(off), ctypes.byref(cnt)), 'info')
         H, W, Ci, Ho, Wo, Co = self.cfg.layer_shapes()[layer]
         raw = self.ws[off.value:off.value + 4 * cnt.value]
-        if self.options.get('precision', 0) == 1:      # f32x3h: fp16 (hi, lo) pairs of value * 2^shift, [pixel][chunk][hi x 32 | lo x 32]
+        if self.L.aae_encoder_split_precision_for_batch(self.h, int(self.B)):      # f32x3h: fp16 (hi, lo) pairs of value * 2^shift, [pixel][chunk][hi x 32 | lo x 32]
             pairs = raw.view(np.float16).reshape(-1, 2, 32).astype(np.float64)          # chunks of the flat [B*Ho*Wo*Co] index
             return ((pairs[:, 0, :] + pairs[:, 1, :]).reshape(self.B, Ho, Wo, Co)
                     / 2.0 ** self.options.get('x3h_act_shift', 4)).astype(np.float32)

@@ -534,6 +534,30 @@ def test_f32x3h_range_flag_on_the_emulated_kernels():
             enc.close()
 
 
+def test_precision_2_uses_split_precision_only_for_batches_that_fill_the_chip():
+    """Encoder option precision = 2: f32x3h where it is faster.  A batch whose first implicit-GEMM layer has fewer than
+    x3h_min_tiles 64 x 64 output tiles runs the exact fp32 path (bit-identical to precision 0, layer outputs are fp32), a
+    larger one runs f32x3h (bit-identical to precision 1, layer outputs are (hi, lo) pairs); the C ABI tells which."""
+    cfg = EncoderConfig((32, 32, 3), [32, 64], [2, 2], 5, 128)
+    w = synth.make_weights(seed=61, shape=cfg.shape, num_filter=cfg.num_filter, strides=cfg.strides, latent=128)
+    enc = eb.EmuEncoder(w, cfg)
+    enc.set_option('x3h_min_tiles', 8)                       # conv2: 64 output pixels per crop x 128 padded channels = two 64 x 64 tiles per crop
+    want = {}
+    for B in (2, 6):
+        x = synth.make_crops(B, seed=62 + B, shape=cfg.shape)
+        for prec in (0, 1):
+            enc.set_option('precision', prec)
+            want[B, prec] = (enc.forward(x), enc.activation(0), enc.activation(1))
+        enc.set_option('precision', 2)
+        split = enc.L.aae_encoder_split_precision_for_batch(enc.h, B)
+        assert split == (1 if B >= 4 else 0)
+        got = (enc.forward(x), enc.activation(0), enc.activation(1))
+        for g, wv in zip(got, want[B, split]):
+            assert np.array_equal(g, wv), (B, split)
+    assert not np.array_equal(want[6, 0][0], want[6, 1][0])  # (the two modes do differ in the last bits)
+    enc.close()
+
+
 @pytest.mark.parametrize('shape,B,filters,bn', [((32, 32, 3), 5, [32, 256], False), ((24, 16, 3), 7, [64, 512], True)])
 def test_f32x3h_256x256_tile_kernel_is_bit_identical(shape, B, filters, bn):
     """conv_igemm_x3h_wide_kernel: 256 x 256 block tiles, 8 waves of 64 x 128, B fragments refreshed in place, A fragments

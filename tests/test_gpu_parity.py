@@ -395,6 +395,20 @@ def test_split_precision_f32x3h_mode_meets_the_same_tolerances(dma):
     enc.set_option('precision', 0)
     z_f32 = enc.encode(crops).cpu().numpy()
     assert np.abs(z_a - z_f32).max() / np.abs(z_f32).max() < 1e-5
+    if dma:
+        import torch
+        # precision 2 = f32x3h where it is faster: per-detection batches take the exact fp32 wave-split-K path (same bits as
+        # precision 0, fp32 layer outputs), B >= 4 of this net runs f32x3h (same bits as precision 1)
+        for B, split in ((1, 0), (3, 0), (4, 1), (8, 1)):
+            xb = synth.make_crops(B, seed=900 + B)
+            enc.set_option('precision', split)
+            zw, aw = enc.encode(xb).clone(), enc.activation(1).clone()
+            enc.set_option('precision', 2)
+            assert enc.lib.aae_encoder_split_precision_for_batch(enc.handle, B) == split
+            zg, labels = enc.encode_timed(xb)
+            assert torch.equal(zg, zw) and torch.equal(enc.activation(1), aw), (B, [l for l, _, _ in labels])
+            assert any('x3h' in l for l, _, _ in labels) == bool(split)
+        enc.set_option('precision', 0)
     enc.close()
 
 
