@@ -116,7 +116,7 @@ __global__ __launch_bounds__(256) void dense_gemv_f32_kernel(const DenseGemvArgs
             }
             *reinterpret_cast<f32x4*>(gsum + group * 128 + (tid & 31) * 4) = s;
             __syncthreads();
-            if (tid < 128 && blockIdx.y * 128 + tid < p.Cout) {
+            if (tid < 128 && (int)(blockIdx.y * 128 + tid) < p.Cout) {
                 const int nn = blockIdx.y * 128 + tid;
                 float v = gsum[tid];
 #pragma unroll
