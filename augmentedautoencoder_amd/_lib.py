@@ -25,11 +25,12 @@ EXPORTED_SYMBOLS = (
     'aae_abi_version', 'aae_last_error',
     'aae_encoder_create', 'aae_encoder_destroy', 'aae_encoder_set_option', 'aae_encoder_workspace_bytes', 'aae_encoder_forward',
     'aae_encoder_forward_timed', 'aae_encoder_kernel_label', 'aae_encoder_kernel_flops',
-    'aae_encoder_activation_info', 'aae_encoder_debug_timeline', 'aae_encoder_x3h_saturated', 'aae_encoder_split_precision_for_batch',
+    'aae_encoder_activation_info', 'aae_encoder_debug_timeline', 'aae_encoder_x3h_saturated', 'aae_encoder_x3h_last_slot', 'aae_encoder_x3h_poll',
+    'aae_encoder_split_precision_for_batch',
     'aae_codebook_create', 'aae_codebook_update', 'aae_codebook_destroy', 'aae_codebook_set_scan_mode',
     'aae_codebook_prepare_upright',
     'aae_codebook_workspace_bytes', 'aae_codebook_nn', 'aae_encode_nn', 'aae_codebook_similarity', 'aae_l2_normalize',
-    'aae_crop_resize_u8', 'aae_pack_pairs',
+    'aae_crop_resize_u8', 'aae_pack_pairs', 'aae_unpack_pairs',
     'aae_decoder_create', 'aae_decoder_destroy', 'aae_decoder_workspace_bytes', 'aae_decoder_forward',
     'aae_decoder_forward_timed', 'aae_decoder_kernel_label', 'aae_decoder_kernel_flops', 'aae_decoder_activation_info',
 )
@@ -89,6 +90,10 @@ def declare(lib):
     lib.aae_encoder_split_precision_for_batch.argtypes = [c_void_p, c_int]
     lib.aae_encoder_x3h_saturated.restype = c_int
     lib.aae_encoder_x3h_saturated.argtypes = [c_void_p, POINTER(c_int), c_void_p]
+    lib.aae_encoder_x3h_last_slot.restype = c_int
+    lib.aae_encoder_x3h_last_slot.argtypes = []
+    lib.aae_encoder_x3h_poll.restype = c_int
+    lib.aae_encoder_x3h_poll.argtypes = [c_void_p, POINTER(c_int), c_int, POINTER(c_int), c_void_p]
     lib.aae_encoder_debug_timeline.restype = c_int
     lib.aae_encoder_debug_timeline.argtypes = [c_void_p, POINTER(c_int64)]
     lib.aae_encoder_activation_info.restype = c_int
@@ -108,6 +113,8 @@ def declare(lib):
     lib.aae_codebook_workspace_bytes.argtypes = [c_void_p, c_int, c_int]
     lib.aae_pack_pairs.restype = c_int
     lib.aae_pack_pairs.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]
+    lib.aae_unpack_pairs.restype = c_int
+    lib.aae_unpack_pairs.argtypes = [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]
     lib.aae_encode_nn.restype = c_int
     lib.aae_encode_nn.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t,
                                   c_void_p, c_size_t, c_void_p]

@@ -129,14 +129,24 @@ class Codebook(object):
         return x
 
     def _encode(self, x):
-        return self._encoder.engine.encode(self._prep(x))
+        """Encoder.z on the device, range-checked: in split-precision mode the flags of the forward are read here (the
+        callers below derive further device results from z), in exact fp32 -- the default -- settle() is a no-op."""
+        return self._encoder.engine.encode_checked(self._prep(x))
+
+    def _encode_nn_host(self, x, stride):
+        """fused encoder + top-1 scan -> indices on the host; the range flag rides along with the result copy"""
+        eng = self._encoder.engine
+        _, idx, _ = eng.encode_nn(self.engine, self._prep(x), stride)
+        idcs = idx[:, 0].cpu().numpy()
+        if eng.settle():                      # (split precision, out of range: recomputed in exact fp32, in place)
+            idcs = idx[:, 0].cpu().numpy()
+        return idcs
 
     def _run_similarity(self, feed):
         return self.engine.similarity(self._encode(self._encoder._feed(feed))).cpu().numpy()
 
     def _run_argmax(self, feed):
-        _, idx, _ = self._encoder.engine.encode_nn(self.engine, self._prep(self._encoder._feed(feed)), 1)
-        return idx[:, 0].cpu().numpy()
+        return self._encode_nn_host(self._encoder._feed(feed), 1)
 
     def _run_query(self, feed, normalized):
         z = self._encode(self._encoder._feed(feed))
@@ -150,8 +160,7 @@ class Codebook(object):
         if top_n == 1:
             # encoder + scan in one C call (aae_encode_nn): per detection that is six launches
             stride = int(self._dataset._kw['num_cyclo']) if upright else 1
-            _, idx, _ = self._encoder.engine.encode_nn(self.engine, self._prep(x), stride)
-            idcs = idx[:, 0].cpu().numpy()
+            idcs = self._encode_nn_host(x, stride)
         else:
             z = self._encode(x)
             if z.shape[0] != 1:
@@ -242,7 +251,7 @@ class Codebook(object):
         obj_bbs = np.empty((embedding_size, 4))
         for a, e in u.batch_iteration_indices(embedding_size, batch_size):
             batch, obj_bbs_batch = self._dataset.render_embedding_image_batch(a, e)
-            embedding_z[a:e] = self._encoder.engine.encode(batch).cpu().numpy()
+            embedding_z[a:e] = self._encode(batch).cpu().numpy()
             if self.embed_bb:
                 obj_bbs[a:e] = obj_bbs_batch
         normalized_embedding = embedding_z / np.linalg.norm(embedding_z, axis=1, keepdims=True)

@@ -92,6 +92,9 @@ struct KernelRecord {
     double flops;
 };
 
+constexpr int kX3hRing = 256;          // range-flag slots of eager f32x3h forwards (reused round-robin)
+constexpr int kX3hCaptured = 64;       // ... of forwards recorded into HIP graphs (one each, never reused)
+
 }  // namespace aae_host
 
 struct aae_encoder {
@@ -99,7 +102,13 @@ struct aae_encoder {
     std::vector<aae_host::Layer> layers;   // conv layers
     aae_host::Layer dense;                 // 1x1 "conv" over the flattened activation
     float* lut = nullptr;                  // device [256] float32(v/255.)
-    int* x3h_sat = nullptr;                // device flag: an f32x3h activation left the range its fp16 (hi, lo) pair carries exactly
+    // f32x3h range flags: "an activation left the range its fp16 (hi, lo) pair carries exactly".  One int per forward, taken
+    // round-robin from a ring (eager forwards) or, for forwards recorded into a HIP graph, from a region that is never recycled
+    // (a graph bakes the address).  Nobody has to wait for the stream after a forward: the flags of many forwards are polled
+    // together when their results are consumed (aae_encoder_x3h_poll).
+    int* x3h_sat = nullptr;                // device [kX3hRing + kX3hCaptured]
+    std::atomic<unsigned long long> x3h_seq{0};
+    std::atomic<int> x3h_captured{0};
     std::vector<void*> allocations;
     std::vector<aae_host::KernelRecord> records;   // of the most recent completed forward (swapped in under rec_mu)
     std::mutex rec_mu;
@@ -168,6 +177,8 @@ namespace aae_host {
 // Kernel records (label, algorithmic flops) of a forward call are collected in a call-local list and
 // published to the handle when the call returns, so concurrent forwards on one handle (distinct streams and
 // workspaces) never touch shared state while they launch.
+static thread_local int* t_x3h_flag = nullptr;        // range flag of the f32x3h forward this thread is launching
+static thread_local int t_x3h_last_slot = -1;         // its slot (-1: the last forward of this thread ran exact fp32)
 static thread_local std::vector<KernelRecord>* t_records = nullptr;
 static void note_kernel(KernelRecord r) {
     if (t_records) t_records->push_back(std::move(r));
@@ -361,6 +372,7 @@ static WaveKPlan plan_wavek(const aae_encoder* enc, const Layer& L, long long M,
     if (g > gmax) g = gmax;
     if (g > (int)aae::kTicketSingleLevelMax) g = (int)aae::kTicketSingleLevelMax;   // one ticket word per tile
     if (g < 1) g = 1;
+    if (tiles > kLayerTicketWords) g = 1;                   // one ticket word per tile of a split layer: never more tiles than words
     w.gsplits = g;
     if (g > 1) w.partial_bytes = (size_t)tiles * g * (w.MT * w.NT * 16) * 64 * sizeof(float);
     return w;
@@ -580,7 +592,7 @@ static int launch_igemm_x3h(aae_encoder* enc, const Layer& L, const void* x, int
     a.x_bytes = (unsigned)in_bytes;
     a.inv_scale = ldexpf(1.f, -(enc->x3h_act_shift + L.w_shift));
     a.out_scale = ldexpf(1.f, enc->x3h_act_shift);
-    a.sat_flag = out_f32 ? nullptr : enc->x3h_sat;
+    a.sat_flag = out_f32 ? nullptr : t_x3h_flag;
     a.slabs_total = (int)(L.K() / 32);
     a.wp_bytes = (unsigned)((unsigned long long)a.slabs_total * 8ull * L.CoutPad * 16ull);
     a.num_mt = ceil_div(M, 128);
@@ -660,7 +672,7 @@ static int launch_igemm_x3h(aae_encoder* enc, const Layer& L, const void* x, int
     aae::SplitKReduceArgs r;
     r.partial = partial; r.bias = L.bias; r.bn_scale = L.bn_scale; r.bn_shift = L.bn_shift; r.out = static_cast<float*>(out);
     r.MN = (long long)M * L.Cout; r.Cout = L.Cout; r.splits = a.splits; r.relu = L.relu;
-    r.out_planes = out_f32 ? 0 : 1; r.out_scale = a.out_scale; r.sat_flag = out_f32 ? nullptr : enc->x3h_sat;
+    r.out_planes = out_f32 ? 0 : 1; r.out_scale = a.out_scale; r.sat_flag = out_f32 ? nullptr : t_x3h_flag;
     launch_splitk_reduce(r, stream, enc->reduce_small != 0);
     snprintf(label, sizeof(label), "%s:splitk_reduce", name);
     note_kernel({label, 0.0});
@@ -704,7 +716,7 @@ static int launch_first(aae_encoder* enc, const Layer& L, const void* x, bool u8
     a.rowlen = a.vec4 ? L.rowlen4 : L.rowlen;
     a.lead = a.vec4 ? L.lead4 : 0;
     a.out_scale = ldexpf(1.f, enc->x3h_act_shift);
-    a.sat_flag = planes ? enc->x3h_sat : nullptr;
+    a.sat_flag = planes ? t_x3h_flag : nullptr;
     a.tiles_per_image = ceil_div(L.Ho * L.Wo, 128);
     a.total_tiles = B * a.tiles_per_image;
     int tpb = ceil_div(a.total_tiles, enc->first_target_blocks);
@@ -820,7 +832,21 @@ static int forward_impl(aae_encoder* enc, const void* x, int x_dtype, int B, flo
 
     const void* cur = x;
     bool cur_u8 = (x_dtype == AAE_DTYPE_U8);
+    t_x3h_last_slot = -1;
     if (runs_split(enc, B)) {
+        // this forward's range flag: a ring slot, or -- while the stream is being captured into a graph -- a slot of its own
+        hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
+        (void)hipStreamIsCapturing(stream, &capture);
+        int slot;
+        if (capture != hipStreamCaptureStatusNone) {
+            const int c = enc->x3h_captured.fetch_add(1, std::memory_order_relaxed);
+            if (c >= kX3hCaptured) return fail(AAE_ERR_UNSUPPORTED, "more than %d f32x3h forwards captured into HIP graphs on one encoder handle", kX3hCaptured);
+            slot = kX3hRing + c;
+        } else {
+            slot = (int)(enc->x3h_seq.fetch_add(1, std::memory_order_relaxed) % kX3hRing);
+        }
+        t_x3h_flag = enc->x3h_sat + slot;
+        t_x3h_last_slot = slot;
         // f32x3h: conv1 (fp32 MFMA, K = 75) emits fp16 hi/lo planes, every later layer runs the
         // split-precision igemm on planes; only the latent z comes back as fp32.
         for (size_t li = 0; li < enc->layers.size(); ++li) {
@@ -1141,10 +1167,10 @@ int aae_encoder_create(const aae_encoder_desc* d, const void* const* hw, int n_w
     for (int v = 0; v < 256; ++v) lut[v] = (float)((double)v / 255.0);   // float64 quotient, float32 feed cast
     if (int rc = upload(enc, lut, 256, &enc->lut)) return bail(rc);
     {
-        const float zero = 0.f;
-        float* flag = nullptr;
-        if (int rc = upload(enc, &zero, 1, &flag)) return bail(rc);
-        enc->x3h_sat = reinterpret_cast<int*>(flag);
+        const std::vector<float> zeros(kX3hRing + kX3hCaptured, 0.f);
+        float* flags = nullptr;
+        if (int rc = upload(enc, zeros.data(), zeros.size(), &flags)) return bail(rc);
+        enc->x3h_sat = reinterpret_cast<int*>(flags);
     }
 
     int H = d->in_h, W = d->in_w, C = d->in_c, wi = 0;
@@ -1288,7 +1314,7 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
     }
     else if (!strcmp(name, "wavek_max_tiles")) enc->wavek_max_tiles = value < 0 ? 0 : (value > 512 ? 512 : value);
     else if (!strcmp(name, "wavek_narrow_max_tiles")) enc->wavek_narrow_max_tiles = value < 0 ? 0 : value;
-    else if (!strcmp(name, "wavek_target_blocks")) enc->wavek_target_blocks = value < 1 ? 1 : value;
+    else if (!strcmp(name, "wavek_target_blocks")) enc->wavek_target_blocks = value < 1 ? 1 : (value > 2 * aae_host::kLayerTicketWords ? 2 * aae_host::kLayerTicketWords : value);
     else if (!strcmp(name, "wavek_tiny_max_tiles")) enc->wavek_tiny_max_tiles = value < 0 ? 0 : value;
     else if (!strcmp(name, "wavek_waves")) {
         if (value != 4 && value != 8) return fail(AAE_ERR_INVALID, "wavek_waves %d: 4 or 8", value);
@@ -1370,11 +1396,35 @@ int aae_encoder_x3h_saturated(aae_encoder* enc, int* flag_out, void* stream_v) {
     using namespace aae_host;
     if (!enc || !flag_out) return fail(AAE_ERR_INVALID, "aae_encoder_x3h_saturated: null argument");
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
-    int v = 0;
-    AAE_HIP_TRY(hipMemcpyAsync(&v, enc->x3h_sat, sizeof(int), hipMemcpyDeviceToHost, stream));
+    int v[kX3hRing + kX3hCaptured];
+    AAE_HIP_TRY(hipMemcpyAsync(v, enc->x3h_sat, sizeof(v), hipMemcpyDeviceToHost, stream));
     AAE_HIP_TRY(hipStreamSynchronize(stream));
-    if (v) AAE_HIP_TRY(hipMemsetAsync(enc->x3h_sat, 0, sizeof(int), stream));
-    *flag_out = v ? 1 : 0;
+    int any = 0;
+    for (int i = 0; i < kX3hRing + kX3hCaptured; ++i) any |= v[i];
+    if (any) AAE_HIP_TRY(hipMemsetAsync(enc->x3h_sat, 0, sizeof(v), stream));
+    *flag_out = any ? 1 : 0;
+    return AAE_OK;
+}
+
+int aae_encoder_x3h_last_slot(void) { return aae_host::t_x3h_last_slot; }
+
+int aae_encoder_x3h_poll(aae_encoder* enc, const int* slots, int n, int* flags_out, void* stream_v) {
+    using namespace aae_host;
+    if (!enc || !slots || !flags_out || n < 0) return fail(AAE_ERR_INVALID, "aae_encoder_x3h_poll: bad argument");
+    for (int i = 0; i < n; ++i)
+        if (slots[i] < 0 || slots[i] >= kX3hRing + kX3hCaptured) return fail(AAE_ERR_INVALID, "aae_encoder_x3h_poll: slot %d out of range", slots[i]);
+    if (n == 0) return AAE_OK;
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    int v[kX3hRing + kX3hCaptured];
+    AAE_HIP_TRY(hipMemcpyAsync(v, enc->x3h_sat, sizeof(v), hipMemcpyDeviceToHost, stream));
+    AAE_HIP_TRY(hipStreamSynchronize(stream));
+    for (int i = 0; i < n; ++i) {
+        flags_out[i] = v[slots[i]] ? 1 : 0;
+        if (v[slots[i]]) {                                   // (rare) clear it for the slot's next user
+            AAE_HIP_TRY(hipMemsetAsync(enc->x3h_sat + slots[i], 0, sizeof(int), stream));
+            v[slots[i]] = 0;
+        }
+    }
     return AAE_OK;
 }
 
@@ -1608,6 +1658,20 @@ int aae_pack_pairs(const int64_t* idx, const float* score, const int32_t* pos, i
     a.idx = reinterpret_cast<const long long*>(idx); a.score = score; a.pos = pos; a.packed = reinterpret_cast<long long*>(packed);
     a.n = n; a.stride = stride;
     AAE_LAUNCH((aae::pack_pairs_kernel), dim3(ceil_div(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream_v), a);
+    AAE_HIP_TRY(hipGetLastError());
+    return AAE_OK;
+}
+
+int aae_unpack_pairs(const int64_t* gathered, const int32_t* owner, int n, int rows_per_rank, int64_t* idx_out, float* score_out,
+                     void* stream_v) {
+    using namespace aae_host;
+    if (!gathered || !idx_out || !score_out) return fail(AAE_ERR_INVALID, "aae_unpack_pairs: null argument");
+    if (n < 0 || rows_per_rank < n) return fail(AAE_ERR_INVALID, "aae_unpack_pairs: n=%d rows_per_rank=%d", n, rows_per_rank);
+    if (n == 0) return AAE_OK;
+    aae::UnpackPairsArgs a;
+    a.gathered = reinterpret_cast<const long long*>(gathered); a.owner = owner; a.idx = reinterpret_cast<long long*>(idx_out);
+    a.score = score_out; a.n = n; a.rows_per_rank = rows_per_rank;
+    AAE_LAUNCH((aae::unpack_pairs_kernel), dim3(ceil_div(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream_v), a);
     AAE_HIP_TRY(hipGetLastError());
     return AAE_OK;
 }

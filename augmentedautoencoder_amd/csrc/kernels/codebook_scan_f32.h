@@ -418,6 +418,23 @@ __global__ __launch_bounds__(256) void pack_pairs_kernel(const PackPairsArgs p) 
     p.packed[2 * row + 1] = (long long)__builtin_bit_cast(int, p.score[(long long)i * p.stride]);
 }
 
+// ... and back: after the all_gather every rank holds world x rows_per_rank pairs; answer i of the batch is row i of its
+// owner's block (dist.py).  One launch instead of a fancy-index gather + two element-wise conversions.
+struct UnpackPairsArgs {
+    const long long* gathered;   // [world * rows_per_rank][2]
+    const int* owner;            // [n] rank that answered batch row i, or nullptr (single block: owner 0)
+    long long* idx;              // [n]
+    float* score;                // [n]
+    int n, rows_per_rank;
+};
+__global__ __launch_bounds__(256) void unpack_pairs_kernel(const UnpackPairsArgs p) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= p.n) return;
+    const long long row = (long long)(p.owner ? p.owner[i] : 0) * p.rows_per_rank + i;
+    p.idx[i] = p.gathered[2 * row];
+    p.score[i] = __builtin_bit_cast(float, (int)p.gathered[2 * row + 1]);
+}
+
 struct ArgmaxReduceArgs {
     const float* pval;
     const int* pidx;

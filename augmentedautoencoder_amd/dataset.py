@@ -50,6 +50,29 @@ class SyntheticViewSource(object):
                 bbs[k] = (0, 0, 1, 1)
         return batch, bbs
 
+    def torch_batch(self, Rs, device, noise=None):
+        """The same pattern for a whole stack of rotations at once, evaluated with framework tensor ops on ``device``
+        (float64): uint8 [n,H,W,C] device tensor, no bounding boxes.  Input plumbing for full-size codebook builds in
+        tests and benchmarks (92232 views in seconds instead of minutes); rounding may differ from __call__ in the
+        last grey level, so a codebook and its queries must come from the same method.  noise: optional float tensor
+        [n,H,W,C] added before the uint8 conversion."""
+        import torch
+        H, W, C = self.shape
+        R = torch.as_tensor(np.asarray(Rs, dtype=np.float64), device=device).reshape(-1, 3, 3)
+        yy, xx = torch.meshgrid(torch.arange(H, dtype=torch.float64, device=device), torch.arange(W, dtype=torch.float64, device=device),
+                                indexing='ij')
+        yy = ((yy - H / 2.0) / H)[None]
+        xx = ((xx - W / 2.0) / W)[None]
+        r = lambda i, j: R[:, i, j].reshape(-1, 1, 1)
+        u = r(0, 0) * xx + r(0, 1) * yy
+        v = r(1, 0) * xx + r(1, 1) * yy
+        mask = (u * u / 0.16 + v * v / (0.04 + 0.1 * r(2, 2).abs())) < 1.0
+        chans = [127.5 + 127.5 * torch.sin(6.0 * (r(2, c % 3) + 1.5) * u + 9.0 * r(c % 3, 2) * v + self.seed) for c in range(C)]
+        img = torch.stack(chans, dim=-1) * mask[..., None]
+        if noise is not None:
+            img = img + noise
+        return img.clamp(0, 255).to(torch.uint8)
+
 
 def vs_calc_2d_bbox(xs, ys, im_size):
     """pysixd_stuff/view_sampler.py:10-15."""

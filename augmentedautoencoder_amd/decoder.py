@@ -87,5 +87,5 @@ class Decoder(object):
                 return self.engine.decode(np.asarray(v, dtype=np.float32)).cpu().numpy()
         if self._encoder is None:
             raise ValueError('feed_dict has no value for decoder._latent_code')
-        z = self._encoder.engine.encode(self._encoder._feed(feed))          # stays on the device
+        z = self._encoder.engine.encode_checked(self._encoder._feed(feed))  # stays on the device
         return self.engine.decode(z).cpu().numpy()

@@ -33,37 +33,72 @@ def route(class_ids, world_size, rank):
     return {o: np.asarray(p, dtype=np.int64) for o, p in out.items()}
 
 
+def _group_shape(dist, group, world_size, rank, what):
+    """(world_size, rank, gather?) of an engine.  Sizes left to None come from the process group (a single-rank group
+    still runs its collective); explicit sizes must agree with an initialised group, except the explicit single-rank
+    engine (world_size = 1, rank 0), which never gathers -- a local engine inside a larger job."""
+    initialised = dist.is_available() and dist.is_initialized()
+    if world_size is None:
+        ws = dist.get_world_size(group) if initialised else 1
+        rk = int(rank) if rank is not None else (dist.get_rank(group) if initialised else 0)
+        return ws, rk, initialised
+    ws = int(world_size)
+    rk = int(rank) if rank is not None else (dist.get_rank(group) if initialised and ws > 1 else 0)
+    if ws > 1 and initialised and ws != dist.get_world_size(group):
+        raise ValueError('%s: world_size=%d but the process group has %d ranks' % (what, ws, dist.get_world_size(group)))
+    # (ws > 1 without a group: shard engines built by hand, e.g. to merge their local candidates in one process --
+    #  only the collective itself needs the group)
+    if not 0 <= rk < ws:
+        raise ValueError('%s: rank %d outside [0, %d)' % (what, rk, ws))
+    return ws, rk, ws > 1
+
+
 class ShardedPoseEngine(object):
     """local_infer(obj_id, crops_subset) -> (idx int64 [n] or [n,1], score float32 likewise); crops_subset is
     ``crops[positions]`` (numpy array or torch tensor, whatever the caller passed in).
 
-    pack_pairs(idx, score, pos int32 tensor, packed): optional one-launch writer of the gather payload (the HIP path
-    passes ``engine.pack_pairs``); without it the pairs are packed with framework tensor ops (CPU / gloo tests)."""
+    pack_pairs(idx, score, pos int32 tensor, packed) / unpack_pairs(gathered, owner int32 tensor, n, rows_per_rank,
+    idx_out, score_out): optional one-launch writers of the gather payload and of its way back (the HIP path passes
+    ``engine.pack_pairs`` / ``engine.unpack_pairs``); without them framework tensor ops do it (CPU / gloo tests).
 
-    def __init__(self, local_infer, world_size=None, rank=None, group=None, device=None, pack_pairs=None):
+    Nothing is allocated per call once a batch layout has been seen: the payload buffer (sentinel -1 in the rows of
+    other ranks, written once), the gather buffer and the outputs belong to the cached plan -- the (idx, score) tensors
+    a call returns are overwritten by the next call with the same layout."""
+
+    def __init__(self, local_infer, world_size=None, rank=None, group=None, device=None, pack_pairs=None, unpack_pairs=None):
         import torch.distributed as dist
         self.dist = dist
         self.group = group
         self.distributed = dist.is_available() and dist.is_initialized()
-        self.world_size = int(world_size) if world_size is not None else (dist.get_world_size(group) if self.distributed else 1)
-        self.rank = int(rank) if rank is not None else (dist.get_rank(group) if self.distributed else 0)
+        self.world_size, self.rank, self._gather = _group_shape(dist, group, world_size, rank, 'ShardedPoseEngine')
         self.local_infer = local_infer
         self.device = device
         self.pack_pairs = pack_pairs
+        self.unpack_pairs = unpack_pairs
         self._plan_key, self._plan = None, None
 
     def plan(self, class_ids):
         """Routing of one batch layout, reusable while the class ids stay the same (a detector's boxes change per frame,
-        a benchmark's do not): this rank's buckets {obj: positions}, their position tensors on the device, and the
-        owner of every batch row for the re-assembly after the gather."""
+        a benchmark's do not): this rank's buckets {obj: positions}, their position tensors on the device, the owner of
+        every batch row, and the buffers of the exchange."""
         import torch
         key = tuple(np.asarray(class_ids).tolist())
         if key != self._plan_key:
             dev = self.device if self.device is not None else torch.device('cpu')
+            B = len(key)
             buckets = route(class_ids, self.world_size, self.rank)
             pos_dev = {o: torch.as_tensor(p, dtype=torch.int32, device=dev) for o, p in buckets.items()}
-            owners = torch.as_tensor([owner_of(o, self.world_size) for o in key], dtype=torch.int64, device=dev)
-            self._plan_key, self._plan = key, (buckets, pos_dev, owners, torch.arange(len(key), device=dev))
+            owners = torch.as_tensor([owner_of(o, self.world_size) for o in key], dtype=torch.int32, device=dev)
+            bufs = {
+                # fixed-capacity payload, -1 sentinel for "not mine" (equal sizes for all_gather); this rank's rows are
+                # overwritten by every call, the others keep the sentinel for the life of the plan
+                'packed': torch.full((B, 2), -1, dtype=torch.int64, device=dev),
+                'gathered': torch.empty((self.world_size * B, 2), dtype=torch.int64, device=dev) if self._gather else None,
+                'idx': torch.empty((B,), dtype=torch.int64, device=dev),
+                'score': torch.empty((B,), dtype=torch.float32, device=dev),
+                'owners64': owners.long(), 'rows': torch.arange(B, device=dev),
+            }
+            self._plan_key, self._plan = key, (buckets, pos_dev, owners, bufs)
         return self._plan
 
     def infer(self, crops, class_ids):
@@ -74,31 +109,33 @@ class ShardedPoseEngine(object):
         import torch
         B = len(class_ids)
         dev = self.device if self.device is not None else torch.device('cpu')
-        buckets, pos_dev, owners, rows = self.plan(class_ids)
-        # fixed-capacity buffers, -1 sentinel for "not mine" (equal sizes for all_gather)
-        packed = torch.full((B, 2), -1, dtype=torch.int64, device=dev)
+        buckets, pos_dev, owners, bufs = self.plan(class_ids)
+        packed = bufs['packed']
         for obj, pos in buckets.items():
             if isinstance(crops, dict):
                 sel = crops[obj]
             else:
                 sel = crops[pos_dev[obj].to(crops.device).long()] if torch.is_tensor(crops) else crops[pos]
             idx, score = self.local_infer(obj, sel)
-            idx = torch.as_tensor(idx, dtype=torch.int64, device=dev)
-            score = torch.as_tensor(score, dtype=torch.float32, device=dev)
+            idx = torch.as_tensor(idx, dtype=torch.int64, device=dev).reshape(len(pos), -1).contiguous()
+            score = torch.as_tensor(score, dtype=torch.float32, device=dev).reshape(len(pos), -1).contiguous()
             if self.pack_pairs is not None:
-                self.pack_pairs(idx.reshape(len(pos), -1), score.reshape(len(pos), -1), pos_dev[obj], packed)
+                self.pack_pairs(idx, score, pos_dev[obj], packed)
             else:
                 p = pos_dev[obj].long()
-                packed[p, 0] = idx.reshape(-1)
-                packed[p, 1] = score.reshape(-1).view(torch.int32).to(torch.int64)
-        if self.distributed or self.world_size > 1:
+                packed[p, 0] = idx[:, 0]
+                packed[p, 1] = score[:, 0].contiguous().view(torch.int32).to(torch.int64)
+        src, own = packed, None
+        if self._gather:
             # the one collective of the path (RCCL over xGMI on the GPUs); a single-rank group runs it too
-            gathered = torch.empty((self.world_size * B, 2), dtype=torch.int64, device=dev)
-            self.dist.all_gather_into_tensor(gathered, packed, group=self.group)
-            packed = gathered.view(self.world_size, B, 2)[owners, rows]
-        idx = packed[:, 0]
-        score = packed[:, 1].to(torch.int32).view(torch.float32)
-        return idx, score
+            self.dist.all_gather_into_tensor(bufs['gathered'], packed, group=self.group)
+            src, own = bufs['gathered'], owners
+        if self.unpack_pairs is not None:
+            self.unpack_pairs(src, own, B, B, bufs['idx'], bufs['score'])
+            return bufs['idx'], bufs['score']
+        if own is not None:
+            src = src.view(self.world_size, B, 2)[bufs['owners64'], bufs['rows']]
+        return src[:, 0], src[:, 1].to(torch.int32).view(torch.float32)
 
 
 # ---- one huge codebook, rows sharded over the ranks ("one exchange step") ----
@@ -134,8 +171,7 @@ class RowShardedCodebook(object):
         self.dist = dist
         self.group = group
         self.distributed = dist.is_available() and dist.is_initialized()
-        self.world_size = int(world_size) if world_size is not None else (dist.get_world_size(group) if self.distributed else 1)
-        self.rank = int(rank) if rank is not None else (dist.get_rank(group) if self.distributed else 0)
+        self.world_size, self.rank, self._gather = _group_shape(dist, group, world_size, rank, 'RowShardedCodebook')
         self.bounds = row_shard_bounds(n_rows, self.world_size, align)
         self.lo, self.hi = self.bounds[self.rank]
         self.local_nn = local_nn
@@ -170,7 +206,7 @@ class RowShardedCodebook(object):
         import torch
         ix, sc = self.local_candidates(z, topk, col_stride)
         B = len(z)
-        if self.distributed or self.world_size > 1:
+        if self._gather:
             packed = torch.stack([ix, sc.view(torch.int32).to(torch.int64)], dim=2).contiguous()        # [B,k,2]
             gathered = torch.empty((self.world_size,) + tuple(packed.shape), dtype=torch.int64, device=ix.device)
             self.dist.all_gather_into_tensor(gathered.view(-1, 2), packed.view(-1, 2), group=self.group)

@@ -27,7 +27,7 @@ class Encoder(object):
         self.weights = None
         self._engine = None
         self._device = None
-        self._z_op = S.Op('encoder/z', lambda feed: self.engine.encode(self._feed(feed)).cpu().numpy())
+        self._z_op = S.Op('encoder/z', lambda feed: self.engine.encode_checked(self._feed(feed)).cpu().numpy())
         self._z_op.owner = self                  # lets Decoder(latent_code=encoder.z) find its encoder
         S.register(encoder=self)
 
@@ -49,7 +49,7 @@ class Encoder(object):
     def encoder_out(self):
         """Flattened conv output (encoder.py:37-56) as a fetchable."""
         def run(feed):
-            self.engine.encode(self._feed(feed))
+            self.engine.encode_checked(self._feed(feed))
             a = self.engine.activation(self.config.num_layers - 1)
             return a.reshape(a.shape[0], -1).cpu().numpy()
         return S.Op('encoder/encoder_out', run)

@@ -69,10 +69,13 @@ class EncoderEngine(object):
         self.ws = _Workspace(self.device)
         self._last_B = None
         self.options = {}
-        # f32x3h mode ('precision' = 1): activations travel as fp16 (hi, lo) pairs that carry |x| < 4094 exactly.  When a
-        # forward reports a value outside that range (aae_encoder_x3h_saturated), the batch is recomputed in exact fp32.
+        # f32x3h mode ('precision' = 1, 2): activations travel as fp16 (hi, lo) pairs that carry |x| < 4094 exactly.  Every
+        # forward raises its own device flag when a value leaves that range; the flags of all forwards queued since the
+        # last check are read in ONE host round trip by settle() -- when results are consumed, never per launch -- and
+        # the affected chunks are recomputed in exact fp32, in place.
         self.x3h_fallback = True
         self.x3h_fallbacks = 0             # how many chunks were recomputed
+        self._x3h_pending = []             # (flag slot, redo closure) of f32x3h forwards not yet checked
 
     def close(self):
         if getattr(self, 'handle', None):
@@ -117,24 +120,59 @@ class EncoderEngine(object):
             raise ValueError('crop batch has shape %s, encoder expects [B,%d,%d,%d]' % ((tuple(t.shape),) + tuple(self.cfg.shape)))
         return t
 
-    def _x3h_left_its_range(self):
-        """True when the f32x3h forwards queued so far met an activation the fp16 pairs cannot carry (waits for the stream)."""
+    def _x3h_note(self, redo):
+        """Called right after a forward / encode_nn C call: if it ran in f32x3h, remember its range-flag slot and how to
+        redo it in exact fp32.  No synchronisation here; settle() looks at the flags."""
+        if not self.x3h_fallback or self.options.get('precision', 0) not in (1, 2):
+            return
+        slot = self.lib.aae_encoder_x3h_last_slot()
+        if slot < 0:
+            return
         torch = _torch()
-        if (self.options.get('precision', 0) not in (1, 2) or not self.x3h_fallback or torch.cuda.is_current_stream_capturing()
-                or not self.lib.aae_encoder_split_precision_for_batch(self.handle, int(self._last_B or 1))):
-            return False
-        flag = ctypes.c_int(0)
+        if torch.cuda.is_current_stream_capturing():
+            self._x3h_captured_slot = slot        # a graph owns this slot; CapturedNearestNeighbour polls it after each replay
+            return
+        self._x3h_pending.append((slot, redo))
+        if len(self._x3h_pending) >= 192:         # the ring has 256 slots: never let un-checked forwards share one
+            self.settle()
+
+    def _x3h_poll(self, slots):
+        torch = _torch()
+        arr = (ctypes.c_int * len(slots))(*slots)
+        flags = (ctypes.c_int * len(slots))()
         with torch.cuda.device(self.device):
-            _lib.check(self.lib, self.lib.aae_encoder_x3h_saturated(self.handle, ctypes.byref(flag), _stream_ptr(torch)),
-                       'aae_encoder_x3h_saturated')
-        if flag.value:
+            _lib.check(self.lib, self.lib.aae_encoder_x3h_poll(self.handle, arr, len(slots), flags, _stream_ptr(torch)),
+                       'aae_encoder_x3h_poll')
+        return [int(f) for f in flags]
+
+    def settle(self):
+        """Check the range flags of every f32x3h forward queued since the last settle() (ONE wait for the stream) and
+        recompute the affected chunks in exact fp32 -- in place, into the tensors the earlier calls returned.  Returns
+        how many chunks were recomputed.  The reference-shaped API (codebook.py) calls this where it copies results to
+        the host; engine-level users in split-precision mode call it before they trust z / idx / score (results that
+        were DERIVED from a recomputed z by another call, e.g. CodebookEngine.nn, have to be derived again)."""
+        pending, self._x3h_pending = self._x3h_pending, []
+        if not pending:
+            return 0
+        flags = self._x3h_poll([slot for slot, _ in pending])
+        redone = 0
+        mode = self.options.get('precision', 0)
+        for (slot, redo), flag in zip(pending, flags):
+            if not flag:
+                continue
+            redone += 1
             self.x3h_fallbacks += 1
             if self.x3h_fallbacks == 1:
                 import warnings
                 warnings.warn('f32x3h: an activation exceeded the range of its fp16 (hi, lo) pair (|x| >= 4094 at the default '
                               'x3h_act_shift); the batch is recomputed in exact fp32 (further occurrences are counted in '
                               'EncoderEngine.x3h_fallbacks)', RuntimeWarning)
-        return bool(flag.value)
+            self.set_option('precision', 0)
+            try:
+                redo()
+            finally:
+                self.set_option('precision', mode)
+        return redone
 
     def _forward_chunk(self, t, z_out, timed=False):
         torch = _torch()
@@ -149,13 +187,7 @@ class EncoderEngine(object):
                                                   ctypes.c_void_p(z_out.data_ptr()), ctypes.c_void_p(ws_ptr), nbytes,
                                                   _stream_ptr(torch))
                 _lib.check(self.lib, rc, 'aae_encoder_forward')
-                if self._x3h_left_its_range():          # documented failure mode of the split-precision mode: redo in fp32
-                    mode = self.options.get('precision', 0)
-                    self.set_option('precision', 0)
-                    try:
-                        self._forward_chunk(t, z_out)
-                    finally:
-                        self.set_option('precision', mode)
+                self._x3h_note(lambda: self._forward_chunk(t, z_out))     # documented failure mode of the split-precision mode: redo in fp32
                 return None
             ms = (ctypes.c_float * 32)()
             n = ctypes.c_int(0)
@@ -177,12 +209,21 @@ class EncoderEngine(object):
             self._forward_chunk(t[a:e], z[a:e])
         return z
 
+    def encode_checked(self, x):
+        """encode() + settle(): latents that other device work may be derived from right away (in exact fp32, the
+        default, settle() has nothing to do)."""
+        z = self.encode(x)
+        self.settle()
+        return z
+
     def encode_nn(self, codebook_engine, x, col_stride=1):
         """Encoder.z + the top-1 codebook query of a batch in one C call per chunk (aae_encode_nn): what
         Codebook.nearest_rotation does per detection.  Returns (z [B,J], idx int64 [B,1], cosine float32 [B,1]) on
         the device; bit-identical to encode() followed by codebook_engine.nn(z, 1, col_stride)."""
         torch = _torch()
         cb = codebook_engine
+        if cb.device != self.device:
+            raise ValueError('encode_nn: encoder on %s, codebook on %s -- one C call needs both on one device' % (self.device, cb.device))
         t = self.to_device_batch(x)
         B = t.shape[0]
         z = torch.empty((B, self.cfg.latent_space_size), dtype=torch.float32, device=self.device)
@@ -206,14 +247,11 @@ class EncoderEngine(object):
                                             ctypes.c_void_p(score[a:e].data_ptr()), ctypes.c_void_p(ws_e), nb_e,
                                             ctypes.c_void_p(ws_c), nb_c, _stream_ptr(torch))
             _lib.check(self.lib, rc, 'aae_encode_nn')
-            if self._x3h_left_its_range():
-                mode = self.options.get('precision', 0)
-                self.set_option('precision', 0)
-                try:
-                    za, ia, sa = self.encode_nn(cb, t[a:e], col_stride)
-                    z[a:e], idx[a:e], score[a:e] = za, ia, sa
-                finally:
-                    self.set_option('precision', mode)
+
+            def redo(a=a, e=e):
+                za, ia, sa = self.encode_nn(cb, t[a:e], col_stride)
+                z[a:e], idx[a:e], score[a:e] = za, ia, sa
+            self._x3h_note(redo)
         return z, idx, score
 
     def encode_timed(self, x):
@@ -372,6 +410,14 @@ class CodebookEngine(object):
         return q
 
 
+def _pair_operand(t, dtype, device, what):
+    torch = _torch()
+    if not torch.is_tensor(t) or t.dtype != dtype or t.device != device:
+        raise ValueError('%s must be a %s tensor on %s, got %s' % (what, dtype, device,
+                                                                   (t.dtype, t.device) if torch.is_tensor(t) else type(t)))
+    return t.contiguous()
+
+
 def pack_pairs(idx, score, pos, packed):
     """packed[pos[i]] = (idx[i, 0], float bits of score[i, 0]) in one launch (aae_pack_pairs): the payload of the
     multi-GPU gather.  idx int64 [n,k], score float32 [n,k], pos int32 [n] device tensor or None (rows 0..n-1),
@@ -381,15 +427,45 @@ def pack_pairs(idx, score, pos, packed):
     n = int(idx.shape[0])
     if n == 0:
         return packed
+    if packed.dtype != torch.int64 or not packed.is_contiguous():
+        raise ValueError('packed must be a contiguous int64 [capacity, 2] tensor')
+    idx = _pair_operand(idx, torch.int64, packed.device, 'idx')
+    score = _pair_operand(score, torch.float32, packed.device, 'score')
+    if tuple(score.shape) != tuple(idx.shape):
+        raise ValueError('idx %s and score %s differ in shape' % (tuple(idx.shape), tuple(score.shape)))
     stride = int(idx.shape[1]) if idx.dim() == 2 else 1
-    if pos is not None and pos.dtype != torch.int32:
-        pos = pos.to(torch.int32)
+    if pos is not None:
+        if pos.dtype != torch.int32:
+            pos = pos.to(torch.int32)
+        pos = _pair_operand(pos, torch.int32, packed.device, 'pos')
     with torch.cuda.device(packed.device):
         rc = lib.aae_pack_pairs(ctypes.c_void_p(idx.data_ptr()), ctypes.c_void_p(score.data_ptr()),
                                 ctypes.c_void_p(pos.data_ptr()) if pos is not None else None, n, stride,
                                 ctypes.c_void_p(packed.data_ptr()), _stream_ptr(torch))
     _lib.check(lib, rc, 'aae_pack_pairs')
     return packed
+
+
+def unpack_pairs(gathered, owner, n, rows_per_rank, idx_out, score_out):
+    """The inverse after the all_gather (aae_unpack_pairs, one launch): idx_out[i], score_out[i] = row i of block
+    owner[i] of gathered [world * rows_per_rank, 2] (owner None: block 0).  Outputs are caller-owned (pre-allocated)."""
+    torch = _torch()
+    lib = _lib.load()
+    if n == 0:
+        return idx_out, score_out
+    dev = gathered.device
+    gathered = _pair_operand(gathered, torch.int64, dev, 'gathered')
+    if owner is not None:
+        owner = _pair_operand(owner, torch.int32, dev, 'owner')
+    if (idx_out.dtype != torch.int64 or score_out.dtype != torch.float32 or not idx_out.is_contiguous() or not score_out.is_contiguous()
+            or idx_out.device != dev or score_out.device != dev or idx_out.numel() < n or score_out.numel() < n):
+        raise ValueError('unpack_pairs: outputs must be contiguous int64 / float32 tensors of at least n elements on %s' % dev)
+    with torch.cuda.device(dev):
+        rc = lib.aae_unpack_pairs(ctypes.c_void_p(gathered.data_ptr()), ctypes.c_void_p(owner.data_ptr()) if owner is not None else None,
+                                  int(n), int(rows_per_rank), ctypes.c_void_p(idx_out.data_ptr()), ctypes.c_void_p(score_out.data_ptr()),
+                                  _stream_ptr(torch))
+    _lib.check(lib, rc, 'aae_unpack_pairs')
+    return idx_out, score_out
 
 
 def crop_resize(image, boxes_xywh_size, out_hw, device=None):
@@ -527,7 +603,10 @@ class CapturedNearestNeighbour(object):
     per-detection loop uses (m3_interface/ae_pose_estimator.py:143-170).  On the GPU side a replay
     takes as long as the eager launches (the chain is kernel-bound); the gain is host time.
     Inputs are copied into a static buffer; outputs are static device tensors, valid until the
-    next call.  Results are bit-identical to the eager calls (same kernels, same order)."""
+    next call.  Results are bit-identical to the eager calls (same kernels, same order).  Captured in
+    split-precision mode ('precision' 1 / 2 on a batch that runs f32x3h) every replay is followed by a look at the
+    forward's range flag (a host round trip) and, if it is up, by an eager exact-fp32 recomputation -- the same
+    guarantee the eager path gives."""
 
     def __init__(self, encoder_engine, codebook_engine, batch, in_dtype='uint8', topk=1, col_stride=1):
         torch = _torch()
@@ -535,6 +614,7 @@ class CapturedNearestNeighbour(object):
         self.batch, self.topk, self.col_stride = int(batch), int(topk), int(col_stride)
         dt = torch.uint8 if in_dtype in ('uint8', torch.uint8) else torch.float32
         dev = encoder_engine.device
+        self._x3h_slot = -1
         self.x = torch.zeros((self.batch,) + tuple(encoder_engine.cfg.shape), dtype=dt, device=dev)
         # The graph bakes raw device addresses: its scratch memory must outlive it and must never be regrown by somebody
         # else.  So the capture runs on PRIVATE workspaces owned by this object (the engines' own grow-only buffers are
@@ -556,9 +636,13 @@ class CapturedNearestNeighbour(object):
                 for _ in range(2):
                     self._query()
             torch.cuda.current_stream().wait_stream(side)
+            self.enc.settle()
+            self.enc._x3h_captured_slot = -1
             self.graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(self.graph):
                 self.z, self.idx, self.score = self._query()
+            # split-precision capture: the recorded forward owns a range-flag slot of its own, looked at after every replay
+            self._x3h_slot = self.enc._x3h_captured_slot if self.enc.x3h_fallback else -1
 
     def _query(self):
         if self.topk == 1:                               # one C call: conv1 prepares the ticket words of the later launches
@@ -581,6 +665,19 @@ class CapturedNearestNeighbour(object):
             raise ValueError('captured for dtype %s, got %s' % (self.x.dtype, x.dtype))
         self.x.copy_(x, non_blocking=True)
         self.graph.replay()
+        if self._x3h_slot >= 0 and self.enc._x3h_poll([self._x3h_slot])[0]:
+            # f32x3h replay that left the fp16 pair range (one host round trip per replay in this mode -- the price of a
+            # checked result; exact-fp32 captures never get here): the same query again, eagerly, in exact fp32
+            self.enc.x3h_fallbacks += 1
+            mode = self.enc.options.get('precision', 0)
+            self.enc.set_option('precision', 0)
+            try:
+                z, idx, score = self._query()
+                self.z.copy_(z)
+                self.idx.copy_(idx)
+                self.score.copy_(score)
+            finally:
+                self.enc.set_option('precision', mode)
         return self.idx, self.score
 
 
@@ -635,7 +732,9 @@ class StreamingNearestNeighbour(object):
             if self.topk == 1:
                 _, idx, score = self.enc.encode_nn(self.cb, self.dev[slot][:n], self.col_stride)
             else:
-                idx, score = self.cb.nn(self.enc.encode(self.dev[slot][:n]), self.topk, self.col_stride)
+                zc = self.enc.encode(self.dev[slot][:n])
+                self.enc.settle()                 # (split precision only) the scan below must read checked latents
+                idx, score = self.cb.nn(zc, self.topk, self.col_stride)
             self.consumed[slot].record(compute)
             try:
                 nxt = next(it)
@@ -644,10 +743,18 @@ class StreamingNearestNeighbour(object):
             if nxt is not None:
                 n_next = self._upload(slot ^ 1, nxt)                # overlaps the kernels just queued
             if pending is not None:
-                yield pending[0].cpu().numpy(), pending[1].cpu().numpy()
+                yield self._fetch(pending)
             pending = (idx, score)
             if nxt is None:
                 break
             slot ^= 1
             n = n_next
-        yield pending[0].cpu().numpy(), pending[1].cpu().numpy()
+        yield self._fetch(pending)
+
+    def _fetch(self, pair):
+        """(idx, score) to the host; the range flags of the split-precision forwards queued so far are read with them --
+        an affected batch has been recomputed in place (exact fp32) when this returns."""
+        idx, score = pair[0].cpu(), pair[1].cpu()
+        if self.enc.settle():
+            idx, score = pair[0].cpu(), pair[1].cpu()
+        return idx.numpy(), score.numpy()

@@ -100,7 +100,7 @@ def main():
 
     import torch
     import torch.distributed as dist
-    from augmentedautoencoder_amd.engine import CodebookEngine, EncoderEngine, pack_pairs
+    from augmentedautoencoder_amd.engine import CodebookEngine, EncoderEngine, pack_pairs, unpack_pairs
     from augmentedautoencoder_amd.weights import EncoderConfig
     from augmentedautoencoder_amd import synth            # seeded synthetic inputs (no oracle code on the measured path)
 
@@ -160,10 +160,16 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
         elapsed = time.perf_counter() - t0
+        rank_ms = None
         if use_dist:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+            mine = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            every = torch.empty((world,), dtype=torch.float64, device=dev)
+            dist.all_gather_into_tensor(every, mine)
+            rank_ms = [round(float(v) / args.steps * 1e3, 4) for v in every.tolist()]
+            elapsed = float(every.max().item())               # the slowest rank's clock
+        # split precision: the range flags of all forwards of the loop are read here, once, outside the timed region (no
+        # host round trip per step); a batch that left the fp16 pair range would have been recomputed in exact fp32
+        x3h_redone = enc.settle()
         per, order = {}, []
         for _ in range(max(args.profile_steps, 1)):
             _, recs = enc.encode_timed(x)
@@ -198,6 +204,8 @@ def main():
                          'flops_per_launch': dom_flops, 'avg_ms': dom['ms']},
             'encoder_tflops': round(cfg.flops_per_crop() * B / (sum(k['ms'] for k in kernels) * 1e-3) / 1e12, 2),
             'kernels': kernels,
+            'rank_ms_per_step': rank_ms,
+            'x3h_batches_recomputed_in_fp32': x3h_redone if precision == 'f32x3h' else None,
         }
 
     main_res = measure(args.precision)
@@ -232,7 +240,7 @@ def main():
         all_crops = torch.from_numpy(synth.make_crops(BATCH, seed=4321)).to(dev)     # the same mixed batch on every rank
         mine = torch.from_numpy(np.flatnonzero(labels == rank)).to(dev)
         my_bucket = {rank: all_crops[mine].contiguous()}                             # host-side routing, outside the timed region
-        spe = ShardedPoseEngine(lambda obj, c: enc.encode_nn(cb, c, 1)[1:], device=dev, pack_pairs=pack_pairs)
+        spe = ShardedPoseEngine(lambda obj, c: enc.encode_nn(cb, c, 1)[1:], device=dev, pack_pairs=pack_pairs, unpack_pairs=unpack_pairs)
         for _ in range(max(args.warmup, 3)):
             spe.infer(my_bucket, labels)
         fence()
@@ -249,7 +257,8 @@ def main():
                                          '(idx, score) pairs padded to %d rows per rank' % (BATCH, world, BATCH),
                              'value': round(BATCH * args.steps / t4, 1), 'unit': 'crops/s', 'ms_per_batch': round(t4 / args.steps * 1e3, 4),
                              'bucket_sizes': np.bincount(labels, minlength=world).tolist(), 'scaling': 'strong (global batch fixed)',
-                             'answers_complete': bool((idx4 >= 0).all().item())}
+                             'answers_complete': bool((idx4 >= 0).all().item()),
+                             'launches_per_step_besides_encode_nn': 'pack_pairs, all_gather, unpack_pairs (buffers owned by the cached plan)'}
     if not use_dist and not args.no_extras and args.precision == 'f32':
         from augmentedautoencoder_amd.engine import CapturedNearestNeighbour, DecoderEngine, StreamingNearestNeighbour
         from augmentedautoencoder_amd.weights import DecoderConfig
@@ -283,13 +292,37 @@ def main():
         cold1 = time_us(cold_call, 320, warm=16)
         for c in copies[1:]:
             c.close()
+        def single_call_us(fn, reps=200):
+            """median over `reps` calls, each between its own pair of HIP events on an otherwise idle stream: one launch
+            incl. its dispatch, without the overlap back-to-back calls get"""
+            ts = []
+            for _ in range(reps):
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                fn()
+                e1.record()
+                e1.synchronize()
+                ts.append(e0.elapsed_time(e1) * 1e3)
+            ts.sort()
+            return ts[len(ts) // 2]
+        solo1 = single_call_us(lambda: cb.nn(z1, 1, 1))
+        scan_traffic = None
+        try:
+            with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
+                scan_traffic = json.load(f).get('scan', None)
+        except Exception:
+            scan_traffic = None
         extras['scan'] = {
+            'kernel_us': round(solo1, 2), 'kernel_frac': round(cb_bytes / solo1 / 1e3 / PEAK_HBM_GBPS, 3),
+            'traffic': scan_traffic,
             'codebook_bytes': cb_bytes, 'peak_GBps': PEAK_HBM_GBPS,
             'B1_whole_call_warm_us': round(warm1, 2), 'B1_warm_GBps': round(cb_bytes / warm1 / 1e3, 1), 'B1_warm_frac': round(cb_bytes / warm1 / 1e3 / PEAK_HBM_GBPS, 3),
             'B1_whole_call_cold_us': round(cold1, 2), 'B1_cold_GBps': round(cb_bytes / cold1 / 1e3, 1), 'B1_cold_frac': round(cb_bytes / cold1 / 1e3 / PEAK_HBM_GBPS, 3),
             'B256_whole_call_us': round(warm256, 2),
-            'note': 'whole aae_codebook_nn call, back-to-back calls on one stream (stand-alone: stream scan + arg-max reduce launch; inside '
-                    'aae_encode_nn the scan is one launch).  warm: the 47 MB codebook stays in the 256 MB Infinity Cache between calls '
+            'note': 'whole aae_codebook_nn call = ONE launch at B <= 4 (normalise + stream + arg-max hand-off inside the scan kernel); whole_call = '
+                    'back-to-back calls on one stream, kernel_us = one call between its own HIP events on an idle stream (median); traffic = HBM-side '
+                    'bytes per launch from the committed rocprofv3 PMC pass (profiles/traffic.json).  warm: the 47 MB codebook stays in the 256 MB Infinity Cache between calls '
                     '(algorithmic bytes, not HBM bytes); cold: 8 codebook copies visited in turn, so every call streams from HBM.  '
                     'B=256 is MFMA-bound (crossover B~39).  Kernel-only durations: profiles/ (rocprofv3 --kernel-trace --stats)'}
         # ---- BASELINE config 3: ae_embed -- encode 92232 views (codebook.py:190-219), encoder only, inputs resident
@@ -368,6 +401,10 @@ def main():
             'encoder_tflops': main_res['encoder_tflops'],
             'kernels': main_res['kernels'],
         }
+        if use_dist:
+            out['rccl_world_size'] = dist.get_world_size()
+            out['rank_ms_per_step'] = {'min': min(main_res['rank_ms_per_step']), 'max': max(main_res['rank_ms_per_step']),
+                                       'per_rank': main_res['rank_ms_per_step']}
         if args.enc_opt:
             out['config']['encoder_options'] = args.enc_opt
         out.update(extras)
@@ -375,6 +412,8 @@ def main():
             out['split_precision'] = {'mode': x3h_label, 'value': split_res['value'], 'unit': 'crops/s',
                                       'ms_per_step': split_res['ms_per_step'], 'roofline': split_res['roofline'],
                                       'encoder_tflops_fp32_equivalent': split_res['encoder_tflops'], 'kernels': split_res['kernels'],
+                                      'batches_recomputed_in_fp32': split_res['x3h_batches_recomputed_in_fp32'],
+                                      'range_check': 'per-forward device flags, read once after the timed loop (no host sync per step)',
                                       'note': 'opt-in mode, same parity tolerances (cosine 1e-5, tie-aware index equality); not the headline'}
         if not use_dist and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(weights, E, crops)

@@ -157,6 +157,18 @@ double aae_encoder_kernel_flops(const aae_encoder* enc, int i);
  * with "precision" = 0 (the Python mirror does that automatically).  Exact fp32 mode never sets the flag. */
 int aae_encoder_x3h_saturated(aae_encoder* enc, int* flag_out, void* stream);
 
+/* The same check without a wait per forward.  Every f32x3h forward raises its OWN flag: one of 256 slots taken round-robin
+ * (a forward recorded into a HIP graph gets one of 64 slots that are never reused -- the graph bakes the address).
+ * aae_encoder_x3h_last_slot(): slot of the most recent forward / aae_encode_nn issued by the calling thread, -1 when that
+ * forward ran in exact fp32.  aae_encoder_x3h_poll(): waits for `stream` ONCE, returns the flags of `n` slots (1 = that
+ * forward met an out-of-range activation: recompute it with "precision" = 0) and clears the raised ones.  A caller can so
+ * queue any number of forwards without a host round trip and check them when it consumes the results (the Python mirror:
+ * EncoderEngine.settle()).  With more than 256 un-polled forwards a slot is shared: a raised flag may then belong to either
+ * user -- a spurious fp32 recomputation at worst, never a missed one.  aae_encoder_x3h_saturated() reports and clears all
+ * slots at once. */
+int aae_encoder_x3h_last_slot(void);
+int aae_encoder_x3h_poll(aae_encoder* enc, const int* slots, int n, int* flags_out, void* stream);
+
 /* 1 when a forward of batch B on this handle runs in f32x3h (precision 1, or precision 2 and a large enough batch):
  * the layer outputs in the workspace are then fp16 (hi, lo) pairs instead of fp32 (aae_encoder_activation_info). */
 int aae_encoder_split_precision_for_batch(const aae_encoder* enc, int B);
@@ -221,6 +233,12 @@ int aae_l2_normalize(const float* z, int B, int J, float* q_out, void* stream);
  * ranks keep the -1 sentinel.  Replaces the per-detection bookkeeping of m3_interface/ae_pose_estimator.py:143-170. */
 int aae_pack_pairs(const int64_t* idx, const float* score, const int32_t* pos, int n, int stride, int64_t* packed,
                    void* stream);
+
+/* The way back after the all_gather: gathered[world * rows_per_rank][2] holds every rank's packed buffer; answer i of the
+ * batch (i < n <= rows_per_rank) is row i of block owner[i] (owner == NULL: block 0).  Writes idx_out[i] (int64) and
+ * score_out[i] (float32) in one launch (replaces a fancy-index gather + two element-wise conversions per step). */
+int aae_unpack_pairs(const int64_t* gathered, const int32_t* owner, int n, int rows_per_rank, int64_t* idx_out, float* score_out,
+                     void* stream);
 
 /* ---- Caller side ("next" row N1): detector crops for a whole image in one launch -------------
  * AePoseEstimator.extract_square_patch(black_borders=True) + cv2.resize(INTER_LINEAR)

@@ -27,3 +27,12 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if 'gpu' in item.keywords:
             item.add_marker(skip)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """GPU parity runs leave their measured flip counts / gaps / layer errors in gpurun_out/parity_report.json."""
+    try:
+        import parity_report
+        parity_report.dump()
+    except Exception:
+        pass

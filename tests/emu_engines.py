@@ -40,6 +40,13 @@ class EmuEncoderEngine(object):
         z, idx, score = eb.encode_nn(self._e, codebook_engine._c, x, col_stride)
         return torch.from_numpy(z), torch.from_numpy(idx), torch.from_numpy(score)
 
+    def settle(self):
+        """engine.EncoderEngine.settle(): the double runs exact fp32 synchronously, nothing is ever pending"""
+        return 0
+
+    def encode_checked(self, x):
+        return self.encode(x)
+
     def activation(self, layer):
         return torch.from_numpy(self._e.activation(layer))
 

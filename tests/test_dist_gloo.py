@@ -73,6 +73,29 @@ def _worker(rank, world, port, out_dir):
     assert torch.equal(idx, idx2) and torch.equal(score, score2) and sum(writes) == sum(len(v) for v in mine.values())
     idx3, _ = eng2.infer(mine, class_ids)                     # the cached routing plan of an unchanged batch layout
     assert torch.equal(idx3, idx)
+    # the one-launch way back (engine.unpack_pairs on the GPU) as a CPU double: same answers, outputs owned by the plan and
+    # re-used by the next call with the same layout (no allocation per step)
+    def unpack(gathered, owner, n, rows_per_rank, idx_out, score_out):
+        g = gathered.view(-1, rows_per_rank, 2)
+        own = owner.long() if owner is not None else torch.zeros(n, dtype=torch.int64)
+        idx_out[:n] = g[own, torch.arange(n), 0]
+        score_out[:n] = g[own, torch.arange(n), 1].to(torch.int32).view(torch.float32)
+
+    eng3 = ShardedPoseEngine(infer, pack_pairs=pack, unpack_pairs=unpack)
+    idx4, score4 = eng3.infer(mine, class_ids)
+    assert torch.equal(idx4, idx) and torch.equal(score4, score)
+    ptrs = (idx4.data_ptr(), score4.data_ptr(), eng3._plan[3]['packed'].data_ptr(), eng3._plan[3]['gathered'].data_ptr())
+    idx5, score5 = eng3.infer(mine, class_ids)
+    assert (idx5.data_ptr(), score5.data_ptr(), eng3._plan[3]['packed'].data_ptr(), eng3._plan[3]['gathered'].data_ptr()) == ptrs
+    assert torch.equal(idx5, idx) and torch.equal(score5, score)
+    # an explicit single-rank engine inside this 2-rank job is a LOCAL engine: it never enters the collective (the
+    # other rank does not call it here -- a gather would hang or fail on the size mismatch)
+    if rank == 0:
+        solo = ShardedPoseEngine(base, world_size=1, rank=0)
+        si, ss = solo.infer(z, class_ids)
+        assert torch.equal(si, idx) and torch.equal(ss, score)
+    with pytest.raises(ValueError):
+        ShardedPoseEngine(base, world_size=3)                 # disagrees with the initialised group
     np.savez(os.path.join(out_dir, 'rank%d.npz' % rank), idx=idx.numpy(), score=score.numpy(), calls=np.array(sorted(set(calls))))
     dist.destroy_process_group()
 

@@ -528,6 +528,18 @@ def test_f32x3h_range_flag_on_the_emulated_kernels():
             enc.set_option('precision', 1)
             z = enc.forward(x)
             assert flag(enc) == want and flag(enc) == 0, (layer, frac)
+            # the per-forward form: every f32x3h forward owns a slot; one poll reads (and clears) several of them
+            slots = []
+            for _ in range(3):
+                enc.forward(x)
+                slots.append(enc.L.aae_encoder_x3h_last_slot())
+            assert len(set(slots)) == 3 and min(slots) >= 0
+            arr, out = (ctypes.c_int * 3)(*slots), (ctypes.c_int * 3)()
+            assert enc.L.aae_encoder_x3h_poll(enc.h, arr, 3, out, None) == 0 and list(out) == [want] * 3
+            assert enc.L.aae_encoder_x3h_poll(enc.h, arr, 3, out, None) == 0 and list(out) == [0, 0, 0]
+            enc.set_option('precision', 0)
+            enc.forward(x)
+            assert enc.L.aae_encoder_x3h_last_slot() == -1
             if not want:
                 z64 = ref.encoder_forward_np(ref.input_to_float(x), ws, cfg.strides, False)
                 assert np.abs(z - z64).max() / np.abs(z64).max() < 5e-6

@@ -104,6 +104,12 @@ class _RowEncoder(object):
         idx, score = codebook_engine.nn(z, 1, col_stride)
         return z, idx, score
 
+    def encode_checked(self, x):
+        return self.encode(x)
+
+    def settle(self):
+        return 0
+
 
 class _RecordedScan(object):
     """nn(z, topk, stride): the codebook scan answered from the recorded similarity matrix."""

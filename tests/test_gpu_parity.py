@@ -11,11 +11,13 @@ import pytest
 
 from oracle import reference_cpu as ref
 from oracle import synth
+import parity_report as report
 
 pytestmark = pytest.mark.gpu
 
 COS_TOL = 1e-5
-GAP_TOL = 2e-5          # 2 x COS_TOL: below this the fp32 result may legitimately flip
+GAP_TOL = 2e-5          # 2 x COS_TOL: the hard bound -- a differing index above this gap fails
+STRICT_GAP_TOL = 2e-6   # SURVEY 8c's figure: flips between the two are counted and reported (parity_report.json)
 STRIDES = [2, 2, 2, 2]
 
 
@@ -36,15 +38,60 @@ def default_model():
     return weights, enc, cb, E, dataset
 
 
-def _check_indices(got, cs64, upright_stride=1):
+def _check_indices(got, cs64, upright_stride=1, where=''):
+    """Tie-aware index equality against the fp64 oracle's similarity.  A differing index FAILS when the oracle's own
+    top-2 gap is >= GAP_TOL (2e-5); differences below that are counted at both thresholds -- SURVEY 8c's 2e-6 and the
+    hard bound -- and land in gpurun_out/parity_report.json (tests/parity_report.py), with a warning when one sits
+    between the two."""
     cs = cs64[:, ::upright_stride]
     want = np.argmax(cs, axis=1) * upright_stride
-    srt = np.sort(cs, axis=1)
-    gap = srt[:, -1] - srt[:, -2]
-    bad = [(b, int(got[b]), int(want[b]), float(gap[b])) for b in range(len(want))
-           if int(got[b]) != int(want[b]) and gap[b] >= GAP_TOL]
+    part = np.partition(cs, cs.shape[1] - 2, axis=1)
+    gap = part[:, -1] - part[:, -2]
+    got = np.asarray(got).reshape(-1)
+    diff = np.flatnonzero(got != want)
+    bad = [(int(b), int(got[b]), int(want[b]), float(gap[b])) for b in diff if gap[b] >= GAP_TOL]
     assert not bad, 'index mismatch outside near-ties (b, got, want, gap): %s' % bad[:5]
-    return int(np.sum(np.asarray(got) != want))
+    # a flipped answer must itself be a (near-)maximum of the oracle's row
+    for b in diff:
+        assert cs64[b, got[b]] >= cs64[b, want[b]] - GAP_TOL and got[b] % upright_stride == 0
+    loose = int(np.sum(gap[diff] >= STRICT_GAP_TOL))
+    report.record('indices', where or report.current_test(), queries=int(len(want)), stride=int(upright_stride), flips=int(len(diff)),
+                  flips_with_gap_above_2e6=loose, min_gap=float(gap.min()), median_gap=float(np.median(gap)))
+    if loose:
+        import warnings
+        warnings.warn('%s: %d index flips where the fp64 top-2 gap lies in [2e-6, 2e-5)' % (where or report.current_test(), loose))
+    return int(len(diff))
+
+
+def _check_topk(got, cs64, k, where=''):
+    """Tie-aware top-k equality: the oracle's canonical list (descending score, lowest row among equals) position by
+    position, a different row accepted only where its fp64 score is within GAP_TOL of the wanted one."""
+    got = np.asarray(got).reshape(len(cs64), k)
+    want = ref.topk_canonical(cs64, k)
+    swaps = 0
+    for b in range(len(cs64)):
+        assert len(set(got[b].tolist())) == k, 'duplicate rows in a top-k answer: %s' % got[b]
+        for j in range(k):
+            if got[b, j] != want[b, j]:
+                swaps += 1
+                d = abs(float(cs64[b, got[b, j]]) - float(cs64[b, want[b, j]]))
+                assert d < GAP_TOL, 'top-%d position %d of query %d: got row %d, oracle row %d, fp64 scores differ by %.3e' % (k, j, b, got[b, j], want[b, j], d)
+    report.record('topk', where or report.current_test(), queries=int(len(cs64)), k=int(k), swapped_positions=int(swaps))
+    return swaps
+
+
+def _check_layer(g, a, where, tol=2e-5, tol_l2=1e-5):
+    """Layer output against the fp64 oracle in two norms: max|d| / max|a| (the bound an fp32 accumulation over K terms
+    can meet for every element) and ||d||_2 / ||a||_2 (which small activations cannot hide behind one large one)."""
+    g = np.asarray(g, dtype=np.float64)
+    a = np.asarray(a, dtype=np.float64)
+    assert g.shape == a.shape, (g.shape, a.shape)
+    e_max = float(np.abs(g - a).max() / np.abs(a).max())
+    e_l2 = float(np.linalg.norm((g - a).ravel()) / np.linalg.norm(a.ravel()))
+    report.record('layers', where, max_rel=e_max, l2_rel=e_l2)
+    assert e_max < tol, '%s: max-norm rel err %.3e' % (where, e_max)
+    assert e_l2 < tol_l2, '%s: l2 rel err %.3e' % (where, e_l2)
+    return e_max, e_l2
 
 
 def test_encoder_layers_match_fp64_oracle(default_model):
@@ -53,11 +100,8 @@ def test_encoder_layers_match_fp64_oracle(default_model):
     z = enc.engine.encode(crops).cpu().numpy()
     z64, acts = ref.encoder_forward_torch(ref.input_to_float(crops), weights, STRIDES, False, 'float64', return_activations=True)
     for i, a in enumerate(acts):
-        g = enc.engine.activation(i).cpu().numpy()
-        assert g.shape == a.shape
-        err = np.abs(g - a).max() / np.abs(a).max()
-        assert err < 2e-5, 'layer %d rel err %.3e' % (i, err)
-    assert np.abs(z - z64).max() / np.abs(z64).max() < 2e-5
+        _check_layer(enc.engine.activation(i).cpu().numpy(), a, 'B=8 layer %d' % i)
+    _check_layer(z, z64, 'B=8 latent')
 
 
 def test_uint8_and_float_inputs_agree_bitwise(default_model):
@@ -125,19 +169,15 @@ def test_headline_kernels_on_the_bench_inputs_match_fp64_oracle(bench_inputs_and
                 'dense:conv_igemm_x3h_dma_splitk', 'dense:splitk_reduce']
     assert len(labels) == len(want) and all(l.startswith(w) for l, w in zip(labels, want)), labels
     for i, a in enumerate(acts):
-        g = enc.activation(i).cpu().numpy()
-        assert g.shape == a.shape
-        err = np.abs(g - a).max() / np.abs(a).max()
-        assert err < 2e-5, 'layer %d rel err %.3e' % (i, err)
-        del g
+        _check_layer(enc.activation(i).cpu().numpy(), a, 'bench inputs precision %d layer %d' % (precision, i))
     zh = z.cpu().numpy()
     assert zh.shape == (B, 128)
-    assert np.abs(zh - z64).max() / np.abs(z64).max() < 2e-5
+    _check_layer(zh, z64, 'bench inputs precision %d latent' % precision)
     cs = cb.similarity(z).cpu().numpy()
     assert np.abs(cs - cs64).max() <= COS_TOL, 'cosine error %.3e' % np.abs(cs - cs64).max()
     idx, score = cb.nn(z, 1, 1)
     idx, score = idx[:, 0].cpu().numpy(), score[:, 0].cpu().numpy()
-    _check_indices(idx, cs64)
+    _check_indices(idx, cs64, where='bench inputs precision %d' % precision)
     assert np.array_equal(idx, np.argmax(cs, axis=1))
     assert np.abs(score - cs64.max(axis=1)).max() <= COS_TOL
     enc.close()
@@ -187,16 +227,26 @@ def test_every_codebook_row_finds_itself(default_model):
 
 
 def test_upright_and_topk(default_model):
+    """upright (codebook.py:65-66) and top-n (:69-71) against the fp64 ORACLE's similarity (tie-aware), and -- exactly --
+    against selections over the kernel's own similarity."""
     weights, enc, cb, E, dataset = default_model
     from augmentedautoencoder_amd import session as S
     crops = synth.make_crops(6, seed=77)
+    z64 = ref.encoder_forward_torch(ref.input_to_float(crops), weights, STRIDES, False, 'float64')
+    cs64 = ref.cos_similarity(z64, E)
     cs = S.Session().run(cb.cos_similarity, {enc.x: crops})
+    assert np.abs(cs - cs64).max() <= COS_TOL
     up = cb.nearest_rotation(None, crops, upright=True, return_idcs=True)
+    _check_indices(up, cs64, 36, where='upright B=6')
     assert np.array_equal(up, ref.nearest_indices_reference(cs, 1, upright=True, num_cyclo=36))
     assert np.all(up % 36 == 0)
-    for k in (2, 8):
+    for b in (1, 3):                                      # per-detection batches: the stream kernel over the compacted copy
+        upb = cb.nearest_rotation(None, crops[:b], upright=True, return_idcs=True)
+        _check_indices(np.atleast_1d(upb), cs64[:b], 36, where='upright B=%d' % b)
+    for k in (2, 5, 8):
         got = cb.nearest_rotation(None, crops[0], top_n=k, return_idcs=True)
         assert got.shape == (k,)
+        _check_topk(got, cs64[:1], k, where='top-%d B=1' % k)
         assert np.array_equal(got, ref.topk_canonical(cs[:1], k)[0])
         # the reference's own (argpartition + argsort) answer agrees wherever scores are distinct
         want = ref.nearest_indices_reference(cs[:1], k)
@@ -210,14 +260,119 @@ def test_upright_and_topk(default_model):
     from augmentedautoencoder_amd import _lib
     z = enc.engine.encode(crops)
     cs_dev = cb.engine.similarity(z).cpu().numpy()
-    for k in (3, 5, 8):
+    for k in (2, 3, 5, 8):
         ik, sk = cb.engine.nn(z, k, 1)
         ik, sk = ik.cpu().numpy(), sk.cpu().numpy()
+        _check_topk(ik, cs64, k, where='top-%d B=6 (in-scan lists)' % k)
+        assert np.abs(sk - np.take_along_axis(cs64, ik, axis=1)).max() <= COS_TOL
         assert np.array_equal(ik, ref.topk_canonical(cs_dev, k)) and np.array_equal(sk, np.take_along_axis(cs_dev, ik, axis=1))
         cb.engine.set_scan_mode(_lib.AAE_SCAN_MFMA)
         im, sm = cb.engine.nn(z, k, 1)
         cb.engine.set_scan_mode(_lib.AAE_SCAN_AUTO)
         assert np.array_equal(im.cpu().numpy(), ik) and np.array_equal(sm.cpu().numpy(), sk)
+
+
+def _small_rotations(rng, n, lo_deg, hi_deg):
+    """n rotation matrices about random axes by angles uniform in [lo, hi] degrees (Rodrigues)."""
+    axis = rng.standard_normal((n, 3))
+    axis /= np.linalg.norm(axis, axis=1, keepdims=True)
+    ang = np.deg2rad(rng.uniform(lo_deg, hi_deg, n))
+    K = np.zeros((n, 3, 3))
+    K[:, 0, 1], K[:, 0, 2], K[:, 1, 0], K[:, 1, 2], K[:, 2, 0], K[:, 2, 1] = -axis[:, 2], axis[:, 1], axis[:, 2], -axis[:, 0], -axis[:, 1], axis[:, 0]
+    s, c = np.sin(ang)[:, None, None], np.cos(ang)[:, None, None]
+    return np.eye(3)[None] + s * K + (1.0 - c) * (K @ K)
+
+
+def test_realistic_full_size_codebook_built_by_the_encoder(default_model):
+    """Index parity where it is hard: a codebook that is a smooth manifold, not iid rows.  E is built as
+    ae_embed builds it (codebook.py:190-219) -- the HIP encoder over all 92232 smoothly varying views of the synthetic
+    view source, float64 row normalisation, float32 storage -- and queried with 256 views at rotations BETWEEN the
+    codebook's (0.3-6 degrees off a row, plus pixel noise).  Every cosine of the 256 x 92232 slice and every index
+    (arg-max, upright, top-5/8, and the per-detection path at B = 1, 4) against the fp64 oracle on the same E; flip
+    counts at 2e-6 and 2e-5 and the gap statistics go to gpurun_out/parity_hard.json."""
+    import json
+    import os
+    import torch
+    from augmentedautoencoder_amd.dataset import SyntheticViewSource
+    from augmentedautoencoder_amd.engine import CodebookEngine
+    weights, enc, _, _, dataset = default_model
+    eng = enc.engine
+    Rs = dataset.viewsphere_for_embedding
+    N = len(Rs)
+    assert N == 92232
+    src = SyntheticViewSource(dataset.shape, seed=1)
+    Z = torch.empty((N, 128), dtype=torch.float32, device=eng.device)
+    for a in range(0, N, 1024):
+        Z[a:a + 1024] = eng.encode(src.torch_batch(Rs[a:a + 1024], eng.device))
+    E = ref.normalize_codebook(Z.cpu().numpy())
+    twins = sum(bool(np.array_equal(E[r], E[r + 35])) for r in range(0, N, 36))
+    cb = CodebookEngine(E)
+    rng = np.random.default_rng(2025)
+    B = 256
+    rows = rng.choice(N, B, replace=False)
+    Rq = _small_rotations(rng, B, 0.3, 6.0) @ Rs[rows]
+    noise = torch.from_numpy(rng.normal(0.0, 3.0, (B,) + tuple(dataset.shape))).to(eng.device)
+    crops = src.torch_batch(Rq, eng.device, noise=noise)
+    z = eng.encode(crops)
+    cs = cb.similarity(z).cpu().numpy()
+    idx, score = cb.nn(z, 1, 1)
+    idx, score = idx[:, 0].cpu().numpy(), score[:, 0].cpu().numpy()
+    z64 = ref.encoder_forward_torch(ref.input_to_float(crops.cpu().numpy()), weights, STRIDES, False, 'float64')
+    cs64 = ref.cos_similarity(z64, E)
+    cos_err = float(np.abs(cs - cs64).max())
+    assert cos_err <= COS_TOL, 'cosine error %.3e on the realistic codebook' % cos_err
+    assert np.abs(score - cs64.max(axis=1)).max() <= COS_TOL
+    flips = _check_indices(idx, cs64, where='realistic codebook B=256')
+    assert np.array_equal(idx, np.argmax(cs, axis=1))
+    # gap statistics with the exact twin of the winner (rows 36k / 36k+35 are one rotation) taken out
+    best = np.argmax(cs64, axis=1)
+    twin = np.where(best % 36 == 0, best + 35, np.where(best % 36 == 35, best - 35, best))
+    masked = cs64.copy()
+    masked[np.arange(B), best] = -np.inf
+    masked[np.arange(B), twin] = -np.inf
+    gap = cs64[np.arange(B), best] - masked.max(axis=1)
+    part = np.partition(cs64, N - 2, axis=1)
+    raw_gap = part[:, -1] - part[:, -2]
+    wrong = idx != best
+    up, _ = cb.nn(z, 1, 36)
+    flips_up = _check_indices(up[:, 0].cpu().numpy(), cs64, 36, where='realistic codebook upright B=256')
+    swaps = {}
+    for k in (5, 8):
+        ik, sk = cb.nn(z, k, 1)
+        swaps[k] = _check_topk(ik.cpu().numpy(), cs64, k, where='realistic codebook top-%d B=256' % k)
+        assert np.abs(sk.cpu().numpy() - np.take_along_axis(cs64, ik.cpu().numpy(), axis=1)).max() <= COS_TOL
+    small = {}
+    for b in (1, 4):                                     # the per-detection chain (fused aae_encode_nn) on the same codebook
+        zb, ib, sb = eng.encode_nn(cb, crops[:b], 1)
+        zb64 = z64[:b]
+        assert np.abs(zb.cpu().numpy() - zb64).max() / np.abs(zb64).max() < 2e-5
+        small[b] = _check_indices(ib[:, 0].cpu().numpy(), cs64[:b], where='realistic codebook fused B=%d' % b)
+        assert np.abs(sb[:, 0].cpu().numpy() - cs64[:b].max(axis=1)).max() <= COS_TOL
+        ub = eng.encode_nn(cb, crops[:b], 36)[1]
+        _check_indices(ub[:, 0].cpu().numpy(), cs64[:b], 36, where='realistic codebook fused upright B=%d' % b)
+    # every view of the codebook retrieves its own row (or its lower twin)
+    own = rng.choice(N, 256, replace=False)
+    io, so = cb.nn(eng.encode(src.torch_batch(Rs[own], eng.device)), 1, 1)
+    io = io[:, 0].cpu().numpy()
+    for got, want in zip(io, own):
+        assert got == want or (abs(int(got) - int(want)) == 35 and np.array_equal(E[got], E[want]) and got < want), (got, want)
+    assert np.abs(so.cpu().numpy() - 1.0).max() < 1e-5
+    out = {
+        'codebook': '92232 x 128 fp32, rows = HIP encoder over SyntheticViewSource(seed 1) views of the reference viewsphere, float64 normalise',
+        'queries': '256 views 0.3-6 deg off a codebook rotation + N(0, 3) pixel noise, B=256 in one chunk',
+        'exact_twin_pairs_in_codebook': int(twins), 'max_cosine_abs_err_256xN': cos_err,
+        'flips_total': int(flips), 'flips_at_2e-6': int(np.sum(wrong & (raw_gap >= STRICT_GAP_TOL))), 'flips_at_2e-5': int(np.sum(wrong & (raw_gap >= GAP_TOL))),
+        'min_gap_raw': float(raw_gap.min()), 'min_gap_without_exact_twin': float(gap.min()), 'median_gap_without_exact_twin': float(np.median(gap)),
+        'queries_with_gap_below_1e-4': int(np.sum(gap < 1e-4)), 'queries_with_gap_below_2e-5': int(np.sum(gap < GAP_TOL)),
+        'upright_flips': int(flips_up), 'top5_swapped_positions': int(swaps[5]), 'top8_swapped_positions': int(swaps[8]),
+        'fused_B1_flips': int(small[1]), 'fused_B4_flips': int(small[4]),
+        'nearest_row_is_the_perturbed_one_or_its_view_neighbour': float(np.mean(np.abs(best // 36 - rows // 36) == 0)),
+    }
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'gpurun_out', 'parity_hard.json')
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, 'w') as f:
+        json.dump(out, f, indent=1, sort_keys=True)
+    cb.close()
 
 
 def test_test_embedding_and_ops(default_model):
@@ -265,9 +420,8 @@ def test_other_encoder_configs(case):
     z = eng.encode(crops).cpu().numpy()
     z64, acts = ref.encoder_forward_np(ref.input_to_float(crops), w, cfg.strides, cfg.batch_norm, return_activations=True)
     for i, a in enumerate(acts):
-        g = eng.activation(i).cpu().numpy()
-        assert np.abs(g - a).max() / np.abs(a).max() < 2e-5, 'layer %d' % i
-    assert np.abs(z - z64).max() / np.abs(z64).max() < 2e-5
+        _check_layer(eng.activation(i).cpu().numpy(), a, '%s layer %d' % (case, i))
+    _check_layer(z, z64, '%s latent' % case)
     eng.close()
 
 
@@ -374,9 +528,8 @@ def test_split_precision_f32x3h_mode_meets_the_same_tolerances(dma):
         z64, acts = ref.encoder_forward_torch(ref.input_to_float(crops), weights, STRIDES, False, 'float64', return_activations=True)
         if B == 5:
             for i, a in enumerate(acts):
-                g = enc.activation(i).cpu().numpy()
-                assert np.abs(g - a).max() / np.abs(a).max() < 2e-5, 'layer %d' % i
-        assert np.abs(z.cpu().numpy() - z64).max() / np.abs(z64).max() < 2e-5
+                _check_layer(enc.activation(i).cpu().numpy(), a, 'f32x3h dma=%d B=5 layer %d' % (dma, i))
+        _check_layer(z.cpu().numpy(), z64, 'f32x3h dma=%d B=%d latent' % (dma, B))
         cs64 = ref.cos_similarity(z64, E)
         cs = cb.similarity(z).cpu().numpy()
         assert np.abs(cs - cs64).max() <= COS_TOL
@@ -528,9 +681,8 @@ def test_non_default_network_shapes_on_the_matrix_core_kernels(kw):
     z, recs = enc.encode_timed(x)
     z64, acts = ref.encoder_forward_torch(ref.input_to_float(x), w, cfg.strides, cfg.batch_norm, 'float64', return_activations=True)
     for i, a in enumerate(acts):
-        g = enc.activation(i).cpu().numpy()
-        assert np.abs(g - a).max() / np.abs(a).max() < 2e-5, 'layer %d (%s)' % (i, [l for l, _, _ in recs])
-    assert np.abs(z.cpu().numpy() - z64).max() / np.abs(z64).max() < 2e-5
+        _check_layer(enc.activation(i).cpu().numpy(), a, 'shape %s layer %d' % (cfg.shape, i))
+    _check_layer(z.cpu().numpy(), z64, 'shape %s latent' % (cfg.shape,))
     assert all('generic' not in l for l, _, _ in recs)                 # all on the MFMA kernels
     enc.set_option('precision', 1)
     z3 = enc.encode(x).cpu().numpy()
@@ -712,10 +864,8 @@ def test_small_batch_wave_split_k_path_matches_fp64_oracle(default_model, B):
         assert any(':conv_wavek_f32_' in l for l in labels) and any('splitk' in l for l in labels), labels
     z64, acts = ref.encoder_forward_torch(ref.input_to_float(crops), weights, STRIDES, False, 'float64', return_activations=True)
     for i, a in enumerate(acts):
-        g = enc.engine.activation(i).cpu().numpy()
-        err = np.abs(g - a).max() / np.abs(a).max()
-        assert err < 2e-5, 'layer %d rel err %.3e (%s)' % (i, err, labels)
-    assert np.abs(z.cpu().numpy() - z64).max() / np.abs(z64).max() < 2e-5
+        _check_layer(enc.engine.activation(i).cpu().numpy(), a, 'small batch B=%d layer %d' % (B, i))
+    _check_layer(z.cpu().numpy(), z64, 'small batch B=%d latent' % B)
     cs64 = ref.cos_similarity(z64, E)
     cs = cb.engine.similarity(z).cpu().numpy()
     assert np.abs(cs - cs64).max() <= COS_TOL
@@ -884,7 +1034,9 @@ def test_f32x3h_adversarial_ranges_and_the_saturation_fallback():
     x64 = ref.input_to_float(crops)
 
     def check(enc, weights, bn, what):
-        z = enc.encode(crops).cpu().numpy()
+        z = enc.encode(crops)
+        assert enc.settle() == 0
+        z = z.cpu().numpy()
         z64, acts = ref.encoder_forward_torch(x64, weights, STRIDES, bn, 'float64', return_activations=True)
         for i, a in enumerate(acts):
             g = enc.activation(i).cpu().numpy()
@@ -944,11 +1096,43 @@ def test_f32x3h_adversarial_ranges_and_the_saturation_fallback():
             enc.x3h_fallback = True
             with warnings.catch_warnings(record=True) as caught:
                 warnings.simplefilter('always')
-                z = enc.encode(crops)
+                z = enc.encode(crops)                                 # queued without a host round trip ...
+                assert enc.x3h_fallbacks == 0 and len(enc._x3h_pending) == 1
+                assert enc.settle() == 1 and enc.settle() == 0        # ... checked (and redone in place) when the result is consumed
             assert torch.equal(z, z32) and enc.x3h_fallbacks == 1 and any('f32x3h' in str(c.message) for c in caught)
             assert enc.options['precision'] == 1                      # the mode itself stays selected
             z64 = ref.encoder_forward_torch(x64, ws, STRIDES, False, 'float64')
             assert np.abs(z.cpu().numpy() - z64).max() / np.abs(z64).max() < 2e-5
+            # several forwards in flight, only the middle one out of range: one settle() finds exactly that one
+            dark = np.zeros_like(crops)
+            enc.set_option('precision', 0)
+            zd32 = enc.encode(dark).clone()
+            enc.set_option('precision', 1)
+            zd_split = enc.encode(dark).clone()
+            assert enc.settle() == 0
+            za, zb, zc = enc.encode(dark), enc.encode(crops), enc.encode(dark)
+            assert len(enc._x3h_pending) == 3 and enc.settle() == 1 and enc.x3h_fallbacks == 2
+            assert torch.equal(zb, z32) and torch.equal(za, zd_split) and torch.equal(zc, zd_split)
+            assert np.abs(zd_split.cpu().numpy() - zd32.cpu().numpy()).max() / np.abs(zd32.cpu().numpy()).max() < 2e-5
+            # fused per-detection call and the reference-shaped API: the check rides along with the result copy
+            from augmentedautoencoder_amd.engine import CapturedNearestNeighbour, CodebookEngine
+            cbe = CodebookEngine(synth.make_codebook(36 * 512, 128, seed=7))
+            enc.set_option('precision', 0)
+            _, i32, s32 = enc.encode_nn(cbe, crops, 1)
+            i32, s32 = i32.clone(), s32.clone()
+            enc.set_option('precision', 1)
+            _, i1, s1 = enc.encode_nn(cbe, crops, 1)
+            assert enc.settle() == 1 and torch.equal(i1, i32) and torch.equal(s1, s32)
+            # a HIP graph captured in split-precision mode: every replay looks at the recorded forward's own flag
+            cap = CapturedNearestNeighbour(enc, cbe, 4)
+            before = enc.x3h_fallbacks
+            ic, sc = cap(crops)
+            assert cap._x3h_slot >= 256 and enc.x3h_fallbacks == before + 1 and torch.equal(ic, i32) and torch.equal(sc, s32)
+            ic, sc = cap(dark)                                        # in range: the replay's own (f32x3h) answer stands
+            assert enc.x3h_fallbacks == before + 1
+            _, id1, sd1 = enc.encode_nn(cbe, dark, 1)
+            assert enc.settle() == 0 and torch.equal(ic, id1) and torch.equal(sc, sd1)
+            cbe.close()
         enc.close()
 
 
