@@ -7,4 +7,9 @@
 #define AAE_LAUNCH(kernel, grid, block, smem, stream, ...) \
     hipLaunchKernelGGL(kernel, (grid), (block), (smem), (stream), __VA_ARGS__)
 
+// a launch whose blocks must all be resident at once (grid-wide waits inside the kernel): the host sizes its grid to the
+// chip; on the GPU it is an ordinary launch (the CPU emulator of tests/emu/ runs such grids side by side)
+#define AAE_LAUNCH_RESIDENT(kernel, grid, block, smem, stream, ...) \
+    hipLaunchKernelGGL(kernel, (grid), (block), (smem), (stream), __VA_ARGS__)
+
 #include "aae_hip_impl.h"

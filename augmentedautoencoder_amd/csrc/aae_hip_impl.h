@@ -31,6 +31,7 @@
 #include "kernels/codebook_scan_bf16.h"
 #include "kernels/codebook_scan_resident.h"
 #include "kernels/crop_resize_u8.h"
+#include "kernels/detect_chain.h"
 
 namespace aae_host {
 
@@ -152,6 +153,10 @@ struct aae_encoder {
     int wavek_ablate = 0;                  // timing experiments (conv_wavek_f32.h ConvWaveKArgs::ablate); results are wrong when != 0
     int gemv_ticket = 1;                   // dense GEMV (B <= 4): chunk sums finished by the last block instead of a reduce launch
     int wavek_dense = 1;                   // dense layer (B > 4) on the wave-split-K kernel instead of split-K igemm + reduce launch
+    // per-detection batches (B <= 4): everything behind conv1 as ONE persistent launch (detect_chain.h); 0 = six launches
+    int detect_chain = 1;
+    int detect_chain_blocks = 256;         // its grid: one block per CU, never more than the device has (every block must be resident)
+    int cu_count = 0;                      // compute units of the device the handle lives on
 };
 
 struct aae_codebook {
@@ -310,10 +315,12 @@ static unsigned next_nonce() {
 // Ticket words at the front of every encoder workspace: a range of single words per layer (conv layers 0..7, then
 // the dense layer) for the wave-split-K tiles, then one two-level slot per 128-column tile of the dense GEMV.  Every
 // ticketed launch has its own words, so the first kernel of a forward can prepare all of them (TicketPrep).
+constexpr int kChainMaxBlocks = 1024;       // upper bound of the persistent per-detection launch's grid (option detect_chain_blocks)
 constexpr int kGemvTicketSlots = 8;
 constexpr int kLayerTicketWords = 256;     // per layer: one word per output tile of a split layer (split => at most 128 tiles)
 constexpr size_t kConvTicketBytes = (size_t)(AAE_MAX_LAYERS + 1) * kLayerTicketWords * 8;
-constexpr size_t kTicketBytes = kConvTicketBytes + (size_t)kGemvTicketSlots * aae::kTicketSlotWords * 8;
+constexpr size_t kGemvTicketBytes = (size_t)kGemvTicketSlots * aae::kTicketSlotWords * 8;
+constexpr size_t kTicketBytes = kConvTicketBytes + kGemvTicketBytes + (size_t)aae::kGridBarrierWords * 8;    // ... then the grid barrier of the persistent per-detection launch
 
 // Launch plan of the wave-split-K igemm (conv_wavek_f32.h) for a layer at M rows, or use == false.
 struct WaveKPlan {
@@ -382,6 +389,9 @@ struct Workspace {
     std::vector<size_t> act_off;   // per conv layer
     size_t ticket_off = 0;
     size_t partial_off = 0, partial_bytes = 0;
+    // B <= 4: one partial region PER split layer (conv layers, then the dense layer) for the persistent per-detection launch --
+    // inside one launch no buffer may be written twice (detect_chain.h)
+    std::vector<size_t> chain_partial_off;
     size_t total = 0;
 };
 
@@ -435,6 +445,20 @@ static Workspace plan_workspace(const aae_encoder* enc, int B) {
     ws.partial_off = off;
     ws.partial_bytes = partial;
     off += align_up(partial, 256);
+    if (B <= 4) {
+        for (size_t li = 0; li <= enc->layers.size(); ++li) {
+            const bool dense = li == enc->layers.size();
+            const Layer& L = dense ? enc->dense : enc->layers[li];
+            size_t bytes = 0;
+            if (L.kind == KIND_IGEMM) {
+                const WaveKPlan wk = plan_wavek(enc, L, dense ? B : (long long)B * L.Ho * L.Wo, false);
+                if (wk.use) bytes = wk.partial_bytes;
+                if (dense) bytes = std::max(bytes, (size_t)ceil_div((int)L.K(), aae::kGemvChunk) * B * L.Cout * sizeof(float));
+            }
+            ws.chain_partial_off.push_back(off);
+            off += align_up(bytes, 256);
+        }
+    }
     ws.total = off;
     return ws;
 }
@@ -545,8 +569,8 @@ static void launch_wavek_t(const aae::ConvWaveKArgs& a, int tag, int nblk, hipSt
     }
 }
 
-static int launch_wavek(aae_encoder* enc, const Layer& L, const WaveKPlan& w, const float* x, int M, float* out, float* partial,
-                        unsigned long long* tickets, unsigned nonce, hipStream_t stream, Timer& tm, const char* name, int tag) {
+static aae::ConvWaveKArgs wavek_args(const aae_encoder* enc, const Layer& L, const WaveKPlan& w, const float* x, int M, float* out, float* partial,
+                                     unsigned long long* tickets, unsigned nonce, int tag) {
     aae::ConvWaveKArgs a;
     a.x = x; a.wp = L.wp; a.bias = L.bias; a.bn_scale = L.bn_scale; a.bn_shift = L.bn_shift; a.out = out;
     a.partial = partial; a.partial_bytes = (unsigned)w.partial_bytes; a.tickets = tickets; a.nonce = nonce;
@@ -558,6 +582,12 @@ static int launch_wavek(aae_encoder* enc, const Layer& L, const WaveKPlan& w, co
     a.slabs_total = (int)(L.K() / 32);
     a.wp_bytes = (unsigned)((unsigned long long)a.slabs_total * 8ull * L.CoutPad * 16ull);
     a.num_mt = w.num_mt; a.num_nt = w.num_nt; a.gsplits = w.gsplits;
+    return a;
+}
+
+static int launch_wavek(aae_encoder* enc, const Layer& L, const WaveKPlan& w, const float* x, int M, float* out, float* partial,
+                        unsigned long long* tickets, unsigned nonce, hipStream_t stream, Timer& tm, const char* name, int tag) {
+    const aae::ConvWaveKArgs a = wavek_args(enc, L, w, x, M, out, partial, tickets, nonce, tag);
     const int nblk = w.num_mt * w.num_nt * w.gsplits;
     const int key = (w.MT == 1 ? 1000 : 0) + w.NT * 100 + w.waves * 10 + w.depth;
     switch (key) {
@@ -758,17 +788,23 @@ static bool gemv_uses_ticket(const aae_encoder* enc, const Layer& D) {
     return enc->gemv_ticket && D.Cout % 4 == 0 && D.CoutPad / 128 <= kGemvTicketSlots;
 }
 
-static int launch_dense_gemv(aae_encoder* enc, const Layer& D, const float* x, int B, float* out, float* partial,
-                             unsigned long long* tickets, unsigned nonce, hipStream_t stream, Timer& tm) {
+static aae::DenseGemvArgs gemv_args(const Layer& D, const float* x, int B, float* partial) {
     aae::DenseGemvArgs a;
     a.x = x; a.wp = D.wp; a.partial = partial; a.B = B; a.K = (int)D.K(); a.Cout = D.Cout; a.CoutPad = D.CoutPad;
     a.wp_bytes = (unsigned)((unsigned long long)(D.K() / 4) * D.CoutPad * 16ull);
+    a.partial_bytes = (unsigned)((size_t)ceil_div(a.K, aae::kGemvChunk) * B * D.Cout * sizeof(float));
+    a.bias = nullptr; a.bn_scale = nullptr; a.bn_shift = nullptr; a.out = nullptr; a.tickets = nullptr; a.nonce = 0; a.relu = 0;
+    return a;
+}
+
+static int launch_dense_gemv(aae_encoder* enc, const Layer& D, const float* x, int B, float* out, float* partial,
+                             unsigned long long* tickets, unsigned nonce, hipStream_t stream, Timer& tm) {
+    aae::DenseGemvArgs a = gemv_args(D, x, B, partial);
     const int chunks = ceil_div(a.K, aae::kGemvChunk);
     const dim3 grid(chunks, D.CoutPad / 128);
     const int MQ = B <= 2 ? B : (B == 3 ? 3 : 4);
     int smem = 2 * MQ * aae::kGemvChunk * (int)sizeof(float);
     const bool ticket = tickets && gemv_uses_ticket(enc, D);
-    a.partial_bytes = (unsigned)((size_t)chunks * B * D.Cout * sizeof(float));
     char label[96];
     if (ticket) {
         a.bias = D.bias; a.bn_scale = D.bn_scale; a.bn_shift = D.bn_shift; a.out = out;
@@ -808,11 +844,86 @@ struct ExtraTicketPrep {
     unsigned long long* words = nullptr;
     int count = 0;
     unsigned nonce = 0;
+    // aae_encode_nn, B <= 4, top-1 on the fp32 stream scan: the scan itself, ready to run as the last phase of the persistent
+    // per-detection launch (tickets / nonce = the words above)
+    bool scan_ready = false;
+    aae::ScanArgs scan;
 };
 
+// The persistent per-detection launch (detect_chain.h) serves a forward when every layer behind the first runs the
+// wave-split-K kernel in one of its three 4-wave / depth-2 shapes, the dense layer is the ticketed GEMV, and each layer
+// output has its own buffer.
+static bool chain_eligible(const aae_encoder* enc, int B, const std::vector<WaveKPlan>& plans, bool dense_gemv_ticket) {
+    const size_t nl = enc->layers.size();
+    if (!enc->detect_chain || B > 4 || nl < 2 || nl - 1 > (size_t)aae::kChainMaxConv || enc->compact_workspace || !dense_gemv_ticket) return false;
+    if (enc->wavek_ablate || enc->wavek_timeline) return false;               // (profiling aids of the stand-alone launches)
+    for (size_t li = 1; li < nl; ++li) {
+        const WaveKPlan& w = plans[li];
+        if (!w.use || w.waves != 4 || w.depth != 2 || enc->layers[li].Cout % 4 != 0) return false;
+        if (!((w.MT == 1 && w.NT == 1) || (w.MT == 2 && w.NT == 1) || (w.MT == 2 && w.NT == 2))) return false;
+    }
+    return enc->dense.Cout % 4 == 0;
+}
+
+static int launch_detect_chain(aae_encoder* enc, int B, const std::vector<WaveKPlan>& plans, const std::vector<unsigned>& nonces, unsigned gemv_nonce,
+                               unsigned barrier_nonce, const float* act0, unsigned char* base, const Workspace& ws, unsigned long long* tickets, float* z_out,
+                               const ExtraTicketPrep* extra, hipStream_t stream, Timer& tm) {
+    const size_t nl = enc->layers.size();
+    const Layer& D = enc->dense;
+    aae::DetectChainArgs a;
+    memset(&a, 0, sizeof(a));
+    a.nconv = (int)nl - 1;
+    const float* cur = act0;
+    double flops = 0.0;
+    for (size_t li = 1; li < nl; ++li) {
+        const Layer& L = enc->layers[li];
+        const WaveKPlan& w = plans[li];
+        float* out = reinterpret_cast<float*>(base + ws.act_off[li]);
+        a.conv[li - 1] = wavek_args(enc, L, w, cur, B * L.Ho * L.Wo, out, reinterpret_cast<float*>(base + ws.chain_partial_off[li]),
+                                    tickets + li * kLayerTicketWords, nonces[li], 0);
+        a.shape[li - 1] = (w.MT == 1) ? 0 : (w.NT == 1 ? 1 : 2);
+        flops += 2.0 * (double)B * L.Ho * L.Wo * (double)L.K() * L.Cout;
+        cur = out;
+    }
+    a.dense = gemv_args(D, cur, B, reinterpret_cast<float*>(base + ws.chain_partial_off[nl]));
+    a.dense.bias = D.bias; a.dense.bn_scale = D.bn_scale; a.dense.bn_shift = D.bn_shift; a.dense.out = z_out; a.dense.relu = D.relu;
+    a.dense.tickets = tickets + kConvTicketBytes / 8; a.dense.nonce = gemv_nonce;
+    a.dense_tiles = D.CoutPad / 128;
+    a.dense_chunks = ceil_div((int)D.K(), aae::kGemvChunk);
+    flops += 2.0 * B * (double)D.K() * D.Cout;
+    a.has_scan = (extra && extra->scan_ready) ? 1 : 0;
+    if (a.has_scan) {
+        a.scan = extra->scan;
+        flops += 2.0 * B * (double)a.scan.N * a.scan.J;
+    }
+    a.barrier.words = tickets + (kConvTicketBytes + kGemvTicketBytes) / 8;
+    a.barrier.nonce = barrier_nonce;
+    int grid = enc->detect_chain_blocks;
+    if (enc->cu_count > 0 && grid > enc->cu_count) grid = enc->cu_count;
+    if (grid < 1) grid = 1;
+    const int MQ = B <= 2 ? B : 4;
+    if (MQ == 1) {
+        (void)hipFuncSetAttribute((const void*)aae::detect_chain_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kChainSmem);
+        AAE_LAUNCH_RESIDENT((aae::detect_chain_kernel<1>), dim3(grid), dim3(256), aae::kChainSmem, stream, a);
+    } else if (MQ == 2) {
+        (void)hipFuncSetAttribute((const void*)aae::detect_chain_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kChainSmem);
+        AAE_LAUNCH_RESIDENT((aae::detect_chain_kernel<2>), dim3(grid), dim3(256), aae::kChainSmem, stream, a);
+    } else {
+        (void)hipFuncSetAttribute((const void*)aae::detect_chain_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kChainSmem);
+        AAE_LAUNCH_RESIDENT((aae::detect_chain_kernel<4>), dim3(grid), dim3(256), aae::kChainSmem, stream, a);
+    }
+    char label[128];
+    snprintf(label, sizeof(label), "chain:detect_chain_f32 B=%d blocks=%d phases=conv2..conv%zu+dense%s", B, grid, nl, a.has_scan ? "+scan" : "");
+    note_kernel({label, flops});
+    AAE_HIP_TRY(hipGetLastError());
+    return tm.mark();
+}
+
 static int forward_impl(aae_encoder* enc, const void* x, int x_dtype, int B, float* z_out, void* workspace,
-                        size_t ws_bytes, void* stream_v, Timer& tm, const ExtraTicketPrep* extra = nullptr, bool* extra_prepared = nullptr) {
+                        size_t ws_bytes, void* stream_v, Timer& tm, const ExtraTicketPrep* extra = nullptr, bool* extra_prepared = nullptr,
+                        bool* scan_done = nullptr) {
     if (extra_prepared) *extra_prepared = false;
+    if (scan_done) *scan_done = false;
     if (!enc || !x || !z_out) return fail(AAE_ERR_INVALID, "aae_encoder_forward: null argument");
     if (B < 1) return fail(AAE_ERR_INVALID, "aae_encoder_forward: batch %d < 1", B);
     if (x_dtype != AAE_DTYPE_U8 && x_dtype != AAE_DTYPE_F32)
@@ -879,7 +990,9 @@ static int forward_impl(aae_encoder* enc, const void* x, int x_dtype, int B, flo
     aae::TicketPrep prep;
     prep.n = 0;
     auto add_prep = [&](unsigned long long* words, int count, unsigned nonce) {
-        if (prep.n < aae::kMaxTicketPrep) { prep.words[prep.n] = words; prep.count[prep.n] = count; prep.nonce[prep.n] = nonce; ++prep.n; }
+        if (prep.n >= aae::kMaxTicketPrep) return false;
+        prep.words[prep.n] = words; prep.count[prep.n] = count; prep.nonce[prep.n] = nonce; ++prep.n;
+        return true;
     };
     for (size_t li = 0; li <= nl; ++li)
         if (plans[li].use && plans[li].gsplits > 1) {
@@ -891,9 +1004,35 @@ static int forward_impl(aae_encoder* enc, const void* x, int x_dtype, int B, flo
         gemv_nonce = next_nonce();
         add_prep(gemv_tickets, (D.CoutPad / 128) * aae::kTicketSlotWords, gemv_nonce);
     }
-    if (extra && extra->words) add_prep(extra->words, extra->count, extra->nonce);
+    const bool extra_listed = extra && extra->words && add_prep(extra->words, extra->count, extra->nonce);
+    // the persistent per-detection launch: its grid-barrier words count monotonically inside a launch and must start from
+    // (nonce, 0) -- also when a captured graph replays the launch with the SAME nonce.  The first kernel resets them with the
+    // other ticket words; where it cannot, a memset in front of the launch does.
+    const bool chain = chain_eligible(enc, B, plans, gemv_ticket);
+    unsigned long long* barrier_words = tickets + (kConvTicketBytes + kGemvTicketBytes) / 8;
+    const unsigned barrier_nonce = chain ? next_nonce() : 0u;
+    const bool barrier_listed = chain && add_prep(barrier_words, aae::kGridBarrierWords, barrier_nonce);
     const bool can_prepare = enc->ticket_prep && enc->layers[0].kind == KIND_FIRST_MFMA && prep.n > 0;
-    if (extra_prepared) *extra_prepared = can_prepare && extra && extra->words;
+    if (extra_prepared) *extra_prepared = can_prepare && extra_listed;
+
+    // ---- per-detection batches: the first layer as its own launch, everything behind it in ONE persistent launch
+    if (chain) {
+        const Layer& L0 = enc->layers[0];
+        float* out0 = reinterpret_cast<float*>(base + ws.act_off[0]);
+        int rc;
+        if (L0.kind == KIND_FIRST_MFMA) rc = launch_first(enc, L0, cur, cur_u8, B, out0, false, stream, tm, can_prepare ? &prep : nullptr);
+        else if (L0.kind == KIND_IGEMM && !cur_u8) {
+            if (plans[0].use)
+                rc = launch_wavek(enc, L0, plans[0], static_cast<const float*>(cur), B * L0.Ho * L0.Wo, out0, partial, layer_tickets(0), nonces[0],
+                                  stream, tm, "conv1", 0);
+            else rc = launch_igemm(enc, L0, static_cast<const float*>(cur), B * L0.Ho * L0.Wo, out0, partial, stream, tm, "conv1", 0);
+        } else rc = launch_generic(enc, L0, cur, cur_u8, B, out0, stream, tm, "conv1");
+        if (rc) return rc;
+        if (!(can_prepare && barrier_listed)) AAE_HIP_TRY(hipMemsetAsync(barrier_words, 0, (size_t)aae::kGridBarrierWords * 8, stream));
+        rc = launch_detect_chain(enc, B, plans, nonces, gemv_nonce, barrier_nonce, out0, base, ws, tickets, z_out, extra, stream, tm);
+        if (rc == AAE_OK && scan_done) *scan_done = extra && extra->scan_ready;
+        return rc;
+    }
 
     for (size_t li = 0; li < nl; ++li) {
         const Layer& L = enc->layers[li];
@@ -975,8 +1114,11 @@ static ScanPlan plan_scan(const aae_codebook* cb, int B, int topk) {
     s.ticket_off = off; off += align_up((size_t)aae::kTicketSlotWords * 8, 256);   // block_ticket_arrive words of the single-launch stream scan
     s.q_off = off;    off += align_up((size_t)B * cb->J * sizeof(float), 256);
     s.qp_off = off;   off += align_up((size_t)s.Jpad * s.Bpad * 6, 256);   // fp32 packing: 4 B/elem; bf16: 3 terms x 2 B
-    s.pval_off = off; off += align_up((size_t)s.nblk * s.Bstride * sizeof(float), 256);
-    s.pidx_off = off; off += align_up((size_t)s.nblk * s.Bstride * sizeof(int), 256);
+    // block partials: one row per scan block -- or per block of the persistent per-detection launch, whose grid (one block per
+    // CU, detect_chain.h) can exceed the block count of a small codebook
+    const int partial_rows = s.stream ? std::max(s.nblk, kChainMaxBlocks) : s.nblk;
+    s.pval_off = off; off += align_up((size_t)partial_rows * s.Bstride * sizeof(float), 256);
+    s.pidx_off = off; off += align_up((size_t)partial_rows * s.Bstride * sizeof(int), 256);
     s.cs_off = off;
     if (topk > 1 && !s.topk_fused) off += align_up((size_t)B * cb->N * sizeof(float), 256);
     s.cand_off = off;
@@ -1163,6 +1305,10 @@ int aae_encoder_create(const aae_encoder_desc* d, const void* const* hw, int n_w
     enc->desc = *d;
     auto bail = [&](int rc) { aae_encoder_destroy(enc); return rc; };
 
+    {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) enc->cu_count = cus;
+    }
     float lut[256];
     for (int v = 0; v < 256; ++v) lut[v] = (float)((double)v / 255.0);   // float64 quotient, float32 feed cast
     if (int rc = upload(enc, lut, 256, &enc->lut)) return bail(rc);
@@ -1302,6 +1448,8 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
     else if (!strcmp(name, "wavek_ablate")) enc->wavek_ablate = value;
     else if (!strcmp(name, "wavek_balance")) enc->wavek_balance = value ? 1 : 0;
     else if (!strcmp(name, "ticket_prep")) enc->ticket_prep = value ? 1 : 0;
+    else if (!strcmp(name, "detect_chain")) enc->detect_chain = value ? 1 : 0;
+    else if (!strcmp(name, "detect_chain_blocks")) enc->detect_chain_blocks = value < 1 ? 1 : (value > aae_host::kChainMaxBlocks ? aae_host::kChainMaxBlocks : value);
     else if (!strcmp(name, "compact_workspace")) enc->compact_workspace = value ? 1 : 0;
     else if (!strcmp(name, "wavek_timeline")) {
         if (value && !enc->wavek_timeline) {
@@ -1622,9 +1770,25 @@ int aae_encode_nn(aae_encoder* enc, aae_codebook* cb, const void* x, int x_dtype
         extra.count = aae::kTicketSlotWords;
         extra.nonce = next_nonce();
     }
-    bool prepared = false;
+    // ... and when the whole query runs as conv1 + ONE persistent launch (detect_chain.h), the scan is that launch's last phase:
+    // fp32 rows, stride 1 (the upright search on its compacted copy), answers written by the last block to arrive
+    if (extra.words && B <= 4 && eff->dtype == AAE_DTYPE_F32 && (col_stride == 1 || eff != cb) && z_out && idx_out && score_out) {
+        const ScanPlan sp = plan_scan(eff, B, 1);
+        unsigned char* cbase = static_cast<unsigned char*>(cb_workspace);
+        aae::ScanArgs& a = extra.scan;
+        a.E = eff->E; a.e_bytes = (unsigned)((size_t)eff->N * eff->J * sizeof(float));
+        a.q = nullptr; a.qp = nullptr; a.cs = nullptr; a.z = z_out;
+        a.pval = reinterpret_cast<float*>(cbase + sp.pval_off);
+        a.pidx = reinterpret_cast<int*>(cbase + sp.pidx_off);
+        a.N = eff->N; a.J = eff->J; a.Jpad = sp.Jpad; a.B = B; a.Bpad = sp.Bpad; a.Bstride = sp.Bstride; a.col_stride = 1;
+        a.tickets = extra.words; a.nonce = extra.nonce;
+        a.idx_out = reinterpret_cast<long long*>(idx_out); a.score_out = score_out; a.idx_scale = eff != cb ? col_stride : 1;
+        extra.scan_ready = true;
+    }
+    bool prepared = false, scan_done = false;
     Timer tm;
-    if (int rc = forward_impl(enc, x, x_dtype, B, z_out, enc_workspace, enc_ws_bytes, stream, tm, extra.words ? &extra : nullptr, &prepared)) return rc;
+    if (int rc = forward_impl(enc, x, x_dtype, B, z_out, enc_workspace, enc_ws_bytes, stream, tm, extra.words ? &extra : nullptr, &prepared, &scan_done)) return rc;
+    if (scan_done) return AAE_OK;
     return nn_impl(cb, z_out, B, 1, col_stride, idx_out, score_out, cb_workspace, cb_ws_bytes, stream, prepared ? extra.nonce : 0u);
 }
 

@@ -260,6 +260,51 @@ __device__ __forceinline__ bool block_ticket_arrive(unsigned long long* words, u
     return block_ticket_take(words, nonce, total, id, lds_flag);
 }
 
+// ---- grid-wide barrier of a persistent launch -------------------------------------------------------------------------
+// For a launch whose blocks are ALL resident (the host sizes the grid to the chip: one block per CU).  Data that crosses the
+// barrier follows the same rule as the ticketed hand-offs above: written with device-coherent (sc1, write-through) stores,
+// every buffer written at most once per launch and never read before its barrier -- so a reader can meet neither a stale
+// L1 nor a stale L2 line, and no cache write-back or invalidate is ever issued.
+// Words (64-bit, 128 B apart): top counter, 16 group counters, 16 group gates.  Counters are the ticket words of above
+// used monotonically -- `nonce << 32 | arrivals so far`, never cleared inside a launch: barrier number `phase` (1, 2, ...)
+// is complete when the top counter reads groups * phase; the last arriver then writes `nonce << 32 | phase` into every
+// gate and each block's lane 0 polls the gate of its group (16 pollers per word).  A foreign nonce (uninitialised memory,
+// an earlier launch) counts as empty / closed: no memset, ever.
+// Split in two halves so that loads which do not depend on the other blocks (the next layer's weights, the first codebook
+// rows) can be requested between arriving and waiting: they fly while the barrier closes.
+constexpr int kGridBarrierWords = (1 + 2 * kTicketGroups) * kTicketGroupStride;
+struct GridBarrier {
+    unsigned long long* words;     // kGridBarrierWords
+    unsigned nonce;                // unique per launch, never 0
+};
+__device__ __forceinline__ void grid_barrier_arrive(const GridBarrier& gb, unsigned nblocks, unsigned block, unsigned phase) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this thread's coherent stores are visible at device scope
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned groups = nblocks < (unsigned)kTicketGroups ? nblocks : (unsigned)kTicketGroups;
+        const unsigned g = block % groups, members = (nblocks - g + groups - 1) / groups;
+        if (ticket_count(gb.words + (1 + g) * kTicketGroupStride, gb.nonce) == members * phase &&
+            ticket_count(gb.words, gb.nonce) == groups * phase) {
+            const unsigned long long open = ((unsigned long long)gb.nonce << 32) | phase;
+            for (unsigned k = 0; k < groups; ++k)
+                __hip_atomic_store(gb.words + (1 + kTicketGroups + k) * kTicketGroupStride, open, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
+}
+__device__ __forceinline__ void grid_barrier_wait(const GridBarrier& gb, unsigned nblocks, unsigned block, unsigned phase) {
+    if (threadIdx.x == 0) {
+        const unsigned groups = nblocks < (unsigned)kTicketGroups ? nblocks : (unsigned)kTicketGroups;
+        const unsigned long long* gate = gb.words + (1 + kTicketGroups + block % groups) * kTicketGroupStride;
+        for (unsigned spin = 0;; ++spin) {
+            const unsigned long long v = __hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(v >> 32) == gb.nonce && (unsigned)v >= phase) break;
+            __builtin_amdgcn_s_sleep(2);
+            if (spin > (1u << 22)) __builtin_trap();       // seconds: a block of the grid is not resident -- never hang the device
+        }
+    }
+    __syncthreads();
+}
+
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 // shader-clock counter (s_memtime): kernel-internal timelines of the profiling tools
 __device__ __forceinline__ long long clock_ticks() { return (long long)__builtin_readcyclecounter(); }

@@ -37,7 +37,7 @@ struct ConvWaveKArgs {
     const float* bn_scale;       // [Cout] or nullptr
     const float* bn_shift;
     float* out;                  // [M][Cout]
-    float* partial;              // [tiles][gsplits][PER/4][threads][4]  (gsplits > 1)
+    float* partial;              // [tiles][gsplits][pieces per thread][threads][4]  (gsplits > 1)
     unsigned partial_bytes;
     unsigned long long* tickets; // [tiles]                              (gsplits > 1; gsplits <= kTicketSingleLevelMax)
     unsigned nonce;              // unique per launch, never 0
@@ -75,26 +75,62 @@ constexpr uint32_t kOobBase = 0xFFFFFF00u;
 template <int MT, int NT, int WAVES>
 constexpr int conv_wavek_smem() { return WAVES * MT * NT * 16 * 64 * 4 + 16; }
 
-// (64 x 64 wave tiles: two blocks per CU asked for -- 209 instead of 288 registers, no spills -- so that the second round of a
-// 257 ... 512-tile layer overlaps the first: conv2 at B = 7 / 8 118.6 / 120.6 -> 112.9 / 114.6 us; the smaller tiles lose 8 % under the
-// same bound and keep the whole register file)
-template <int MT, int NT, int WAVES, int DEPTH, int TAG = 0>
-__global__ __launch_bounds__(64 * WAVES, (MT * NT == 4 && WAVES == 4 && DEPTH == 2 ? 2 : 1)) void conv_wavek_f32_kernel(const ConvWaveKArgs p) {
+// B fragments of a wave's first slab, fetched ahead of time (detect_chain.h: the weights of the NEXT layer are requested
+// before the grid barrier that ends the current one; they do not depend on it)
+struct WaveKPrefetch {
+    f32x4 b[2][4];           // [ni][k-group]  (NT <= 2)
+};
+
+// this lane's B-fragment offset of slab t, column tile tn (see the B fragment comment in conv_wavek_block)
+__device__ __forceinline__ void conv_wavek_prefetch_b(const ConvWaveKArgs& p, int L, int nblk, int NT, int WAVES, WaveKPrefetch& pf) {
+    const int lane = threadIdx.x & 63, wave = wave_uniform(threadIdx.x >> 6);
+    const int i = lane & 31, h = lane >> 5;
+    const int tiles = p.num_mt * p.num_nt;
+    const bool live = L < nblk;
+    const int Lr = live ? xcd_remap(L, nblk) : 0;
+    const int tn = (Lr / p.num_mt) % p.num_nt;
+    const int g = Lr / tiles;
+    const int b0 = (int)((long long)g * p.slabs_total / p.gsplits);
+    const int b1 = (int)((long long)(g + 1) * p.slabs_total / p.gsplits);
+    const int s0 = b0 + wave * (b1 - b0) / WAVES, s1 = b0 + (wave + 1) * (b1 - b0) / WAVES;
+    const buffer_rsrc wbuf = make_buffer(p.wp, p.wp_bytes);
+    const unsigned bo = (unsigned)((h * p.CoutPad + tn * (32 * NT) + i) * 16) + (unsigned)s0 * (unsigned)(8 * p.CoutPad * 16);
+    const unsigned bw_group = (unsigned)(2 * p.CoutPad * 16);
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            pf.b[ni][c] = buffer_load4(wbuf, (live && s0 < s1 && ni < NT) ? bo + c * bw_group + 512u * ni : kOobBase);
+}
+
+// One block's share of a layer: logical block L of nblk = tiles x gsplits.  red: conv_wavek_smem<MT, NT, WAVES>() bytes of LDS.
+//   CHAIN = false: the stand-alone kernel below (plain output stores; the next launch is the consumer);
+//   CHAIN = true : a phase of the persistent per-detection kernel (detect_chain.h): the outputs are read by OTHER blocks of
+//                  the same launch after a grid barrier, so they leave as device-coherent write-through (sc1) stores, and
+//                  `pf` (use_pf) carries this wave's first B fragments, requested before the barrier.
+// The epilogue hands every thread whole 16-byte pieces of an output row: thread t finishes float4 number t + T j of the
+// tile, i.e. sub-tile (t + T j) / 256, row q / 8, columns 4 (q % 8) ... + 3 of it (q = (t + T j) % 256).  In the lane-linear
+// LDS image of an accumulator (register r of lane l at [r][l]) those four values are neighbours -- register
+// (row & 3) + 4 (row >> 3), lanes 4 (q % 8) + 32 ((row >> 2) & 1) ... + 3 -- so the cross-wave sum reads one ds_read_b128
+// per wave, conflict-free, and the row leaves as ONE 16-byte store instead of four 4-byte ones (a 4-byte sc1 store costs
+// about six times a 16-byte one per byte).  Sums run in wave order, then split order: the bits do not depend on who finishes.
+template <int MT, int NT, int WAVES, int DEPTH, bool CHAIN>
+__device__ __forceinline__ void conv_wavek_block(const ConvWaveKArgs& p, const int Lphys, const int nblk, float* red, int* flag,
+                                                 const WaveKPrefetch& pf, const bool use_pf) {
     constexpr int COMBOS = MT * NT * 16;                       // accumulator registers per lane
-    static_assert(COMBOS % WAVES == 0, "the cross-wave sum gives every wave COMBOS / WAVES register rows");
-    AAE_DYN_SMEM(smem_raw);
-    float* red = reinterpret_cast<float*>(smem_raw);           // [WAVES][COMBOS][64]
-    int* flag = reinterpret_cast<int*>(red + WAVES * COMBOS * 64);
+    constexpr int T = 64 * WAVES;
+    constexpr int NF4 = 256 * MT * NT / T;                     // float4 pieces of the tile a thread finishes
+    static_assert((256 * MT * NT) % T == 0 && NF4 >= 1, "every thread finishes whole float4 pieces");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
     auto stamp = [&](int k) {
-        if (p.timeline && tid == 0) p.timeline[(long long)blockIdx.x * 8 + k] = clock_ticks();
+        if (p.timeline && tid == 0) p.timeline[(long long)Lphys * 8 + k] = clock_ticks();
     };
     stamp(0);
 
     const int tiles = p.num_mt * p.num_nt;
-    const int L = xcd_remap(blockIdx.x, tiles * p.gsplits);
+    const int L = xcd_remap(Lphys, nblk);
     const int tm = L % p.num_mt;                               // M tiles of one (N tile, K split) are neighbours: they share its weights in L2
     const int tn = (L / p.num_mt) % p.num_nt;
     const int g = L / tiles;
@@ -136,7 +172,8 @@ __global__ __launch_bounds__(64 * WAVES, (MT * NT == 4 && WAVES == 4 && DEPTH ==
     int t_load = s0;
 
     f32x4 fa[DEPTH][MT][4], fb[DEPTH][NT][4];
-    auto load_stage = [&](int d) {
+    // with_b = false: this slab's B fragments are already there (prefetched)
+    auto load_stage = [&](int d, bool with_b) {
         const bool live = t_load < s1;                          // past the wave's range: every load is forced out of range (zeros, no traffic)
         const bool live_a = live && !(p.ablate & 1), live_b = live && !(p.ablate & 2);
         const unsigned tap_off = (unsigned)(((kh * p.W + kw) * p.Cin + cc * 32) * 4);
@@ -151,8 +188,10 @@ __global__ __launch_bounds__(64 * WAVES, (MT * NT == 4 && WAVES == 4 && DEPTH ==
         for (int c = 0; c < 4; ++c) {                           // k-group order = consumption order
 #pragma unroll
             for (int mi = 0; mi < MT; ++mi) fa[d][mi][c] = buffer_load4(xbuf, ao[mi] + 32u * c);
+            if (with_b) {
 #pragma unroll
-            for (int ni = 0; ni < NT; ++ni) fb[d][ni][c] = buffer_load4(wbuf, live_b ? bo + c * bw_group + 512u * ni : kOobBase);
+                for (int ni = 0; ni < NT; ++ni) fb[d][ni][c] = buffer_load4(wbuf, live_b ? bo + c * bw_group + 512u * ni : kOobBase);
+            }
         }
         ++t_load;
         if (++kw == p.KS) { kw = 0; if (++kh == p.KS) { kh = 0; ++cc; } }
@@ -178,28 +217,44 @@ __global__ __launch_bounds__(64 * WAVES, (MT * NT == 4 && WAVES == 4 && DEPTH ==
     };
 
     stamp(1);                                                   // index arithmetic done
+    if (CHAIN && use_pf) {                                      // first slab: B came in ahead of the barrier, A now
 #pragma unroll
-    for (int d = 0; d < DEPTH - 1; ++d) load_stage(d);
-    // epilogue constants of this lane's columns, fetched now: the block that finishes the tile must not start its
-    // epilogue with a round trip to L2 (2.5 -> 0.5 us on the critical path of every split layer)
-    float ep_bias[NT], ep_sc[NT], ep_sh[NT];
+        for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
-    for (int ni = 0; ni < NT; ++ni) {
-        const int n = tn * (32 * NT) + 32 * ni + i;
-        const bool ok = n < p.Cout;
-        ep_bias[ni] = ok ? p.bias[n] : 0.f;
-        ep_sc[ni] = (ok && p.bn_scale) ? p.bn_scale[n] : 1.f;
-        ep_sh[ni] = (ok && p.bn_scale) ? p.bn_shift[n] : 0.f;
+            for (int c = 0; c < 4; ++c) fb[0][ni][c] = pf.b[ni][c];
+        load_stage(0, false);
+#pragma unroll
+        for (int d = 1; d < DEPTH - 1; ++d) load_stage(d, true);
+    } else {
+#pragma unroll
+        for (int d = 0; d < DEPTH - 1; ++d) load_stage(d, true);
     }
-    // (block 0, its first loads in flight) the tile words get this launch's nonce long before the first arrival
-    if (p.gsplits > 1 && blockIdx.x == 0)
-        for (int w = tid; w < tiles; w += 64 * WAVES) ticket_prepare_word(p.tickets + w, p.nonce);
+    // epilogue constants of this thread's output pieces, fetched now: the block that finishes the tile must not start its
+    // epilogue with a round trip to L2 (2.5 -> 0.5 us on the critical path of every split layer)
+    const bool vec_ok = (p.Cout & 3) == 0;                      // rows of the output are whole float4 pieces
+    auto piece_mn = [&](int j, int& m, int& n) {                // output row / first column of this thread's j-th piece
+        const int f = tid + T * j, sub = f >> 8, q = f & 255;
+        const int mi = sub / NT, ni = sub - mi * NT;
+        m = tm * (32 * MT) + 32 * mi + (q >> 3);
+        n = tn * (32 * NT) + 32 * ni + 4 * (q & 7);
+    };
+    f32x4 ep_bias[NF4];
+#pragma unroll
+    for (int j = 0; j < NF4; ++j) {
+        int m, n;
+        piece_mn(j, m, n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ep_bias[j][e] = (n + e < p.Cout) ? p.bias[n + e] : 0.f;
+    }
+    // (logical block 0, its first loads in flight) the tile words get this launch's nonce long before the first arrival
+    if (p.gsplits > 1 && Lphys == 0)
+        for (int w = tid; w < tiles; w += T) ticket_prepare_word(p.tickets + w, p.nonce);
     for (int t = s0; t < s1; t += DEPTH) {
 #pragma unroll
         for (int d = 0; d < DEPTH; ++d) {
             if (t + d < s1) {                                   // wave-uniform
                 sched_fence();
-                load_stage((d + DEPTH - 1) % DEPTH);            // slab t + d + DEPTH - 1 (dead loads once past s1)
+                load_stage((d + DEPTH - 1) % DEPTH, true);      // slab t + d + DEPTH - 1 (dead loads once past s1)
                 sched_fence();
                 if (!(p.ablate & 4)) mfma_stage(d);
             }
@@ -215,69 +270,93 @@ __global__ __launch_bounds__(64 * WAVES, (MT * NT == 4 && WAVES == 4 && DEPTH ==
 #pragma unroll
             for (int r = 0; r < 16; ++r) red[(wave * COMBOS + (mi * NT + ni) * 16 + r) * 64 + lane] = acc[mi][ni][r];
     __syncthreads();
-    constexpr int PER = COMBOS / WAVES;                         // register rows this thread finishes: combo = wave + WAVES*j
-    float v[PER];
+    f32x4 v[NF4];
 #pragma unroll
-    for (int j = 0; j < PER; ++j) {
-        const int combo = wave + WAVES * j;
-        float s = red[combo * 64 + lane];
+    for (int j = 0; j < NF4; ++j) {
+        const int f = tid + T * j, sub = f >> 8, q = f & 255, row = q >> 3;
+        const int at = (sub * 16 + (row & 3) + 4 * (row >> 3)) * 64 + 4 * (q & 7) + 32 * ((row >> 2) & 1);
+        f32x4 s = lds_read4(red + at);
 #pragma unroll
-        for (int w = 1; w < WAVES; ++w) s += red[(w * COMBOS + combo) * 64 + lane];
+        for (int w = 1; w < WAVES; ++w) s += lds_read4(red + w * COMBOS * 64 + at);
         v[j] = s;
     }
+    __syncthreads();                                            // (CHAIN: the next work item of this block reuses red)
 
     stamp(3);                                                   // cross-wave sum done
     if (p.gsplits > 1 && !(p.ablate & 8)) {
-        // this block's tile partial: four register rows per 16-B coherent store, lane-linear (coalesced)
-        constexpr unsigned kThreads = 64 * WAVES;
+        // this block's tile partial: one 16-B coherent store per piece, thread-linear (coalesced)
         const buffer_rsrc pbuf = make_buffer(p.partial, p.partial_bytes);
-        const unsigned tile_base = (unsigned)tile * (unsigned)p.gsplits * (PER / 4) * kThreads * 16u;
-        const unsigned mine = tile_base + (unsigned)g * (PER / 4) * kThreads * 16u + (unsigned)tid * 16u;
+        const unsigned tile_base = (unsigned)tile * (unsigned)p.gsplits * NF4 * T * 16u;
+        const unsigned mine = tile_base + (unsigned)g * NF4 * T * 16u + (unsigned)tid * 16u;
 #pragma unroll
-        for (int j4 = 0; j4 < PER / 4; ++j4)
-            coherent_store4(pbuf, mine + j4 * kThreads * 16u, f32x4{v[4 * j4], v[4 * j4 + 1], v[4 * j4 + 2], v[4 * j4 + 3]});
+        for (int j = 0; j < NF4; ++j) coherent_store4(pbuf, mine + j * T * 16u, v[j]);
         block_ticket_publish();
         stamp(4);                                               // partial stores complete (device scope)
         const bool last_block = block_ticket_take(p.tickets + tile, p.nonce, (unsigned)p.gsplits, (unsigned)g, flag);
         stamp(5);                                               // ticket taken
         if (!last_block) return;
 #pragma unroll
-        for (int j = 0; j < PER; ++j) v[j] = 0.f;
+        for (int j = 0; j < NF4; ++j) v[j] = f32x4{0.f, 0.f, 0.f, 0.f};
         // all partials of up to 8 splits in flight at once (a coherent load is a round trip to the memory side: one at a
         // time they cost more than the K loop); splits beyond gsplits read out of range = zeros.  Split order: the same
         // sum whichever block arrives last.
         constexpr int kBatch = 8;
-        const unsigned split_stride = (PER / 4) * kThreads * 16u;
+        const unsigned split_stride = NF4 * T * 16u;
         for (int sb = 0; sb < p.gsplits; sb += kBatch) {
-            f32x4 t[kBatch][PER / 4];
+            f32x4 t[kBatch][NF4];
 #pragma unroll
             for (int u = 0; u < kBatch; ++u)
 #pragma unroll
-                for (int j4 = 0; j4 < PER / 4; ++j4)
-                    t[u][j4] = coherent_load4(pbuf, sb + u < p.gsplits ? tile_base + (unsigned)(sb + u) * split_stride + (unsigned)tid * 16u + j4 * kThreads * 16u
-                                                                         : kOobBase);
+                for (int j = 0; j < NF4; ++j)
+                    t[u][j] = coherent_load4(pbuf, sb + u < p.gsplits ? tile_base + (unsigned)(sb + u) * split_stride + (unsigned)tid * 16u + j * T * 16u
+                                                                      : kOobBase);
 #pragma unroll
             for (int u = 0; u < kBatch; ++u)
 #pragma unroll
-                for (int j = 0; j < PER; ++j) v[j] += t[u][j >> 2][j & 3];
+                for (int j = 0; j < NF4; ++j) v[j] += t[u][j];
         }
     }
 
     stamp(6);                                                   // (last block) all partials summed
-    // ---- epilogue: bias, ReLU, folded BN; register row combo = (mi, ni, r) of lane -> (m, n) ---------------------
+    // ---- epilogue: bias, ReLU, folded BN; one output row piece (m, n ... n + 3) per v[j] ------------------------------
+    const buffer_rsrc obuf = make_buffer(p.out, (unsigned)((unsigned long long)p.M * p.Cout * 4ull));
 #pragma unroll
-    for (int j = 0; j < PER; ++j) {
-        const int combo = wave + WAVES * j;
-        const int r = combo & 15, ni = (combo >> 4) % NT, mi = (combo >> 4) / NT;
-        const int m = tm * (32 * MT) + 32 * mi + acc_row(r, lane);
-        const int n = tn * (32 * NT) + 32 * ni + i;
+    for (int j = 0; j < NF4; ++j) {
+        int m, n;
+        piece_mn(j, m, n);
         if (m >= p.M || n >= p.Cout) continue;
-        float o = v[j] + (NT > 1 && ni ? ep_bias[NT - 1] : ep_bias[0]);
-        if (p.relu) o = fmaxf(o, 0.f);
-        if (p.bn_scale) o = o * (NT > 1 && ni ? ep_sc[NT - 1] : ep_sc[0]) + (NT > 1 && ni ? ep_sh[NT - 1] : ep_sh[0]);
-        p.out[(long long)m * p.Cout + n] = o;
+        f32x4 o = v[j] + ep_bias[j];
+        if (p.relu) { o[0] = fmaxf(o[0], 0.f); o[1] = fmaxf(o[1], 0.f); o[2] = fmaxf(o[2], 0.f); o[3] = fmaxf(o[3], 0.f); }
+        if (p.bn_scale) {                                       // (inference batch-norm after the ReLU: encoder.py:51-52)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (n + e < p.Cout) o[e] = o[e] * p.bn_scale[n + e] + p.bn_shift[n + e];
+        }
+        if (vec_ok) {                                           // (n % 4 == 0 and Cout % 4 == 0: the piece lies inside the row, 16-B aligned)
+            if (CHAIN) coherent_store4(obuf, (unsigned)(((long long)m * p.Cout + n) * 4), o);
+            else *reinterpret_cast<f32x4*>(p.out + (long long)m * p.Cout + n) = o;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (n + e < p.Cout) {
+                    if (CHAIN) coherent_store1(obuf, (unsigned)(((long long)m * p.Cout + n + e) * 4), __builtin_bit_cast(uint32_t, o[e]));
+                    else p.out[(long long)m * p.Cout + n + e] = o[e];
+                }
+        }
     }
     stamp(7);
+}
+
+// (64 x 64 wave tiles: two blocks per CU asked for -- 209 instead of 288 registers, no spills -- so that the second round of a
+// 257 ... 512-tile layer overlaps the first: conv2 at B = 7 / 8 118.6 / 120.6 -> 112.9 / 114.6 us; the smaller tiles lose 8 % under the
+// same bound and keep the whole register file)
+template <int MT, int NT, int WAVES, int DEPTH, int TAG = 0>
+__global__ __launch_bounds__(64 * WAVES, (MT * NT == 4 && WAVES == 4 && DEPTH == 2 ? 2 : 1)) void conv_wavek_f32_kernel(const ConvWaveKArgs p) {
+    AAE_DYN_SMEM(smem_raw);
+    float* red = reinterpret_cast<float*>(smem_raw);           // [WAVES][COMBOS][64]
+    int* flag = reinterpret_cast<int*>(red + WAVES * MT * NT * 16 * 64);
+    WaveKPrefetch none;
+    conv_wavek_block<MT, NT, WAVES, DEPTH, false>(p, (int)blockIdx.x, p.num_mt * p.num_nt * p.gsplits, red, flag, none, false);
 }
 
 }  // namespace aae

@@ -31,26 +31,42 @@ constexpr int kGemvChunk = 128;            // k per block = 32 slot rows: 64 KB 
 
 constexpr int kGemvTicketSmem = 8 * 128 * 4 + 16;                // the finishing block's 8 row-group sums + the ticket flag
 
-template <int MQ, bool TICKET = false>
-__global__ __launch_bounds__(256) void dense_gemv_f32_kernel(const DenseGemvArgs p) {
-    AAE_DYN_SMEM(smem_raw);
+// this thread's 16 weight pieces of chunk bx, column tile by (all in flight at once; out of range = zeros, no traffic)
+__device__ __forceinline__ void dense_gemv_load_weights(const DenseGemvArgs& p, int bx, int by, bool live, f32x4 (&w)[16]) {
+    const int tid = threadIdx.x;
+    const int n = by * 128 + (tid & 127), half = tid >> 7;
+    const int k0 = bx * kGemvChunk;
+    const buffer_rsrc wbuf = make_buffer(p.wp, p.wp_bytes);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int slot = (k0 >> 2) + half * 16 + j;
+        w[j] = buffer_load4(wbuf, (live && slot * 4 < p.K && n < p.CoutPad) ? (unsigned)((slot * p.CoutPad + n) * 16) : kOobOffset);
+    }
+}
+
+// One (chunk bx of nbx, column tile by) work item.  CHAIN: a phase of the persistent per-detection kernel (detect_chain.h):
+// z is read by other blocks of the same launch after a grid barrier -> device-coherent stores; `wpre` (use_wpre): the
+// weights were requested ahead of time.
+template <int MQ, bool TICKET, bool CHAIN>
+__device__ __forceinline__ void dense_gemv_block(const DenseGemvArgs& p, const int bx, const int by, const int nbx, unsigned char* smem_raw,
+                                                 const f32x4 (&wpre)[16], const bool use_wpre) {
     float* xs = reinterpret_cast<float*>(smem_raw);              // [MQ][128] activation chunk
     float* red = xs + MQ * kGemvChunk;                           // [MQ][128] second half's sums
     const int tid = threadIdx.x;
-    const int n = blockIdx.y * 128 + (tid & 127), half = tid >> 7;   // two k-halves of 16 slot rows each
-    const int k0 = blockIdx.x * kGemvChunk;
+    const int n = by * 128 + (tid & 127), half = tid >> 7;       // two k-halves of 16 slot rows each
+    const int k0 = bx * kGemvChunk;
     for (int e = tid; e < MQ * kGemvChunk; e += 256) {
         const int m = e / kGemvChunk, k = e - m * kGemvChunk;
         xs[e] = (m < p.B && k0 + k < p.K) ? p.x[(long long)m * p.K + k0 + k] : 0.f;
     }
-    const buffer_rsrc wbuf = make_buffer(p.wp, p.wp_bytes);
     f32x4 w[16];
+    if (CHAIN && use_wpre) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {                               // all 16 loads in flight before the first use
-        const int slot = (k0 >> 2) + half * 16 + j;
-        w[j] = buffer_load4(wbuf, (slot * 4 < p.K && n < p.CoutPad) ? (unsigned)((slot * p.CoutPad + n) * 16) : kOobOffset);
+        for (int j = 0; j < 16; ++j) w[j] = wpre[j];
+    } else {
+        dense_gemv_load_weights(p, bx, by, true, w);             // all 16 loads in flight before the first use
     }
-    if (TICKET && blockIdx.x == 0) ticket_prepare_slot(p.tickets + blockIdx.y * kTicketSlotWords, p.nonce, gridDim.x);   // loads in flight; arrivals come later
+    if (TICKET && bx == 0) ticket_prepare_slot(p.tickets + by * kTicketSlotWords, p.nonce, nbx);   // loads in flight; arrivals come later
     __syncthreads();
     float acc[MQ];
 #pragma unroll
@@ -78,26 +94,27 @@ __global__ __launch_bounds__(256) void dense_gemv_f32_kernel(const DenseGemvArgs
         for (int m = 0; m < MQ; ++m)
             if (m < p.B) {
                 const float sum = acc[m] + red[m * 128 + (tid & 127)];
-                const unsigned at = (unsigned)(((blockIdx.x * p.B + m) * p.Cout + n) * 4);
+                const unsigned at = (unsigned)(((bx * p.B + m) * p.Cout + n) * 4);
                 if (TICKET) coherent_store1(pbuf, at, __builtin_bit_cast(uint32_t, sum));      // read back by another block of this launch
-                else p.partial[((long long)blockIdx.x * p.B + m) * p.Cout + n] = sum;
+                else p.partial[((long long)bx * p.B + m) * p.Cout + n] = sum;
             }
     }
     if constexpr (TICKET) {
-        // The last of the gridDim.x chunk blocks of this column tile adds the chunk rows: thread (group = tid / 32,
+        // The last of the nbx chunk blocks of this column tile adds the chunk rows: thread (group = tid / 32,
         // n4 = tid % 32) sums chunks group, group + 8, ... of four neighbouring columns (16-B loads, all of a batch
         // row's loads in flight), the 8 group sums meet in LDS and are added in group order -- one fixed tree,
         // whichever block happens to finish last.  (Needs Cout % 4 == 0; the host checks.)
         float* gsum = reinterpret_cast<float*>(smem_raw);        // [8][128] (xs / red are dead by now)
         int* flag = reinterpret_cast<int*>(gsum + 8 * 128);
         __syncthreads();
-        if (!block_ticket_arrive(p.tickets + blockIdx.y * kTicketSlotWords, p.nonce, gridDim.x, blockIdx.x, flag)) return;
-        const int group = tid >> 5, n4 = blockIdx.y * 128 + (tid & 31) * 4;
-        const int chunks = (int)gridDim.x;
-        const int nn_e = blockIdx.y * 128 + (tid & 127);        // epilogue constants first: their latency hides under the partial loads
+        if (!block_ticket_arrive(p.tickets + by * kTicketSlotWords, p.nonce, nbx, bx, flag)) return;
+        const int group = tid >> 5, n4 = by * 128 + (tid & 31) * 4;
+        const int chunks = nbx;
+        const int nn_e = by * 128 + (tid & 127);                // epilogue constants first: their latency hides under the partial loads
         const bool nn_ok = tid < 128 && nn_e < p.Cout;
         const float e_bias = nn_ok ? p.bias[nn_e] : 0.f;
         const float e_sc = (nn_ok && p.bn_scale) ? p.bn_scale[nn_e] : 1.f, e_sh = (nn_ok && p.bn_scale) ? p.bn_shift[nn_e] : 0.f;
+        const buffer_rsrc zbuf = make_buffer(p.out, (unsigned)(p.B * p.Cout * 4));
         // A coherent load is a round trip to the memory side (~0.7 us): up to 32 of a thread's chunk rows are in flight at
         // once (rows beyond `chunks` read out of range = zeros), added in chunk order.  With 8 in flight the default net's
         // 256 chunks cost four round trips per batch row: 2.5 us of the 7.6 us kernel at B = 1, 10 of 15 us at B = 4.
@@ -116,19 +133,27 @@ __global__ __launch_bounds__(256) void dense_gemv_f32_kernel(const DenseGemvArgs
             }
             *reinterpret_cast<f32x4*>(gsum + group * 128 + (tid & 31) * 4) = s;
             __syncthreads();
-            if (tid < 128 && (int)(blockIdx.y * 128 + tid) < p.Cout) {
-                const int nn = blockIdx.y * 128 + tid;
+            if (tid < 128 && (int)(by * 128 + tid) < p.Cout) {
+                const int nn = by * 128 + tid;
                 float v = gsum[tid];
 #pragma unroll
                 for (int k = 1; k < 8; ++k) v += gsum[k * 128 + tid];
                 v += e_bias;
                 if (p.relu) v = fmaxf(v, 0.f);
                 if (p.bn_scale) v = v * e_sc + e_sh;
-                p.out[(long long)m * p.Cout + nn] = v;
+                if (CHAIN) coherent_store1(zbuf, (unsigned)((m * p.Cout + nn) * 4), __builtin_bit_cast(uint32_t, v));
+                else p.out[(long long)m * p.Cout + nn] = v;
             }
             __syncthreads();
         }
     }
+}
+
+template <int MQ, bool TICKET = false>
+__global__ __launch_bounds__(256) void dense_gemv_f32_kernel(const DenseGemvArgs p) {
+    AAE_DYN_SMEM(smem_raw);
+    f32x4 none[16];
+    dense_gemv_block<MQ, TICKET, false>(p, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, smem_raw, none, false);
 }
 
 }  // namespace aae

@@ -31,7 +31,7 @@ struct uint3_emu { unsigned x, y, z; };
 
 extern uint3_emu threadIdx, blockIdx;
 extern dim3 blockDim, gridDim;
-extern unsigned char aae_emu_dyn_smem[];
+extern unsigned char* aae_emu_dyn_smem;      // LDS image of the running block
 
 #define __global__ static
 #define __device__
@@ -51,6 +51,10 @@ namespace aae_emu {
 typedef unsigned char lane_slot[64];
 const lane_slot* wave_exchange(const void* mine, int nbytes);
 void launch(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()>& body);
+// all blocks alive side by side (persistent kernels with grid-wide waits); at most 16 blocks
+void launch_resident(dim3 grid, dim3 block, size_t smem_bytes, const std::function<void()>& body);
+void spin_yield();          // inside a grid-wide wait: let the other blocks run
+void note_progress();
 }  // namespace aae_emu
 
 namespace aae {
@@ -230,6 +234,39 @@ inline bool block_ticket_arrive(unsigned long long* words, unsigned nonce, unsig
     return block_ticket_take(words, nonce, total, id, lds_flag);
 }
 
+// grid-wide barrier of a persistent launch (device_intrinsics.h): same words, same protocol, plain accesses; a waiting
+// thread hands the processor to the other blocks of the resident launch (aae_emu::launch_resident)
+constexpr int kGridBarrierWords = (1 + 2 * kTicketGroups) * kTicketGroupStride;
+struct GridBarrier {
+    unsigned long long* words;
+    unsigned nonce;
+};
+inline void grid_barrier_arrive(const GridBarrier& gb, unsigned nblocks, unsigned block, unsigned phase) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned groups = nblocks < (unsigned)kTicketGroups ? nblocks : (unsigned)kTicketGroups;
+        const unsigned g = block % groups, members = (nblocks - g + groups - 1) / groups;
+        if (ticket_count(gb.words + (1 + g) * kTicketGroupStride, gb.nonce) == members * phase &&
+            ticket_count(gb.words, gb.nonce) == groups * phase) {
+            for (unsigned k = 0; k < groups; ++k) gb.words[(1 + kTicketGroups + k) * kTicketGroupStride] = ((unsigned long long)gb.nonce << 32) | phase;
+        }
+        aae_emu::note_progress();
+    }
+}
+inline void grid_barrier_wait(const GridBarrier& gb, unsigned nblocks, unsigned block, unsigned phase) {
+    if (threadIdx.x == 0) {
+        const unsigned groups = nblocks < (unsigned)kTicketGroups ? nblocks : (unsigned)kTicketGroups;
+        const volatile unsigned long long* gate = gb.words + (1 + kTicketGroups + block % groups) * kTicketGroupStride;
+        for (;;) {
+            const unsigned long long v = *gate;
+            if ((unsigned)(v >> 32) == gb.nonce && (unsigned)v >= phase) break;
+            aae_emu::spin_yield();
+        }
+        aae_emu::note_progress();
+    }
+    __syncthreads();
+}
+
 // f32x3h activation pairs (device_intrinsics.h): 32-channel chunks of 32 hi halves + 32 lo halves
 inline long long x3h_pair_index(long long e) { return ((e >> 5) << 6) + (e & 31); }
 constexpr float kHalfPairLimit = 65504.f;
@@ -302,6 +339,10 @@ inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 enum hipStreamCaptureStatus { hipStreamCaptureStatusNone = 0, hipStreamCaptureStatusActive = 1 };
 inline hipError_t hipStreamIsCapturing(hipStream_t, hipStreamCaptureStatus* s) { *s = hipStreamCaptureStatusNone; return hipSuccess; }
 inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+// the emulated "device" has three compute units: persistent launches size their grid to it (aae_emu::launch_resident)
+enum { hipDeviceAttributeMultiprocessorCount = 63 };
+inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+inline hipError_t hipDeviceGetAttribute(int* v, int, int) { *v = 3; return hipSuccess; }
 inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 struct hipEvent_emu {};
 typedef hipEvent_emu* hipEvent_t;
@@ -315,3 +356,6 @@ enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 
 #define AAE_LAUNCH(kernel, grid, block, smem, stream, ...) \
     aae_emu::launch((grid), (block), (smem), [&]() { kernel(__VA_ARGS__); })
+// a launch whose blocks must all be resident (grid-wide waits inside the kernel)
+#define AAE_LAUNCH_RESIDENT(kernel, grid, block, smem, stream, ...) \
+    aae_emu::launch_resident((grid), (block), (smem), [&]() { kernel(__VA_ARGS__); })
