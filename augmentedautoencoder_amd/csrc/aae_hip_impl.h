@@ -157,6 +157,7 @@ struct aae_encoder {
     int detect_chain = 1;
     int detect_chain_blocks = 256;         // its grid: one block per CU, never more than the device has (every block must be resident)
     int cu_count = 0;                      // compute units of the device the handle lives on
+    int chain_timeline = 0;                // profiling aid: the persistent launch stamps its phase edges into the wavek_timeline buffer
 };
 
 struct aae_codebook {
@@ -853,16 +854,32 @@ struct ExtraTicketPrep {
 // The persistent per-detection launch (detect_chain.h) serves a forward when every layer behind the first runs the
 // wave-split-K kernel in one of its three 4-wave / depth-2 shapes, the dense layer is the ticketed GEMV, and each layer
 // output has its own buffer.
+static int chain_shape_code(const WaveKPlan& w) { return w.MT == 1 ? 0 : (w.NT == 1 ? 1 : 2); }
+
+// the instantiated (batch class, shape sequence) kernels: what plan_wavek gives the reference network at B = 1, 2, 3, 4
+struct ChainVariant { int mq, s0, s1, s2; };
+static const ChainVariant kChainVariants[] = {{1, 0, 0, 0}, {2, 1, 0, 0}, {4, 0, 1, 0}, {4, 2, 1, 0}};
+
 static bool chain_eligible(const aae_encoder* enc, int B, const std::vector<WaveKPlan>& plans, bool dense_gemv_ticket) {
     const size_t nl = enc->layers.size();
-    if (!enc->detect_chain || B > 4 || nl < 2 || nl - 1 > (size_t)aae::kChainMaxConv || enc->compact_workspace || !dense_gemv_ticket) return false;
-    if (enc->wavek_ablate || enc->wavek_timeline) return false;               // (profiling aids of the stand-alone launches)
+    if (!enc->detect_chain || B > 4 || nl != (size_t)aae::kChainConv + 1 || enc->compact_workspace || !dense_gemv_ticket) return false;
+    if (enc->wavek_ablate || (enc->wavek_timeline && !enc->chain_timeline)) return false;   // (profiling aids of the stand-alone launches)
     for (size_t li = 1; li < nl; ++li) {
         const WaveKPlan& w = plans[li];
         if (!w.use || w.waves != 4 || w.depth != 2 || enc->layers[li].Cout % 4 != 0) return false;
         if (!((w.MT == 1 && w.NT == 1) || (w.MT == 2 && w.NT == 1) || (w.MT == 2 && w.NT == 2))) return false;
     }
-    return enc->dense.Cout % 4 == 0;
+    if (enc->dense.Cout % 4 != 0) return false;
+    const int mq = B <= 2 ? B : 4;
+    for (const ChainVariant& v : kChainVariants)
+        if (v.mq == mq && v.s0 == chain_shape_code(plans[1]) && v.s1 == chain_shape_code(plans[2]) && v.s2 == chain_shape_code(plans[3])) return true;
+    return false;
+}
+
+template <int MQ, int S0, int S1, int S2>
+static void launch_chain_t(const aae::DetectChainArgs& a, int grid, hipStream_t stream) {
+    (void)hipFuncSetAttribute((const void*)aae::detect_chain_kernel<MQ, S0, S1, S2>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kChainSmem);
+    AAE_LAUNCH_RESIDENT((aae::detect_chain_kernel<MQ, S0, S1, S2>), dim3(grid), dim3(256), aae::kChainSmem, stream, a);
 }
 
 static int launch_detect_chain(aae_encoder* enc, int B, const std::vector<WaveKPlan>& plans, const std::vector<unsigned>& nonces, unsigned gemv_nonce,
@@ -872,7 +889,6 @@ static int launch_detect_chain(aae_encoder* enc, int B, const std::vector<WaveKP
     const Layer& D = enc->dense;
     aae::DetectChainArgs a;
     memset(&a, 0, sizeof(a));
-    a.nconv = (int)nl - 1;
     const float* cur = act0;
     double flops = 0.0;
     for (size_t li = 1; li < nl; ++li) {
@@ -880,8 +896,10 @@ static int launch_detect_chain(aae_encoder* enc, int B, const std::vector<WaveKP
         const WaveKPlan& w = plans[li];
         float* out = reinterpret_cast<float*>(base + ws.act_off[li]);
         a.conv[li - 1] = wavek_args(enc, L, w, cur, B * L.Ho * L.Wo, out, reinterpret_cast<float*>(base + ws.chain_partial_off[li]),
-                                    tickets + li * kLayerTicketWords, nonces[li], 0);
-        a.shape[li - 1] = (w.MT == 1) ? 0 : (w.NT == 1 ? 1 : 2);
+                                    tickets + li * kLayerTicketWords, nonces[li], 0);          // (tag 0: no per-layer stamps ...)
+        // ... unless option chain_timeline = 1 + layer asks for the phase stamps of ONE conv layer, kept behind the launch's own stamps
+        if (enc->chain_timeline == 1 + (int)li && enc->wavek_timeline && w.num_mt * w.num_nt * w.gsplits <= 256)
+            a.conv[li - 1].timeline = enc->wavek_timeline + 256 * aae::kChainStamps;
         flops += 2.0 * (double)B * L.Ho * L.Wo * (double)L.K() * L.Cout;
         cur = out;
     }
@@ -898,22 +916,22 @@ static int launch_detect_chain(aae_encoder* enc, int B, const std::vector<WaveKP
     }
     a.barrier.words = tickets + (kConvTicketBytes + kGemvTicketBytes) / 8;
     a.barrier.nonce = barrier_nonce;
+    a.timeline = (enc->chain_timeline && enc->wavek_timeline) ? enc->wavek_timeline : nullptr;      // (3 * 512 * 8 stamps: up to 307 blocks x 40)
+    if (a.timeline && (size_t)std::min(enc->detect_chain_blocks, enc->cu_count > 0 ? enc->cu_count : enc->detect_chain_blocks) * aae::kChainStamps > 3u * 512u * 8u) a.timeline = nullptr;
     int grid = enc->detect_chain_blocks;
     if (enc->cu_count > 0 && grid > enc->cu_count) grid = enc->cu_count;
     if (grid < 1) grid = 1;
-    const int MQ = B <= 2 ? B : 4;
-    if (MQ == 1) {
-        (void)hipFuncSetAttribute((const void*)aae::detect_chain_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kChainSmem);
-        AAE_LAUNCH_RESIDENT((aae::detect_chain_kernel<1>), dim3(grid), dim3(256), aae::kChainSmem, stream, a);
-    } else if (MQ == 2) {
-        (void)hipFuncSetAttribute((const void*)aae::detect_chain_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kChainSmem);
-        AAE_LAUNCH_RESIDENT((aae::detect_chain_kernel<2>), dim3(grid), dim3(256), aae::kChainSmem, stream, a);
-    } else {
-        (void)hipFuncSetAttribute((const void*)aae::detect_chain_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kChainSmem);
-        AAE_LAUNCH_RESIDENT((aae::detect_chain_kernel<4>), dim3(grid), dim3(256), aae::kChainSmem, stream, a);
+    const int key = (B <= 2 ? B : 4) * 1000 + chain_shape_code(plans[1]) * 100 + chain_shape_code(plans[2]) * 10 + chain_shape_code(plans[3]);
+    switch (key) {                                              // (kChainVariants)
+        case 1000: launch_chain_t<1, 0, 0, 0>(a, grid, stream); break;
+        case 2100: launch_chain_t<2, 1, 0, 0>(a, grid, stream); break;
+        case 4010: launch_chain_t<4, 0, 1, 0>(a, grid, stream); break;
+        case 4210: launch_chain_t<4, 2, 1, 0>(a, grid, stream); break;
+        default: return fail(AAE_ERR_RUNTIME, "no persistent per-detection kernel for batch %d / wave-tile shapes %d", B, key % 1000);
     }
     char label[128];
-    snprintf(label, sizeof(label), "chain:detect_chain_f32 B=%d blocks=%d phases=conv2..conv%zu+dense%s", B, grid, nl, a.has_scan ? "+scan" : "");
+    snprintf(label, sizeof(label), "chain:detect_chain_f32 B=%d blocks=%d shapes=%d%d%d phases=conv2..conv%zu+dense%s", B, grid, chain_shape_code(plans[1]),
+             chain_shape_code(plans[2]), chain_shape_code(plans[3]), nl, a.has_scan ? "+scan" : "");
     note_kernel({label, flops});
     AAE_HIP_TRY(hipGetLastError());
     return tm.mark();
@@ -1451,6 +1469,16 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
     else if (!strcmp(name, "detect_chain")) enc->detect_chain = value ? 1 : 0;
     else if (!strcmp(name, "detect_chain_blocks")) enc->detect_chain_blocks = value < 1 ? 1 : (value > aae_host::kChainMaxBlocks ? aae_host::kChainMaxBlocks : value);
     else if (!strcmp(name, "compact_workspace")) enc->compact_workspace = value ? 1 : 0;
+    else if (!strcmp(name, "chain_timeline")) {
+        if (value && !enc->wavek_timeline) {
+            void* p = nullptr;
+            AAE_HIP_TRY(hipMalloc(&p, 3 * 512 * 8 * sizeof(long long)));
+            enc->allocations.push_back(p);
+            enc->wavek_timeline = static_cast<long long*>(p);
+        }
+        enc->chain_timeline = value < 0 ? 0 : value;           // 1: phase edges of the launch; 1 + l: also the inner stamps of conv layer l (2 = conv2 ...)
+        if (!value) enc->wavek_timeline = nullptr;
+    }
     else if (!strcmp(name, "wavek_timeline")) {
         if (value && !enc->wavek_timeline) {
             void* p = nullptr;

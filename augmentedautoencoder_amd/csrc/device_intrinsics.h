@@ -308,6 +308,8 @@ __device__ __forceinline__ void grid_barrier_wait(const GridBarrier& gb, unsigne
 __device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
 // shader-clock counter (s_memtime): kernel-internal timelines of the profiling tools
 __device__ __forceinline__ long long clock_ticks() { return (long long)__builtin_readcyclecounter(); }
+// constant 100 MHz counter (s_memrealtime): the same across CUs, independent of the shader clock
+__device__ __forceinline__ long long wall_ticks() { return (long long)__builtin_amdgcn_s_memrealtime(); }
 
 __device__ __forceinline__ float shfl_xor(float v, int mask) { return __shfl_xor(v, mask, 64); }
 __device__ __forceinline__ int shfl_xor(int v, int mask) { return __shfl_xor(v, mask, 64); }

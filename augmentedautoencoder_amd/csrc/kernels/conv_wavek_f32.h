@@ -124,11 +124,13 @@ __device__ __forceinline__ void conv_wavek_block(const ConvWaveKArgs& p, const i
 
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
-    auto stamp = [&](int k) {
-        if (p.timeline && tid == 0) p.timeline[(long long)Lphys * 8 + k] = clock_ticks();
+    auto stamp = [&](int k) {                                   // (CHAIN: the 100 MHz wall clock of the launch's other stamps)
+        if (p.timeline && tid == 0) p.timeline[(long long)Lphys * 8 + k] = CHAIN ? wall_ticks() : clock_ticks();
     };
     stamp(0);
 
+    const int pH = p.H, pW = p.W, pCin = p.Cin, pKS = p.KS;
+    const int ablate = CHAIN ? 0 : p.ablate;                    // (timing experiments exist for the stand-alone launches only)
     const int tiles = p.num_mt * p.num_nt;
     const int L = xcd_remap(Lphys, nblk);
     const int tm = L % p.num_mt;                               // M tiles of one (N tile, K split) are neighbours: they share its weights in L2
@@ -156,7 +158,7 @@ __device__ __forceinline__ void conv_wavek_block(const ConvWaveKArgs& p, const i
         const int oh = rem / p.Wo, ow = rem - oh * p.Wo;
         a_ih0[mi] = oh * p.S - p.pt;
         a_iw0[mi] = ow * p.S - p.pl;
-        a_off[mi] = (unsigned)(((((long long)b * p.H + a_ih0[mi]) * p.W + a_iw0[mi]) * (long long)p.Cin + h * 4) * 4);
+        a_off[mi] = (unsigned)(((((long long)b * pH + a_ih0[mi]) * pW + a_iw0[mi]) * (long long)pCin + h * 4) * 4);
     }
     // ---- B fragments: lane (i, h) reads column n0 + 32*ni + i of slot row slab*8 + 2c + h
     const buffer_rsrc wbuf = make_buffer(p.wp, p.wp_bytes);
@@ -165,22 +167,22 @@ __device__ __forceinline__ void conv_wavek_block(const ConvWaveKArgs& p, const i
     const unsigned bw_group = (unsigned)(2 * p.CoutPad * 16);
 
     // (cc, kh, kw) of the next slab to load; K order = 32-channel chunk, kh, kw (pack_weights)
-    const int taps = p.KS * p.KS;
+    const int taps = pKS * pKS;
     int cc = s0 / taps;
-    int kh = (s0 - cc * taps) / p.KS;
-    int kw = (s0 - cc * taps) - kh * p.KS;
+    int kh = (s0 - cc * taps) / pKS;
+    int kw = (s0 - cc * taps) - kh * pKS;
     int t_load = s0;
 
     f32x4 fa[DEPTH][MT][4], fb[DEPTH][NT][4];
     // with_b = false: this slab's B fragments are already there (prefetched)
     auto load_stage = [&](int d, bool with_b) {
         const bool live = t_load < s1;                          // past the wave's range: every load is forced out of range (zeros, no traffic)
-        const bool live_a = live && !(p.ablate & 1), live_b = live && !(p.ablate & 2);
-        const unsigned tap_off = (unsigned)(((kh * p.W + kw) * p.Cin + cc * 32) * 4);
+        const bool live_a = live && !(ablate & 1), live_b = live && !(ablate & 2);
+        const unsigned tap_off = (unsigned)(((kh * pW + kw) * pCin + cc * 32) * 4);
         unsigned ao[MT];
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi) {
-            const bool ok = live_a && a_ok[mi] && (unsigned)(a_ih0[mi] + kh) < (unsigned)p.H && (unsigned)(a_iw0[mi] + kw) < (unsigned)p.W;
+            const bool ok = live_a && a_ok[mi] && (unsigned)(a_ih0[mi] + kh) < (unsigned)pH && (unsigned)(a_iw0[mi] + kw) < (unsigned)pW;
             ao[mi] = ok ? a_off[mi] + tap_off : kOobBase;
         }
         const unsigned bo = live_b ? bw_off + (unsigned)t_load * bw_slab : kOobBase;
@@ -194,7 +196,7 @@ __device__ __forceinline__ void conv_wavek_block(const ConvWaveKArgs& p, const i
             }
         }
         ++t_load;
-        if (++kw == p.KS) { kw = 0; if (++kh == p.KS) { kh = 0; ++cc; } }
+        if (++kw == pKS) { kw = 0; if (++kh == pKS) { kh = 0; ++cc; } }
     };
 
     f32x16 acc[MT][NT];
@@ -256,7 +258,7 @@ __device__ __forceinline__ void conv_wavek_block(const ConvWaveKArgs& p, const i
                 sched_fence();
                 load_stage((d + DEPTH - 1) % DEPTH, true);      // slab t + d + DEPTH - 1 (dead loads once past s1)
                 sched_fence();
-                if (!(p.ablate & 4)) mfma_stage(d);
+                if (!(ablate & 4)) mfma_stage(d);
             }
         }
     }
@@ -283,7 +285,7 @@ __device__ __forceinline__ void conv_wavek_block(const ConvWaveKArgs& p, const i
     __syncthreads();                                            // (CHAIN: the next work item of this block reuses red)
 
     stamp(3);                                                   // cross-wave sum done
-    if (p.gsplits > 1 && !(p.ablate & 8)) {
+    if (p.gsplits > 1 && !(ablate & 8)) {
         // this block's tile partial: one 16-B coherent store per piece, thread-linear (coalesced)
         const buffer_rsrc pbuf = make_buffer(p.partial, p.partial_bytes);
         const unsigned tile_base = (unsigned)tile * (unsigned)p.gsplits * NF4 * T * 16u;

@@ -13,6 +13,14 @@
 // depend on the previous phase BEFORE the barrier closes: the next layer's first weight fragments, the dense layer's whole
 // weight chunk, the first rows of the codebook.  They fly while the barrier's atomics travel (arrive -> prefetch -> wait).
 //
+// One kernel per (batch class, wave-tile shape of each of the three conv phases): the shapes are TEMPLATE parameters and the phases
+// are written out one after the other, so every layer's arguments sit at fixed offsets of the kernel-argument segment and
+// each slab loop is compiled as in its stand-alone kernel.  (A first version chose layer and shape at run time inside one
+// loop: under that kernel's register pressure the compiler re-read the slab loop's scalars from the argument segment in
+// every slab and kept the wave-uniform K cursor in vector registers -- conv2 at B = 1 took 23.5 us instead of 16,
+// profiles/r11_small/chain_first_version_timeline.jsonl.)  Instantiated for the shape sequences the planner produces for
+// B = 1 ... 4 of the reference network (4 conv layers: train_template.cfg:50); every other network keeps the six launches.
+//
 // Phases (every phase = a grid-stride loop over the work items of the six-launch plan, same decomposition, same
 // summation orders -> bit-identical to the six launches, which stay as the reference path and serve every other case):
 //   conv layer l = 2 ... L : conv_wavek_block<MT, NT, 4, 2, CHAIN> (wave-split-K implicit GEMM; split layers finish inside
@@ -27,22 +35,35 @@
 
 namespace aae {
 
-constexpr int kChainMaxConv = AAE_MAX_LAYERS;
+constexpr int kChainConv = 3;                    // conv phases of the persistent launch: layers 2, 3, 4 of a four-layer encoder
 constexpr int kChainSmem = 96 * 1024;            // > half a CU's LDS: one block per CU (also covers the 64 x 64 tile's 64 KB)
 
 struct DetectChainArgs {
-    ConvWaveKArgs conv[kChainMaxConv];           // layers 2 ... L of the encoder, planned as for the stand-alone launches
-    int shape[kChainMaxConv];                    // wave tile of each: 0 = 32x32, 1 = 64x32, 2 = 64x64
-    int nconv;
+    ConvWaveKArgs conv[kChainConv];              // layers 2 ... 4 of the encoder, planned as for the stand-alone launches
     DenseGemvArgs dense;
     int dense_tiles;                             // CoutPad / 128
     int dense_chunks;                            // K / 128
     ScanArgs scan;                               // tickets / idx_out / score_out set: the scan answers inside the launch
     int has_scan;
     GridBarrier barrier;
+    long long* timeline;                         // optional [blocks][kChainStamps] wall-clock stamps (100 MHz) of thread 0 per phase edge (tools/chain_timeline.py)
 };
 
-__device__ __forceinline__ int chain_shape_nt(int shape) { return shape == 2 ? 2 : 1; }
+constexpr int kChainStamps = 40;
+
+// wave-tile shape codes: 0 = 32 x 32, 1 = 64 x 32, 2 = 64 x 64
+template <int SHAPE>
+struct ChainShape {
+    static constexpr int MT = SHAPE == 0 ? 1 : 2, NT = SHAPE == 2 ? 2 : 1;
+};
+
+// one conv phase: this block's work items of layer `a` (the first one may find its first B fragments in pf)
+template <int SHAPE>
+__device__ __forceinline__ void chain_conv_phase(const ConvWaveKArgs& a, int blk, int G, float* red, int* flag, const WaveKPrefetch& pf, bool have_pf) {
+    const int nblk = a.num_mt * a.num_nt * a.gsplits;
+    for (int L = blk; L < nblk; L += G)
+        conv_wavek_block<ChainShape<SHAPE>::MT, ChainShape<SHAPE>::NT, 4, 2, true>(a, L, nblk, red, flag, pf, have_pf && L == blk);
+}
 
 // codebook rows [row, row + 32) of this wave: 16 loads of two rows each (one 512-B row per half-wave), clipped at row_end
 __device__ __forceinline__ void chain_scan_issue(const ScanArgs& p, const buffer_rsrc& ebuf, int row, int row_end, f32x4 (&e)[16]) {
@@ -75,7 +96,7 @@ __device__ __forceinline__ void chain_scan_consume(const ScanArgs& p, int row, i
     }
 }
 
-template <int MQ>
+template <int MQ, int S0, int S1, int S2>
 __global__ __launch_bounds__(256, 1) void detect_chain_kernel(const DetectChainArgs p) {
     AAE_DYN_SMEM(smem_raw);
     float* red = reinterpret_cast<float*>(smem_raw);
@@ -83,43 +104,46 @@ __global__ __launch_bounds__(256, 1) void detect_chain_kernel(const DetectChainA
     const int G = (int)gridDim.x, blk = (int)blockIdx.x;
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
     unsigned phase = 0;
-
-    WaveKPrefetch pf;
-    bool have_pf = false;
-    f32x4 wdense[16];
-    bool have_wdense = false;
-
-    // ---------------------------------------------------------------- conv layers 2 ... L
-    for (int li = 0; li < p.nconv; ++li) {
-        const ConvWaveKArgs& a = p.conv[li];
-        const int nblk = a.num_mt * a.num_nt * a.gsplits;
-        for (int L = blk; L < nblk; L += G) {
-            const bool use = have_pf && L == blk;
-            if (p.shape[li] == 0) conv_wavek_block<1, 1, 4, 2, true>(a, L, nblk, red, flag, pf, use);
-            else if (p.shape[li] == 1) conv_wavek_block<2, 1, 4, 2, true>(a, L, nblk, red, flag, pf, use);
-            else conv_wavek_block<2, 2, 4, 2, true>(a, L, nblk, red, flag, pf, use);
-        }
+    int stamp_no = 0;
+    auto stamp = [&]() {                                         // phase edges of this block, in order (profiling aid; nullptr in production)
+        if (p.timeline && tid == 0 && stamp_no < kChainStamps) p.timeline[(long long)blk * kChainStamps + stamp_no] = wall_ticks();
+        ++stamp_no;
+    };
+    stamp();
+    // ---------------------------------------------------------------- conv layers 2, 3, 4
+    {
+        WaveKPrefetch pf;
+        chain_conv_phase<S0>(p.conv[0], blk, G, red, flag, pf, false);
+        stamp();                                                 // work of the phase done
         grid_barrier_arrive(p.barrier, (unsigned)G, (unsigned)blk, ++phase);
+        stamp();                                                 // arrived
         // what the next phase needs and this one does not produce, requested while the barrier closes
-        have_pf = false;
-        if (li + 1 < p.nconv) {
-            const ConvWaveKArgs& nx = p.conv[li + 1];
-            conv_wavek_prefetch_b(nx, blk, nx.num_mt * nx.num_nt * nx.gsplits, chain_shape_nt(p.shape[li + 1]), 4, pf);
-            have_pf = true;
-        } else {
-            const int items = p.dense_chunks * p.dense_tiles;
-            dense_gemv_load_weights(p.dense, blk % p.dense_chunks, blk / p.dense_chunks, blk < items, wdense);
-            have_wdense = blk < items;
-        }
+        conv_wavek_prefetch_b(p.conv[1], blk, p.conv[1].num_mt * p.conv[1].num_nt * p.conv[1].gsplits, ChainShape<S1>::NT, 4, pf);
         grid_barrier_wait(p.barrier, (unsigned)G, (unsigned)blk, phase);
+        stamp();                                                 // released
+        chain_conv_phase<S1>(p.conv[1], blk, G, red, flag, pf, true);
+        stamp();
+        grid_barrier_arrive(p.barrier, (unsigned)G, (unsigned)blk, ++phase);
+        stamp();
+        conv_wavek_prefetch_b(p.conv[2], blk, p.conv[2].num_mt * p.conv[2].num_nt * p.conv[2].gsplits, ChainShape<S2>::NT, 4, pf);
+        grid_barrier_wait(p.barrier, (unsigned)G, (unsigned)blk, phase);
+        stamp();
+        chain_conv_phase<S2>(p.conv[2], blk, G, red, flag, pf, true);
+        stamp();
     }
 
     // ---------------------------------------------------------------- dense layer
     {
         const int items = p.dense_chunks * p.dense_tiles;
+        f32x4 wdense[16];                                        // (live only from here to the first work item: not across the conv loops)
+        grid_barrier_arrive(p.barrier, (unsigned)G, (unsigned)blk, ++phase);
+        stamp();
+        dense_gemv_load_weights(p.dense, blk % p.dense_chunks, blk / p.dense_chunks, blk < items, wdense);
+        grid_barrier_wait(p.barrier, (unsigned)G, (unsigned)blk, phase);
+        stamp();
         for (int it = blk; it < items; it += G)
-            dense_gemv_block<MQ, true, true>(p.dense, it % p.dense_chunks, it / p.dense_chunks, p.dense_chunks, smem_raw, wdense,
-                                             have_wdense && it == blk);
+            dense_gemv_block<MQ, true, true>(p.dense, it % p.dense_chunks, it / p.dense_chunks, p.dense_chunks, smem_raw, wdense, it == blk);
+        stamp();                                                 // dense work done
     }
     if (!p.has_scan) return;
 
@@ -132,9 +156,11 @@ __global__ __launch_bounds__(256, 1) void detect_chain_kernel(const DetectChainA
     const buffer_rsrc ebuf = make_buffer(s.E, s.e_bytes);
     f32x4 ea[16], eb[16];
     grid_barrier_arrive(p.barrier, (unsigned)G, (unsigned)blk, ++phase);
+    stamp();
     chain_scan_issue(s, ebuf, row_begin, row_end, ea);          // the first 64 KB of this block's rows fly while the barrier closes
     if (blk == 0) ticket_prepare_slot(s.tickets, s.nonce, (unsigned)G);
     grid_barrier_wait(p.barrier, (unsigned)G, (unsigned)blk, phase);
+    stamp();
 
     // tf.nn.l2_normalize(z, 1) (codebook.py:27), per query, replicated in every lane -- as scan_stream_kernel does it
     const int kq = lane & 31, col = kq * 4;
@@ -183,7 +209,9 @@ __global__ __launch_bounds__(256, 1) void detect_chain_kernel(const DetectChainA
             if (better(red_v[w * MQ + tid], red_i[w * MQ + tid], v, ix)) { v = red_v[w * MQ + tid]; ix = red_i[w * MQ + tid]; }
         scan_store_block_partial(s, tid, v, ix);
     }
+    stamp();                                                     // this block's rows scanned
     scan_ticket_finish(s, red_v + 32);
+    stamp();
 }
 
 }  // namespace aae

@@ -61,6 +61,7 @@ namespace aae {
 
 inline int lane_id() { return threadIdx.x & 63; }
 inline long long clock_ticks() { return 0; }
+inline long long wall_ticks() { return 0; }
 inline void sleep_kcycles(int) {}
 inline void sched_fence() {}
 template <int P>

@@ -469,7 +469,6 @@ def test_fused_encode_nn_prepares_every_ticket_and_equals_the_two_calls(B, strid
                 enc.set_option('ticket_prep', prep)
                 z1, i1, s1 = eb.encode_nn(enc, cb, x, stride)
                 assert np.array_equal(z1, z0) and np.array_equal(i1, i0) and np.array_equal(s1, s0), (chain, prep)
-                assert any(l.startswith('chain:detect_chain_f32') and l.endswith('+scan') for l in enc.labels()) == bool(chain and B <= 4), enc.labels()
         cb.set_mode(_lib.AAE_SCAN_STREAM)          # single-launch scan without preparation: the install path
         i2, s2 = cb.nn(z0, 1, stride)
         assert np.array_equal(i2, i0) and np.array_equal(s2, s0)
@@ -482,71 +481,88 @@ def test_fused_encode_nn_prepares_every_ticket_and_equals_the_two_calls(B, strid
         eb.set_block_order(0)
 
 
+# (batch, filters of the four conv layers, planner thresholds) that make plan_wavek choose each instantiated shape sequence of the
+# persistent launch on a 16 x 16 input: a layer of <= 64 rows has CoutPad / 64 tiles of 64 x 64, so the filter counts steer the shapes
+_CHAIN_CASES = {
+    '000': (1, [32, 64, 64, 64], {}),
+    '100': (2, [32, 256, 64, 64], {'wavek_tiny_max_tiles': 2, 'wavek_narrow_max_tiles': 128}),
+    '010': (3, [32, 64, 256, 64], {'wavek_tiny_max_tiles': 2, 'wavek_narrow_max_tiles': 128}),
+    '210': (4, [32, 384, 256, 64], {'wavek_tiny_max_tiles': 2, 'wavek_narrow_max_tiles': 4}),
+}
+
+
 @pytest.mark.parametrize('order', [0, 1, 2])
-@pytest.mark.parametrize('shape', ['32x32', '64x32', '64x64'])
-def test_persistent_detect_chain_equals_the_stand_alone_launches(shape, order):
-    """detect_chain.h: conv2 ... dense + scan as phases of ONE resident launch (grid barriers between them, operands of the
-    next phase requested while a barrier closes).  Same work items, same summation orders: every layer output, the latents,
-    the index and the score must be the bits of the six stand-alone launches -- for every wave-tile shape, batch size 1 ... 4,
-    grids of 1, 2 and 3 resident blocks (work items walked grid-stride; K splits of one tile on different blocks or on
-    the same one), any interleaving of the blocks, workspaces full of garbage, with and without batch-norm."""
-    opts = {'32x32': {}, '64x32': {'wavek_tiny_max_tiles': 0, 'wavek_narrow_max_tiles': 128},
-            '64x64': {'wavek_tiny_max_tiles': 0, 'wavek_narrow_max_tiles': 0}}[shape]
+@pytest.mark.parametrize('shapes', ['000', '100', '010', '210'])
+def test_persistent_detect_chain_equals_the_stand_alone_launches(shapes, order):
+    """detect_chain.h: conv2 ... conv4, dense and the scan as phases of ONE resident launch (grid barriers between them, operands
+    of the next phase requested while a barrier closes).  Same work items, same summation orders: every layer output, the latents,
+    the index and the score must be the bits of the six stand-alone launches -- for each instantiated (batch class, wave-tile
+    shape sequence), grids of 1, 2 and 3 resident blocks (work items walked grid-stride; the K splits of one tile on different
+    blocks or on the same one), any interleaving of the blocks, workspaces full of garbage, with batch-norm."""
+    B, filters, opts = _CHAIN_CASES[shapes]
     eb.set_block_order(order)
     try:
-        for bn in (False, True):
-            cfg = EncoderConfig((16, 16, 3), [32, 64, 64], [2, 2, 1], 5, 128, bn)
-            w = synth.make_weights(seed=31, shape=cfg.shape, num_filter=cfg.num_filter, strides=cfg.strides, latent=128, batch_norm=bn)
-            E = synth.make_codebook(36 * 9 + 7, 128, seed=8, planted_duplicates=9)
-            enc, cb = eb.EmuEncoder(w, cfg), eb.EmuCodebook(E)
-            for k, v in opts.items():
-                enc.set_option(k, v)
-            for B in ((1, 2, 3, 4) if not bn else (3,)):
-                x = synth.make_crops(B, seed=40 + B, shape=cfg.shape)
-                enc.set_option('detect_chain', 0)
-                z0, i0, s0 = eb.encode_nn(enc, cb, x, 1)
-                acts0 = [enc.activation(i) for i in range(3)]
-                labels0 = enc.labels()
-                assert ('conv_wavek_f32_%s_' % shape) in labels0[1], labels0
-                enc.set_option('detect_chain', 1)
-                for blocks in (3, 2, 1):
-                    enc.set_option('detect_chain_blocks', blocks)
-                    z1, i1, s1 = eb.encode_nn(enc, cb, x, 1)
-                    labels = enc.labels()
-                    assert len(labels) == 2 and labels[1] == 'chain:detect_chain_f32 B=%d blocks=%d phases=conv2..conv3+dense+scan' % (B, blocks), labels
-                    assert np.array_equal(z1, z0) and np.array_equal(i1, i0) and np.array_equal(s1, s0), (bn, B, blocks)
-                    for i in range(3):
-                        assert np.array_equal(enc.activation(i), acts0[i]), (bn, B, blocks, i)
-                    zf = enc.forward(x)                          # encoder alone: the same launch without its scan phase
-                    assert np.array_equal(zf, z0) and enc.labels()[1].endswith('+dense'), enc.labels()
-            enc.close()
-            cb.close()
+        cfg = EncoderConfig((16, 16, 3), filters, [2, 2, 2, 1], 5, 128, True)
+        w = synth.make_weights(seed=31, shape=cfg.shape, num_filter=cfg.num_filter, strides=cfg.strides, latent=128, batch_norm=True)
+        E = synth.make_codebook(36 * 9 + 7, 128, seed=8, planted_duplicates=9)
+        enc, cb = eb.EmuEncoder(w, cfg), eb.EmuCodebook(E)
+        enc.set_option('wavek_balance', 0)
+        for k, v in opts.items():
+            enc.set_option(k, v)
+        x = synth.make_crops(B, seed=40 + B, shape=cfg.shape)
+        enc.set_option('detect_chain', 0)
+        z0, i0, s0 = eb.encode_nn(enc, cb, x, 1)
+        acts0 = [enc.activation(i) for i in range(4)]
+        names = {'0': '32x32', '1': '64x32', '2': '64x64'}
+        assert all(('conv_wavek_f32_%s_' % names[c]) in l for c, l in zip(shapes, enc.labels()[1:4])), enc.labels()
+        enc.set_option('detect_chain', 1)
+        for blocks in ((3, 2, 1) if order == 0 else (3,)):
+            enc.set_option('detect_chain_blocks', blocks)
+            z1, i1, s1 = eb.encode_nn(enc, cb, x, 1)
+            labels = enc.labels()
+            assert len(labels) == 2 and labels[1] == 'chain:detect_chain_f32 B=%d blocks=%d shapes=%s phases=conv2..conv4+dense+scan' % (B, blocks, shapes), labels
+            assert np.array_equal(z1, z0) and np.array_equal(i1, i0) and np.array_equal(s1, s0), (B, blocks)
+            for i in range(4):
+                assert np.array_equal(enc.activation(i), acts0[i]), (B, blocks, i)
+        zf = enc.forward(x)                                      # encoder alone: the same launch without its scan phase
+        assert np.array_equal(zf, z0) and enc.labels()[1].endswith('+dense'), enc.labels()
+        enc.close()
+        cb.close()
     finally:
         eb.set_block_order(0)
 
 
 def test_detect_chain_falls_back_where_it_does_not_apply():
-    """B > 4, compact workspaces, an un-prepared upright stride (masked scan) and split precision keep the stand-alone launches."""
-    cfg = EncoderConfig((16, 16, 3), [32, 64], [2, 2], 5, 128)
+    """B > 4, other depths than four conv layers, shape sequences without a kernel, compact workspaces, an un-prepared upright
+    stride (masked scan) and split precision keep the stand-alone launches."""
+    B, filters, opts = _CHAIN_CASES['000']
+    cfg = EncoderConfig((16, 16, 3), filters, [2, 2, 2, 1], 5, 128)
     w = synth.make_weights(seed=21, shape=cfg.shape, num_filter=cfg.num_filter, strides=cfg.strides, latent=128)
     E = synth.make_codebook(36 * 5, 128, seed=7, planted_duplicates=3)
     enc, cb = eb.EmuEncoder(w, cfg), eb.EmuCodebook(E)
     x = synth.make_crops(5, seed=2, shape=cfg.shape)
     eb.encode_nn(enc, cb, x, 1)
-    assert not any('chain' in l for l in enc.labels())
-    z, i, s = eb.encode_nn(enc, cb, x[:2], 36)               # no compacted copy for stride 36: chain without the scan phase, masked scan launch
+    assert not any('chain' in l for l in enc.labels())           # B = 5
+    z, i, s = eb.encode_nn(enc, cb, x[:1], 36)               # no compacted copy for stride 36: chain without the scan phase, masked scan launch
     assert enc.labels()[1].endswith('+dense'), enc.labels()
     cs = cb.similarity(z)
     assert np.array_equal(i[:, 0], ref.nearest_indices_reference(cs, 1, upright=True, num_cyclo=36))
+    eb.encode_nn(enc, cb, x[:2], 1)                          # B = 2 with shapes 000: no kernel for that pair
+    assert not any('chain' in l for l in enc.labels())
     enc.set_option('compact_workspace', 1)
-    z2 = enc.forward(x[:2])
+    z2 = enc.forward(x[:1])
     assert not any('chain' in l for l in enc.labels()) and np.array_equal(z2, z)
     enc.set_option('compact_workspace', 0)
     enc.set_option('precision', 1)
-    enc.forward(x[:2])
+    enc.forward(x[:1])
     assert not any('chain' in l for l in enc.labels())
     enc.close()
     cb.close()
+    cfg3 = EncoderConfig((16, 16, 3), [32, 64, 64], [2, 2, 1], 5, 128)      # three conv layers
+    enc3 = eb.EmuEncoder(synth.make_weights(seed=5, shape=cfg3.shape, num_filter=cfg3.num_filter, strides=cfg3.strides, latent=128), cfg3)
+    enc3.forward(synth.make_crops(1, seed=3, shape=cfg3.shape))
+    assert not any('chain' in l for l in enc3.labels())
+    enc3.close()
 
 
 def test_compact_workspace_alternates_two_activation_buffers():
