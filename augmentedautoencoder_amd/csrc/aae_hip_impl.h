@@ -153,8 +153,10 @@ struct aae_encoder {
     int wavek_ablate = 0;                  // timing experiments (conv_wavek_f32.h ConvWaveKArgs::ablate); results are wrong when != 0
     int gemv_ticket = 1;                   // dense GEMV (B <= 4): chunk sums finished by the last block instead of a reduce launch
     int wavek_dense = 1;                   // dense layer (B > 4) on the wave-split-K kernel instead of split-K igemm + reduce launch
-    // per-detection batches (B <= 4): everything behind conv1 as ONE persistent launch (detect_chain.h); 0 = six launches
-    int detect_chain = 1;
+    // per-detection batches (B <= 4): everything behind conv1 as ONE persistent launch (detect_chain.h).  Opt-in: measured on MI355X it
+    // is SLOWER than the six launches it replaces (B = 1: 92 vs 82 us, B = 4: 215 vs 200 -- a grid barrier costs 3-4 us in there, more
+    // than the 1.5-2 us kernel boundary it removes, and the cross-barrier prefetch wins back less; profiles/r11_small/chain_*).
+    int detect_chain = 0;
     int detect_chain_blocks = 256;         // its grid: one block per CU, never more than the device has (every block must be resident)
     int cu_count = 0;                      // compute units of the device the handle lives on
     int chain_timeline = 0;                // profiling aid: the persistent launch stamps its phase edges into the wavek_timeline buffer

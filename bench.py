@@ -275,10 +275,10 @@ def main():
             lat['B%d' % b] = {'encode+nn_us': round(eager, 2), 'graph_replay_us': round(graph, 2), 'crops_per_s': round(b / eager * 1e6, 1),
                               'launches': len(recs) if any(l.startswith('chain:') for l, _, _ in recs) else len(recs) + 1}
             del cap
-        lat['note'] = ('fused aae_encode_nn: conv1, then conv2 ... conv4, the dense GEMV and the stream scan as phases of ONE persistent launch '
-                       '(detect_chain.h: grid barriers between the phases, the next phase\'s weights / first codebook rows requested while a barrier '
-                       'closes; split reductions finished by the last block of a tile); floor = 27 us of fp32 MFMA work (4.28 GFLOP at 157 TF) + '
-                       '107 MB of weights/codebook')
+        lat['note'] = ('fused aae_encode_nn: conv1, three wave-split-K convolutions, dense GEMV, stream scan -- each split reduction finished '
+                       'inside its own launch; floor of this chain = 27 us of fp32 MFMA work (4.28 GFLOP at 157 TF) + 107 MB of weights/codebook.  '
+                       'The same query as conv1 + ONE persistent launch (option detect_chain, grid barriers between the phases) is built, '
+                       'bit-identical and measured slower: profiles/r11_small/chain_vs_six_launches_latency.jsonl')
         extras['latency'] = lat
         # ---- the codebook query alone
         z = enc.encode(x)

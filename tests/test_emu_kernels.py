@@ -541,6 +541,11 @@ def test_detect_chain_falls_back_where_it_does_not_apply():
     E = synth.make_codebook(36 * 5, 128, seed=7, planted_duplicates=3)
     enc, cb = eb.EmuEncoder(w, cfg), eb.EmuCodebook(E)
     x = synth.make_crops(5, seed=2, shape=cfg.shape)
+    eb.encode_nn(enc, cb, x[:1], 1)
+    assert not any('chain' in l for l in enc.labels())           # opt-in: off unless asked for
+    enc.set_option('detect_chain', 1)
+    eb.encode_nn(enc, cb, x[:1], 1)
+    assert enc.labels()[1].endswith('+dense+scan'), enc.labels()
     eb.encode_nn(enc, cb, x, 1)
     assert not any('chain' in l for l in enc.labels())           # B = 5
     z, i, s = eb.encode_nn(enc, cb, x[:1], 36)               # no compacted copy for stride 36: chain without the scan phase, masked scan launch
@@ -560,6 +565,7 @@ def test_detect_chain_falls_back_where_it_does_not_apply():
     cb.close()
     cfg3 = EncoderConfig((16, 16, 3), [32, 64, 64], [2, 2, 1], 5, 128)      # three conv layers
     enc3 = eb.EmuEncoder(synth.make_weights(seed=5, shape=cfg3.shape, num_filter=cfg3.num_filter, strides=cfg3.strides, latent=128), cfg3)
+    enc3.set_option('detect_chain', 1)
     enc3.forward(synth.make_crops(1, seed=3, shape=cfg3.shape))
     assert not any('chain' in l for l in enc3.labels())
     enc3.close()

@@ -847,9 +847,9 @@ def test_upright_search_uses_the_compacted_copy_and_follows_updates():
 # ---- small batches: the reference's one-crop-per-detection usage (m3_interface/ae_pose_estimator.py:143-170) ----
 @pytest.mark.parametrize('B,chain', [(1, 1), (2, 1), (3, 1), (4, 1), (1, 0), (3, 0), (4, 0), (7, 1), (12, 1)])
 def test_small_batch_wave_split_k_path_matches_fp64_oracle(default_model, B, chain):
-    """B <= 4 (the reference's per-detection batches): conv1, then conv2 ... dense (+ the scan in the fused call) as ONE persistent
-    launch (detect_chain.h; chain = 0: the stand-alone form -- conv2..conv4 on the wave-split-K igemm with the in-launch ticketed K
-    reduction, dense as the ticketed GEMV: five encoder launches, one scan launch).  Every layer, the latents, the similarity and
+    """B <= 4 (the reference's per-detection batches): conv2..conv4 on the wave-split-K igemm with the in-launch ticketed K reduction,
+    dense as the ticketed GEMV: five encoder launches, one scan launch (chain = 1: the opt-in form -- conv1, then conv2 ... dense, and in
+    the fused call the scan, as ONE persistent launch, detect_chain.h; bit-identical, measured slower, so not the default).  Every layer, the latents, the similarity and
     the indices against the fp64 oracle; B = 7: every layer still on the wave-split-K kernels (two rounds of blocks, balanced tile
     shapes); B = 12 mixes both kernel families (conv2 on the 128 x 128 split-K path)."""
     weights, enc, cb, E, _ = default_model
@@ -859,11 +859,11 @@ def test_small_batch_wave_split_k_path_matches_fp64_oracle(default_model, B, cha
         z, recs = enc.engine.encode_timed(crops)
         zf, idx_f, score_f = enc.engine.encode_nn(cb.engine, crops, 1)          # the fused per-detection call on the same crops
     finally:
-        enc.engine.set_option('detect_chain', 1)
+        enc.engine.set_option('detect_chain', 0)
     assert np.array_equal(zf.cpu().numpy(), z.cpu().numpy())
     labels = [l for l, _, _ in recs]
     if B <= 4 and chain:
-        assert len(labels) == 2 and labels[0].startswith('conv1:conv_first_f32') and labels[1].startswith('chain:detect_chain_f32 B=%d blocks=256 ' % B), labels
+        assert len(labels) == 2 and labels[0].startswith('conv1:conv_first_f32') and labels[1].startswith('chain:detect_chain_f32 B=%d blocks=256 shapes=' % B), labels
     elif B <= 4:
         assert len(labels) == 5 and labels[0].startswith('conv1:conv_first_f32') and labels[4].startswith('dense:dense_gemv_f32_ticket'), labels
         assert all(':conv_wavek_f32_' in l for l in labels[1:4]), labels
@@ -948,7 +948,7 @@ def test_in_launch_ticketed_reductions_are_race_free_and_order_independent():
                 cb.set_scan_mode(_lib.AAE_SCAN_AUTO)
                 assert torch.equal(i3, i2) and torch.equal(s3, s2), (B, rep)
         enc.set_option('ticket_prep', 1)
-        enc.set_option('detect_chain', 1)
+        enc.set_option('detect_chain', 0)
         torch.cuda.synchronize()
     # exact ties through the single-launch scan: the lower twin must win in every form
     dup = [r for r in range(35, E.shape[0], 36) if np.array_equal(E[r], E[r - 35])][:3]
@@ -1167,7 +1167,7 @@ def test_ticketed_partials_are_never_read_stale_across_launches():
     weights = synth.make_weights(seed=2024)
     E = synth.make_codebook(92232, 128, seed=7, planted_duplicates=16)
     ex, ey = EncoderEngine(EncoderConfig(), weights), EncoderEngine(EncoderConfig(), weights)
-    ey.set_option('detect_chain', 0)     # X: conv1 + the persistent launch on ONE long-lived workspace; Y: six launches on fresh memory
+    ex.set_option('detect_chain', 1)     # X: conv1 + the (opt-in) persistent launch on ONE long-lived workspace; Y: six launches on fresh memory
     cx, cy = CodebookEngine(E), CodebookEngine(E)
     rng = np.random.default_rng(5)
     side = torch.cuda.Stream()

@@ -21,6 +21,7 @@ for kv in (sys.argv[2].split(',') if len(sys.argv) > 2 else []):
     name, value = kv.split('=')
     enc.set_option(name, int(value))
 inner = int(os.environ.get('CHAIN_INNER_LAYER', '0'))          # 2, 3, 4: also the stamps inside that conv layer's phase
+enc.set_option('detect_chain', 1)
 enc.set_option('chain_timeline', inner if inner else 1)
 cb = CodebookEngine(synth.make_codebook(92232, 128, seed=7))
 x = torch.from_numpy(synth.make_crops(B, seed=3)).cuda()
