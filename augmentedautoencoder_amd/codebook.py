@@ -34,6 +34,26 @@ def _parse_K(text):
     return ev(ast.parse(text.strip(), mode='eval').body)
 
 
+_BATCH_GEOMETRY_OK = None
+
+
+def _batch_geometry_matches_scalar():
+    """Once per process: do NumPy's array loops of arctan / cos / sin / sqrt give an element the bits the scalar calls of
+    auto_pose6d (codebook.py:118-127) get?  (One ufunc inner loop serves both on the builds seen so far; a build whose SIMD
+    kernels disagree with its scalar path makes poses_from_indices fall back to the per-detection loop.)"""
+    global _BATCH_GEOMETRY_OK
+    if _BATCH_GEOMETRY_OK is None:
+        rng = np.random.default_rng(12345)
+        v = np.concatenate([rng.uniform(-3.0, 3.0, 509), rng.uniform(-1e-3, 1e-3, 64), rng.uniform(-300.0, 300.0, 64), [0.0, 1.0, -1.0]])
+        ok = True
+        for fn in (np.arctan, np.cos, np.sin):
+            ok = ok and np.array_equal(fn(v), np.array([fn(x) for x in v]))
+        a = np.abs(v) + 1e-9
+        ok = ok and np.array_equal(np.sqrt(a), np.array([np.sqrt(x) for x in a]))
+        _BATCH_GEOMETRY_OK = bool(ok)
+    return _BATCH_GEOMETRY_OK
+
+
 class Codebook(object):
 
     def __init__(self, encoder, dataset, embed_bb):
@@ -191,16 +211,9 @@ class Codebook(object):
         top_n = len(idcs)
         Rs_est = self._dataset.viewsphere_for_embedding[idcs]      # fancy index -> copy
 
-        # [Dataset] K / RADIUS are parsed once per distinct config text (the per-detection estimator flow
-        # calls this for every box; the parse was 40 % of the call)
-        key = (train_args.get('Dataset', 'K'), train_args.get('Dataset', 'RADIUS'))
-        cached = self._train_geometry.get(key) if hasattr(self, '_train_geometry') else None
-        if cached is None:
-            cached = (np.array(_parse_K(key[0])).reshape(3, 3), float(key[1]))
-            if not hasattr(self, '_train_geometry'):
-                self._train_geometry = {}
-            self._train_geometry[key] = cached
-        K_train, render_radius = cached
+        # [Dataset] K / RADIUS are parsed once per config (the per-detection estimator flow calls this for every box; the
+        # parse was 40 % of the call, the two configparser lookups another 10 us)
+        K_train, render_radius = self._train_geometry_of(train_args)
         K_diag_ratio = np.sqrt(K_test[0, 0] ** 2 + K_test[1, 1] ** 2) / np.sqrt(K_train[0, 0] ** 2 + K_train[1, 1] ** 2)
 
         if self.embed_obj_bbs_values is None:
@@ -228,6 +241,63 @@ class Codebook(object):
             Ry = np.array([[np.cos(ay), 0, np.sin(ay)], [0, 1, 0], [-np.sin(ay), 0, np.cos(ay)]])
             Rs_est[i] = np.dot(Ry, np.dot(Rx, Rs_est[i]))
         return (Rs_est, ts_est)
+
+    def _train_geometry_of(self, train_args):
+        """(K_train 3x3, render radius) of a training config: [Dataset] K / RADIUS parsed once per config object and text"""
+        cache = self.__dict__.setdefault('_train_geometry_by_id', {})
+        hit = cache.get(id(train_args))
+        if hit is None or hit[0] is not train_args:
+            key = (train_args.get('Dataset', 'K'), train_args.get('Dataset', 'RADIUS'))
+            hit = (train_args, np.array(_parse_K(key[0])).reshape(3, 3), float(key[1]))
+            cache[id(train_args)] = hit
+        return hit[1], hit[2]
+
+    def poses_from_indices(self, idcs, predicted_bbs, K_test, train_args, depth_preds=None):
+        """pose_from_indices for n detections of one object at once: idcs [n] (top-1 rows), predicted_bbs [n][4] ->
+        (Rs [n,3,3], ts [n,3]), every number bit-identical to n scalar calls (codebook.py:84-129).  Array arithmetic is used
+        only where NumPy gives the same bits for an element of an array as for a scalar: + - * / sqrt and the ufuncs arctan /
+        cos / sin (one inner loop serves both; checked once per process against the scalar form, which is kept as the
+        fallback).  The two float32 norms, the scalar power z ** 2 (libm pow, not x * x) and the BLAS 3 x 3 products stay per
+        detection -- their array forms round differently."""
+        idcs = np.asarray(idcs, dtype=np.int64).reshape(-1)
+        n = len(idcs)
+        if n == 0:
+            return np.empty((0, 3, 3)), np.empty((0, 3))
+        if not _batch_geometry_matches_scalar():
+            out = [self.pose_from_indices([int(i)], bb, K_test, train_args, depth_pred=None if depth_preds is None else depth_preds[k])
+                   for k, (i, bb) in enumerate(zip(idcs, predicted_bbs))]
+            return np.concatenate([r for r, _ in out], axis=0), np.concatenate([t for _, t in out], axis=0)
+        Rs_est = self._dataset.viewsphere_for_embedding[idcs]      # fancy index -> copy
+        K_train, render_radius = self._train_geometry_of(train_args)
+        K_diag_ratio = np.sqrt(K_test[0, 0] ** 2 + K_test[1, 1] ** 2) / np.sqrt(K_train[0, 0] ** 2 + K_train[1, 1] ** 2)
+        if self.embed_obj_bbs_values is None:
+            self.embed_obj_bbs_values = self.embed_obj_bbs_value()
+        rb = self.embed_obj_bbs_values[idcs]                       # [n,4] int32
+        # predicted boxes keep their Python-float arithmetic (x + w / 2 ...): float64 arrays of the same values give the same bits
+        pb = np.array([[float(v) for v in bb] for bb in predicted_bbs], dtype=np.float64).reshape(n, 4)
+        if depth_preds is None:
+            num = np.array([np.linalg.norm(np.float32(r[2:])) for r in rb], dtype=np.float32)
+            den = np.array([np.linalg.norm(np.float32(bb[2:])) for bb in predicted_bbs], dtype=np.float32)
+            z = (num / den) * K_diag_ratio * render_radius          # float32 quotient, then float64 products: as the scalar code
+        else:
+            z = np.array([float(d) for d in depth_preds], dtype=np.float64)
+        cx_train = rb[:, 0] + rb[:, 2] / 2. - K_train[0, 2]
+        cy_train = rb[:, 1] + rb[:, 3] / 2. - K_train[1, 2]
+        cx_test = pb[:, 0] + pb[:, 2] / 2 - K_test[0, 2]
+        cy_test = pb[:, 1] + pb[:, 3] / 2 - K_test[1, 2]
+        tx = cx_test * z / K_test[0, 0] - cx_train * render_radius / K_train[0, 0]
+        ty = cy_test * z / K_test[1, 1] - cy_train * render_radius / K_train[1, 1]
+        ts_est = np.stack([tx, ty, z], axis=1)
+        zz = np.array([v ** 2 for v in z])                         # scalar power (pow), element by element
+        tyy = np.array([v ** 2 for v in ty])
+        ay = np.arctan(tx / np.sqrt(zz + tyy))
+        ax = -np.arctan(ty / z)
+        cax, sax, cay, say = np.cos(ax), np.sin(ax), np.cos(ay), np.sin(ay)
+        for i in range(n):
+            Rx = np.array([[1, 0, 0], [0, cax[i], -sax[i]], [0, sax[i], cax[i]]])
+            Ry = np.array([[cay[i], 0, say[i]], [0, 1, 0], [-say[i], 0, cay[i]]])
+            Rs_est[i] = np.dot(Ry, np.dot(Rx, Rs_est[i]))
+        return Rs_est, ts_est
 
     def nearest_rotation_batch(self, session, x):
         """Batched arg-max on the device (codebook.py:131-133)."""

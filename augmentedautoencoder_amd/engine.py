@@ -14,16 +14,45 @@ from . import _lib
 from .weights import EncoderConfig, as_pointer_array, ordered_weight_arrays
 
 
+_TORCH = None
+
+
 def _torch():
-    import torch
-    if not torch.cuda.is_available():
-        raise RuntimeError('augmentedautoencoder_amd needs an AMD GPU (MI355X / gfx950); '
-                           'torch.cuda.is_available() is False and there is no CPU fallback.')
-    return torch
+    """torch, once it has been seen with a GPU (the check costs ~8 us per call: asked once per process, not per launch)."""
+    global _TORCH
+    if _TORCH is None:
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError('augmentedautoencoder_amd needs an AMD GPU (MI355X / gfx950); '
+                               'torch.cuda.is_available() is False and there is no CPU fallback.')
+        _TORCH = torch
+    return _TORCH
 
 
 def _stream_ptr(torch):
+    """raw handle of the current stream of the current device (the fast accessor where torch has it: ~0.3 us instead of ~4)"""
+    raw = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+    if raw is not None:
+        return ctypes.c_void_p(raw(torch.cuda.current_device()))
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _on_device(object):
+    """`with torch.cuda.device(d)` without its cost when d is current already (the per-detection loop: one GPU per process)."""
+
+    def __init__(self, device):
+        self.idx = device.index if device.index is not None else 0
+
+    def __enter__(self):
+        torch = _torch()
+        self.prev = torch.cuda.current_device()
+        if self.prev != self.idx:
+            torch.cuda.set_device(self.idx)
+
+    def __exit__(self, *exc):
+        if self.prev != self.idx:
+            _torch().cuda.set_device(self.prev)
+        return False
 
 
 class _Workspace(object):
@@ -62,13 +91,14 @@ class EncoderEngine(object):
         arrays = ordered_weight_arrays(weights, cfg)
         handle = ctypes.c_void_p()
         desc = cfg.to_desc()
-        with torch.cuda.device(self.device):
+        with _on_device(self.device):
             rc = self.lib.aae_encoder_create(ctypes.byref(desc), as_pointer_array(arrays), len(arrays), ctypes.byref(handle))
         _lib.check(self.lib, rc, 'aae_encoder_create')
         self.handle = handle
         self.ws = _Workspace(self.device)
         self._last_B = None
         self.options = {}
+        self._ws_bytes = {}                # batch -> aae_encoder_workspace_bytes (depends on the options: cleared by set_option)
         # f32x3h mode ('precision' = 1, 2): activations travel as fp16 (hi, lo) pairs that carry |x| < 4094 exactly.  Every
         # forward raises its own device flag when a value leaves that range; the flags of all forwards queued since the
         # last check are read in ONE host round trip by settle() -- when results are consumed, never per launch -- and
@@ -95,6 +125,13 @@ class EncoderEngine(object):
         (B >= 4 of the default net; per-detection batches stay on the exact fp32 wave-split-K path); default 0 = exact fp32."""
         _lib.check(self.lib, self.lib.aae_encoder_set_option(self.handle, name.encode(), int(value)), 'aae_encoder_set_option')
         self.options[name] = int(value)
+        self._ws_bytes.clear()
+
+    def workspace_bytes(self, B):
+        n = self._ws_bytes.get(B)
+        if n is None:
+            n = self._ws_bytes[B] = self.lib.aae_encoder_workspace_bytes(self.handle, B)
+        return n
 
     # ---- input handling: codebook.py:58-61 --------------------------------
     def to_device_batch(self, x):
@@ -140,7 +177,7 @@ class EncoderEngine(object):
         torch = _torch()
         arr = (ctypes.c_int * len(slots))(*slots)
         flags = (ctypes.c_int * len(slots))()
-        with torch.cuda.device(self.device):
+        with _on_device(self.device):
             _lib.check(self.lib, self.lib.aae_encoder_x3h_poll(self.handle, arr, len(slots), flags, _stream_ptr(torch)),
                        'aae_encoder_x3h_poll')
         return [int(f) for f in flags]
@@ -178,10 +215,10 @@ class EncoderEngine(object):
         torch = _torch()
         B = t.shape[0]
         dt = _lib.AAE_DTYPE_U8 if t.dtype == torch.uint8 else _lib.AAE_DTYPE_F32
-        nbytes = self.lib.aae_encoder_workspace_bytes(self.handle, B)
+        nbytes = self.workspace_bytes(B)
         _, ws_ptr = self.ws.get(nbytes)
         self._last_B = B
-        with torch.cuda.device(self.device):
+        with _on_device(self.device):
             if not timed:
                 rc = self.lib.aae_encoder_forward(self.handle, ctypes.c_void_p(t.data_ptr()), dt, B,
                                                   ctypes.c_void_p(z_out.data_ptr()), ctypes.c_void_p(ws_ptr), nbytes,
@@ -216,19 +253,27 @@ class EncoderEngine(object):
         self.settle()
         return z
 
-    def encode_nn(self, codebook_engine, x, col_stride=1):
+    def encode_nn(self, codebook_engine, x, col_stride=1, out=None):
         """Encoder.z + the top-1 codebook query of a batch in one C call per chunk (aae_encode_nn): what
         Codebook.nearest_rotation does per detection.  Returns (z [B,J], idx int64 [B,1], cosine float32 [B,1]) on
-        the device; bit-identical to encode() followed by codebook_engine.nn(z, 1, col_stride)."""
+        the device; bit-identical to encode() followed by codebook_engine.nn(z, 1, col_stride).  out: optional
+        caller-owned (z, idx, score) device tensors of at least B rows to write into (a per-frame loop then allocates nothing)."""
         torch = _torch()
         cb = codebook_engine
         if cb.device != self.device:
             raise ValueError('encode_nn: encoder on %s, codebook on %s -- one C call needs both on one device' % (self.device, cb.device))
         t = self.to_device_batch(x)
         B = t.shape[0]
-        z = torch.empty((B, self.cfg.latent_space_size), dtype=torch.float32, device=self.device)
-        idx = torch.empty((B, 1), dtype=torch.int64, device=self.device)
-        score = torch.empty((B, 1), dtype=torch.float32, device=self.device)
+        if out is not None:
+            z, idx, score = out[0][:B], out[1][:B], out[2][:B]
+            if (z.shape != (B, self.cfg.latent_space_size) or idx.shape != (B, 1) or score.shape != (B, 1) or z.dtype != torch.float32
+                    or idx.dtype != torch.int64 or score.dtype != torch.float32 or not (z.is_contiguous() and idx.is_contiguous() and score.is_contiguous())
+                    or z.device != self.device or idx.device != self.device or score.device != self.device):
+                raise ValueError('encode_nn(out=...): need contiguous float32 [>=B,J], int64 [>=B,1], float32 [>=B,1] tensors on %s' % (self.device,))
+        else:
+            z = torch.empty((B, self.cfg.latent_space_size), dtype=torch.float32, device=self.device)
+            idx = torch.empty((B, 1), dtype=torch.int64, device=self.device)
+            score = torch.empty((B, 1), dtype=torch.float32, device=self.device)
         if B == 0:
             return z, idx, score
         cb.ensure_upright(col_stride, 1)
@@ -236,12 +281,12 @@ class EncoderEngine(object):
         for a in range(0, B, self.max_batch):
             e = min(a + self.max_batch, B)
             n = e - a
-            nb_e = self.lib.aae_encoder_workspace_bytes(self.handle, n)
-            nb_c = self.lib.aae_codebook_workspace_bytes(cb.handle, n, 1)
+            nb_e = self.workspace_bytes(n)
+            nb_c = cb.workspace_bytes(n, 1)
             _, ws_e = self.ws.get(nb_e)
             _, ws_c = cb.ws.get(nb_c)
             self._last_B = n
-            with torch.cuda.device(self.device):
+            with _on_device(self.device):
                 rc = self.lib.aae_encode_nn(self.handle, cb.handle, ctypes.c_void_p(t[a:e].data_ptr()), dt, n, int(col_stride),
                                             ctypes.c_void_p(z[a:e].data_ptr()), ctypes.c_void_p(idx[a:e].data_ptr()),
                                             ctypes.c_void_p(score[a:e].data_ptr()), ctypes.c_void_p(ws_e), nb_e,
@@ -294,7 +339,7 @@ class CodebookEngine(object):
         self.lib = _lib.load()
         self.dtype = dtype
         handle = ctypes.c_void_p()
-        with torch.cuda.device(self.device):
+        with _on_device(self.device):
             if dtype == 'bf16':
                 from .weights import to_bf16_bits
                 src = embedding_normalized.cpu().numpy() if torch.is_tensor(embedding_normalized) else embedding_normalized
@@ -315,6 +360,7 @@ class CodebookEngine(object):
         _lib.check(self.lib, rc, 'aae_codebook_create')
         self.handle = handle
         self.ws = _Workspace(self.device)
+        self._ws_bytes = {}               # (batch, topk) -> aae_codebook_workspace_bytes
         self._upright_stride = 0          # stride the compacted upright copy was prepared for (0 = none yet)
 
     def close(self):
@@ -330,6 +376,13 @@ class CodebookEngine(object):
 
     def set_scan_mode(self, mode):
         _lib.check(self.lib, self.lib.aae_codebook_set_scan_mode(self.handle, int(mode)), 'aae_codebook_set_scan_mode')
+        self._ws_bytes.clear()
+
+    def workspace_bytes(self, B, topk):
+        n = self._ws_bytes.get((B, topk))
+        if n is None:
+            n = self._ws_bytes[(B, topk)] = self.lib.aae_codebook_workspace_bytes(self.handle, B, topk)
+        return n
 
     def update(self, embedding_normalized):
         torch = _torch()
@@ -339,7 +392,7 @@ class CodebookEngine(object):
         if self.dtype == 'bf16':
             from .weights import to_bf16_bits
             E = to_bf16_bits(E)
-        with torch.cuda.device(self.device):
+        with _on_device(self.device):
             rc = self.lib.aae_codebook_update(self.handle, E.ctypes.data, 0, _stream_ptr(torch))
         _lib.check(self.lib, rc, 'aae_codebook_update')
 
@@ -357,7 +410,7 @@ class CodebookEngine(object):
         a CapturedNearestNeighbour reaches this in its eager warm-up call, before the capture starts)."""
         if col_stride > 1 and topk == 1 and self._upright_stride != int(col_stride):
             torch = _torch()
-            with torch.cuda.device(self.device):
+            with _on_device(self.device):
                 rc = self.lib.aae_codebook_prepare_upright(self.handle, int(col_stride), _stream_ptr(torch))
             _lib.check(self.lib, rc, 'aae_codebook_prepare_upright')
             self._upright_stride = int(col_stride)
@@ -372,9 +425,9 @@ class CodebookEngine(object):
         if B == 0:                    # an empty batch is an empty answer (TF/NumPy semantics of the reference), not an error
             return idx, score
         self.ensure_upright(col_stride, topk)
-        nbytes = self.lib.aae_codebook_workspace_bytes(self.handle, B, topk)
+        nbytes = self.workspace_bytes(B, topk)
         _, ws_ptr = self.ws.get(nbytes)
-        with torch.cuda.device(self.device):
+        with _on_device(self.device):
             rc = self.lib.aae_codebook_nn(self.handle, ctypes.c_void_p(z.data_ptr()), B, int(topk), int(col_stride),
                                           ctypes.c_void_p(idx.data_ptr()), ctypes.c_void_p(score.data_ptr()),
                                           ctypes.c_void_p(ws_ptr), nbytes, _stream_ptr(torch))
@@ -389,9 +442,9 @@ class CodebookEngine(object):
         cs = torch.empty((B, self.N), dtype=torch.float32, device=self.device)
         if B == 0:
             return cs
-        nbytes = self.lib.aae_codebook_workspace_bytes(self.handle, B, 1)
+        nbytes = self.workspace_bytes(B, 1)
         _, ws_ptr = self.ws.get(nbytes)
-        with torch.cuda.device(self.device):
+        with _on_device(self.device):
             rc = self.lib.aae_codebook_similarity(self.handle, ctypes.c_void_p(z.data_ptr()), B, ctypes.c_void_p(cs.data_ptr()),
                                                   ctypes.c_void_p(ws_ptr), nbytes, _stream_ptr(torch))
         _lib.check(self.lib, rc, 'aae_codebook_similarity')
@@ -403,7 +456,7 @@ class CodebookEngine(object):
         q = torch.empty_like(z)
         if z.shape[0] == 0:
             return q
-        with torch.cuda.device(self.device):
+        with _on_device(self.device):
             rc = self.lib.aae_l2_normalize(ctypes.c_void_p(z.data_ptr()), z.shape[0], z.shape[1], ctypes.c_void_p(q.data_ptr()),
                                            _stream_ptr(torch))
         _lib.check(self.lib, rc, 'aae_l2_normalize')
@@ -438,7 +491,7 @@ def pack_pairs(idx, score, pos, packed):
         if pos.dtype != torch.int32:
             pos = pos.to(torch.int32)
         pos = _pair_operand(pos, torch.int32, packed.device, 'pos')
-    with torch.cuda.device(packed.device):
+    with _on_device(packed.device):
         rc = lib.aae_pack_pairs(ctypes.c_void_p(idx.data_ptr()), ctypes.c_void_p(score.data_ptr()),
                                 ctypes.c_void_p(pos.data_ptr()) if pos is not None else None, n, stride,
                                 ctypes.c_void_p(packed.data_ptr()), _stream_ptr(torch))
@@ -460,12 +513,33 @@ def unpack_pairs(gathered, owner, n, rows_per_rank, idx_out, score_out):
     if (idx_out.dtype != torch.int64 or score_out.dtype != torch.float32 or not idx_out.is_contiguous() or not score_out.is_contiguous()
             or idx_out.device != dev or score_out.device != dev or idx_out.numel() < n or score_out.numel() < n):
         raise ValueError('unpack_pairs: outputs must be contiguous int64 / float32 tensors of at least n elements on %s' % dev)
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         rc = lib.aae_unpack_pairs(ctypes.c_void_p(gathered.data_ptr()), ctypes.c_void_p(owner.data_ptr()) if owner is not None else None,
                                   int(n), int(rows_per_rank), ctypes.c_void_p(idx_out.data_ptr()), ctypes.c_void_p(score_out.data_ptr()),
                                   _stream_ptr(torch))
     _lib.check(lib, rc, 'aae_unpack_pairs')
     return idx_out, score_out
+
+
+def crop_resize_into(image_dev, boxes_dev, out):
+    """The launch alone, on buffers the caller owns: image_dev uint8 [H,W,C], boxes_dev int32 [D,5] rows (x, y, w, h, size),
+    out uint8 [D,out_h,out_w,C] -- contiguous tensors on one device; nothing is allocated or copied here."""
+    torch = _torch()
+    lib = _lib.load()
+    dev = out.device
+    if (image_dev.dtype != torch.uint8 or out.dtype != torch.uint8 or boxes_dev.dtype != torch.int32 or image_dev.dim() != 3 or out.dim() != 4
+            or boxes_dev.dim() != 2 or boxes_dev.shape[1] != 5 or boxes_dev.shape[0] != out.shape[0] or out.shape[3] != image_dev.shape[2]
+            or image_dev.device != dev or boxes_dev.device != dev
+            or not (image_dev.is_contiguous() and boxes_dev.is_contiguous() and out.is_contiguous())):
+        raise ValueError('crop_resize_into: need contiguous uint8 [H,W,C], int32 [D,5], uint8 [D,h,w,C] tensors on one device')
+    if out.shape[0] == 0:
+        return out
+    with _on_device(dev):
+        rc = lib.aae_crop_resize_u8(ctypes.c_void_p(image_dev.data_ptr()), int(image_dev.shape[0]), int(image_dev.shape[1]), int(image_dev.shape[2]),
+                                    ctypes.c_void_p(boxes_dev.data_ptr()), int(out.shape[0]), int(out.shape[1]), int(out.shape[2]),
+                                    ctypes.c_void_p(out.data_ptr()), _stream_ptr(torch))
+    _lib.check(lib, rc, 'aae_crop_resize_u8')
+    return out
 
 
 def crop_resize(image, boxes_xywh_size, out_hw, device=None):
@@ -492,7 +566,7 @@ def crop_resize(image, boxes_xywh_size, out_hw, device=None):
     out = torch.empty((D, oh, ow, int(img.shape[2])), dtype=torch.uint8, device=dev)
     if D == 0:
         return out
-    with torch.cuda.device(dev):
+    with _on_device(dev):
         rc = lib.aae_crop_resize_u8(ctypes.c_void_p(img.data_ptr()), int(img.shape[0]), int(img.shape[1]), int(img.shape[2]),
                                     ctypes.c_void_p(boxes.data_ptr()), D, oh, ow, ctypes.c_void_p(out.data_ptr()),
                                     _stream_ptr(torch))
@@ -514,7 +588,7 @@ class DecoderEngine(object):
         arrays = ordered_decoder_weight_arrays(weights, cfg)
         handle = ctypes.c_void_p()
         desc = cfg.to_desc()
-        with torch.cuda.device(self.device):
+        with _on_device(self.device):
             rc = self.lib.aae_decoder_create(ctypes.byref(desc), as_pointer_array(arrays), len(arrays), ctypes.byref(handle))
         _lib.check(self.lib, rc, 'aae_decoder_create')
         self.handle = handle
@@ -549,7 +623,7 @@ class DecoderEngine(object):
         nbytes = self.lib.aae_decoder_workspace_bytes(self.handle, B)
         _, ws_ptr = self.ws.get(nbytes)
         self._last_B = B
-        with torch.cuda.device(self.device):
+        with _on_device(self.device):
             if not timed:
                 rc = self.lib.aae_decoder_forward(self.handle, ctypes.c_void_p(z.data_ptr()), B, ctypes.c_void_p(out.data_ptr()),
                                                   ctypes.c_void_p(ws_ptr), nbytes, _stream_ptr(torch))
@@ -629,7 +703,7 @@ class CapturedNearestNeighbour(object):
             self.enc.ws, self.cb.ws = saved
 
     def _capture(self, torch, dev):
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):                # warm-up: sizes the engines' workspaces outside the capture
@@ -699,7 +773,7 @@ class StreamingNearestNeighbour(object):
         dev = encoder_engine.device
         shape = (self.batch,) + tuple(encoder_engine.cfg.shape)
         self.dev = [torch.empty(shape, dtype=dt, device=dev) for _ in range(2)]
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             self.copy_stream = torch.cuda.Stream()
             self.copied = [torch.cuda.Event() for _ in range(2)]
             self.consumed = [torch.cuda.Event() for _ in range(2)]

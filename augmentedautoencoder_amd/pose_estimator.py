@@ -46,6 +46,47 @@ class BoundingBox(object):
         self.classes = classes if classes is not None else {}
 
 
+class _FrameStage(object):
+    """Grow-only pinned-host and device buffers of one estimator on one GPU: the frame (or the union rectangle of its boxes), the
+    box rows, the crops, the per-crop results.  process() then allocates nothing per frame and every copy is asynchronous on the
+    caller's stream: host -> pinned is a memcpy, pinned -> device and device -> pinned are queued behind / in front of the kernels."""
+
+    def __init__(self, device):
+        self.device = device
+        self.img_host = self.img_dev = None
+        self.rows_host = self.rows_dev = None
+        self.crops = self.z = self.idx = self.score = self.idx_host = None
+
+    @staticmethod
+    def _grow(torch, old, n, dtype, device=None, pin=False):
+        if old is not None and old.numel() >= n:
+            return old
+        n = max(int(n), 1)
+        return torch.empty((n,), dtype=dtype, pin_memory=True) if pin else torch.empty((n,), dtype=dtype, device=device)
+
+    def upload_image(self, torch, frame):
+        """frame: uint8 [h,w,c] (any strides) -> contiguous device tensor [h,w,c], queued on the current stream"""
+        h, w, c = frame.shape
+        n = h * w * c
+        self.img_host = self._grow(torch, self.img_host, n, torch.uint8, pin=True)
+        self.img_dev = self._grow(torch, self.img_dev, n, torch.uint8, self.device)
+        np.copyto(self.img_host.numpy()[:n].reshape(h, w, c), frame)
+        dev = self.img_dev[:n]
+        dev.copy_(self.img_host[:n], non_blocking=True)
+        return dev.view(h, w, c)
+
+    def reserve(self, torch, total, latent, crop_shape):
+        """room for `total` detections of this frame: box rows, crops [total,h,w,c], latents, indices, scores"""
+        per_crop = int(np.prod(crop_shape))
+        self.rows_host = self._grow(torch, self.rows_host, total * 5, torch.int32, pin=True)
+        self.rows_dev = self._grow(torch, self.rows_dev, total * 5, torch.int32, self.device)
+        self.crops = self._grow(torch, self.crops, total * per_crop, torch.uint8, self.device)
+        self.z = self._grow(torch, self.z, total * latent, torch.float32, self.device)
+        self.idx = self._grow(torch, self.idx, total, torch.int64, self.device)
+        self.score = self._grow(torch, self.score, total, torch.float32, self.device)
+        self.idx_host = self._grow(torch, self.idx_host, total, torch.int64, pin=True)
+
+
 class AePoseEstimator(object):
 
     def __init__(self, test_config_path=None, codebooks=None, train_args=None, upright=False, topk=1, camPose=False):
@@ -141,9 +182,11 @@ class AePoseEstimator(object):
         """[x, y, w, h, size] int32 rows exactly as extract_square_patch derives them
         (ae_pose_estimator.py:108-109): astype(int32) truncation, size = int(max(h, w) * pad)."""
         rows = np.empty((len(boxes_xywh), 5), dtype=np.int32)
-        for i, bb in enumerate(boxes_xywh):
-            x, y, w, h = np.array(bb).astype(np.int32)
-            rows[i] = (x, y, w, h, int(np.maximum(h, w) * pad_factor))
+        if len(boxes_xywh):
+            xywh = np.array(boxes_xywh, dtype=np.float64).reshape(-1, 4).astype(np.int32)      # float64 -> int32 truncates like the per-box cast
+            rows[:, :4] = xywh
+            # size: int(np.maximum(h, w) * pad) -- int32 maximum times a Python float = float64 product, truncated
+            rows[:, 4] = (np.maximum(xywh[:, 3], xywh[:, 2]) * float(pad_factor)).astype(np.int64)
         return rows
 
     def extract_square_patches(self, scene_img, boxes_xywh, pad_factor, resize=(128, 128)):
@@ -184,9 +227,30 @@ class AePoseEstimator(object):
             if L < R and T < Bm and (R - L) * (Bm - T) <= 0.6 * W * H:
                 frame = color_img[T:Bm, L:R]
                 off_x, off_y = L, T
+        classes = sorted(set(c for _, c, _ in accepted))
+        first = self.all_codebooks[classes[0]]
+        device = getattr(first._encoder.engine, 'device', None)
+        if isinstance(frame, np.ndarray) and device is not None and getattr(device, 'type', 'cpu') == 'cuda' and all(
+                getattr(self.all_codebooks[c]._encoder.engine, 'device', None) == device for c in classes):
+            poses = self._process_staged(accepted, classes, frame, off_x, off_y, camK, device)
+        else:
+            poses = self._process_plain(accepted, classes, frame, off_x, off_y, camK)
+        out = []
+        for j in sorted(poses):
+            clas, R, t = poses[j]
+            H_est = np.eye(4)
+            H_est[:3, :3] = R
+            H_est[:3, 3] = t if mm else t / 1000.
+            if self._camPose:
+                H_est = np.dot(camPose, H_est)
+            out.append(PoseEstimate(name=clas, trafo=H_est))
+        return out
+
+    def _process_plain(self, accepted, classes, frame, off_x, off_y, camK):
+        """{detection index: (class, R [3,3], t [3])} through the public Codebook calls (any engine, e.g. the CPU doubles of the tests)"""
         image_dev = None
         poses = {}
-        for clas in sorted(set(c for _, c, _ in accepted)):
+        for clas in classes:
             members = [(j, bb) for j, c, bb in accepted if c == clas]
             codebook = self.all_codebooks[clas]
             if image_dev is None:
@@ -195,12 +259,66 @@ class AePoseEstimator(object):
             crops = self.extract_square_patches(image_dev, [[bb[0] - off_x, bb[1] - off_y, bb[2], bb[3]] for _, bb in members],
                                                 self.pad_factors[clas], resize=self.patch_sizes[clas])
             idcs = np.atleast_1d(codebook.nearest_rotation(self.sess, crops, top_n=1, upright=self._upright, return_idcs=True))
-            for (j, bb), idx in zip(members, idcs):
-                Rs_est, ts_est = codebook.pose_from_indices([idx], bb, camK, self.all_train_args[clas])
-                H_est = np.eye(4)
-                H_est[:3, :3] = Rs_est.squeeze()
-                H_est[:3, 3] = ts_est.squeeze() if mm else ts_est.squeeze() / 1000.
-                if self._camPose:
-                    H_est = np.dot(camPose, H_est)
-                poses[j] = PoseEstimate(name=clas, trafo=H_est)
-        return [poses[j] for j in sorted(poses)]
+            if hasattr(codebook, 'poses_from_indices'):
+                Rs, ts = codebook.poses_from_indices(idcs, [bb for _, bb in members], camK, self.all_train_args[clas])
+            else:                                                  # (a stand-in with the reference's per-detection method only)
+                per = [codebook.pose_from_indices([idx], bb, camK, self.all_train_args[clas]) for (_, bb), idx in zip(members, idcs)]
+                Rs, ts = [r.squeeze() for r, _ in per], [t.squeeze() for _, t in per]
+            for k, (j, _) in enumerate(members):
+                poses[j] = (clas, Rs[k], ts[k])
+        return poses
+
+    def _process_staged(self, accepted, classes, frame, off_x, off_y, camK, device):
+        """The same on the GPU with everything queued before the first wait: frame (union rectangle) and box rows go through
+        pinned staging buffers, all classes' crop + encode + scan launches follow on the caller's stream, each class's indices
+        come back by an asynchronous copy with an event behind it -- the float64 geometry of class k then runs on the host
+        while the GPU is busy with class k + 1.  Nothing is allocated per frame; bit-identical to _process_plain."""
+        import torch
+        from .engine import crop_resize_into
+        stage = self.__dict__.setdefault('_stages', {}).get(device)
+        if stage is None:
+            stage = self._stages[device] = _FrameStage(device)
+        crop_shapes = set((self.patch_sizes[c][1], self.patch_sizes[c][0]) for c in classes)
+        if len(crop_shapes) != 1:
+            return self._process_plain(accepted, classes, frame, off_x, off_y, camK)      # (objects trained at different crop sizes)
+        oh, ow = crop_shapes.pop()
+        C = int(frame.shape[2])
+        total = len(accepted)
+        J = int(self.all_codebooks[classes[0]]._encoder.latent_space_size)
+        with torch.cuda.device(device):
+            image_dev = stage.upload_image(torch, frame)
+            stage.reserve(torch, total, J, (oh, ow, C))
+            rows_host = stage.rows_host.numpy()[:total * 5].reshape(total, 5)
+            groups, at = [], 0
+            for clas in classes:
+                members = [(j, bb) for j, c, bb in accepted if c == clas]
+                n = len(members)
+                rows_host[at:at + n] = self.box_rows([[bb[0] - off_x, bb[1] - off_y, bb[2], bb[3]] for _, bb in members], self.pad_factors[clas])
+                groups.append((clas, members, at, n))
+                at += n
+            stage.rows_dev[:total * 5].copy_(stage.rows_host[:total * 5], non_blocking=True)
+            rows_dev = stage.rows_dev[:total * 5].view(total, 5)
+            crops_all = stage.crops[:total * oh * ow * C].view(total, oh, ow, C)
+            z_all, idx_all, score_all = stage.z[:total * J].view(total, J), stage.idx[:total].view(total, 1), stage.score[:total].view(total, 1)
+            events = []
+            for clas, members, a, n in groups:
+                codebook = self.all_codebooks[clas]
+                eng = codebook._encoder.engine
+                crop_resize_into(image_dev, rows_dev[a:a + n], crops_all[a:a + n])
+                stride = int(codebook._dataset._kw['num_cyclo']) if self._upright else 1
+                eng.encode_nn(codebook.engine, crops_all[a:a + n], stride, out=(z_all[a:a + n], idx_all[a:a + n], score_all[a:a + n]))
+                stage.idx_host[a:a + n].copy_(stage.idx[a:a + n], non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+                events.append(ev)
+            poses = {}
+            for (clas, members, a, n), ev in zip(groups, events):
+                ev.synchronize()
+                codebook = self.all_codebooks[clas]
+                if codebook._encoder.engine.settle():             # (split precision, out of range: recomputed in fp32, in place)
+                    stage.idx_host[a:a + n].copy_(stage.idx[a:a + n])
+                idcs = stage.idx_host.numpy()[a:a + n].copy()
+                Rs, ts = codebook.poses_from_indices(idcs, [bb for _, bb in members], camK, self.all_train_args[clas])
+                for k, (j, _) in enumerate(members):
+                    poses[j] = (clas, Rs[k], ts[k])
+        return poses

@@ -158,3 +158,36 @@ def test_product_codebook_api_reproduces_reference_outputs(recorded_codebook):
                               depth_pred=None if depth < 0 else float(depth), upright=bool(upright))
         assert R.shape == G['pose%d_R' % ci].shape and np.array_equal(R, G['pose%d_R' % ci])
         assert np.array_equal(t, G['pose%d_t' % ci])
+        if int(top_n) == 1:
+            # the batched form the estimator uses for all detections of an object (array arithmetic where NumPy gives an
+            # array element the bits of a scalar, per-detection calls elsewhere): the reference's recorded numbers, bit for bit
+            idx = cb.nearest_rotation(None, crops[int(G['pose%d_crop_row' % ci])], upright=bool(upright), return_idcs=True)
+            Rb, tb = cb.poses_from_indices(np.atleast_1d(idx), [G['pose%d_bb' % ci]], G['K_test'], args,
+                                           depth_preds=None if depth < 0 else [float(depth)])
+            assert np.array_equal(Rb.squeeze(), G['pose%d_R' % ci].squeeze()) and np.array_equal(tb.squeeze(), G['pose%d_t' % ci].squeeze())
+
+
+def test_batched_pose_geometry_equals_the_per_detection_calls(recorded_codebook):
+    """Codebook.poses_from_indices against pose_from_indices (itself pinned to the reference above) on a few hundred random
+    boxes / rows, with and without a depth prediction; AePoseEstimator.box_rows against the reference's per-box expression."""
+    from augmentedautoencoder_amd.codebook import _batch_geometry_matches_scalar
+    from augmentedautoencoder_amd.pose_estimator import AePoseEstimator
+    cb, args = recorded_codebook, _train_args()
+    cb.embed_obj_bbs_values = None
+    assert _batch_geometry_matches_scalar()                   # (else the batched form is not in use on this NumPy build)
+    rng = np.random.default_rng(17)
+    N = cb._dataset.embedding_size
+    n = 300
+    idcs = rng.integers(0, N, n)
+    bbs = [[float(rng.uniform(0, 600)), float(rng.uniform(0, 400)), float(rng.uniform(5, 300)), float(rng.uniform(5, 300))] for _ in range(n)]
+    for depths in (None, [float(d) for d in rng.uniform(200, 2000, n)]):
+        Rb, tb = cb.poses_from_indices(idcs, bbs, G['K_test'], args, depth_preds=depths)
+        for i in range(n):
+            R, t = cb.pose_from_indices([idcs[i]], bbs[i], G['K_test'], args, depth_pred=None if depths is None else depths[i])
+            assert np.array_equal(Rb[i], R[0]) and np.array_equal(tb[i], t[0]), i
+    boxes = [[rng.uniform(-5, 2000), rng.uniform(-5, 1100), rng.uniform(0.2, 900), rng.uniform(0.2, 700)] for _ in range(200)]
+    for pad in (1.2, 1.0, 1.5):
+        want = np.array([list(np.array(bb).astype(np.int32)) + [int(np.maximum(np.array(bb).astype(np.int32)[3], np.array(bb).astype(np.int32)[2]) * pad)]
+                         for bb in boxes], dtype=np.int32)
+        assert np.array_equal(AePoseEstimator.box_rows(boxes, pad), want)
+    assert AePoseEstimator.box_rows([], 1.2).shape == (0, 5)

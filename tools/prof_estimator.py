@@ -1,0 +1,74 @@
+#!/usr/bin/env python
+"""Host-side profile of AePoseEstimator.process (N1) on a 1080p frame: cProfile over repeated calls with D detections.
+Usage: python tools/prof_estimator.py [D] [reps]"""
+import cProfile
+import configparser
+import io
+import os
+import pstats
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+
+from augmentedautoencoder_amd import session as S
+from augmentedautoencoder_amd import synth
+from augmentedautoencoder_amd.codebook import Codebook
+from augmentedautoencoder_amd.dataset import Dataset
+from augmentedautoencoder_amd.encoder import Encoder
+from augmentedautoencoder_amd.pose_estimator import AePoseEstimator, BoundingBox
+
+
+def build():
+    targs = configparser.ConfigParser()
+    targs.read_string("[Dataset]\nH: 128\nW: 128\nC: 3\nRADIUS: 700\nPAD_FACTOR: 1.2\nK: [1075.65, 0, 720/2, 0, 1073.90, 540/2, 0, 0, 1]\n"
+                      "[Embedding]\nEMBED_BB: True\nMIN_N_VIEWS: 2562\nNUM_CYCLO: 36\n")
+    S.reset_default_graph()
+    books = {}
+    for k, name in enumerate(['obj_a', 'obj_b']):
+        ds = Dataset('', h=128, w=128, c=3, min_n_views=2562, radius=700, num_cyclo=36)
+        with S.variable_scope(name):
+            e = Encoder(S.Placeholder((128, 128, 3)), 128, [128, 256, 512, 512], 5, [2, 2, 2, 2], False)
+            c = Codebook(e, ds, True)
+        e.load_weights(synth.make_weights(seed=50 + k))
+        c.assign_embedding(synth.make_codebook(92232, 128, seed=60 + k))
+        r = np.random.default_rng(70 + k)
+        c.assign_obj_bbs(np.stack([r.integers(250, 350, 92232), r.integers(180, 260, 92232), r.integers(80, 200, 92232), r.integers(80, 200, 92232)], 1))
+        books[name] = c
+    return AePoseEstimator(codebooks=books, train_args={'obj_a': targs, 'obj_b': targs})
+
+
+def detections(rng, D):
+    dets = []
+    for i in range(D):
+        x, y, w, h = rng.uniform(0, 1500), rng.uniform(0, 800), rng.uniform(60, 400), rng.uniform(60, 270)
+        dets.append(BoundingBox(xmin=x / 1920, xmax=(x + w) / 1920, ymin=y / 1080, ymax=(y + h) / 1080, classes={'obj_a' if i % 3 else 'obj_b': 1.0}))
+    return dets
+
+
+if __name__ == '__main__':
+    D = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+    reps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
+    est = build()
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (1080, 1920, 3), dtype=np.uint8)
+    camK = np.array([[1075.65, 0, 960.0], [0, 1073.9, 540.0], [0, 0, 1]])
+    dets = detections(rng, D)
+    for _ in range(5):
+        est.process(dets, img, camK)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        est.process(dets, img, camK)
+    torch.cuda.synchronize()
+    print('D=%d: %.1f us per process() call' % (D, (time.perf_counter() - t0) / reps * 1e6))
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(reps):
+        est.process(dets, img, camK)
+    pr.disable()
+    out = io.StringIO()
+    pstats.Stats(pr, stream=out).sort_stats('tottime').print_stats(28)
+    print('\n'.join(l[:150] for l in out.getvalue().splitlines()[:48]))
