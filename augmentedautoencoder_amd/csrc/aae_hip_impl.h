@@ -73,6 +73,7 @@ struct Layer {
     int H = 0, W = 0, Cin = 0, Ho = 0, Wo = 0, Cout = 0, CoutPad = 0;
     int KS = 0, S = 0, pt = 0, pl = 0;
     int relu = 1;
+    int index = -1;             // position among the conv layers (0 = first); -1: the dense layer
     LayerKind kind = KIND_GENERIC;
     float* w_hwio = nullptr;    // device [KS*KS*Cin][Cout]
     float* wp = nullptr;        // device [K/4][CoutPad][4]      (igemm)
@@ -150,6 +151,7 @@ struct aae_encoder {
     int compact_workspace = 0;             // 1: two alternating activation buffers instead of one per layer (layer outputs are then not inspectable)
     int ticket_prep = 1;                   // conv1 installs the nonces of the later ticketed launches of its forward call (0: every launch installs its own)
     int wavek_balance = 1;                 // wave-split-K tile shape: prefer a smaller wave tile when the larger one leaves CUs idle in its last round of blocks (plan_wavek)
+    int planner_cost_model = 1;            // B >= 5: kernel family and wave-tile shape of every conv layer by estimated time (plan_by_cost) instead of tile-count thresholds
     int wavek_ablate = 0;                  // timing experiments (conv_wavek_f32.h ConvWaveKArgs::ablate); results are wrong when != 0
     int gemv_ticket = 1;                   // dense GEMV (B <= 4): chunk sums finished by the last block instead of a reduce launch
     int wavek_dense = 1;                   // dense layer (B > 4) on the wave-split-K kernel instead of split-K igemm + reduce launch
@@ -325,6 +327,8 @@ constexpr size_t kConvTicketBytes = (size_t)(AAE_MAX_LAYERS + 1) * kLayerTicketW
 constexpr size_t kGemvTicketBytes = (size_t)kGemvTicketSlots * aae::kTicketSlotWords * 8;
 constexpr size_t kTicketBytes = kConvTicketBytes + kGemvTicketBytes + (size_t)aae::kGridBarrierWords * 8;    // ... then the grid barrier of the persistent per-detection launch
 
+constexpr int kWaveKTileCap = 8192;        // 64 x 64 output tiles the wave-split-K kernel is ever asked to walk (option wavek_max_tiles is clamped to it)
+
 // Launch plan of the wave-split-K igemm (conv_wavek_f32.h) for a layer at M rows, or use == false.
 struct WaveKPlan {
     bool use = false;
@@ -345,16 +349,83 @@ static bool runs_split(const aae_encoder* enc, int B) {
     return ((M + 63) / 64) * (L.CoutPad / 64) >= enc->x3h_min_tiles;
 }
 
+// K splits of a wave-split-K layer of `tiles` output tiles: one block per CU, never a second round of blocks; every wave keeps
+// at least two slabs; one ticket word per tile
+static int wavek_gsplits(const aae_encoder* enc, int tiles, int slabs, int waves) {
+    int g = enc->wavek_target_blocks / tiles;
+    const int gmax = slabs / (2 * waves);
+    if (g > gmax) g = gmax;
+    if (g > (int)aae::kTicketSingleLevelMax) g = (int)aae::kTicketSingleLevelMax;
+    if (g < 1) g = 1;
+    if (tiles > kLayerTicketWords) g = 1;
+    return g;
+}
+
+// ---- planner by cost (B >= 5) ------------------------------------------------------------------------------------------
+// Which implicit-GEMM family, which wave tile?  Both families lose time to block-count quantisation, in different places:
+// the 128 x 128 (x 256) tiles of conv_igemm_f32.h come in few large blocks (conv2 at B = 40: 640 blocks = 2.5 "rounds" of the
+// chip, paid as 3 or 4), the wave-split-K kernel's tiles are 4 ... 16 times smaller but move 2 ... 4 times the operand bytes per
+// MFMA.  Tile-count thresholds cannot see that; an estimate of each candidate's time can:
+//     rounds = ceil(blocks / CUs);   t = rounds * (slabs one wave walks [+ pipeline fill]) * (MFMA time of its tile per slab) / efficiency + fixed
+// with the efficiencies and fixed costs fitted to per-layer HIP-event times of every candidate at B = 5 ... 128 on MI355X
+// (tools/sweep_planner.py -> profiles/r11/planner_sweep_*.jsonl: rms error 5-11 %, and the candidate it picks is the
+// measured best at 38 of 42 (layer, batch) points, within 5 % at 40): wave-split-K 32 x 32 0.65, 64 x 32 0.66, 64 x 64 0.82
+// (+ 10 us), + 3 us when K is split across blocks; 128-row igemm 0.86 with 2 slabs of fill, + 5 us, + 10 us for the split-K
+// reduce launch.  A 32 x 32 x 2 fp32 MFMA occupies its pipe for 64 cycles: 16 per slab and 32 x 32 sub-tile = 0.4267 us at 2.4 GHz.
+constexpr double kSlabUs = 16.0 * 64.0 / 2400.0;
+
+static double wavek_cost_us(const aae_encoder* enc, int tiles, int g, int slabs, int mt, int nt) {
+    static const double eff[3] = {0.65, 0.66, 0.82}, fixed[3] = {0.0, 0.0, 10.0};
+    const int shape = mt == 1 ? 0 : (nt == 1 ? 1 : 2);
+    const int cus = enc->wavek_target_blocks > 0 ? enc->wavek_target_blocks : 256;
+    return (double)ceil_div(tiles * g, cus) * ceil_div(slabs, 4 * g) * (mt * nt) * kSlabUs / eff[shape] + fixed[shape] + (g > 1 ? 3.0 : 0.0);
+}
+
+static double igemm_cost_us(const aae_encoder* enc, const Layer& L, long long M) {
+    const int mt = ceil_div((int)M, 128), nt = L.CoutPad / 128, slabs = (int)(L.K() / 32);
+    int s, per;
+    choose_splits(enc, mt * nt, slabs, &s, &per);
+    const bool wide = s == 1 && enc->igemm_dma && enc->igemm_breg && enc->igemm_breg_wide && (L.index == 1 || L.index == 2) && L.CoutPad % 256 == 0 &&
+                      mt * (L.CoutPad / 256) >= enc->igemm_breg_wide_min_blocks;          // (launch_igemm's 128 x 256 tiles)
+    const int blocks = wide ? mt * (L.CoutPad / 256) : mt * nt * s;
+    const int cus = enc->wavek_target_blocks > 0 ? enc->wavek_target_blocks : 256;
+    return (double)ceil_div(blocks, cus) * (ceil_div(slabs, s) + 2) * (4 * kSlabUs) * (wide ? 2.0 : 1.0) / 0.86 + (s > 1 ? 10.0 : 0.0) + 5.0;
+}
+
 static WaveKPlan plan_wavek(const aae_encoder* enc, const Layer& L, long long M, bool split) {
     WaveKPlan w;
     if (!enc->wavek || split || L.kind != KIND_IGEMM) return w;
     const long long tiles22 = ((M + 63) / 64) * (L.CoutPad / 64);
-    if (tiles22 > enc->wavek_max_tiles || tiles22 > 512) return w;
+    const bool by_cost = enc->planner_cost_model && L.index >= 0 && M / ((long long)L.Ho * L.Wo) >= 5 && enc->wavek_waves != 8;
+    if (tiles22 > kWaveKTileCap || (!by_cost && tiles22 > enc->wavek_max_tiles)) return w;
     const unsigned long long x_bytes = (unsigned long long)(M / (L.Ho * L.Wo)) * L.H * L.W * L.Cin * sizeof(float);
     if (x_bytes >= 0xFFFFFF00ull) return w;
     w.use = true;
     w.waves = enc->wavek_waves == 8 ? 8 : 4;
     w.depth = (enc->wavek_depth == 2 || w.waves == 8) ? 2 : 3;    // 8 waves share the register file two per SIMD: two slabs in flight each
+    const long long batch = L.index >= 0 ? M / ((long long)L.Ho * L.Wo) : M;
+    if (enc->planner_cost_model && L.index >= 0 && batch >= 5 && w.waves == 4) {
+        // conv layers of batches beyond the per-detection regime: cheapest of {igemm, wave-split-K 32 x 32 | 64 x 32 | 64 x 64} by estimate
+        const int slabs = (int)(L.K() / 32);
+        double best = igemm_cost_us(enc, L, M);
+        int best_mt = 0, best_nt = 0;
+        static const int shapes[3][2] = {{2, 2}, {2, 1}, {1, 1}};
+        for (const auto& sh : shapes) {
+            const long long tiles = ((M + 32 * sh[0] - 1) / (32 * sh[0])) * (long long)(L.CoutPad / (32 * sh[1]));
+            if (tiles > (1 << 20)) continue;
+            const int g = wavek_gsplits(enc, (int)tiles, slabs, w.waves);
+            const double c = wavek_cost_us(enc, (int)tiles, g, slabs, sh[0], sh[1]);
+            if (c < best) { best = c; best_mt = sh[0]; best_nt = sh[1]; }
+        }
+        if (best_mt == 0) { w.use = false; return w; }           // the 128-row igemm (+ reduce launch) is estimated faster
+        w.MT = best_mt; w.NT = best_nt;
+        w.num_mt = (int)((M + 32 * w.MT - 1) / (32 * w.MT));
+        w.num_nt = L.CoutPad / (32 * w.NT);
+        const int tiles = w.num_mt * w.num_nt;
+        w.gsplits = wavek_gsplits(enc, tiles, slabs, w.waves);
+        if (w.gsplits > 1) w.partial_bytes = (size_t)tiles * w.gsplits * (w.MT * w.NT * 16) * 64 * sizeof(float);
+        return w;
+    }
     w.NT = tiles22 <= enc->wavek_narrow_max_tiles ? 1 : 2;
     w.MT = (tiles22 <= enc->wavek_tiny_max_tiles && w.waves == 4) ? 1 : 2;       // 32 x 32 wave tiles (NT = 1 then: the narrow threshold is the larger one)
     if (w.MT == 1) w.NT = 1;
@@ -377,12 +448,7 @@ static WaveKPlan plan_wavek(const aae_encoder* enc, const Layer& L, long long M,
     w.num_nt = L.CoutPad / (32 * w.NT);
     const int tiles = w.num_mt * w.num_nt;
     const int slabs = (int)(L.K() / 32);
-    int g = enc->wavek_target_blocks / tiles;              // one block per CU; never a second round of blocks
-    const int gmax = slabs / (2 * w.waves);                // every wave keeps at least two slabs
-    if (g > gmax) g = gmax;
-    if (g > (int)aae::kTicketSingleLevelMax) g = (int)aae::kTicketSingleLevelMax;   // one ticket word per tile
-    if (g < 1) g = 1;
-    if (tiles > kLayerTicketWords) g = 1;                   // one ticket word per tile of a split layer: never more tiles than words
+    const int g = wavek_gsplits(enc, tiles, slabs, w.waves);
     w.gsplits = g;
     if (g > 1) w.partial_bytes = (size_t)tiles * g * (w.MT * w.NT * 16) * 64 * sizeof(float);
     return w;
@@ -1343,6 +1409,7 @@ int aae_encoder_create(const aae_encoder_desc* d, const void* const* hw, int n_w
     const float eps = d->bn_eps > 0.f ? d->bn_eps : 1e-3f;
     for (int li = 0; li < d->num_layers; ++li) {
         Layer L;
+        L.index = li;
         L.H = H; L.W = W; L.Cin = C; L.Cout = d->num_filters[li]; L.KS = d->kernel_size; L.S = d->strides[li];
         if (L.Cout < 1 || L.S < 1) return bail(fail(AAE_ERR_INVALID, "layer %d: filters %d stride %d", li, L.Cout, L.S));
         same_pad(H, L.KS, L.S, &L.Ho, &L.pt);
@@ -1467,6 +1534,7 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
     else if (!strcmp(name, "wavek_dense")) enc->wavek_dense = value ? 1 : 0;
     else if (!strcmp(name, "wavek_ablate")) enc->wavek_ablate = value;
     else if (!strcmp(name, "wavek_balance")) enc->wavek_balance = value ? 1 : 0;
+    else if (!strcmp(name, "planner_cost_model")) enc->planner_cost_model = value ? 1 : 0;
     else if (!strcmp(name, "ticket_prep")) enc->ticket_prep = value ? 1 : 0;
     else if (!strcmp(name, "detect_chain")) enc->detect_chain = value ? 1 : 0;
     else if (!strcmp(name, "detect_chain_blocks")) enc->detect_chain_blocks = value < 1 ? 1 : (value > aae_host::kChainMaxBlocks ? aae_host::kChainMaxBlocks : value);
@@ -1490,7 +1558,7 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
         }
         if (!value) enc->wavek_timeline = nullptr;     // (the buffer stays in `allocations` until the handle goes)
     }
-    else if (!strcmp(name, "wavek_max_tiles")) enc->wavek_max_tiles = value < 0 ? 0 : (value > 512 ? 512 : value);
+    else if (!strcmp(name, "wavek_max_tiles")) enc->wavek_max_tiles = value < 0 ? 0 : (value > aae_host::kWaveKTileCap ? aae_host::kWaveKTileCap : value);
     else if (!strcmp(name, "wavek_narrow_max_tiles")) enc->wavek_narrow_max_tiles = value < 0 ? 0 : value;
     else if (!strcmp(name, "wavek_target_blocks")) enc->wavek_target_blocks = value < 1 ? 1 : (value > 2 * aae_host::kLayerTicketWords ? 2 * aae_host::kLayerTicketWords : value);
     else if (!strcmp(name, "wavek_tiny_max_tiles")) enc->wavek_tiny_max_tiles = value < 0 ? 0 : value;

@@ -122,6 +122,12 @@ void aae_encoder_destroy(aae_encoder* enc);
  *                        "wavek_narrow_max_tiles" (128), 64x64 above; "wavek_waves" (4 | 8), "wavek_depth" (2 | 3 slabs in
  *                        flight), "wavek_target_blocks" (256), "wavek_balance" (1: a smaller wave tile when the larger one would leave CUs idle
  *                        in its last round of blocks) -- defaults set from per-layer rocprofv3 sweeps;
+ *   "planner_cost_model" (1): B >= 5: each conv layer runs the implicit-GEMM family and wave-tile shape with the smallest ESTIMATED time
+ *                        (block-count rounds x slabs x MFMA time / fitted efficiency, plan_wavek) instead of the tile-count thresholds above
+ *                        ("wavek_max_tiles" etc. then steer B <= 4 and the dense layer only); B = 24 / 40 / 96 gain 14 / 17 / 6 %;
+ *   "detect_chain" (0), "detect_chain_blocks" (256): B <= 4 of a four-layer encoder as conv1 + ONE persistent launch (conv2 ... dense,
+ *                        in aae_encode_nn also the scan; grid barriers between the phases) -- bit-identical to the stand-alone launches and,
+ *                        measured on MI355X, slower than them (92 vs 82 us at B = 1): opt-in, kept for the record and for other parts;
  *   "gemv_ticket" (1): dense GEMV (B <= 4) adds its chunk rows in the same launch; "ticket_prep" (1): the first kernel of a
  *                        forward installs the ticket nonces of the later launches; "first_group_split_max_tiles" (128): conv1
  *                        runs one block per 32-pixel group for batches of at most that many 128-pixel tiles;

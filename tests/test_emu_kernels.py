@@ -27,6 +27,7 @@ def _run(cfg, B, seed, f32_in=False, nosplit=False, dma=0, breg=0, wavek=0, opti
     enc.set_option('wavek_dense', wavek)
     enc.set_option('gemv_ticket', wavek)
     enc.set_option('detect_chain', chain)      # 0: B <= 4 as stand-alone launches (the kernels most tests here are about)
+    enc.set_option('planner_cost_model', 0)    # kernel family / tile shape by the thresholds the tests steer (the cost model has its own test)
     for k, v in (options or {}).items():
         enc.set_option(k, v)
     z = enc.forward(xin)
@@ -569,6 +570,25 @@ def test_detect_chain_falls_back_where_it_does_not_apply():
     enc3.forward(synth.make_crops(1, seed=3, shape=cfg3.shape))
     assert not any('chain' in l for l in enc3.labels())
     enc3.close()
+
+
+def test_planner_by_cost_picks_a_family_and_a_tile_shape_per_layer():
+    """B >= 5: plan_wavek estimates the time of the 128-row igemm and of the three wave-split-K tile shapes for every conv layer and
+    takes the cheapest (fitted on MI355X, tools/sweep_planner.py); whatever it picks must compute the layer: every activation and
+    the latents against the oracle, for batch sizes on both sides of the families' block-count steps, and identically with the
+    threshold planner's kernels where both pick the same."""
+    cfg = EncoderConfig((32, 32, 3), [32, 64, 64], [2, 2, 2], 5, 128)
+    seen = set()
+    for B in (5, 9, 16):
+        # ("wavek_target_blocks" is the model's CU count: 8 instead of 256 puts this small network's layers on both sides of the round steps)
+        labels = _run(cfg, B, 90 + B, wavek=1, options={'planner_cost_model': 1, 'wavek_target_blocks': 8})
+        assert all(('conv_wavek_f32_' in l) or ('conv_igemm_f32' in l) or ('splitk_reduce' in l) for l in labels[1:-1]), labels
+        seen.update(l.split(':')[1].split(' ')[0].split('_w4')[0].split('_splitk')[0] for l in labels[1:-1])
+    assert len(seen) >= 2, seen                                  # more than one kernel form was chosen over these batches
+    # B <= 4 stays with the hand-tuned per-detection plan whatever the option says
+    a = _run(cfg, 3, 95, wavek=1, options={'planner_cost_model': 1})
+    b = _run(cfg, 3, 95, wavek=1, options={'planner_cost_model': 0})
+    assert a == b
 
 
 def test_compact_workspace_alternates_two_activation_buffers():

@@ -850,8 +850,7 @@ def test_small_batch_wave_split_k_path_matches_fp64_oracle(default_model, B, cha
     """B <= 4 (the reference's per-detection batches): conv2..conv4 on the wave-split-K igemm with the in-launch ticketed K reduction,
     dense as the ticketed GEMV: five encoder launches, one scan launch (chain = 1: the opt-in form -- conv1, then conv2 ... dense, and in
     the fused call the scan, as ONE persistent launch, detect_chain.h; bit-identical, measured slower, so not the default).  Every layer, the latents, the similarity and
-    the indices against the fp64 oracle; B = 7: every layer still on the wave-split-K kernels (two rounds of blocks, balanced tile
-    shapes); B = 12 mixes both kernel families (conv2 on the 128 x 128 split-K path)."""
+    the indices against the fp64 oracle; B = 7, 12: kernel family and wave-tile shape of every layer chosen by estimated time."""
     weights, enc, cb, E, _ = default_model
     crops = synth.make_crops(B, seed=2000 + B)
     enc.engine.set_option('detect_chain', chain)
@@ -867,10 +866,8 @@ def test_small_batch_wave_split_k_path_matches_fp64_oracle(default_model, B, cha
     elif B <= 4:
         assert len(labels) == 5 and labels[0].startswith('conv1:conv_first_f32') and labels[4].startswith('dense:dense_gemv_f32_ticket'), labels
         assert all(':conv_wavek_f32_' in l for l in labels[1:4]), labels
-    elif B == 7:
-        assert all(':conv_wavek_f32_' in l for l in labels[1:]), labels
-    else:
-        assert any(':conv_wavek_f32_' in l for l in labels) and any('splitk' in l for l in labels), labels
+    else:                                                       # B >= 5: family and tile shape per layer by the planner's cost model
+        assert all((':conv_wavek_f32_' in l) or (':conv_igemm_f32' in l) or l.endswith(':splitk_reduce') for l in labels[1:]), labels
     z64, acts = ref.encoder_forward_torch(ref.input_to_float(crops), weights, STRIDES, False, 'float64', return_activations=True)
     for i, a in enumerate(acts):
         _check_layer(enc.engine.activation(i).cpu().numpy(), a, 'small batch B=%d layer %d' % (B, i))
@@ -883,6 +880,35 @@ def test_small_batch_wave_split_k_path_matches_fp64_oracle(default_model, B, cha
     assert np.array_equal(idx[:, 0].cpu().numpy(), np.argmax(cs, axis=1))
     assert np.abs(score[:, 0].cpu().numpy() - cs64.max(axis=1)).max() <= COS_TOL
     assert np.array_equal(idx_f.cpu().numpy(), idx.cpu().numpy()) and np.array_equal(score_f.cpu().numpy(), score.cpu().numpy())
+
+
+@pytest.mark.parametrize('B', [5, 6, 10, 24, 48, 96])
+def test_planner_by_cost_model_batches_match_fp64_oracle(default_model, B):
+    """Mid-size batches (the reference embeds in batches of 64, train_template.cfg:61): each conv layer runs whichever of the
+    128-row igemm / wave-split-K 32x32 | 64x32 | 64x64 the planner estimates fastest (plan_wavek, fitted to
+    profiles/r11/planner_sweep_*.jsonl).  Every layer, the latents and the indices against the fp64 oracle, the labels of the
+    chosen kernels recorded; the threshold planner (option off) must agree to rounding."""
+    weights, enc, cb, E, _ = default_model
+    eng = enc.engine
+    crops = synth.make_crops(B, seed=2500 + B)
+    z, recs = eng.encode_timed(crops)
+    labels = [l.split(' ')[0] for l, _, _ in recs]
+    z64, acts = ref.encoder_forward_torch(ref.input_to_float(crops), weights, STRIDES, False, 'float64', return_activations=True)
+    for i, a in enumerate(acts):
+        _check_layer(eng.activation(i).cpu().numpy(), a, 'cost-model plan B=%d layer %d (%s)' % (B, i, labels))
+    _check_layer(z.cpu().numpy(), z64, 'cost-model plan B=%d latent' % B)
+    cs64 = ref.cos_similarity(z64, E)
+    idx, score = cb.engine.nn(z, 1, 1)
+    _check_indices(idx[:, 0].cpu().numpy(), cs64, where='cost-model plan B=%d' % B)
+    report.record('planner', 'B=%d' % B, kernels=labels)
+    eng.set_option('planner_cost_model', 0)
+    try:
+        z_thr, recs_thr = eng.encode_timed(crops)
+    finally:
+        eng.set_option('planner_cost_model', 1)
+    assert float((z_thr - z).abs().max() / z.abs().max()) < 1e-5
+    if [l for l, _, _ in recs_thr] == [l for l, _, _ in recs]:
+        assert bool((z_thr == z).all())
 
 
 def test_in_launch_ticketed_reductions_are_race_free_and_order_independent():
