@@ -368,17 +368,18 @@ static int wavek_gsplits(const aae_encoder* enc, int tiles, int slabs, int waves
 // MFMA.  Tile-count thresholds cannot see that; an estimate of each candidate's time can:
 //     rounds = ceil(blocks / CUs);   t = rounds * (slabs one wave walks [+ pipeline fill]) * (MFMA time of its tile per slab) / efficiency + fixed
 // with the efficiencies and fixed costs fitted to per-layer HIP-event times of every candidate at B = 5 ... 128 on MI355X
-// (tools/sweep_planner.py -> profiles/r11/planner_sweep_*.jsonl: rms error 5-11 %, and the candidate it picks is the
-// measured best at 38 of 42 (layer, batch) points, within 5 % at 40): wave-split-K 32 x 32 0.65, 64 x 32 0.66, 64 x 64 0.82
-// (+ 10 us), + 3 us when K is split across blocks; 128-row igemm 0.86 with 2 slabs of fill, + 5 us, + 10 us for the split-K
-// reduce launch.  A 32 x 32 x 2 fp32 MFMA occupies its pipe for 64 cycles: 16 per slab and 32 x 32 sub-tile = 0.4267 us at 2.4 GHz.
+// (tools/sweep_planner.py -> profiles/r11/planner_sweep_*.jsonl: rms error 3-7 %, and the candidate it picks is the measured
+// best at 40 of 42 (layer, batch) points): wave-split-K 32 x 32 0.71, 64 x 32 0.72, 64 x 64 0.88 (+ 5 us), each with 4 slabs
+// of fill per block, + 3 us when K is split across blocks; 128 x 128 igemm 0.86 with 2 slabs of fill, + 5 us, + 10 us for the
+// split-K reduce launch; its 128 x 256 form sits two blocks to a CU and is paid in rounds of two (0.90).
+// A 32 x 32 x 2 fp32 MFMA occupies its pipe for 64 cycles: 16 per slab and 32 x 32 sub-tile = 0.4267 us at 2.4 GHz.
 constexpr double kSlabUs = 16.0 * 64.0 / 2400.0;
 
 static double wavek_cost_us(const aae_encoder* enc, int tiles, int g, int slabs, int mt, int nt) {
-    static const double eff[3] = {0.65, 0.66, 0.82}, fixed[3] = {0.0, 0.0, 10.0};
+    static const double eff[3] = {0.71, 0.72, 0.88}, fixed[3] = {0.0, 0.0, 5.0};
     const int shape = mt == 1 ? 0 : (nt == 1 ? 1 : 2);
     const int cus = enc->wavek_target_blocks > 0 ? enc->wavek_target_blocks : 256;
-    return (double)ceil_div(tiles * g, cus) * ceil_div(slabs, 4 * g) * (mt * nt) * kSlabUs / eff[shape] + fixed[shape] + (g > 1 ? 3.0 : 0.0);
+    return (double)ceil_div(tiles * g, cus) * (ceil_div(slabs, 4 * g) + 4) * (mt * nt) * kSlabUs / eff[shape] + fixed[shape] + (g > 1 ? 3.0 : 0.0);
 }
 
 static double igemm_cost_us(const aae_encoder* enc, const Layer& L, long long M) {
@@ -389,7 +390,8 @@ static double igemm_cost_us(const aae_encoder* enc, const Layer& L, long long M)
                       mt * (L.CoutPad / 256) >= enc->igemm_breg_wide_min_blocks;          // (launch_igemm's 128 x 256 tiles)
     const int blocks = wide ? mt * (L.CoutPad / 256) : mt * nt * s;
     const int cus = enc->wavek_target_blocks > 0 ? enc->wavek_target_blocks : 256;
-    return (double)ceil_div(blocks, cus) * (ceil_div(slabs, s) + 2) * (4 * kSlabUs) * (wide ? 2.0 : 1.0) / 0.86 + (s > 1 ? 10.0 : 0.0) + 5.0;
+    if (wide) return (double)ceil_div(blocks, 2 * cus) * 2.0 * (slabs + 2) * (8 * kSlabUs) / 0.90 + 5.0;
+    return (double)ceil_div(blocks, cus) * (ceil_div(slabs, s) + 2) * (4 * kSlabUs) / 0.86 + (s > 1 ? 10.0 : 0.0) + 5.0;
 }
 
 static WaveKPlan plan_wavek(const aae_encoder* enc, const Layer& L, long long M, bool split) {
@@ -1150,7 +1152,7 @@ struct ScanPlan {
     int nblk, Bpad, Bstride, Jpad, NT;
     bool gemv, stream;
     bool resident_ok;              // query-resident streaming kernel eligible (top-1, no similarity output, stride 1 decided at run time)
-    int res_tiles_per_block, res_blocks;
+    int res_tiles_per_block, res_blocks, res_rh;
     bool topk_fused;               // top-k (2..8) inside the query-resident kernel: no [B][N] similarity matrix
     int cand_chunks;               // candidate lists per query that topk_merge_kernel merges
     size_t ticket_off, q_off, qp_off, pval_off, pidx_off, cs_off, cand_off, total;
@@ -1182,11 +1184,13 @@ static ScanPlan plan_scan(const aae_codebook* cb, int B, int topk) {
     // B > 4: queries resident in registers, codebook streamed (codebook_scan_resident.h); about one block (8 waves)
     // per CU: row ranges x 128-query chunks.  Measured against the tile-resident kernels (whole nn call): B=8 0.035 ->
     // 0.024 ms, B=32 0.036 -> 0.024, B=256 0.106 -> 0.063; bf16 4x codebook B=32 0.083 -> 0.034, B=256 0.25 -> 0.078
-    s.resident_ok = false; s.res_tiles_per_block = 0; s.res_blocks = 0;
+    s.resident_ok = false; s.res_tiles_per_block = 0; s.res_blocks = 0; s.res_rh = 2;
     if (cb->scan_mode == AAE_SCAN_AUTO && cb->J == 128 && !s.stream && !s.gemv && B > 4) {
         const int tile_rows = cb->dtype == AAE_DTYPE_BF16 ? 128 : 64;
         const int ntiles = ceil_div(cb->N, tile_rows);
-        const int qchunks = ceil_div(s.Bpad, aae::kScanResidentQueries);
+        // B > 128: 256 queries per block, every wave all rows of a tile (the codebook streamed once per 256 queries)
+        s.res_rh = s.Bpad > 128 ? 1 : 2;
+        const int qchunks = ceil_div(s.Bpad, s.res_rh == 1 ? 256 : 128);
         int row_blocks = 256 / qchunks;
         if (row_blocks < 1) row_blocks = 1;
         s.res_tiles_per_block = ceil_div(ntiles, row_blocks);
@@ -1233,17 +1237,18 @@ static void launch_scan_stream_t(const aae::ScanArgs& a, bool upright, int nblk,
     else AAE_LAUNCH((aae::scan_stream_kernel<NQ, false>), dim3(nblk), dim3(256), smem, stream, a);
 }
 
-template <bool BF16, int K>
+template <bool BF16, int K, int RH>
 static void launch_scan_resident_t(const aae::ScanResidentArgs& a, dim3 grid, hipStream_t stream) {
-    (void)hipFuncSetAttribute((const void*)aae::scan_resident_kernel<BF16, K>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kScanResidentSmem);
-    AAE_LAUNCH((aae::scan_resident_kernel<BF16, K>), grid, dim3(aae::kScanResidentThreads), aae::kScanResidentSmem, stream, a);
+    (void)hipFuncSetAttribute((const void*)aae::scan_resident_kernel<BF16, K, RH>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kScanResidentSmem);
+    AAE_LAUNCH((aae::scan_resident_kernel<BF16, K, RH>), grid, dim3(aae::kScanResidentThreads), aae::kScanResidentSmem, stream, a);
 }
-template <bool BF16>
-static void launch_scan_resident_topk(const aae::ScanResidentArgs& a, dim3 grid, hipStream_t stream) {
-    if (a.k <= 2) launch_scan_resident_t<BF16, 2>(a, grid, stream);            // list slots: the smallest instantiated K >= k
-    else if (a.k <= 4) launch_scan_resident_t<BF16, 4>(a, grid, stream);
-    else if (a.k == 5) launch_scan_resident_t<BF16, 5>(a, grid, stream);
-    else launch_scan_resident_t<BF16, 8>(a, grid, stream);
+template <bool BF16, int RH>
+static void launch_scan_resident_k(const aae::ScanResidentArgs& a, dim3 grid, hipStream_t stream) {
+    if (a.k <= 1) launch_scan_resident_t<BF16, 0, RH>(a, grid, stream);
+    else if (a.k <= 2) launch_scan_resident_t<BF16, 2, RH>(a, grid, stream);    // list slots: the smallest instantiated K >= k
+    else if (a.k <= 4) launch_scan_resident_t<BF16, 4, RH>(a, grid, stream);
+    else if (a.k == 5) launch_scan_resident_t<BF16, 5, RH>(a, grid, stream);
+    else launch_scan_resident_t<BF16, 8, RH>(a, grid, stream);
 }
 
 // topk == 1: block partials (pval, pidx) for argmax_reduce_kernel; topk 2..8: candidate lists for topk_merge_kernel
@@ -1255,18 +1260,17 @@ static int launch_scan_resident(const aae_codebook* cb, const void* qp, int B, c
     a.pval = reinterpret_cast<float*>(base + s.pval_off);
     a.pidx = reinterpret_cast<int*>(base + s.pidx_off);
     a.N = cb->N; a.B = B; a.Bpad = s.Bpad; a.Bstride = s.Bstride; a.tiles_per_block = s.res_tiles_per_block;
-    const dim3 grid(s.res_blocks, ceil_div(s.Bpad, aae::kScanResidentQueries));
+    const dim3 grid(s.res_blocks, ceil_div(s.Bpad, s.res_rh == 1 ? 256 : 128));
+    a.k = topk > 1 ? topk : 0;
     if (topk > 1) {
-        a.k = topk;
         a.cand_v = reinterpret_cast<float*>(base + s.cand_off);
         a.cand_i = reinterpret_cast<int*>(base + s.cand_off + align_up((size_t)B * s.cand_chunks * topk * sizeof(float), 256));
-        if (cb->dtype == AAE_DTYPE_BF16) launch_scan_resident_topk<true>(a, grid, stream);
-        else launch_scan_resident_topk<false>(a, grid, stream);
-    } else if (cb->dtype == AAE_DTYPE_BF16) {
-        launch_scan_resident_t<true, 0>(a, grid, stream);
-    } else {
-        launch_scan_resident_t<false, 0>(a, grid, stream);
     }
+    const bool bf16 = cb->dtype == AAE_DTYPE_BF16;
+    if (bf16 && s.res_rh == 1) launch_scan_resident_k<true, 1>(a, grid, stream);
+    else if (bf16) launch_scan_resident_k<true, 2>(a, grid, stream);
+    else if (s.res_rh == 1) launch_scan_resident_k<false, 1>(a, grid, stream);
+    else launch_scan_resident_k<false, 2>(a, grid, stream);
     AAE_HIP_TRY(hipGetLastError());
     return AAE_OK;
 }
