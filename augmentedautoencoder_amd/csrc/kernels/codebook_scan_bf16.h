@@ -1,9 +1,15 @@
 // Codebook scan against a bf16 codebook (BASELINE config 5: 4x rows, bf16 storage, batched
 // queries on the bf16 matrix cores).  Same contract as codebook_scan_f32.h
 // (/root/reference/auto_pose/ae/codebook.py:27,50,64-71) -- the codebook rows are bf16, the
-// cosine is still accurate to fp32 roundoff: each normalised query is carried as THREE bf16
-// terms q = t0 + t1 + t2 (24 significant bits) and every 32x32x16 tile takes three
-// v_mfma_f32_32x32x16_bf16 with fp32 accumulation; the bf16 rows are used exactly as stored.
+// cosine stays inside the 1e-5 contract: each normalised query is split into bf16 terms
+// q = t0 + t1 + t2 (24 significant bits) of which the matrix-core kernels use the first
+// kBf16QueryTerms = 2 -- one v_mfma_f32_32x32x16_bf16 per term and 32x32x16 tile, fp32
+// accumulation; the bf16 rows are used exactly as stored.
+// Error of two terms: |q_j - t0 - t1| <= 2^-18 |q_j| (each rounding to bf16's 8-bit significand is
+// within 2^-9 of what it rounds), so |cos - cos_exact| <= 2^-18 sum |q_j||e_j| <= 2^-18 |q||e| = 3.8e-6
+// for unit vectors (Cauchy-Schwarz), typically ten times less; fp32 accumulation adds ~1e-6.  The third
+// term bought 2^-26 at 50 % more MFMAs: config 5 (B = 256, 368928 rows) is bound by the bf16 matrix pipe --
+// 82 -> ? us (profiles/r11).  The B <= 4 streaming kernel keeps full fp32 queries (vector ALU).
 //
 // Block = 128 codebook rows (32 KB, staged once in LDS with coalesced 16-B loads, XOR
 // swizzled so the fragment reads are conflict-free) x passes of 64 queries; the running
@@ -11,6 +17,8 @@
 #pragma once
 
 namespace aae {
+
+constexpr int kBf16QueryTerms = 2;       // bf16 terms of a query the MFMA kernels multiply (of the three that are packed)
 
 struct L2NormBf16Args {
     const float* z;          // [B][J]
@@ -83,7 +91,7 @@ __global__ __launch_bounds__(256) void scan_bf16_kernel(const ScanBf16Args p) {
     const long long qplane = (long long)16 * p.Bpad * 8;           // halves per term plane
     for (int qt = 0; qt < p.Bpad; qt += QC) {
         __syncthreads();
-        for (int idx = tid; idx < 3 * 16 * QC; idx += 256) {
+        for (int idx = tid; idx < kBf16QueryTerms * 16 * QC; idx += 256) {
             const int term = idx / (16 * QC), rem = idx - term * (16 * QC);
             const int slot = rem / QC, c = rem - slot * QC;
             const f32x4 v = *reinterpret_cast<const f32x4*>(p.qp3 + term * qplane + ((long long)slot * p.Bpad + qt + c) * 8);
@@ -103,7 +111,7 @@ __global__ __launch_bounds__(256) void scan_bf16_kernel(const ScanBf16Args p) {
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
 #pragma unroll
-                for (int term = 2; term >= 0; --term) {            // smallest term first
+                for (int term = kBf16QueryTerms - 1; term >= 0; --term) {   // smallest term first
                     const u32x4 b = __builtin_bit_cast(u32x4, lds_read4(Qt + ((term * 16 + slot) * QC + ni * 32 + i) * 4));
                     acc[ni] = mfma_32x32x16_bf16(a, b, acc[ni]);
                 }

@@ -77,13 +77,13 @@ __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(con
     const int query = q0 + i;
 
     // this wave's query fragments, for good
-    f32x4 bq[BF16 ? 24 : 16];
+    f32x4 bq[BF16 ? 8 * kBf16QueryTerms : 16];
     if (active) {
         if (BF16) {
             const unsigned short* qp3 = reinterpret_cast<const unsigned short*>(p.qp);
             const long long qplane = (long long)16 * p.Bpad * 8;
 #pragma unroll
-            for (int term = 0; term < 3; ++term)
+            for (int term = 0; term < kBf16QueryTerms; ++term)
 #pragma unroll
                 for (int s = 0; s < 8; ++s)
                     bq[term * 8 + s] = *reinterpret_cast<const f32x4*>(qp3 + term * qplane + ((long long)(2 * s + h) * p.Bpad + query) * 8);
@@ -143,9 +143,9 @@ __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(con
                 for (int mi = 0; mi < kMi; ++mi)
                     a[mi] = __builtin_bit_cast(u32x4, lds_read4(Eb + e16_tile_off(rh * (32 * kMi) + mi * 32 + i, 2 * s + h)));
 #pragma unroll
-                for (int mi = 0; mi < kMi; ++mi)
-#pragma unroll
-                    for (int term = 2; term >= 0; --term)              // smallest term first
+                for (int term = kBf16QueryTerms - 1; term >= 0; --term)       // smallest term first; the accumulator tiles take
+#pragma unroll                                                                  // turns, so no MFMA sits behind the one it depends on
+                    for (int mi = 0; mi < kMi; ++mi)
                         acc[mi] = mfma_32x32x16_bf16(a[mi], __builtin_bit_cast(u32x4, bq[term * 8 + s]), acc[mi]);
             }
         } else {
@@ -155,9 +155,9 @@ __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(con
 #pragma unroll
                 for (int mi = 0; mi < kMi; ++mi) a[mi] = lds_read4(Eb + e_tile_off(rh * (32 * kMi) + mi * 32 + i, 2 * c + h));
 #pragma unroll
-                for (int mi = 0; mi < kMi; ++mi)
+                for (int q = 0; q < 4; ++q)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[mi] = mfma_32x32x2(a[mi][q], bq[c][q], acc[mi]);
+                    for (int mi = 0; mi < kMi; ++mi) acc[mi] = mfma_32x32x2(a[mi][q], bq[c][q], acc[mi]);
             }
         }
         const int row_base = t * kTileRows + rh * 32 * kMi;
