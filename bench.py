@@ -316,15 +316,19 @@ def main():
         except Exception:
             scan_traffic = None
         extras['scan'] = {
-            'kernel_us': round(solo1, 2), 'kernel_frac': round(cb_bytes / solo1 / 1e3 / PEAK_HBM_GBPS, 3),
-            'traffic': scan_traffic,
+            'single_call_between_events_us': round(solo1, 2),
+            'kernel_us': (scan_traffic or {}).get('kernel_us_avg'), 'kernel_us_min': (scan_traffic or {}).get('kernel_us_min'),
+            'traffic': (scan_traffic or {}).get('hbm_side_bytes_warm'), 'traffic_cold': (scan_traffic or {}).get('hbm_side_bytes_cold'),
+            'kernel_and_traffic_source': 'profiles/traffic.json <- profiles/r11_small (rocprofv3 --stats and PMC passes of tools/prof_mix.py, an earlier run: not measured in this one)',
+
             'codebook_bytes': cb_bytes, 'peak_GBps': PEAK_HBM_GBPS,
             'B1_whole_call_warm_us': round(warm1, 2), 'B1_warm_GBps': round(cb_bytes / warm1 / 1e3, 1), 'B1_warm_frac': round(cb_bytes / warm1 / 1e3 / PEAK_HBM_GBPS, 3),
             'B1_whole_call_cold_us': round(cold1, 2), 'B1_cold_GBps': round(cb_bytes / cold1 / 1e3, 1), 'B1_cold_frac': round(cb_bytes / cold1 / 1e3 / PEAK_HBM_GBPS, 3),
             'B256_whole_call_us': round(warm256, 2),
             'note': 'whole aae_codebook_nn call = ONE launch at B <= 4 (normalise + stream + arg-max hand-off inside the scan kernel); whole_call = '
-                    'back-to-back calls on one stream, kernel_us = one call between its own HIP events on an idle stream (median); traffic = HBM-side '
-                    'bytes per launch from the committed rocprofv3 PMC pass (profiles/traffic.json).  warm: the 47 MB codebook stays in the 256 MB Infinity Cache between calls '
+                    'back-to-back calls on one stream (consecutive launches overlap: a call can cost less than the duration of its own kernel); '
+                    'single_call_between_events = one call between its own HIP events on an idle stream (median; includes the host launch latency); '
+                    'kernel_us / traffic = the committed rocprofv3 figures.  warm: the 47 MB codebook stays in the 256 MB Infinity Cache between calls '
                     '(algorithmic bytes, not HBM bytes); cold: 8 codebook copies visited in turn, so every call streams from HBM.  '
                     'B=256 is MFMA-bound (crossover B~39).  Kernel-only durations: profiles/ (rocprofv3 --kernel-trace --stats)'}
         # ---- BASELINE config 3: ae_embed -- encode 92232 views (codebook.py:190-219), encoder only, inputs resident
