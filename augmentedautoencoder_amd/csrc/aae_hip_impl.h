@@ -169,6 +169,7 @@ struct aae_codebook {
     int dtype = AAE_DTYPE_F32;
     int N = 0, J = 0;
     int scan_mode = AAE_SCAN_AUTO;
+    int topk_prune = 1;    // top-k inside the query-resident scan: drop candidates below the bound the blocks publish (AAE_SCAN_AUTO_NO_PRUNE: 0)
     // upright search (col_stride k > 1): a compacted copy of rows 0, k, 2k, ... prepared by
     // aae_codebook_prepare_upright; the scan then runs over N/k rows and the winning row id is scaled by k
     aae_codebook* upright = nullptr;   // the copy for the stride asked for last (one of upright_copies)
@@ -1155,7 +1156,7 @@ struct ScanPlan {
     int res_tiles_per_block, res_blocks, res_rh;
     bool topk_fused;               // top-k (2..8) inside the query-resident kernel: no [B][N] similarity matrix
     int cand_chunks;               // candidate lists per query that topk_merge_kernel merges
-    size_t ticket_off, q_off, qp_off, pval_off, pidx_off, cs_off, cand_off, total;
+    size_t ticket_off, q_off, qp_off, pval_off, pidx_off, cs_off, cand_off, prune_off, total;
 };
 
 // answers of a top-1 stream scan that finishes inside its own launch (scan_ticket_finish)
@@ -1214,6 +1215,8 @@ static ScanPlan plan_scan(const aae_codebook* cb, int B, int topk) {
     s.cand_off = off;
     s.cand_chunks = s.topk_fused ? s.res_blocks : ceil_div(cb->N, aae::kTopKChunk);
     if (topk > 1) off += 2 * align_up((size_t)B * s.cand_chunks * topk * sizeof(float), 256);
+    s.prune_off = off;                                  // shared bound words of the pruned top-k scan
+    if (s.topk_fused) off += align_up((size_t)aae::kPruneReplicas * s.Bpad * aae::kPruneGroups * sizeof(int), 256);
     s.total = off;
     return s;
 }
@@ -1265,6 +1268,7 @@ static int launch_scan_resident(const aae_codebook* cb, const void* qp, int B, c
     if (topk > 1) {
         a.cand_v = reinterpret_cast<float*>(base + s.cand_off);
         a.cand_i = reinterpret_cast<int*>(base + s.cand_off + align_up((size_t)B * s.cand_chunks * topk * sizeof(float), 256));
+        if (cb->topk_prune) a.prune = reinterpret_cast<int*>(base + s.prune_off);      // (reset by the normalise kernel in front)
     }
     const bool bf16 = cb->dtype == AAE_DTYPE_BF16;
     if (bf16 && s.res_rh == 1) launch_scan_resident_k<true, 1>(a, grid, stream);
@@ -1312,6 +1316,7 @@ static int run_scan(aae_codebook* cb, const float* z, int B, int col_stride, flo
     if (cb->dtype == AAE_DTYPE_BF16) {
         aae::L2NormBf16Args n;
         n.z = z; n.qp3 = reinterpret_cast<unsigned short*>(qp); n.B = B; n.J = cb->J; n.Jpad = 128; n.Bpad = s.Bpad;
+        if (resident && topk > 1 && cb->topk_prune) n.prune = reinterpret_cast<int*>(base + s.prune_off);
         AAE_LAUNCH((aae::l2norm_pack_bf16x3_kernel), dim3(ceil_div(s.Bpad, 4)), dim3(256), 0, stream, n);
         AAE_HIP_TRY(hipGetLastError());
         if (resident) return launch_scan_resident(cb, n.qp3, B, s, base, stream, topk);
@@ -1336,6 +1341,7 @@ static int run_scan(aae_codebook* cb, const float* z, int B, int col_stride, flo
     if (!s.stream) {                     // the stream kernel normalises the queries itself
         aae::L2NormArgs n;
         n.z = z; n.q = q; n.qp = s.gemv ? nullptr : qp; n.B = B; n.J = cb->J; n.Jpad = s.Jpad; n.Bpad = s.gemv ? B : s.Bpad;
+        if (resident && topk > 1 && cb->topk_prune) n.prune = reinterpret_cast<int*>(base + s.prune_off);
         AAE_LAUNCH((aae::l2norm_pack_kernel), dim3(ceil_div(n.Bpad, 4)), dim3(256), 0, stream, n);
         AAE_HIP_TRY(hipGetLastError());
     }
@@ -1756,7 +1762,7 @@ int aae_codebook_prepare_upright(aae_codebook* cb, int col_stride, void* stream_
             sub->E = static_cast<float*>(p);
             cb->upright_copies.push_back({col_stride, sub});
         }
-        sub->scan_mode = cb->scan_mode; sub->scan_ticket = cb->scan_ticket;
+        sub->scan_mode = cb->scan_mode; sub->scan_ticket = cb->scan_ticket; sub->topk_prune = cb->topk_prune;
         cb->upright = sub; cb->upright_stride = col_stride;
     }
     if (int rc = gather_upright_rows(cb, cb->upright, cb->upright_stride, stream)) return rc;
@@ -1785,11 +1791,13 @@ void aae_codebook_destroy(aae_codebook* cb) {
 int aae_codebook_set_scan_mode(aae_codebook* cb, int mode) {
     using namespace aae_host;
     if (!cb) return fail(AAE_ERR_INVALID, "aae_codebook_set_scan_mode: null handle");
-    if (mode != AAE_SCAN_AUTO && mode != AAE_SCAN_GEMV && mode != AAE_SCAN_MFMA && mode != AAE_SCAN_STREAM && mode != AAE_SCAN_STREAM_2L)
+    if (mode != AAE_SCAN_AUTO && mode != AAE_SCAN_GEMV && mode != AAE_SCAN_MFMA && mode != AAE_SCAN_STREAM && mode != AAE_SCAN_STREAM_2L &&
+        mode != AAE_SCAN_AUTO_NO_PRUNE)
         return fail(AAE_ERR_INVALID, "scan mode %d", mode);
     cb->scan_ticket = mode == AAE_SCAN_STREAM_2L ? 0 : 1;
-    cb->scan_mode = mode == AAE_SCAN_STREAM_2L ? AAE_SCAN_STREAM : mode;
-    for (auto& c : cb->upright_copies) { c.second->scan_mode = cb->scan_mode; c.second->scan_ticket = cb->scan_ticket; }
+    cb->topk_prune = mode == AAE_SCAN_AUTO_NO_PRUNE ? 0 : 1;
+    cb->scan_mode = mode == AAE_SCAN_STREAM_2L ? AAE_SCAN_STREAM : (mode == AAE_SCAN_AUTO_NO_PRUNE ? AAE_SCAN_AUTO : mode);
+    for (auto& c : cb->upright_copies) { c.second->scan_mode = cb->scan_mode; c.second->scan_ticket = cb->scan_ticket; c.second->topk_prune = cb->topk_prune; }
     return AAE_OK;
 }
 

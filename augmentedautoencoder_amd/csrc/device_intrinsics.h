@@ -140,6 +140,8 @@ __device__ __forceinline__ void wave_priority() { __builtin_amdgcn_s_setprio(P);
 
 // instruction-scheduling fence: nothing is moved across it by the compiler's scheduler
 __device__ __forceinline__ void sched_fence() { __builtin_amdgcn_sched_barrier(0); }
+// device-scope max on a word other blocks publish to as well (no return value wanted)
+__device__ __forceinline__ void shared_word_max(int* word, int v) { (void)__hip_atomic_fetch_max(word, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // coarse start delay: n x 1024 shader cycles
 __device__ __forceinline__ void sleep_kcycles(int n) {

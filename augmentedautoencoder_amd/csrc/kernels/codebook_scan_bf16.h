@@ -24,6 +24,7 @@ struct L2NormBf16Args {
     const float* z;          // [B][J]
     unsigned short* qp3;     // [3 terms][Jpad/8 slots][Bpad][8] bf16
     int B, J, Jpad, Bpad;
+    int* prune = nullptr;    // optional [kPruneReplicas][Bpad][kPruneGroups]: reset for the top-k scan that follows (codebook_scan_resident.h)
 };
 
 // one wave per query row b < Bpad (rows >= B are written as zeros)
@@ -31,6 +32,8 @@ __global__ __launch_bounds__(256) void l2norm_pack_bf16x3_kernel(const L2NormBf1
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= p.Bpad) return;
+    if (p.prune)
+        for (int w = lane; w < kPruneReplicas * kPruneGroups; w += 64) p.prune[((w / kPruneGroups) * p.Bpad + b) * kPruneGroups + w % kPruneGroups] = kScoreKeyEmpty;
     const bool real = b < p.B;
     float ss = 0.f;
     if (real)

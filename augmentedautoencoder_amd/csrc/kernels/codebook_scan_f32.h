@@ -34,12 +34,15 @@ struct L2NormArgs {
     float* q;         // [B][J]   (may be nullptr)
     float* qp;        // [Jpad/4][Bpad][4] (may be nullptr)
     int B, J, Jpad, Bpad;
+    int* prune = nullptr;   // optional [kPruneReplicas][Bpad][kPruneGroups]: reset for the top-k scan that follows (codebook_scan_resident.h)
 };
 
 __global__ __launch_bounds__(256) void l2norm_pack_kernel(const L2NormArgs p) {
     const int lane = threadIdx.x & 63;
     const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (b >= p.Bpad) return;                      // whole wave exits together
+    if (p.prune)
+        for (int w = lane; w < kPruneReplicas * kPruneGroups; w += 64) p.prune[((w / kPruneGroups) * p.Bpad + b) * kPruneGroups + w % kPruneGroups] = kScoreKeyEmpty;
     const bool real = b < p.B;
     float ss = 0.f;
     if (real)

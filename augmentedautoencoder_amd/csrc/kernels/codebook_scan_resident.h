@@ -1,15 +1,15 @@
 // Batched codebook arg-max with the QUERIES resident in registers and the codebook streamed
 // through LDS -- the batched (B > 4) form of
 //   tf.matmul(q, E, transpose_b=True) + argmax   (/root/reference/auto_pose/ae/codebook.py:50-51, 63-64)
-// for fp32 rows (exact fp32 MFMA) and bf16 rows (three bf16 MFMA terms per product, fp32 accumulate).
+// for fp32 rows (exact fp32 MFMA) and bf16 rows (kBf16QueryTerms = 2 bf16 MFMA terms per product, fp32 accumulate).
 //
 // scan_mfma_kernel / scan_bf16_kernel keep one 128-row codebook tile in LDS and walk the query
 // chunks through LDS as well: one block per CU (128 KB of LDS), every chunk pays a staging round
 // trip, two barriers and an epilogue, and each MFMA needs more than one 16-byte LDS read.  Here a
 // block of 8 waves owns 128 (or 256) queries for its whole life: a wave keeps the MFMA B fragments
-// of its query group (32 queries) in registers (64 VGPRs fp32, 96 bf16) and accumulates its rows
-// of every 32-KB row tile (64 fp32 rows / 128 bf16 rows) that streams through two LDS images:
-// one barrier and one 16-byte LDS read per 4 (fp32) or 3 (bf16) MFMAs, the global loads of tiles
+// of its query group (32 queries) in registers (64 VGPRs) and accumulates its rows
+// of every 32-KB row tile (64 fp32 rows / 128 bf16 rows) that streams through three LDS images:
+// one barrier and one 16-byte LDS read per 4 (fp32) or 2 (bf16) MFMAs, the LDS-DMA pieces of tiles
 // t+1 and t+2 in flight under the MFMAs of tile t, a running (best score, first row) pair per lane, and
 // one partial per (row range, query) at the very end.  The per-accumulator MFMA
 // order is the one of the tile-resident kernels, so scores and indices are bit-identical to theirs.
@@ -17,6 +17,14 @@
 // Restrictions (the tile-resident kernels remain for the rest): J == 128, top-1, col_stride == 1,
 // no similarity output.
 #pragma once
+
+// timing experiments only (tools/ubench/scan_resident_ablate.hip builds the kernel with parts of a tile's work removed;
+// results are then wrong): 1 no arg-max / list fold, 2 no LDS fragment reads, 4 no MFMAs, 8 no codebook stream, 16 (top-k) the
+// list insertion replaced by one maximum, 32 (top-k) accumulator tiles that pass the pretest are not looked at value by value,
+// 64 (top-k) nothing is published to the shared bound words, 128 (top-k) they are never read
+#ifndef AAE_SCAN_RESIDENT_ABLATE
+#define AAE_SCAN_RESIDENT_ABLATE 0
+#endif
 
 namespace aae {
 
@@ -33,11 +41,14 @@ struct ScanResidentArgs {
     float* cand_v = nullptr;    // [B][gridDim.x][k]
     int* cand_i = nullptr;
     int k = 0;
+    // top-k pruning across blocks (optional): [kPruneReplicas][Bpad][kPruneGroups] score keys, reset by the normalise kernel in front of the
+    // scan; block b raises word b % kPruneGroups of a query to the best score it has seen for it
+    int* prune = nullptr;
 };
 
 constexpr int kScanResidentThreads = 512;
 constexpr int kScanResidentTileFloats = 8192;                               // 32 KB
-constexpr int kScanResidentStages = 2;                                      // LDS images of the codebook stream
+constexpr int kScanResidentStages = 3;                                      // LDS images of the codebook stream: one in use, two in flight
 // queries one block owns: 8 waves = RH row parts x (8 / RH) groups of 32 queries
 template <int RH>
 constexpr int scan_resident_queries() { return 32 * (8 / RH); }
@@ -49,14 +60,25 @@ constexpr int kScanResidentSmem = kScanResidentStages * kScanResidentTileFloats 
 // share a query (row parts x two lane halves) are merged at the end.  The insertion is ~5 VALU instructions per list slot
 // and candidate, skipped when no lane of the wave has a score above its K-th best.
 //
+// Top-k pruning across blocks.  The per-lane lists of a block are YOUNG -- a lane sees 64 rows per tile, a dozen tiles -- so in
+// almost every value slot some lane of the wave has a candidate and the whole wave walks the insertion (config 5: 125 us for
+// top-5 against 45 for the arg-max).  But most of those candidates cannot be in the final answer: every block raises one of
+// kPruneGroups shared words per query to the best score it has seen; the maxima of different words belong to different rows,
+// so the K-th largest word is a LOWER BOUND of the query's final K-th best score, and a value below it is dropped before it
+// costs anything (a value equal to it is kept: ties are decided by row later).  After the first tile of every block the bound
+// is about the 8th best of 30 000 rows; one value slot in 60 still has a candidate.  The words are read without any
+// ordering -- whatever has been published so far is a valid bound -- so the result does not depend on timing.
+//
 // RH = 2 (B <= 128): wave (rh, qg) accumulates half the rows of a tile for query group qg -- four query groups per block.
 // RH = 1 (B > 128): every wave takes ALL rows of a tile for its own query group -- eight groups = 256 queries per block, so
 // the codebook is streamed ONCE for 256 queries instead of once per 128 (config 5, B = 256: 189 -> 94 MB per scan; the kernel
 // was bound by that stream at one 32-KB tile in flight per CU: 2.6 TB/s, profiles/r11_small).
-// Round 3, all forms: (a) two tiles in flight behind the one in use (a second register set) instead of one; (b) top-k: a
-// tile is looked at value by value only if its maximum beats some lane's K-th best.  Same MFMA order per accumulator:
-// bit-identical scores and indices.  (A running maximum per accumulator position -- 3 instead of 5 vector instructions per
-// value -- was tried for the arg-max: 128 more registers at four accumulator tiles, 300 spilled: dropped.)
+// Round 3, all forms: (a) the stream goes global -> LDS by LDS-DMA into three images -- two tiles in flight behind the one in
+// use, no staging registers, no LDS writes (was: one tile ahead through registers); (b) top-k: a tile is looked at value by
+// value only if its maximum beats some lane's K-th best; (c) arg-max with two or more accumulator tiles per wave: the fold of
+// finished accumulators and the LDS fragment reads sit between the MFMAs of the next ones (below).  Same MFMA order per
+// accumulator: bit-identical scores and indices.  (A running maximum per accumulator position -- 3 instead of 5 vector
+// instructions per value -- was tried for the arg-max: 128 more registers at four accumulator tiles, 300 spilled: dropped.)
 template <bool BF16, int K = 0, int RH = 2>
 __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(const ScanResidentArgs p) {
     constexpr int kTileRows = BF16 ? 128 : 64;
@@ -68,6 +90,7 @@ __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(con
     float* Et = reinterpret_cast<float*>(smem_raw);                        // [kScanResidentStages][32 KB]
     float* red_v = Et + kScanResidentStages * kScanResidentTileFloats;     // [RH row parts][QB queries]
     int* red_i = reinterpret_cast<int*>(red_v + 2 * 256);
+    float* tau = red_v;                                                    // top-k: [QB] pruning bound per query of the block
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
@@ -98,30 +121,37 @@ __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(con
     const int tile0 = blockIdx.x * p.tiles_per_block;
     const int tile1 = min(tile0 + p.tiles_per_block, ntiles);
 
-    // staging: 2048 16-byte pieces per tile, 4 per thread, coalesced along the row; two register sets = two tiles in flight
+    // staging by LDS-DMA: the codebook goes global -> LDS without passing through registers.  A tile is 2048 16-byte
+    // pieces = 32 wave instructions of 64 lanes x 16 B (lane-linear in LDS), four per wave.  The XOR swizzle of the image is
+    // applied on the SOURCE side: the lane that owns piece position row * kSlots + ps fetches logical slot ps ^ (row & 15)
+    // of that row.  Rows past N lie beyond the buffer's size: the hardware delivers zeros.
     const buffer_rsrc ebuf = make_buffer(p.E, p.e_bytes);
-    f32x4 st[2][4];
-    auto fetch = [&](int t, int set) {
+    constexpr int kAblate = AAE_SCAN_RESIDENT_ABLATE;
+    unsigned dma_off[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int idx = tid + kScanResidentThreads * u;
-            const int r = idx / kSlots, slot = idx % kSlots;
-            const int row = t * kTileRows + r;
-            st[set][u] = buffer_load4(ebuf, (t < tile1 && row < p.N) ? (unsigned)row * kRowBytes + slot * 16 : kOobOffset);
-        }
-    };
-    auto put = [&](float* dst, int set) {
+    for (int j = 0; j < 4; ++j) {
+        const int pos = (wave * 4 + j) * 64 + lane;
+        const int r = pos / kSlots, ps = pos % kSlots;
+        dma_off[j] = (unsigned)(r * kRowBytes + ((ps ^ (r & 15)) << 4));
+    }
+    auto dma = [&](int t, float* img) {
+        if (kAblate & 8) return;
+        const unsigned tile_off = (unsigned)t * (unsigned)(kTileRows * kRowBytes);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int idx = tid + kScanResidentThreads * u;
-            const int r = idx / kSlots, slot = idx % kSlots;
-            lds_write4(dst + (BF16 ? e16_tile_off(r, slot) : e_tile_off(r, slot)), st[set][u]);
-        }
+        for (int j = 0; j < 4; ++j) lds_dma16(ebuf, t < tile1 ? tile_off + dma_off[j] : kOobOffset, img + (wave * 4 + j) * 256);
     };
 
     // arg-max state: running (best score, first row) of this lane
+    // arg-max state: running best of this lane, remembered as (score, tile, accumulator slot mi * 16 + r) -- the slot an
+    // inline constant of the select -- and decoded to a row once at the end: a compare and two selects per value
     float bv = kNegInf;
-    int bi = tile0 * kTileRows + rh * 32 * kMi + acc_row(0, lane);
+    int bt = tile0, bs = 0;
+    float tau_l = kNegInf;                         // top-k: this lane's pruning bound (a lower bound of its query's final K-th best)
+    auto publish = [&](float best) {               // top-k: raise this block's word of the lane's query, in every replica
+#pragma unroll
+        for (int rep = 0; rep < kPruneReplicas; ++rep)
+            shared_word_max(p.prune + ((long long)rep * p.Bpad + query) * kPruneGroups + (blockIdx.x & (kPruneGroups - 1)), score_key(best));
+    };
     constexpr int KL = K > 0 ? K : 1;
     float tv[KL];
     int ti[KL];
@@ -140,13 +170,17 @@ __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(con
             for (int s = 0; s < 8; ++s) {
                 u32x4 a[kMi];
 #pragma unroll
-                for (int mi = 0; mi < kMi; ++mi)
-                    a[mi] = __builtin_bit_cast(u32x4, lds_read4(Eb + e16_tile_off(rh * (32 * kMi) + mi * 32 + i, 2 * s + h)));
+                for (int mi = 0; mi < kMi; ++mi) {
+                    if (kAblate & 2) a[mi] = u32x4{(unsigned)(lane + mi), (unsigned)s, 0x3f803f80u, (unsigned)t};
+                    else a[mi] = __builtin_bit_cast(u32x4, lds_read4(Eb + e16_tile_off(rh * (32 * kMi) + mi * 32 + i, 2 * s + h)));
+                }
 #pragma unroll
                 for (int term = kBf16QueryTerms - 1; term >= 0; --term)       // smallest term first; the accumulator tiles take
 #pragma unroll                                                                  // turns, so no MFMA sits behind the one it depends on
-                    for (int mi = 0; mi < kMi; ++mi)
-                        acc[mi] = mfma_32x32x16_bf16(a[mi], __builtin_bit_cast(u32x4, bq[term * 8 + s]), acc[mi]);
+                    for (int mi = 0; mi < kMi; ++mi) {
+                        if (kAblate & 4) acc[mi][s] += (float)a[mi][term] * bq[term * 8 + s][mi];
+                        else acc[mi] = mfma_32x32x16_bf16(a[mi], __builtin_bit_cast(u32x4, bq[term * 8 + s]), acc[mi]);
+                    }
             }
         } else {
 #pragma unroll
@@ -162,33 +196,54 @@ __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(con
         }
         const int row_base = t * kTileRows + rh * 32 * kMi;
         const bool inside = (t + 1) * kTileRows <= p.N;
-        if constexpr (K == 0) {
-            // running (max, first row): rows ascend with mi, r for a fixed lane, tiles ascend with t
+        if constexpr ((kAblate & 1) != 0) {
 #pragma unroll
             for (int mi = 0; mi < kMi; ++mi)
+                if (acc[mi][0] + acc[mi][7] > bv) { bv = acc[mi][0]; bs = mi; bt = t; }
+            if (K > 0) tv[0] = bv;
+        } else if constexpr (K == 0) {
+            // running (max, first row): rows ascend with mi, r for a fixed lane, tiles ascend with t.  The row itself is not
+            // formed per value: the winner is remembered as (tile, accumulator slot) -- compare + two selects per value,
+            // the slot an inline constant -- and decoded once at the end.
+            const float before = bv;
+            if (inside) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = row_base + mi * 32 + acc_row(r, lane);
-                    const float v = acc[mi][r];
-                    if ((inside || row < p.N) && v > bv) { bv = v; bi = row; }
-                }
+                for (int mi = 0; mi < kMi; ++mi)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (acc[mi][r] > bv) { bv = acc[mi][r]; bs = mi * 16 + r; }
+            } else {
+#pragma unroll
+                for (int mi = 0; mi < kMi; ++mi)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        if (row_base + mi * 32 + acc_row(r, lane) < p.N && acc[mi][r] > bv) { bv = acc[mi][r]; bs = mi * 16 + r; }
+            }
+            bt = bv > before ? t : bt;
         } else {
-            // does any value of this tile enter any lane's list?  (the tile maximum against the K-th best: two vector
-            // instructions per three values; the value-by-value insertion below runs for the few tiles that pass)
-            float tmax = kNegInf;
+            // Does any value of an accumulator tile (16 values per lane) enter any lane's list?  Its maximum against the lane's
+            // K-th best and the query's bound decides for the wave; only the few accumulator tiles that pass are looked at value
+            // by value, and there the K-slot insertion runs only for value slots in which some lane has a candidate.
 #pragma unroll
-            for (int mi = 0; mi < kMi; ++mi)
+            for (int mi = 0; mi < kMi; ++mi) {
+                float m16 = acc[mi][0];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) tmax = fmaxf(tmax, acc[mi][r]);
-            if (!wave_any(tmax > tv[K - 1])) return;
-#pragma unroll
-            for (int mi = 0; mi < kMi; ++mi)
+                for (int r = 1; r < 16; ++r) m16 = fmaxf(m16, acc[mi][r]);
+                if (mi == 0 && t == tile0 && p.prune != nullptr && blockIdx.x < 4 * kPruneGroups && !(kAblate & 64)) {
+                    // the first word of the bound: the best of this wave's first 32 rows, from four blocks per word -- in place
+                    // long before the end of step 0, where every block reads the words for the first time
+                    const float best = fmaxf(m16, shfl_xor(m16, 32));
+                    if (h == 0 && (inside || row_base + 32 <= p.N)) publish(best);
+                }
+                if (!wave_any(m16 > tv[K - 1] && m16 >= tau_l)) continue;
+                if (kAblate & 32) { tv[0] = fmaxf(tv[0], m16); continue; }
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = row_base + mi * 32 + acc_row(r, lane);
                     const float v = acc[mi][r];
-                    const bool enters = (inside || row < p.N) && v > tv[K - 1];
+                    const bool enters = (inside || row < p.N) && v > tv[K - 1] && v >= tau_l;
                     if (wave_any(enters)) {
+                        if (kAblate & 16) { tv[0] = fmaxf(tv[0], v); continue; }
                         float cv = enters ? v : kNegInf;
                         int ci = row;
                         bool ins = false;
@@ -202,34 +257,80 @@ __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(con
                         }
                     }
                 }
+            }
         }
     };
 
-    // The stream: tile t is used from LDS image t % 2 while tile t + 1 waits in one register set and tile t + 2 is requested
-    // into the other -- two tiles (64 KB per CU) in flight.  Tile t + 1 goes to its image at the END of step t: that image
-    // was last read in step t - 1, and every wave has passed the barrier of step t since.  One barrier per tile.
-    // (bf16 top-k lists at four accumulator tiles per wave leave no room for the second register set: one tile ahead there)
-    constexpr bool kDeep = !(BF16 && RH == 1 && K > 0);
-    fetch(tile0, 0);
-    if (kDeep) fetch(tile0 + 1, 1);
-    if (tile0 < tile1) put(Et, 0);
+    // The stream: tile t is used from LDS image t % 3 while the DMA pieces of tiles t + 1 and t + 2 are in flight (64 KB per
+    // CU).  Tile t + 2 is requested right after the barrier of step t into the image tile t - 1 was read from -- every wave
+    // has passed that barrier, so nobody reads it any more.  One barrier per tile; a wave waits only for its OWN pieces of
+    // tile t (vmcnt counts in issue order: the four of tile t + 1 stay in flight), the barrier covers the other waves'.
+    dma(tile0, Et);
+    dma(tile0 + 1, Et + kScanResidentTileFloats);
+    int img = 0;
+    const bool prune = K > 0 && p.prune != nullptr;
+    if (K > 0 && tid < QB) tau[tid] = kNegInf;                 // (in place at the first barrier)
+    float published = kNegInf;
+    // The schedule of the shared bound (measured at config 5, tools/ubench/scan_resident_ablate.hip; 148 us unpruned):
+    // publications inside step 0, after a quarter of the first tile, by a quarter of the blocks (consume()), and after steps
+    // 1, 2, 4, 7 by every block whose best can still move the bound; re-reads by the first QB threads at the END of steps 0, 1,
+    // 2, 4, 7 (in place for everybody behind the next barrier): 96 us.  Dense early, when the bound moves.  What lost: a
+    // publication by every block at the end of step 0 -- a burst of 60 000 atomics per replica right in front of the first
+    // re-read of the same lines -- 115 us in any schedule that had it; only two re-reads (end of step 0 + a pipelined one in
+    // step 2) 120 us: the early bound is weak (7th best of 2000 rows), it has to be followed up; re-reading every step 116 us.
+    constexpr unsigned kPublishSteps = 0x96u, kRefreshSteps = 0x97u;       // after steps {1, 2, 4, 7} / at the end of steps {0, 1, 2, 4, 7}
     for (int t = tile0; t < tile1; ++t) {
-        const int step = t - tile0;
-        float* Eb = Et + (step & 1) * kScanResidentTileFloats;
-        float* En = Et + ((step + 1) & 1) * kScanResidentTileFloats;
-        __syncthreads();                                       // image of tile t complete
-        if (!kDeep) {
-            fetch(t + 1, 0);
-            if (active) consume(Eb, t);
-            if (t + 1 < tile1) put(En, 0);
-        } else if (step & 1) {
-            fetch(t + 2, 1);
-            if (active) consume(Eb, t);
-            if (t + 1 < tile1) put(En, 0);
+        const float* Eb = Et + img * kScanResidentTileFloats;
+        wait_dma_keep_and_lds<4>();
+        block_barrier();                                       // image of tile t complete
+        [[maybe_unused]] const int step = t - tile0;
+        [[maybe_unused]] u32x4 pw[kPruneGroups / 4];
+        [[maybe_unused]] const bool reader = prune && tid < QB && blockIdx.y * QB + tid < p.Bpad && !(kAblate & 128);
+        [[maybe_unused]] auto load_words = [&]() {
+            const buffer_rsrc pb = make_buffer(p.prune, (unsigned)(kPruneReplicas * p.Bpad) * kPruneGroups * 4u);
+            const int rq = (int)(blockIdx.x & (kPruneReplicas - 1)) * p.Bpad + blockIdx.y * QB + tid;      // this block's replica
+#pragma unroll
+            for (int w4 = 0; w4 < kPruneGroups / 4; ++w4)      // (whole-vector casts: a bit_cast of one element indexed by a loop
+                pw[w4] = __builtin_bit_cast(u32x4, coherent_load4(pb, (unsigned)(rq * kPruneGroups + w4 * 4) * 4u));   // variable picked element 0 under clang -O2)
+        };
+        if constexpr (K > 0) {
+        }
+        dma(t + 2, Et + (img == 0 ? 2 : img - 1) * kScanResidentTileFloats);
+        img = img == 2 ? 0 : img + 1;
+        if constexpr (K > 0) {
+            if (active) {
+                tau_l = tau[qg * 32 + i];                      // (a bound of any age is valid)
+                consume(Eb, t);
+                if (prune && step < 32 && ((kPublishSteps >> step) & 1) && !(kAblate & 64)) {
+                    // one lane per query and wave, and only what can move the bound (a score at or below it cannot become one
+                    // of the K largest words): device-scope atomics on a few thousand words are not free (every lane of every
+                    // block publishing at five steps cost 60 us at config 5)
+                    const float best = fmaxf(tv[0], shfl_xor(tv[0], 32));
+                    if (h == 0 && best > published && best > tau_l) {
+                        published = best;
+                        publish(best);
+                    }
+                }
+            }
+            if (reader && step < 32 && ((kRefreshSteps >> step) & 1)) {
+                // K-th largest of the query's shared words (K slots kept sorted by max / min exchanges): in place for everybody
+                // behind the next barrier
+                load_words();
+                int top[K];
+#pragma unroll
+                for (int j = 0; j < K; ++j) top[j] = kScoreKeyEmpty;
+#pragma unroll
+                for (int w4 = 0; w4 < kPruneGroups / 4; ++w4)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        int x = (int)pw[w4][e];
+#pragma unroll
+                        for (int j = 0; j < K; ++j) { const int hi = max(top[j], x); x = min(top[j], x); top[j] = hi; }
+                    }
+                tau[tid] = score_of_key(top[K - 1]);
+            }
         } else {
-            fetch(t + 2, 0);
             if (active) consume(Eb, t);
-            if (t + 1 < tile1) put(En, 1);
         }
     }
 
@@ -237,6 +338,7 @@ __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(con
         // ---- the sorted lists of a query (row part rh, lane half h) meet in LDS (the tile images are free) and
         // are merged by one thread per query: k rounds over the list heads, canonical order
         constexpr int NL = 2 * RH;
+        wait_dma_and_lds();                                                   // (the zero pieces of the tiles past the end are still landing)
         __syncthreads();
         float* lv = Et;                                                       // [NL lists][QB queries][K]
         int* li = reinterpret_cast<int*>(Et + NL * QB * K);
@@ -271,6 +373,7 @@ __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(con
         return;
     }
     if (active) {
+        int bi = bt * kTileRows + rh * 32 * kMi + (bs >> 4) * 32 + acc_row(bs & 15, lane);
         const float ov = shfl_xor(bv, 32);
         const int oi = shfl_xor(bi, 32);
         if (better(ov, oi, bv, bi)) { bv = ov; bi = oi; }

@@ -338,10 +338,11 @@ __device__ __forceinline__ void conv_wavek_block(const ConvWaveKArgs& p, const i
             if (CHAIN) coherent_store4(obuf, (unsigned)(((long long)m * p.Cout + n) * 4), o);
             else *reinterpret_cast<f32x4*>(p.out + (long long)m * p.Cout + n) = o;
         } else {
-#pragma unroll
+            const u32x4 ob = __builtin_bit_cast(u32x4, o);       // (whole vector: a bit_cast of ONE element indexed by the loop variable was
+#pragma unroll                                                    //  seen to pick element 0 under clang -O2 on the host)
             for (int e = 0; e < 4; ++e)
                 if (n + e < p.Cout) {
-                    if (CHAIN) coherent_store1(obuf, (unsigned)(((long long)m * p.Cout + n + e) * 4), __builtin_bit_cast(uint32_t, o[e]));
+                    if (CHAIN) coherent_store1(obuf, (unsigned)(((long long)m * p.Cout + n + e) * 4), ob[e]);
                     else p.out[(long long)m * p.Cout + n + e] = o[e];
                 }
         }

@@ -96,6 +96,18 @@ __device__ __forceinline__ void frag_mfma_q(const f32x4 (&a)[MT], const f32x4 (&
 // accumulator register r of a 32x32 tile -> row inside the tile
 __device__ __forceinline__ int acc_row(int r, int lane) { return (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5); }
 
+// Scores as integers that order like the scores (for integer max on words shared between blocks); kScoreKeyEmpty is
+// below every score's key, -inf included.
+constexpr int kScoreKeyEmpty = (int)0x80000000;
+__device__ __forceinline__ int score_key(float v) { const int b = __builtin_bit_cast(int, v); return b >= 0 ? b : b ^ 0x7fffffff; }
+__device__ __forceinline__ float score_of_key(int k) {
+    return k == kScoreKeyEmpty ? -__builtin_huge_valf() : __builtin_bit_cast(float, k >= 0 ? k : k ^ 0x7fffffff);
+}
+constexpr int kPruneGroups = 16;      // shared words per query: block b publishes to word b % 16 ...
+constexpr int kPruneReplicas = 8;     // ... of EVERY replica [replica][query][word]; block b reads replica b % 8 -- 241 blocks re-reading
+                                      // the same 64-byte line with device-coherent loads queue up behind each other (12 us per refresh at
+                                      // config 5), 30 do not, and the few publications that happen cost nothing measurable
+
 // (score, index) ordering of np.argmax: higher score wins, lower index wins ties.
 __device__ __forceinline__ bool better(float v, int i, float bv, int bi) {
     return (v > bv) || (v == bv && i < bi);

@@ -49,6 +49,8 @@ extern "C" {
 #define AAE_SCAN_STREAM 3         /* fused normalise + HBM stream + DPP reductions, B <= 4 (AUTO picks it); top-1 finishes
                                      inside the same launch (the last block to arrive merges the block partials) */
 #define AAE_SCAN_STREAM_2L 4      /* the same stream kernel followed by a separate arg-max reduce launch (A/B, race screen) */
+#define AAE_SCAN_AUTO_NO_PRUNE 5  /* AUTO, but the top-k lists inside the query-resident scan take every candidate (no bound shared
+                                     between the blocks): A/B of the pruning, same answers */
 
 typedef struct aae_encoder aae_encoder;
 typedef struct aae_codebook aae_codebook;

@@ -64,6 +64,7 @@ inline long long clock_ticks() { return 0; }
 inline long long wall_ticks() { return 0; }
 inline void sleep_kcycles(int) {}
 inline void sched_fence() {}
+inline void shared_word_max(int* word, int v) { if (v > *word) *word = v; }
 template <int P>
 inline void wave_priority() {}
 inline float pin_value(float v) { return v; }

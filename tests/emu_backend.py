@@ -17,7 +17,10 @@ _EMU = None
 def lib():
     global _EMU
     if _EMU is None:
-        subprocess.check_call(['make', '-s', '-C', os.path.join(HERE, 'emu')])
+        import fcntl
+        with open(os.path.join(HERE, 'emu', '.build.lock'), 'w') as lock:      # pytest -n: one worker builds, the others wait
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            subprocess.check_call(['make', '-s', '-C', os.path.join(HERE, 'emu')])
         _EMU = _lib.declare(ctypes.CDLL(os.path.join(HERE, 'emu', 'libaae_emu.so')))
     return _EMU
 

@@ -321,7 +321,8 @@ def test_few_split_reduce_kernel_matches_the_grouped_one_bitwise(precision, bn):
     assert np.abs(outs[0][1] - z64).max() / np.abs(z64).max() < 5e-6
 
 
-@pytest.mark.parametrize('dtype,N,B', [('f32', 1000, 40), ('f32', 700, 130), ('f32', 520, 5), ('bf16', 1100, 70), ('bf16', 640, 129), ('bf16', 400, 9)])
+@pytest.mark.parametrize('dtype,N,B', [('f32', 1000, 40), ('f32', 700, 130), ('f32', 520, 5), ('bf16', 1100, 70), ('bf16', 640, 129), ('bf16', 400, 9),
+                                       ('bf16', 1100, 200), ('f32', 1000, 256)])
 def test_query_resident_scan_equals_the_tile_resident_kernels_bitwise(dtype, N, B):
     """Batches (B > 4, top-1, stride 1) keep the queries in registers and stream the codebook through LDS
     (codebook_scan_resident.h).  Same per-accumulator MFMA order as the tile-resident kernels -> the same bits:
@@ -340,7 +341,7 @@ def test_query_resident_scan_equals_the_tile_resident_kernels_bitwise(dtype, N, 
     cb.close()
 
 
-@pytest.mark.parametrize('dtype,N,B', [('f32', 700, 130), ('f32', 520, 5), ('bf16', 1100, 70), ('bf16', 300, 9)])
+@pytest.mark.parametrize('dtype,N,B', [('f32', 700, 130), ('f32', 520, 5), ('bf16', 1100, 70), ('bf16', 300, 9), ('bf16', 2100, 140), ('f32', 2500, 33)])
 def test_topk_inside_the_query_resident_scan_equals_the_similarity_matrix_path(dtype, N, B):
     """top-k for 2 <= k <= 8 and B > 4 keeps K sorted (score, row) pairs per lane inside scan_resident_kernel<.., K> and merges
     the per-block lists (topk_merge_kernel) -- no [B][N] similarity matrix.  Canonical order (score descending, lower row
@@ -362,6 +363,17 @@ def test_topk_inside_the_query_resident_scan_equals_the_similarity_matrix_path(d
         cb.set_mode(_lib.AAE_SCAN_MFMA)
         im, sm = cb.nn(z, topk=k)
         assert np.array_equal(ik, im) and np.array_equal(sk, sm), k
+        # the lists drop candidates below the bound the blocks publish to each other (a lower bound of the final k-th best,
+        # ties kept): the answers must not depend on it, nor on the order in which the blocks run and publish
+        cb.set_mode(_lib.AAE_SCAN_AUTO_NO_PRUNE)
+        iu, su = cb.nn(z, topk=k)
+        assert np.array_equal(ik, iu) and np.array_equal(sk, su), k
+        for order in (1, 2):
+            eb.set_block_order(order)
+            cb.set_mode(_lib.AAE_SCAN_AUTO)
+            io, so = cb.nn(z, topk=k)
+            eb.set_block_order(0)
+            assert np.array_equal(ik, io) and np.array_equal(sk, so), (k, order)
     cb.close()
 
 
