@@ -9,7 +9,8 @@
 // within 2^-9 of what it rounds), so |cos - cos_exact| <= 2^-18 sum |q_j||e_j| <= 2^-18 |q||e| = 3.8e-6
 // for unit vectors (Cauchy-Schwarz), typically ten times less; fp32 accumulation adds ~1e-6.  The third
 // term bought 2^-26 at 50 % more MFMAs: config 5 (B = 256, 368928 rows) is bound by the bf16 matrix pipe --
-// 82 -> ? us (profiles/r11).  The B <= 4 streaming kernel keeps full fp32 queries (vector ALU).
+// arg-max 82 -> 68 us at the time (round 3, profiles/r11; 50 us after the other changes of codebook_scan_resident.h).
+// The B <= 4 streaming kernel keeps full fp32 queries (vector ALU).
 //
 // Block = 128 codebook rows (32 KB, staged once in LDS with coalesced 16-B loads, XOR
 // swizzled so the fragment reads are conflict-free) x passes of 64 queries; the running
