@@ -278,6 +278,8 @@ __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(con
     // publication by every block at the end of step 0 -- a burst of 60 000 atomics per replica right in front of the first
     // re-read of the same lines -- 115 us in any schedule that had it; only two re-reads (end of step 0 + a pipelined one in
     // step 2) 120 us: the early bound is weak (7th best of 2000 rows), it has to be followed up; re-reading every step 116 us.
+    // Requesting the later re-reads at the start of their step (in front of the DMA pieces) and using them at its end, or
+    // dropping the re-reads after step 2: 97-99 us, the same.
     constexpr unsigned kPublishSteps = 0x96u, kRefreshSteps = 0x97u;       // after steps {1, 2, 4, 7} / at the end of steps {0, 1, 2, 4, 7}
     for (int t = tile0; t < tile1; ++t) {
         const float* Eb = Et + img * kScanResidentTileFloats;
@@ -293,8 +295,6 @@ __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(con
             for (int w4 = 0; w4 < kPruneGroups / 4; ++w4)      // (whole-vector casts: a bit_cast of one element indexed by a loop
                 pw[w4] = __builtin_bit_cast(u32x4, coherent_load4(pb, (unsigned)(rq * kPruneGroups + w4 * 4) * 4u));   // variable picked element 0 under clang -O2)
         };
-        if constexpr (K > 0) {
-        }
         dma(t + 2, Et + (img == 0 ? 2 : img - 1) * kScanResidentTileFloats);
         img = img == 2 ? 0 : img + 1;
         if constexpr (K > 0) {
