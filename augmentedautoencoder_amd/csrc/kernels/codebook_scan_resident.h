@@ -44,6 +44,9 @@ struct ScanResidentArgs {
     // top-k pruning across blocks (optional): [kPruneReplicas][Bpad][kPruneGroups] score keys, reset by the normalise kernel in front of the
     // scan; block b raises word b % kPruneGroups of a query to the best score it has seen for it
     int* prune = nullptr;
+#ifdef AAE_SCAN_COUNT
+    int* dbg = nullptr;         // [32 steps][2]: accumulator tiles that passed the pretest, value slots that ran the insertion
+#endif
 };
 
 constexpr int kScanResidentThreads = 512;
@@ -237,6 +240,9 @@ __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(con
                 }
                 if (!wave_any(m16 > tv[K - 1] && m16 >= tau_l)) continue;
                 if (kAblate & 32) { tv[0] = fmaxf(tv[0], m16); continue; }
+#if defined(AAE_SCAN_COUNT) && AAE_SCAN_COUNT == 2
+                if (lane == 0 && t - tile0 < 32) atomicAdd(p.dbg + (t - tile0) * 2, 1);
+#endif
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = row_base + mi * 32 + acc_row(r, lane);
@@ -244,6 +250,9 @@ __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(con
                     const bool enters = (inside || row < p.N) && v > tv[K - 1] && v >= tau_l;
                     if (wave_any(enters)) {
                         if (kAblate & 16) { tv[0] = fmaxf(tv[0], v); continue; }
+#if defined(AAE_SCAN_COUNT) && AAE_SCAN_COUNT == 2
+                        if (lane == 0 && t - tile0 < 32) atomicAdd(p.dbg + (t - tile0) * 2 + 1, 1);
+#endif
                         float cv = enters ? v : kNegInf;
                         int ci = row;
                         bool ins = false;
@@ -286,6 +295,9 @@ __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(con
         wait_dma_keep_and_lds<4>();
         block_barrier();                                       // image of tile t complete
         [[maybe_unused]] const int step = t - tile0;
+#ifdef AAE_SCAN_COUNT
+        if (tid == 0 && blockIdx.x == 100 && step < 16) reinterpret_cast<long long*>(p.dbg + 64)[step] = (long long)wall_ticks();
+#endif
         [[maybe_unused]] u32x4 pw[kPruneGroups / 4];
         [[maybe_unused]] const bool reader = prune && tid < QB && blockIdx.y * QB + tid < p.Bpad && !(kAblate & 128);
         [[maybe_unused]] auto load_words = [&]() {
@@ -301,10 +313,12 @@ __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(con
             if (active) {
                 tau_l = tau[qg * 32 + i];                      // (a bound of any age is valid)
                 consume(Eb, t);
-                if (prune && step < 32 && ((kPublishSteps >> step) & 1) && !(kAblate & 64)) {
-                    // one lane per query and wave, and only what can move the bound (a score at or below it cannot become one
-                    // of the K largest words): device-scope atomics on a few thousand words are not free (every lane of every
-                    // block publishing at five steps cost 60 us at config 5)
+                if (prune && step < 32 && ((kPublishSteps >> step) & 1) && !(kAblate & 64) &&
+                    ((blockIdx.x >> 6) & 3) == (step == 1 ? 1u : step == 2 ? 2u : step == 4 ? 3u : 0u)) {     // a quarter of the blocks per step
+                    // one lane per query and wave, only what can move the bound (a score at or below it cannot become one of
+                    // the K largest words), and a quarter of the blocks per step: a burst of device-scope atomics on a few thousand
+                    // words right in front of the re-read of the same lines stalls it (every block publishing after step 1 made
+                    // that step 30 us long instead of 8, in-kernel stamps; every lane of every block at five steps cost 60 us)
                     const float best = fmaxf(tv[0], shfl_xor(tv[0], 32));
                     if (h == 0 && best > published && best > tau_l) {
                         published = best;
@@ -334,6 +348,9 @@ __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(con
         }
     }
 
+#ifdef AAE_SCAN_COUNT
+    if (tid == 0 && blockIdx.x == 100) reinterpret_cast<long long*>(p.dbg + 64)[tile1 - tile0 < 16 ? tile1 - tile0 : 15] = (long long)wall_ticks();
+#endif
     if constexpr (K > 0) {
         // ---- the sorted lists of a query (row part rh, lane half h) meet in LDS (the tile images are free) and
         // are merged by one thread per query: k rounds over the list heads, canonical order

@@ -37,6 +37,9 @@ static int run(const char* what, int N, int B, const void* E, const void* qp, fl
     a.tiles_per_block = (ntiles + blocks - 1) / blocks;
     const int gx = (ntiles + a.tiles_per_block - 1) / a.tiles_per_block;
     a.k = K; a.cand_v = cv; a.cand_i = ci; a.prune = prune;
+#ifdef AAE_SCAN_COUNT
+    int* dbg; CHECK(hipMalloc(&dbg, 64 * 4 + 16 * 8)); CHECK(hipMemset(dbg, 0, 64 * 4 + 16 * 8)); a.dbg = dbg;
+#endif
     const int pw = aae::kPruneReplicas * a.Bpad * aae::kPruneGroups;
     CHECK(hipFuncSetAttribute((const void*)aae::scan_resident_kernel<true, K, RH>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kScanResidentSmem));
     hipEvent_t e0, e1;
@@ -55,6 +58,13 @@ static int run(const char* what, int N, int B, const void* E, const void* qp, fl
     CHECK(hipEventSynchronize(e1));
     float ms = 0.f;
     CHECK(hipEventElapsedTime(&ms, e0, e1));
+#ifdef AAE_SCAN_COUNT
+    { int h[64]; CHECK(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost)); const double per = 55.0 * gx * chunks * 8;   // launches x waves
+      printf("%s: per wave and step (accumulator tiles passed of %d, value slots inserted of %d):", what, RH == 1 ? 4 : 2, RH == 1 ? 64 : 32);
+      for (int st = 0; st < 12; ++st) printf(" [%.2f %.2f]", h[2 * st] / per, h[2 * st + 1] / per); printf("\n");
+      long long tk[16]; CHECK(hipMemcpy(tk, dbg + 64, sizeof(tk), hipMemcpyDeviceToHost));
+      printf("   step durations of block 100 in the last launch (us):"); for (int st = 0; st < 12; ++st) printf(" %.2f", (tk[st + 1] - tk[st]) * 0.01); printf("\n"); }
+#endif
     printf("{\"what\": \"scan_resident_ablate\", \"ablate\": %d, \"kernel\": \"%s\", \"N\": %d, \"B\": %d, \"grid\": [%d, %d], \"tiles_per_block\": %d, \"us_per_launch\": %.2f}\n",
            AAE_SCAN_RESIDENT_ABLATE, what, N, B, gx, chunks, a.tiles_per_block, ms * 1000.f / reps);
     return 0;
