@@ -289,7 +289,7 @@ __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(con
     // step 2) 120 us: the early bound is weak (7th best of 2000 rows), it has to be followed up; re-reading every step 116 us.
     // Requesting the later re-reads at the start of their step (in front of the DMA pieces) and using them at its end, or
     // dropping the re-reads after step 2: 97-99 us, the same.
-    constexpr unsigned kPublishSteps = 0x96u, kRefreshSteps = 0x97u;       // after steps {1, 2, 4, 7} / at the end of steps {0, 1, 2, 4, 7}
+    constexpr unsigned kPublishSteps = 0x96u, kRefreshSteps = 0x12fu;      // after steps {1, 2, 4, 7} / at the end of steps {0, 1, 2, 3, 5, 8}
     for (int t = tile0; t < tile1; ++t) {
         const float* Eb = Et + img * kScanResidentTileFloats;
         wait_dma_keep_and_lds<4>();
@@ -313,18 +313,6 @@ __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(con
             if (active) {
                 tau_l = tau[qg * 32 + i];                      // (a bound of any age is valid)
                 consume(Eb, t);
-                if (prune && step < 32 && ((kPublishSteps >> step) & 1) && !(kAblate & 64) &&
-                    ((blockIdx.x >> 6) & 3) == (step == 1 ? 1u : step == 2 ? 2u : step == 4 ? 3u : 0u)) {     // a quarter of the blocks per step
-                    // one lane per query and wave, only what can move the bound (a score at or below it cannot become one of
-                    // the K largest words), and a quarter of the blocks per step: a burst of device-scope atomics on a few thousand
-                    // words right in front of the re-read of the same lines stalls it (every block publishing after step 1 made
-                    // that step 30 us long instead of 8, in-kernel stamps; every lane of every block at five steps cost 60 us)
-                    const float best = fmaxf(tv[0], shfl_xor(tv[0], 32));
-                    if (h == 0 && best > published && best > tau_l) {
-                        published = best;
-                        publish(best);
-                    }
-                }
             }
             if (reader && step < 32 && ((kRefreshSteps >> step) & 1)) {
                 // K-th largest of the query's shared words (K slots kept sorted by max / min exchanges): in place for everybody
@@ -342,6 +330,20 @@ __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(con
                         for (int j = 0; j < K; ++j) { const int hi = max(top[j], x); x = min(top[j], x); top[j] = hi; }
                     }
                 tau[tid] = score_of_key(top[K - 1]);
+            }
+            if (active) {                                  // (published AFTER this block's own re-read: its loads do not queue behind its atomics)
+                if (prune && step < 32 && ((kPublishSteps >> step) & 1) && !(kAblate & 64) &&
+                    ((blockIdx.x >> 6) & 3) == (step == 1 ? 1u : step == 2 ? 2u : step == 4 ? 3u : 0u)) {     // a quarter of the blocks per step
+                    // one lane per query and wave, only what can move the bound (a score at or below it cannot become one of
+                    // the K largest words), and a quarter of the blocks per step: a burst of device-scope atomics on a few thousand
+                    // words right in front of the re-read of the same lines stalls it (every block publishing after step 1 made
+                    // that step 30 us long instead of 8, in-kernel stamps; every lane of every block at five steps cost 60 us)
+                    const float best = fmaxf(tv[0], shfl_xor(tv[0], 32));
+                    if (h == 0 && best > published && best > tau_l) {
+                        published = best;
+                        publish(best);
+                    }
+                }
             }
         } else {
             if (active) consume(Eb, t);
@@ -387,6 +389,10 @@ __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(con
                 p.cand_i[obase + j] = wi;
             }
         }
+#ifdef AAE_SCAN_COUNT
+        __syncthreads();
+        if (tid == 0 && blockIdx.x == 100) { reinterpret_cast<long long*>(p.dbg + 64)[13] = (long long)wall_ticks(); }
+#endif
         return;
     }
     if (active) {
