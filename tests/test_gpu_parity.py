@@ -1226,3 +1226,45 @@ def test_ticketed_partials_are_never_read_stale_across_launches():
     torch.cuda.synchronize()
     for e in (ex, ey, cx, cy):
         e.close()
+
+
+def test_pruned_topk_answers_do_not_depend_on_the_bound_or_its_timing():
+    """The top-k lists inside the query-resident scan drop candidates below a bound the blocks publish to each other and read
+    back with no ordering (codebook_scan_resident.h): which candidates a block drops depends on timing, the answer must not.
+    400 queries (new latents, batch size and k each; fp32 and bf16 codebooks; a third close to codebook rows, a third under an
+    HBM-saturating side stream): pruned == unpruned (AAE_SCAN_AUTO_NO_PRUNE) bit for bit, indices and scores; every 10th also
+    against the similarity-matrix path.  (tools/soak_prune.py is the long form: profiles/r11_small/soak_prune.json.)"""
+    import torch
+    from augmentedautoencoder_amd import _lib
+    from augmentedautoencoder_amd.engine import CodebookEngine
+    books = []
+    for dtype, N in (('f32', 92232), ('bf16', 4 * 92232)):
+        E = synth.make_codebook(N, 128, seed=17, planted_duplicates=12)
+        a, b, m = CodebookEngine(E, dtype=dtype), CodebookEngine(E, dtype=dtype), CodebookEngine(E, dtype=dtype)
+        b.set_scan_mode(_lib.AAE_SCAN_AUTO_NO_PRUNE)
+        m.set_scan_mode(_lib.AAE_SCAN_MFMA)
+        books.append((torch.from_numpy(E[:2048]).cuda(), a, b, m))
+    side = torch.cuda.Stream()
+    big_a = torch.empty(1 << 29, dtype=torch.uint8, device='cuda')
+    big_b = torch.zeros(1 << 29, dtype=torch.uint8, device='cuda')
+    rng = np.random.default_rng(23)
+    gen = torch.Generator(device='cuda').manual_seed(29)
+    for it in range(400):
+        rows, a, b, m = books[it % 2]
+        B = int(rng.choice([5, 9, 32, 33, 64, 128, 129, 256]))
+        k = int(rng.choice([2, 3, 5, 8]))
+        z = torch.randn(B, 128, device='cuda', generator=gen)
+        if it % 3 == 0:
+            z = rows[torch.randint(0, rows.shape[0], (B,), device='cuda', generator=gen)] * 3.0 + 0.05 * z
+        if it % 3 == 1:
+            with torch.cuda.stream(side):
+                big_a.copy_(big_b)
+        ia, sa = a.nn(z, k, 1)
+        ib, sb = b.nn(z, k, 1)
+        assert torch.equal(ia, ib) and torch.equal(sa, sb), (it, B, k)
+        if it % 10 == 0:
+            im, sm = m.nn(z, k, 1)
+            assert torch.equal(ia, im) and torch.equal(sa, sm), (it, B, k)
+    torch.cuda.synchronize()
+    for _, a, b, m in books:
+        a.close(); b.close(); m.close()
