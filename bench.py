@@ -364,7 +364,8 @@ def main():
                              'B256_argmax_frac_of_bf16_mfma_peak_nominal': round(flops5 / t_arg / 1e6 / 2500.0, 3),
                              'B256_argmax_frac_of_bf16_mfma_peak_issued': round(2 * flops5 / t_arg / 1e6 / 2500.0, 3),
                              'B1_argmax_GBps': round(N5 * 256 / t_b1 / 1e3, 1), 'B1_frac_of_HBM_peak': round(N5 * 256 / t_b1 / 1e3 / PEAK_HBM_GBPS, 3),
-                             'note': 'frac ..._nominal: 2*B*N*128 FLOP against 2.5 PFLOP/s dense bf16; ..._issued counts the 2 MFMAs per product of the query split'}
+                             'note': 'frac ..._nominal: 2*B*N*128 FLOP against 2.5 PFLOP/s dense bf16; ..._issued counts the 2 MFMAs per product of the query split.  top-5: sorted lists inside the scan, '
+                                     'candidates below a bound the blocks publish to each other are dropped (same answers as the unpruned lists and the similarity-matrix path: tests + tools/soak_prune.py)'}
         cb5.close()
         del E5
         # ---- PCIe-inclusive: host uint8 batches, H2D of batch i+1 overlapped with compute of batch i
