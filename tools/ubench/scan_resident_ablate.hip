@@ -63,7 +63,7 @@ static int run(const char* what, int N, int B, const void* E, const void* qp, fl
       printf("%s: per wave and step (accumulator tiles passed of %d, value slots inserted of %d):", what, RH == 1 ? 4 : 2, RH == 1 ? 64 : 32);
       for (int st = 0; st < 12; ++st) printf(" [%.2f %.2f]", h[2 * st] / per, h[2 * st + 1] / per); printf("\n");
       long long tk[16]; CHECK(hipMemcpy(tk, dbg + 64, sizeof(tk), hipMemcpyDeviceToHost));
-      printf("   step durations of block 100 in the last launch (us):"); for (int st = 0; st < 12; ++st) printf(" %.2f", (tk[st + 1] - tk[st]) * 0.01); printf(" | after the loop %.2f\n", (tk[13] - tk[12]) * 0.01); }
+      printf("   step durations of block 100 in the last launch (us):"); for (int st = 0; st < 12; ++st) printf(" %.2f", (tk[st + 1] - tk[st]) * 0.01); if (K > 0) printf(" | after the loop %.2f", (tk[13] - tk[12]) * 0.01); printf("\n"); }
 #endif
     printf("{\"what\": \"scan_resident_ablate\", \"ablate\": %d, \"kernel\": \"%s\", \"N\": %d, \"B\": %d, \"grid\": [%d, %d], \"tiles_per_block\": %d, \"us_per_launch\": %.2f}\n",
            AAE_SCAN_RESIDENT_ABLATE, what, N, B, gx, chunks, a.tiles_per_block, ms * 1000.f / reps);
