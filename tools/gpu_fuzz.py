@@ -50,6 +50,8 @@ def main():
         opts['first_group_split_max_tiles'] = int(rng.choice([0, 128, 4096]))   # conv1: one block per 32-pixel group
         opts['x3h_wide256'] = int(rng.integers(0, 2))                            # f32x3h: 256 x 256 tiles ...
         opts['x3h_wide256_min_blocks'] = int(rng.choice([1, 256]))               # ... also on grids that do not fill the chip
+        opts['planner_cost_model'] = int(rng.integers(0, 2))                     # per-layer kernel choice by estimated time (5 <= B < 256)
+        opts['detect_chain'] = int(rng.integers(0, 2))                           # B <= 4: conv2 ... scan as one persistent launch where it applies
         for k, v in opts.items():
             enc.set_option(k, v)
         precision = int(rng.integers(0, 2)) if cfg.shape[2] in (1, 3) and all(f % 32 == 0 for f in filters) else 0
