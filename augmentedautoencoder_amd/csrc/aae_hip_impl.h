@@ -169,6 +169,7 @@ struct aae_codebook {
     int dtype = AAE_DTYPE_F32;
     int N = 0, J = 0;
     int scan_mode = AAE_SCAN_AUTO;
+    int cu_count = 256;    // compute units of the device the handle lives on: the query-resident scan puts one block on each
     int topk_prune = 1;    // top-k inside the query-resident scan: drop candidates below the bound the blocks publish (AAE_SCAN_AUTO_NO_PRUNE: 0)
     // upright search (col_stride k > 1): a compacted copy of rows 0, k, 2k, ... prepared by
     // aae_codebook_prepare_upright; the scan then runs over N/k rows and the winning row id is scaled by k
@@ -1192,7 +1193,7 @@ static ScanPlan plan_scan(const aae_codebook* cb, int B, int topk) {
         // B > 128: 256 queries per block, every wave all rows of a tile (the codebook streamed once per 256 queries)
         s.res_rh = s.Bpad > 128 ? 1 : 2;
         const int qchunks = ceil_div(s.Bpad, s.res_rh == 1 ? 256 : 128);
-        int row_blocks = 256 / qchunks;
+        int row_blocks = (cb->cu_count > 0 ? cb->cu_count : 256) / qchunks;
         if (row_blocks < 1) row_blocks = 1;
         s.res_tiles_per_block = ceil_div(ntiles, row_blocks);
         if (s.res_tiles_per_block < 128 / tile_rows) s.res_tiles_per_block = 128 / tile_rows;   // never more row blocks than nblk
@@ -1719,6 +1720,10 @@ int aae_codebook_create(const void* E, int N, int J, int dtype, int src_is_devic
     if ((unsigned long long)N * J * sizeof(float) >= 0xFFFFFFF0ull) return fail(AAE_ERR_UNSUPPORTED, "codebook of %d x %d floats exceeds the 4 GiB buffer view", N, J);
     aae_codebook* cb = new aae_codebook();
     cb->N = N; cb->J = J; cb->dtype = dtype;
+    {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) cb->cu_count = cus;
+    }
     const size_t bytes = (size_t)N * J * (dtype == AAE_DTYPE_BF16 ? 2 : 4);
     void* p = nullptr;
     hipError_t e = hipMalloc(&p, bytes);
@@ -1762,7 +1767,7 @@ int aae_codebook_prepare_upright(aae_codebook* cb, int col_stride, void* stream_
             sub->E = static_cast<float*>(p);
             cb->upright_copies.push_back({col_stride, sub});
         }
-        sub->scan_mode = cb->scan_mode; sub->scan_ticket = cb->scan_ticket; sub->topk_prune = cb->topk_prune;
+        sub->scan_mode = cb->scan_mode; sub->scan_ticket = cb->scan_ticket; sub->topk_prune = cb->topk_prune; sub->cu_count = cb->cu_count;
         cb->upright = sub; cb->upright_stride = col_stride;
     }
     if (int rc = gather_upright_rows(cb, cb->upright, cb->upright_stride, stream)) return rc;
