@@ -269,8 +269,11 @@ static std::vector<unsigned short> pack_weights_x3h(const float* w, int taps, in
 // split-K partial sums -> layer output: few splits over a large tile take the barrier-free float4 kernel
 static void launch_splitk_reduce(const aae::SplitKReduceArgs& r, hipStream_t stream, bool allow_small = true) {
     if (allow_small && r.splits <= aae::kReduceGroups && r.MN % 4 == 0 && r.Cout % 4 == 0 && r.MN >= 16384) {
-        const long long blocks = (r.MN / 4 + 255) / 256;
-        AAE_LAUNCH((aae::splitk_reduce_small_kernel), dim3((unsigned)blocks), dim3(256), 0, stream, r);
+        const long long chunks = (r.MN / 4 + 255) / 256;           // 1024-element segments
+        if (r.splits == 2) AAE_LAUNCH((aae::splitk_reduce_small_kernel<2, 4>), dim3((unsigned)((chunks + 3) / 4)), dim3(256), 0, stream, r);
+        else if (r.splits == 3) AAE_LAUNCH((aae::splitk_reduce_small_kernel<3, 4>), dim3((unsigned)((chunks + 3) / 4)), dim3(256), 0, stream, r);
+        else if (r.splits == 4) AAE_LAUNCH((aae::splitk_reduce_small_kernel<4, 4>), dim3((unsigned)((chunks + 3) / 4)), dim3(256), 0, stream, r);
+        else AAE_LAUNCH((aae::splitk_reduce_small_kernel<0, 1>), dim3((unsigned)chunks), dim3(256), 0, stream, r);
         return;
     }
     long long blocks = (r.MN + 63) / 64;

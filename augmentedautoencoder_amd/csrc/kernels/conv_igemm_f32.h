@@ -404,46 +404,59 @@ __global__ __launch_bounds__(512) void splitk_reduce_kernel(const SplitKReduceAr
 // order as splitk_reduce_kernel (there group g holds split g alone and the groups are added in order),
 // including its "+ 0.f" canonicalisation of each term, so both kernels give the same bits.
 // Requires MN % 4 == 0 and Cout % 4 == 0.
+// U chunks of four elements per thread (a block covers U consecutive 1024-element segments), all loads of all splits in
+// flight before the first add: with one chunk per thread the kernel moved 50 MB in 17 us (B = 16, conv2: two splits), i.e.
+// it was bound by the latency of two loads per thread, not by HBM.  SPLITS > 0: exactly that many splits (registers for
+// SPLITS x U float4); SPLITS == 0: any number up to kReduceGroups, one chunk.
+template <int SPLITS, int U>
 __global__ __launch_bounds__(256) void splitk_reduce_small_kernel(const SplitKReduceArgs p) {
-    const long long e = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
-    if (e >= p.MN) return;
-    f32x4 t[kReduceGroups];
+    constexpr int NS = SPLITS > 0 ? SPLITS : kReduceGroups;
+    f32x4 t[NS][U];
+    long long e[U];
 #pragma unroll
-    for (int s = 0; s < kReduceGroups; ++s) {
-        t[s] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (s < p.splits) t[s] = *reinterpret_cast<const f32x4*>(p.partial + (long long)s * p.MN + e);
-    }
-    const int n = (int)(e % p.Cout);
-    const f32x4 bias = *reinterpret_cast<const f32x4*>(p.bias + n);
-    f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-    if (p.bn_scale) {
-        sc = *reinterpret_cast<const f32x4*>(p.bn_scale + n);
-        sh = *reinterpret_cast<const f32x4*>(p.bn_shift + n);
-    }
-    f32x4 v;
+    for (int u = 0; u < U; ++u) {
+        e[u] = (((long long)blockIdx.x * U + u) * 256 + threadIdx.x) * 4;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        float a = (t[0][j] + 0.f) + (0.f + 0.f);
-#pragma unroll
-        for (int s = 1; s < kReduceGroups; ++s) a += (t[s][j] + 0.f) + (0.f + 0.f);
-        a += bias[j];
-        if (p.relu) a = fmaxf(a, 0.f);
-        if (p.bn_scale) a = a * sc[j] + sh[j];
-        v[j] = a;
+        for (int s = 0; s < NS; ++s) {
+            t[s][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (e[u] < p.MN && s < p.splits) t[s][u] = *reinterpret_cast<const f32x4*>(p.partial + (long long)s * p.MN + e[u]);
+        }
     }
-    if (p.out_planes) {
-        u16x4 hi, lo;
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        if (e[u] >= p.MN) continue;
+        const int n = (int)(e[u] % p.Cout);
+        const f32x4 bias = *reinterpret_cast<const f32x4*>(p.bias + n);
+        f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (p.bn_scale) {
+            sc = *reinterpret_cast<const f32x4*>(p.bn_scale + n);
+            sh = *reinterpret_cast<const f32x4*>(p.bn_shift + n);
+        }
+        f32x4 v;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            unsigned short h16, l16;
-            split_f16_checked(v[j] * p.out_scale, h16, l16, p.sat_flag);
-            hi[j] = h16; lo[j] = l16;
+            float a = (t[0][u][j] + 0.f) + (0.f + 0.f);
+#pragma unroll
+            for (int s = 1; s < kReduceGroups; ++s) a += ((s < NS ? t[s < NS ? s : 0][u][j] : 0.f) + 0.f) + (0.f + 0.f);
+            a += bias[j];
+            if (p.relu) a = fmaxf(a, 0.f);
+            if (p.bn_scale) a = a * sc[j] + sh[j];
+            v[j] = a;
         }
-        unsigned short* op = reinterpret_cast<unsigned short*>(p.out);
-        *reinterpret_cast<u16x4*>(op + x3h_pair_index(e)) = hi;              // (e % 4 == 0: the four halves stay inside one chunk)
-        *reinterpret_cast<u16x4*>(op + x3h_pair_index(e) + 32) = lo;
-    } else {
-        *reinterpret_cast<f32x4*>(p.out + e) = v;
+        if (p.out_planes) {
+            u16x4 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                unsigned short h16, l16;
+                split_f16_checked(v[j] * p.out_scale, h16, l16, p.sat_flag);
+                hi[j] = h16; lo[j] = l16;
+            }
+            unsigned short* op = reinterpret_cast<unsigned short*>(p.out);
+            *reinterpret_cast<u16x4*>(op + x3h_pair_index(e[u])) = hi;           // (e % 4 == 0: the four halves stay inside one chunk)
+            *reinterpret_cast<u16x4*>(op + x3h_pair_index(e[u]) + 32) = lo;
+        } else {
+            *reinterpret_cast<f32x4*>(p.out + e[u]) = v;
+        }
     }
 }
 
