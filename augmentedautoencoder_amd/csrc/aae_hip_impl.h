@@ -1860,7 +1860,8 @@ static int nn_impl(aae_codebook* cb, const float* z, int B, int topk, int col_st
         t.cand_v = reinterpret_cast<float*>(base + s.cand_off);
         t.cand_i = reinterpret_cast<int*>(base + s.cand_off + align_up((size_t)B * t.chunks * topk * sizeof(float), 256));
         if (!s.topk_fused) AAE_LAUNCH((aae::topk_chunks_kernel), dim3(t.chunks, B), dim3(256), 64, stream, t);   // (fused: the scan wrote the lists)
-        AAE_LAUNCH((aae::topk_merge_kernel), dim3(B), dim3(256), 64, stream, t);
+        if (t.chunks * topk <= 256 * aae::kTopKMergeSlots) AAE_LAUNCH((aae::topk_merge_kernel<true>), dim3(B), dim3(256), 64, stream, t);
+        else AAE_LAUNCH((aae::topk_merge_kernel<false>), dim3(B), dim3(256), 64, stream, t);
     }
     AAE_HIP_TRY(hipGetLastError());
     return AAE_OK;
