@@ -270,6 +270,12 @@ def test_upright_and_topk(default_model):
         im, sm = cb.engine.nn(z, k, 1)
         cb.engine.set_scan_mode(_lib.AAE_SCAN_AUTO)
         assert np.array_equal(im.cpu().numpy(), ik) and np.array_equal(sm.cpu().numpy(), sk)
+    # k beyond the in-scan lists (similarity matrix + two-level selection): 40 keeps the merge's candidates in registers
+    # (46 chunks x 40 <= 2048), 60 takes its form that re-reads them from memory
+    for k in (40, 60):
+        ik, sk = cb.engine.nn(z, k, 1)
+        ik, sk = ik.cpu().numpy(), sk.cpu().numpy()
+        assert np.array_equal(ik, ref.topk_canonical(cs_dev, k)) and np.array_equal(sk, np.take_along_axis(cs_dev, ik, axis=1)), k
 
 
 def _small_rotations(rng, n, lo_deg, hi_deg):
