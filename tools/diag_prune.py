@@ -42,7 +42,11 @@ for B in (32, 256):
     buf, ptr = cb.ws.get(nbytes)
     off = ptr - buf.data_ptr()
     Bpad = 64 * ((B + 63) // 64)
-    words = buf[off + nbytes - ((Bpad * 16 * 4 + 255) // 256) * 256: off + nbytes][:Bpad * 64].view(torch.int32).view(Bpad, 16).cpu().numpy()
+    REPLICAS = 8                                              # kPruneReplicas: [replica][query][16 words], the region ends the workspace
+    region = ((REPLICAS * Bpad * 16 * 4 + 255) // 256) * 256
+    allw = buf[off + nbytes - region: off + nbytes][:REPLICAS * Bpad * 64].view(torch.int32).view(REPLICAS, Bpad, 16).cpu().numpy()
+    out['replicas_identical'] = bool(all(np.array_equal(allw[0], allw[r]) for r in range(1, REPLICAS)))
+    words = allw[0]
     keys = words.astype(np.int64)
     bits = np.where(keys >= 0, keys, keys ^ 0x7fffffff).astype(np.int64) & 0xffffffff
     vals = bits.astype(np.uint32).view(np.float32).reshape(Bpad, 16)
