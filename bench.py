@@ -3,7 +3,13 @@
 92232x128 fp32 codebook (BASELINE.json metric), one object per GPU.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+
+Launch forms.  N = 1: this process is the only rank.  N > 1: either start it under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...`
+(RANK / LOCAL_RANK / WORLD_SIZE in the environment), or start it plainly -- `python bench.py --gpus N ...` with no
+WORLD_SIZE in the environment re-executes itself under torch.distributed.run on a free local port, one rank per visible
+GPU, and passes rank 0's JSON line through.  Fewer than N visible GPUs: ONE JSON line with an `error` field, exit code 2,
+no traceback.  `--dry-run-dist` takes the same launch path on CPU (gloo) up to process-group creation and one all_gather.
 
 A step = one pass of the hot path over one batch of 256 device-resident uint8
 crops per GPU: 4-conv encoder -> dense -> l2-normalise -> codebook scan ->
@@ -77,6 +83,52 @@ def cpu_baseline(weights, E, crops, min_seconds=12.0, max_iters=60):
                      'note': 'threads = best point of a sweep (8..256) on this host; more threads are slower'}}
 
 
+METRIC = 'crops/sec (encode+codebook-NN), 128x128x3 vs 92232x128 codebook, 1/8 GPU'
+
+
+def self_launch(args, argv):
+    """`python bench.py --gpus N` (N > 1) without a launcher: become the launcher.  One rank per GPU under
+    torch.distributed.run on 127.0.0.1 and a free port; the children inherit stdout, so rank 0's JSON line is this
+    command's JSON line.  Returns the exit code."""
+    import socket
+    import subprocess
+    if not args.dry_run_dist:
+        import torch
+        visible = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if visible < args.gpus:
+            print(json.dumps({'metric': METRIC, 'value': None, 'unit': 'crops/s', 'n_gpus': args.gpus, 'steps': args.steps,
+                              'warmup': args.warmup, 'error': '--gpus %d but %d GPU(s) visible to this process' % (args.gpus, visible),
+                              'visible_gpus': visible}))
+            return 2
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')          # dmabuf IPC only on this host driver (RCCL needs it)
+    env.setdefault('OMP_NUM_THREADS', '8')
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run_dist(args):
+    """The N-rank launch path up to process-group creation, on CPU: gloo group, one all_gather of the rank ids, rank 0
+    prints one JSON line.  (tests/test_bench_launch.py; the GPU path differs only in backend and device.)"""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    dist.init_process_group('gloo')
+    mine = torch.tensor([rank], dtype=torch.int64)
+    every = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+    dist.all_gather(every, mine)
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({'dry_run_dist': True, 'backend': 'gloo', 'n_gpus': args.gpus, 'world_size': dist.get_world_size(),
+                          'ranks_seen': [int(t.item()) for t in every], 'launched_by': os.environ.get('AAE_BENCH_LAUNCHER', 'external')}))
+    dist.destroy_process_group()
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -96,7 +148,20 @@ def main():
     ap.add_argument('--enc-opt', action='append', default=[], metavar='NAME=INT',
                     help='set an encoder option before measuring (kernel-variant A/B under a profiler); recorded in config')
     ap.add_argument('--no-extras', action='store_true', help='skip the secondary measurements (latency, scan, config3, config5, pcie, decoder)')
+    ap.add_argument('--no-config4', action='store_true', help='(process-group runs) skip the mixed-batch config4 measurement')
+    ap.add_argument('--dry-run-dist', action='store_true',
+                    help='take the N-rank launch path on CPU (gloo): process group + one all_gather, no GPU work (launch-path test)')
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        raise SystemExit('--gpus must be >= 1')
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        os.environ['AAE_BENCH_LAUNCHER'] = 'self'
+        sys.exit(self_launch(args, sys.argv[1:]))
+    if args.dry_run_dist:
+        if 'WORLD_SIZE' not in os.environ:                  # N = 1 without a launcher: a one-rank group in this process
+            os.environ.update({'RANK': '0', 'WORLD_SIZE': '1', 'MASTER_ADDR': '127.0.0.1', 'MASTER_PORT': '29534'})
+        sys.exit(dry_run_dist(args))
 
     import torch
     import torch.distributed as dist
@@ -108,7 +173,15 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus:
-        raise SystemExit('--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run for N > 1)' % (args.gpus, world))
+        if rank == 0:
+            print(json.dumps({'metric': METRIC, 'value': None, 'unit': 'crops/s', 'n_gpus': args.gpus,
+                              'error': '--gpus %d but the launcher started WORLD_SIZE=%d ranks' % (args.gpus, world)}))
+        sys.exit(2)
+    if not torch.cuda.is_available() or local_rank >= torch.cuda.device_count():
+        if rank == 0:
+            print(json.dumps({'metric': METRIC, 'value': None, 'unit': 'crops/s', 'n_gpus': args.gpus,
+                              'error': 'rank %d has no GPU (local rank %d, %d visible)' % (rank, local_rank, torch.cuda.device_count() if torch.cuda.is_available() else 0)}))
+        sys.exit(2)
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     use_dist = world > 1 or args.force_dist        # one process per GPU over RCCL; --force-dist runs that path on a single GPU
@@ -228,7 +301,7 @@ def main():
         return e0.elapsed_time(e1) / reps * 1e3
 
     extras = {}
-    if use_dist and not args.no_extras and args.precision == 'f32':
+    if use_dist and not args.no_config4 and args.precision == 'f32':
         # ---- BASELINE config 4 as SURVEY 8d defines it: ONE mixed batch of 256 crops, class labels integers(0, N_obj), N_obj = N
         # objects sharded one per GPU; every rank runs encode + scan on its bucket (the host routes by class id, as the
         # reference's per-box loop does, m3_interface/ae_pose_estimator.py:143-170) and one RCCL all_gather of the padded
@@ -393,7 +466,7 @@ def main():
     if rank == 0:
         x3h_label = 'f32 in/out, 3xfp16-split MFMA with fp32 accumulate (f32x3h)'
         out = {
-            'metric': 'crops/sec (encode+codebook-NN), 128x128x3 vs 92232x128 codebook, 1/8 GPU',
+            'metric': METRIC,
             'value': main_res['value'],
             'unit': 'crops/s',
             'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -411,6 +484,10 @@ def main():
         }
         if use_dist:
             out['rccl_world_size'] = dist.get_world_size()
+            out['launched_by'] = os.environ.get('AAE_BENCH_LAUNCHER', 'external launcher (torch.distributed.run)')
+            if world > 1:
+                out['multi_gpu_note'] = ('N > 1: the line carries the weak-scaling headline and config4 only; cpu_baseline, latency, scan, config3, '
+                                         'config5, pcie_inclusive and decoder are single-GPU measurements and are reported by the N = 1 run')
             out['rank_ms_per_step'] = {'min': min(main_res['rank_ms_per_step']), 'max': max(main_res['rank_ms_per_step']),
                                        'per_rank': main_res['rank_ms_per_step']}
         if args.enc_opt:
