@@ -142,6 +142,8 @@ struct aae_encoder {
                                            // measured: wins up to 64 tiles (B=1: 94 -> 87 us), loses from 128 on (twice the operand loads per MFMA)
     int wavek_target_blocks = 256;         // blocks a split layer is cut into (tiles x K splits): one per CU
     int wavek_waves = 4;                   // waves per block (4 | 8), each with its own K range
+    int wavek_tiny_waves = 4;              // ... of the 32 x 32 wave tiles (per-detection batches): 8 = two waves per SIMD, so that one wave's operand-load issue
+                                           // (~250 cycles per slab in which its dependent MFMA chain stands still) runs under the other wave's MFMAs
     // measured per layer with rocprofv3 at B = 1 ... 8 (profiles/r09_small/variants_*.txt): depth 2 beats 3 by 0.5-1 us per launch
     // (208 instead of 272 registers, the second slab in flight is enough); 64 x 32 wave tiles win up to 128 tiles of 64 x 64 --
     // fewer blocks per tile to hand over, smaller partials -- and lose beyond (conv2 at B = 4: 68.6 vs 61.5 us)
@@ -435,7 +437,10 @@ static WaveKPlan plan_wavek(const aae_encoder* enc, const Layer& L, long long M,
     }
     w.NT = tiles22 <= enc->wavek_narrow_max_tiles ? 1 : 2;
     w.MT = (tiles22 <= enc->wavek_tiny_max_tiles && w.waves == 4) ? 1 : 2;       // 32 x 32 wave tiles (NT = 1 then: the narrow threshold is the larger one)
-    if (w.MT == 1) w.NT = 1;
+    if (w.MT == 1) {
+        w.NT = 1;
+        if (enc->wavek_tiny_waves == 8) { w.waves = 8; w.depth = 2; }
+    }
     // Balance: when the chosen tile shape needs no K split but leaves CUs idle in its last round of blocks (192 blocks of 64 x 64 on
     // 256 CUs: B = 3 conv2), a smaller wave tile can win although it moves more operand bytes per MFMA.  Blocks that share a CU share
     // its matrix pipe, so a layer costs about  ceil(tiles / CUs) * (MT * NT) / efficiency  -- efficiencies from the per-layer A/B
@@ -448,7 +453,7 @@ static WaveKPlan plan_wavek(const aae_encoder* enc, const Layer& L, long long M,
         if (tiles_of(w.MT, w.NT) >= cus / 2) {                    // (fewer tiles than that: the layer splits K)
             double best = cost_of(w.MT, w.NT, w.NT == 2 ? 1.0 : 0.97);
             if (w.NT == 2 && cost_of(2, 1, 0.97) < 0.97 * best) { best = cost_of(2, 1, 0.97); w.NT = 1; }
-            if (cost_of(1, 1, 0.88) < 0.97 * best) { w.MT = 1; w.NT = 1; }
+            if (cost_of(1, 1, 0.88) < 0.97 * best) { w.MT = 1; w.NT = 1; if (enc->wavek_tiny_waves == 8) { w.waves = 8; w.depth = 2; } }
         }
     }
     w.num_mt = (int)((M + 32 * w.MT - 1) / (32 * w.MT));
@@ -459,6 +464,11 @@ static WaveKPlan plan_wavek(const aae_encoder* enc, const Layer& L, long long M,
     w.gsplits = g;
     if (g > 1) w.partial_bytes = (size_t)tiles * g * (w.MT * w.NT * 16) * 64 * sizeof(float);
     return w;
+}
+
+// partial rows of the GEMV form of the dense layer (B <= 4): one per 128-k chunk, then the group rows of its two-level finish
+static size_t gemv_partial_bytes(const Layer& D, int B) {
+    return (size_t)(ceil_div((int)D.K(), aae::kGemvChunk) + aae::kGemvGroups) * B * D.Cout * sizeof(float);
 }
 
 struct Workspace {
@@ -515,7 +525,7 @@ static Workspace plan_workspace(const aae_encoder* enc, int B) {
         if (bytes > partial) partial = bytes;
     }
     if (B <= 4 && enc->dense.kind == KIND_IGEMM) {           // the GEMV form of the dense layer: one partial row per 128-k chunk
-        const size_t gemv = (size_t)ceil_div((int)enc->dense.K(), aae::kGemvChunk) * B * enc->dense.Cout * sizeof(float);
+        const size_t gemv = gemv_partial_bytes(enc->dense, B);
         if (gemv > partial) partial = gemv;
     }
     ws.partial_off = off;
@@ -529,7 +539,7 @@ static Workspace plan_workspace(const aae_encoder* enc, int B) {
             if (L.kind == KIND_IGEMM) {
                 const WaveKPlan wk = plan_wavek(enc, L, dense ? B : (long long)B * L.Ho * L.Wo, false);
                 if (wk.use) bytes = wk.partial_bytes;
-                if (dense) bytes = std::max(bytes, (size_t)ceil_div((int)L.K(), aae::kGemvChunk) * B * L.Cout * sizeof(float));
+                if (dense) bytes = std::max(bytes, gemv_partial_bytes(L, B));
             }
             ws.chain_partial_off.push_back(off);
             off += align_up(bytes, 256);
@@ -675,6 +685,7 @@ static int launch_wavek(aae_encoder* enc, const Layer& L, const WaveKPlan& w, co
         case 1142: launch_wavek_t<1, 1, 4, 2>(a, tag, nblk, stream); break;
         case 1143: launch_wavek_t<1, 1, 4, 3>(a, tag, nblk, stream); break;
         case 182: launch_wavek_t<2, 1, 8, 2>(a, tag, nblk, stream); break;
+        case 1182: launch_wavek_t<1, 1, 8, 2>(a, tag, nblk, stream); break;
         default: return fail(AAE_ERR_RUNTIME, "%s: no wave-split-K instantiation for NT=%d waves=%d depth=%d", name, w.NT, w.waves, w.depth);
     }
     char label[112];
@@ -868,7 +879,7 @@ static aae::DenseGemvArgs gemv_args(const Layer& D, const float* x, int B, float
     aae::DenseGemvArgs a;
     a.x = x; a.wp = D.wp; a.partial = partial; a.B = B; a.K = (int)D.K(); a.Cout = D.Cout; a.CoutPad = D.CoutPad;
     a.wp_bytes = (unsigned)((unsigned long long)(D.K() / 4) * D.CoutPad * 16ull);
-    a.partial_bytes = (unsigned)((size_t)ceil_div(a.K, aae::kGemvChunk) * B * D.Cout * sizeof(float));
+    a.partial_bytes = (unsigned)gemv_partial_bytes(D, B);
     a.bias = nullptr; a.bn_scale = nullptr; a.bn_shift = nullptr; a.out = nullptr; a.tickets = nullptr; a.nonce = 0; a.relu = 0;
     return a;
 }
@@ -1237,11 +1248,29 @@ static void launch_scan_mfma_t(const aae::ScanArgs& a, bool upright, int nblk, h
     }
 }
 
+// (the similarity output is a template parameter of the stream kernels: as a run-time branch inside the row loop it split the
+// loop into 64 basic blocks and serialised the cross-lane reductions)
 template <int NQ>
 static void launch_scan_stream_t(const aae::ScanArgs& a, bool upright, int nblk, hipStream_t stream) {
-    const int smem = std::max(2 * 4 * NQ * (int)sizeof(float), aae::kScanTicketSmem);
-    if (upright) AAE_LAUNCH((aae::scan_stream_kernel<NQ, true>), dim3(nblk), dim3(256), smem, stream, a);
-    else AAE_LAUNCH((aae::scan_stream_kernel<NQ, false>), dim3(nblk), dim3(256), smem, stream, a);
+    const int smem = 8 * NQ * (int)sizeof(float) + aae::kScanTicketSmem;
+    if (a.cs) {
+        if (upright) AAE_LAUNCH((aae::scan_stream_kernel<NQ, true, true>), dim3(nblk), dim3(256), smem, stream, a);
+        else AAE_LAUNCH((aae::scan_stream_kernel<NQ, false, true>), dim3(nblk), dim3(256), smem, stream, a);
+    } else {
+        if (upright) AAE_LAUNCH((aae::scan_stream_kernel<NQ, true, false>), dim3(nblk), dim3(256), smem, stream, a);
+        else AAE_LAUNCH((aae::scan_stream_kernel<NQ, false, false>), dim3(nblk), dim3(256), smem, stream, a);
+    }
+}
+template <int NQ>
+static void launch_scan_stream_bf16_t(const aae::ScanArgs& a, bool upright, int nblk, hipStream_t stream) {
+    const int smem = 8 * NQ * (int)sizeof(float) + aae::kScanTicketSmem;
+    if (a.cs) {
+        if (upright) AAE_LAUNCH((aae::scan_stream_bf16_kernel<NQ, true, true>), dim3(nblk), dim3(256), smem, stream, a);
+        else AAE_LAUNCH((aae::scan_stream_bf16_kernel<NQ, false, true>), dim3(nblk), dim3(256), smem, stream, a);
+    } else {
+        if (upright) AAE_LAUNCH((aae::scan_stream_bf16_kernel<NQ, true, false>), dim3(nblk), dim3(256), smem, stream, a);
+        else AAE_LAUNCH((aae::scan_stream_bf16_kernel<NQ, false, false>), dim3(nblk), dim3(256), smem, stream, a);
+    }
 }
 
 template <bool BF16, int K, int RH>
@@ -1304,16 +1333,9 @@ static int run_scan(aae_codebook* cb, const float* z, int B, int col_stride, flo
             a.idx_out = reinterpret_cast<long long*>(fin->idx_out); a.score_out = fin->score_out; a.idx_scale = fin->idx_scale;
         }
         const bool up = col_stride > 1;
-        if (B == 1) {
-            if (up) AAE_LAUNCH((aae::scan_stream_bf16_kernel<1, true>), dim3(s.nblk), dim3(256), 64, stream, a);
-            else AAE_LAUNCH((aae::scan_stream_bf16_kernel<1, false>), dim3(s.nblk), dim3(256), 64, stream, a);
-        } else if (B == 2) {
-            if (up) AAE_LAUNCH((aae::scan_stream_bf16_kernel<2, true>), dim3(s.nblk), dim3(256), 128, stream, a);
-            else AAE_LAUNCH((aae::scan_stream_bf16_kernel<2, false>), dim3(s.nblk), dim3(256), 128, stream, a);
-        } else {
-            if (up) AAE_LAUNCH((aae::scan_stream_bf16_kernel<4, true>), dim3(s.nblk), dim3(256), 256, stream, a);
-            else AAE_LAUNCH((aae::scan_stream_bf16_kernel<4, false>), dim3(s.nblk), dim3(256), 256, stream, a);
-        }
+        if (B == 1) launch_scan_stream_bf16_t<1>(a, up, s.nblk, stream);
+        else if (B == 2) launch_scan_stream_bf16_t<2>(a, up, s.nblk, stream);
+        else launch_scan_stream_bf16_t<4>(a, up, s.nblk, stream);
         AAE_HIP_TRY(hipGetLastError());
         return AAE_OK;
     }
@@ -1579,6 +1601,9 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
     else if (!strcmp(name, "wavek_waves")) {
         if (value != 4 && value != 8) return fail(AAE_ERR_INVALID, "wavek_waves %d: 4 or 8", value);
         enc->wavek_waves = value;
+    } else if (!strcmp(name, "wavek_tiny_waves")) {
+        if (value != 4 && value != 8) return fail(AAE_ERR_INVALID, "wavek_tiny_waves %d: 4 or 8", value);
+        enc->wavek_tiny_waves = value;
     } else if (!strcmp(name, "wavek_depth")) {
         if (value != 2 && value != 3) return fail(AAE_ERR_INVALID, "wavek_depth %d: 2 or 3", value);
         enc->wavek_depth = value;

@@ -130,6 +130,105 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// ---- reduce-scatter: 16 quantities summed over the lanes, each total left in its own lane ---------------------------
+// d[u], u = 0 ... 15: this lane's partial sums of 16 different quantities (the stream scans: 16 codebook rows against one
+// query).  Sixteen separate butterfly trees (half_wave_sum) cost 16 x 5 cross-lane adds and leave every total in every
+// lane; nobody needs that.  Here every level of the tree halves the quantities a lane still carries -- a lane keeps the
+// upper or the lower half of them according to the lane bit that level reduces over -- so the work shrinks 16, 8, 4, 2, 1:
+//   level 1, lane bit 4: v_permlane16_swap exchanges the odd 16-lane rows of d[u] with the even rows of d[u + 8]; one add
+//            then gives (rows 0 / 2) d[u] and (rows 1 / 3) d[u + 8], each summed over lane bit 4          2 instr. per pair
+//   level 2, lane bit 3: X + X[l ^ 8], Y + Y[l ^ 8] (DPP row_ror:8), banks 0-1 keep X, banks 2-3 keep Y   3 per pair
+//   level 3, lane bit 2: X + X[l + 4] (row_shl:4) kept by banks 0 / 2, Y + Y[l - 4] (row_shr:4) by banks 1 / 3
+//   level 4, lane bit 1: quad_perm [2,3,0,1], select by lane bit 1;   level 5, lane bit 0: quad_perm [1,0,3,2]
+// = 16 + 12 + 6 + 3 + 1 = 38 instructions for the 16 quantities.  The two 32-lane halves of the wave are independent
+// (nothing crosses lane bit 5).  Result: lane l holds the total of quantity (l >> 1) & 15 over its half-wave (both lanes
+// of a pair the same value).  Every level adds a value to its partner's, so the summation tree is fixed and symmetric:
+// tests/emu/hip_emu.h restates it.
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ float dpp_move(float old, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, ROW_MASK, BANK_MASK, false));
+}
+__device__ __forceinline__ float half_wave_reduce_scatter16(const float (&d)[16]) {
+    float t8[8], t4[4], t2[2];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const auto sw = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, d[u]), __builtin_bit_cast(unsigned, d[u + 8]), false, false);
+        const unsigned s0 = sw[0], s1 = sw[1];                   // (scalars first: a bit_cast of ONE vector element has been seen to pick element 0)
+        t8[u] = __builtin_bit_cast(float, s0) + __builtin_bit_cast(float, s1);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const float a1 = t8[u] + dpp_take<0x128, 0xF>(t8[u]);            // row_ror:8
+        const float a2 = t8[u + 4] + dpp_take<0x128, 0xF>(t8[u + 4]);
+        t4[u] = dpp_move<0xE4, 0xF, 0x3>(a2, a1);                         // banks 0, 1 (lane bit 3 = 0): a1, banks 2, 3: a2
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const float a1 = t4[u] + dpp_take<0x104, 0xF>(t4[u]);            // row_shl:4: lane l reads l + 4 (used where lane bit 2 = 0)
+        const float a2 = t4[u + 2] + dpp_take<0x114, 0xF>(t4[u + 2]);    // row_shr:4: lane l reads l - 4 (used where lane bit 2 = 1)
+        t2[u] = dpp_move<0xE4, 0xF, 0x5>(a2, a1);                         // banks 0, 2: a1, banks 1, 3: a2
+    }
+    const float a1 = t2[0] + dpp_take<0x4E, 0xF>(t2[0]);                 // quad_perm [2,3,0,1]
+    const float a2 = t2[1] + dpp_take<0x4E, 0xF>(t2[1]);
+    const float t1 = (threadIdx.x & 2) ? a2 : a1;
+    return t1 + dpp_take<0xB1, 0xF>(t1);                                  // quad_perm [1,0,3,2]
+}
+
+// Same idea inside each 16-lane row (the bf16 stream scan: a 256-byte row = 16 lanes x 16 B): d[u] summed over the 16
+// lanes of the row, lane l of the row left with the total of quantity l (levels: lane bit 3, 2, 1, 0 -> 24 + 12 + 6 + 3 = 45
+// instructions instead of 16 x 4 = 64).
+__device__ __forceinline__ float row16_reduce_scatter16(const float (&d)[16]) {
+    float t8[8], t4[4], t2[2];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        const float a1 = d[u] + dpp_take<0x128, 0xF>(d[u]);
+        const float a2 = d[u + 8] + dpp_take<0x128, 0xF>(d[u + 8]);
+        t8[u] = dpp_move<0xE4, 0xF, 0x3>(a2, a1);
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const float a1 = t8[u] + dpp_take<0x104, 0xF>(t8[u]);
+        const float a2 = t8[u + 4] + dpp_take<0x114, 0xF>(t8[u + 4]);
+        t4[u] = dpp_move<0xE4, 0xF, 0x5>(a2, a1);
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const float a1 = t4[u] + dpp_take<0x4E, 0xF>(t4[u]);
+        const float a2 = t4[u + 2] + dpp_take<0x4E, 0xF>(t4[u + 2]);
+        t2[u] = (threadIdx.x & 2) ? a2 : a1;
+    }
+    const float a1 = t2[0] + dpp_take<0xB1, 0xF>(t2[0]);
+    const float a2 = t2[1] + dpp_take<0xB1, 0xF>(t2[1]);
+    return (threadIdx.x & 1) ? a2 : a1;
+}
+
+// Largest v of the wave and the LOWEST lane that holds it, both wave-uniform; NaNs rank as -inf (a wave of NaNs answers
+// (-inf, lane 0)), -0 as +0.  The maximum is taken on integer keys that order like the floats (v_max_i32 fuses with its DPP
+// operand and needs no NaN canonicalisation: one instruction per step where fmaxf costs four): row maxima by DPP, lane 63
+// collects the four rows, the lane search is one compare + a scalar find-first-set -- np.argmax's first-index rule when
+// lanes are ordered like rows.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ int dpp_max_step(int k) {
+    const int o = __builtin_amdgcn_update_dpp((int)0x80000000, k, CTRL, ROW_MASK, 0xF, false);     // disabled lanes: the identity of max (the combine then folds the move into v_max_i32_dpp)
+    return o > k ? o : k;
+}
+__device__ __forceinline__ float wave_max_first_lane(float v, int& first_lane) {
+    const float z = v + 0.f;                                              // -0 -> +0
+    const float s = (z == z) ? z : -__builtin_huge_valf();
+    const int b = __builtin_bit_cast(int, s);
+    int k = b ^ ((b >> 31) & 0x7fffffff);                                 // orders like s
+    k = dpp_max_step<0xB1, 0xF>(k);                                       // quad_perm [1,0,3,2]
+    k = dpp_max_step<0x4E, 0xF>(k);                                       // quad_perm [2,3,0,1]
+    k = dpp_max_step<0x141, 0xF>(k);                                      // row_half_mirror
+    k = dpp_max_step<0x140, 0xF>(k);                                      // row_mirror: every lane of a row holds the row maximum
+    k = dpp_max_step<0x142, 0xA>(k);                                      // row_bcast15 -> rows 1 and 3
+    k = dpp_max_step<0x143, 0xC>(k);                                      // row_bcast31 -> rows 2 and 3: lane 63 has seen all four
+    const int wk = __builtin_amdgcn_readlane(k, 63);
+    const unsigned long long hit = __builtin_amdgcn_ballot_w64((b ^ ((b >> 31) & 0x7fffffff)) == wk);
+    first_lane = (int)__builtin_ctzll(hit);                               // (never empty: the maximum is some lane's key)
+    return __builtin_bit_cast(float, wk ^ ((wk >> 31) & 0x7fffffff));
+}
+
 // makes v available HERE (the compiler must finish the load that produces it before this point instead of
 // waiting in front of every later use in its own basic block)
 __device__ __forceinline__ float pin_value(float v) { asm volatile("" : "+v"(v)); return v; }

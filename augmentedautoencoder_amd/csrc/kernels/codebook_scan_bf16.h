@@ -154,26 +154,38 @@ __global__ __launch_bounds__(256) void scan_bf16_kernel(const ScanBf16Args p) {
 
 // ---------------------------------------------------------------- scan_stream_bf16
 // B <= 4 against a bf16 codebook: the HBM-streaming form (cf. scan_stream_kernel in codebook_scan_f32.h).
-// A row is 256 B = 16 lanes x 16 B, so one 1-KiB wave load covers 4 rows; a wave owns 64 consecutive rows and
-// puts all 16 loads in flight before it touches any.  The bf16 elements are widened exactly (<< 16), the dot
-// products are fp32 fma chains against the fp32-normalised queries (no query splitting needed off the matrix
-// cores) and finished with 4 DPP adds inside each 16-lane row group.
-template <int NQ, bool UPRIGHT>
+// A row is 256 B = 16 lanes x 16 B, so one 1-KiB wave load covers 4 rows; a wave owns 64 consecutive rows -- the 16-lane
+// group g reads rows 16 g ... 16 g + 15, one per load -- and puts all 16 loads in flight (behind the query loads) before
+// it touches any.  The bf16 elements are widened exactly (<< 16), the dot products are fp32 fma chains against the
+// fp32-normalised queries (no query splitting needed off the matrix cores); row16_reduce_scatter16 sums the 16 rows of a
+// group over its 16 lanes in 45 cross-lane instructions (16 separate four-step trees: 64) and leaves row l of the wave's
+// 64 in lane l, so (max, first row) is one wave_max_first_lane per query.
+template <int NQ, bool UPRIGHT, bool WITH_CS>
 __global__ __launch_bounds__(256) void scan_stream_bf16_kernel(const ScanArgs p) {
     AAE_DYN_SMEM(smem_raw);
     float* red_v = reinterpret_cast<float*>(smem_raw);           // [4][NQ]
     int* red_i = reinterpret_cast<int*>(red_v + 4 * NQ);         // [4][NQ]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rs = lane >> 4, kq = lane & 15;                    // row within the 4-row load, 8-element column group
+    const int rs = lane >> 4, kq = lane & 15;                    // 16-lane group, 8-element column group
     const int row_first = blockIdx.x * 256 + wave * 64;
 
+    f32x4 z0[NQ], z1[NQ];
+#pragma unroll
+    for (int b = 0; b < NQ; ++b) {
+        z0[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        z1[b] = z0[b];
+        if (b < p.B) {
+            z0[b] = *reinterpret_cast<const f32x4*>(p.z + (long long)b * 128 + kq * 8);
+            z1[b] = *reinterpret_cast<const f32x4*>(p.z + (long long)b * 128 + kq * 8 + 4);
+        }
+    }
     const buffer_rsrc ebuf = make_buffer(p.E, p.e_bytes);
     u32x4 e[16];
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
-        const int row = row_first + 4 * u + rs;
-        e[u] = __builtin_bit_cast(u32x4, buffer_load4(ebuf, row < p.N ? (unsigned)(row * 256 + kq * 16) : kOobOffset));
+        const int r = row_first + 16 * rs + u;
+        e[u] = __builtin_bit_cast(u32x4, buffer_load4(ebuf, r < p.N ? (unsigned)(r * 256 + kq * 16) : kOobOffset));
     }
 
     if (p.tickets && blockIdx.x == 0) ticket_prepare_slot(p.tickets, p.nonce, gridDim.x);   // loads in flight; arrivals come later
@@ -182,57 +194,49 @@ __global__ __launch_bounds__(256) void scan_stream_bf16_kernel(const ScanArgs p)
     float qv[NQ][8];
 #pragma unroll
     for (int b = 0; b < NQ; ++b) {
-        f32x4 z0 = {0.f, 0.f, 0.f, 0.f}, z1 = z0;
-        if (b < p.B) {
-            z0 = *reinterpret_cast<const f32x4*>(p.z + (long long)b * 128 + kq * 8);
-            z1 = *reinterpret_cast<const f32x4*>(p.z + (long long)b * 128 + kq * 8 + 4);
-        }
-        float ss = z0.x * z0.x;
-        ss = fmaf(z0.y, z0.y, ss); ss = fmaf(z0.z, z0.z, ss); ss = fmaf(z0.w, z0.w, ss);
-        ss = fmaf(z1.x, z1.x, ss); ss = fmaf(z1.y, z1.y, ss); ss = fmaf(z1.z, z1.z, ss); ss = fmaf(z1.w, z1.w, ss);
+        float ss = z0[b].x * z0[b].x;
+        ss = fmaf(z0[b].y, z0[b].y, ss); ss = fmaf(z0[b].z, z0[b].z, ss); ss = fmaf(z0[b].w, z0[b].w, ss);
+        ss = fmaf(z1[b].x, z1[b].x, ss); ss = fmaf(z1[b].y, z1[b].y, ss); ss = fmaf(z1[b].z, z1[b].z, ss); ss = fmaf(z1[b].w, z1[b].w, ss);
 #pragma unroll
         for (int m = 8; m >= 1; m >>= 1) ss += shfl_xor(ss, m);
         const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
-        qv[b][0] = z0.x * inv; qv[b][1] = z0.y * inv; qv[b][2] = z0.z * inv; qv[b][3] = z0.w * inv;
-        qv[b][4] = z1.x * inv; qv[b][5] = z1.y * inv; qv[b][6] = z1.z * inv; qv[b][7] = z1.w * inv;
+        qv[b][0] = z0[b].x * inv; qv[b][1] = z0[b].y * inv; qv[b][2] = z0[b].z * inv; qv[b][3] = z0[b].w * inv;
+        qv[b][4] = z1[b].x * inv; qv[b][5] = z1[b].y * inv; qv[b][6] = z1[b].z * inv; qv[b][7] = z1[b].w * inv;
     }
 
-    float best_v[NQ];
-    int best_i[NQ];
-#pragma unroll
-    for (int b = 0; b < NQ; ++b) { best_v[b] = kNegInf; best_i[b] = row_first + rs; }
-
+    const int row = row_first + lane;
+    bool cand = row < p.N;
+    if (UPRIGHT) cand = cand && (row % p.col_stride == 0);
+    float d[NQ][16];                                             // the lane's share of row 16 rs + u against query b
 #pragma unroll
     for (int u = 0; u < 16; ++u) {
-        const int row = row_first + 4 * u + rs;
-        bool cand = row < p.N;
-        if (UPRIGHT) cand = cand && (row % p.col_stride == 0);
-        float ev[8];
-#pragma unroll
-        for (int w = 0; w < 4; ++w) {
-            ev[2 * w] = __builtin_bit_cast(float, e[u][w] << 16);            // element 2w   (low half)
-            ev[2 * w + 1] = __builtin_bit_cast(float, e[u][w] & 0xFFFF0000u); // element 2w+1 (high half)
-        }
+        const u32x4 eu = e[u];                                    // (whole vector first: see device_intrinsics.h on bit_casts of single elements)
+        const uint32_t w0 = eu[0], w1 = eu[1], w2 = eu[2], w3 = eu[3];
+        float ev[8];                                              // element 2w (low half), 2w + 1 (high half), widened exactly
+        ev[0] = __builtin_bit_cast(float, w0 << 16); ev[1] = __builtin_bit_cast(float, w0 & 0xFFFF0000u);
+        ev[2] = __builtin_bit_cast(float, w1 << 16); ev[3] = __builtin_bit_cast(float, w1 & 0xFFFF0000u);
+        ev[4] = __builtin_bit_cast(float, w2 << 16); ev[5] = __builtin_bit_cast(float, w2 & 0xFFFF0000u);
+        ev[6] = __builtin_bit_cast(float, w3 << 16); ev[7] = __builtin_bit_cast(float, w3 & 0xFFFF0000u);
 #pragma unroll
         for (int b = 0; b < NQ; ++b) {
-            float d = ev[0] * qv[b][0];
+            float t = ev[0] * qv[b][0];
 #pragma unroll
-            for (int j = 1; j < 8; ++j) d = fmaf(ev[j], qv[b][j], d);
-            d = row16_sum(d);                     // every lane of the 16-lane group holds the row's dot product
-            if (p.cs && kq == 0 && row < p.N && b < p.B) p.cs[(long long)b * p.N + row] = d;
-            if (cand && d > best_v[b]) { best_v[b] = d; best_i[b] = row; }
+            for (int j = 1; j < 8; ++j) t = fmaf(ev[j], qv[b][j], t);
+            d[b][u] = t;
         }
     }
-    // rows rs = 0..3 live in the four 16-lane groups: fold groups, then the four waves
 #pragma unroll
     for (int b = 0; b < NQ; ++b) {
-#pragma unroll
-        for (int m = 16; m <= 32; m <<= 1) {
-            const float ov = shfl_xor(best_v[b], m);
-            const int oi = shfl_xor(best_i[b], m);
-            if (better(ov, oi, best_v[b], best_i[b])) { best_v[b] = ov; best_i[b] = oi; }
+        const float dot = row16_reduce_scatter16(d[b]);          // lane l: row row_first + l
+        if (WITH_CS) {
+            if (row < p.N && b < p.B) p.cs[(long long)b * p.N + row] = dot;
         }
-        if (lane == 0) { red_v[wave * NQ + b] = best_v[b]; red_i[wave * NQ + b] = best_i[b]; }
+        int first;
+        const float m = wave_max_first_lane(cand ? dot : kNegInf, first);
+        if (lane == 0) {
+            red_v[wave * NQ + b] = m;
+            red_i[wave * NQ + b] = (first >= 0 && m > kNegInf) ? row_first + first : 0x7fffffff;
+        }
     }
     __syncthreads();
     if (tid < NQ && tid < p.B) {
@@ -242,7 +246,7 @@ __global__ __launch_bounds__(256) void scan_stream_bf16_kernel(const ScanArgs p)
             if (better(red_v[w * NQ + tid], red_i[w * NQ + tid], v, ix)) { v = red_v[w * NQ + tid]; ix = red_i[w * NQ + tid]; }
         scan_store_block_partial(p, tid, v, ix);
     }
-    if (p.tickets) scan_ticket_finish(p, red_v);
+    if (p.tickets) scan_ticket_finish<NQ>(p, red_v + 8 * NQ);
 }
 
 }  // namespace aae

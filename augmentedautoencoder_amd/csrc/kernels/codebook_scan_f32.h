@@ -111,109 +111,164 @@ __device__ __forceinline__ void scan_store_block_partial(const ScanArgs& p, int 
 
 // Called by every thread of a stream-scan block after its block partial is written.  The last of the gridDim.x
 // blocks merges all partials (the arg-max reduce of argmax_reduce_kernel: same order, lowest row wins ties) and
-// writes (index, score) per query.  red: >= 12 dwords of LDS.
-constexpr int kScanTicketSmem = 64;
+// writes (index, score) per query.  red: >= 12 + 8 NQ dwords of LDS.
+// Every partial of every query is requested before the first one is looked at: a device-coherent load is a round trip to
+// the memory side (~0.7 us), and one query after the other (round 3) the finish of a B = 4 scan cost four of them plus
+// eight block barriers.
+constexpr int kScanTicketSmem = 64 + 8 * 4 * 4;
+template <int NQ>
 __device__ __forceinline__ void scan_ticket_finish(const ScanArgs& p, float* red) {
     int* flag = reinterpret_cast<int*>(red) + 10;
     if (!block_ticket_arrive(p.tickets, p.nonce, gridDim.x, blockIdx.x, flag)) return;
-    const int tid = threadIdx.x, nblk = (int)gridDim.x;
+    float* fin_v = red + 16;                                     // [4][NQ]
+    int* fin_i = reinterpret_cast<int*>(fin_v + 4 * NQ);         // [4][NQ]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nblk = (int)gridDim.x;
     const buffer_rsrc vbuf = make_buffer(p.pval, (unsigned)nblk * p.Bstride * 4u);
     const buffer_rsrc ibuf = make_buffer(p.pidx, (unsigned)nblk * p.Bstride * 4u);
-    for (int b = 0; b < p.B; ++b) {
-        float bv = kNegInf;
-        int bi = 0x7fffffff;
-        for (int k = tid; k < nblk; k += 256) {
-            const float v = __builtin_bit_cast(float, coherent_load1(vbuf, (unsigned)(k * p.Bstride + b) * 4u));
-            const int ix = (int)coherent_load1(ibuf, (unsigned)(k * p.Bstride + b) * 4u);
-            if (better(v, ix, bv, bi)) { bv = v; bi = ix; }
+    float bv[NQ];
+    int bi[NQ];
+#pragma unroll
+    for (int b = 0; b < NQ; ++b) { bv[b] = kNegInf; bi[b] = 0x7fffffff; }
+    constexpr int KP = 3;                                        // partial rows per thread and round: 768 blocks = the 92232-row codebook in one round
+    for (int k0 = tid; k0 < nblk; k0 += 256 * KP) {
+        uint32_t v[NQ][KP], ix[NQ][KP];
+#pragma unroll
+        for (int j = 0; j < KP; ++j)
+#pragma unroll
+            for (int b = 0; b < NQ; ++b) {
+                const int k = k0 + 256 * j;
+                const unsigned at = (k < nblk && b < p.B) ? (unsigned)(k * p.Bstride + b) * 4u : kOobOffset;
+                v[b][j] = coherent_load1(vbuf, at);
+                ix[b][j] = coherent_load1(ibuf, at);
+            }
+#pragma unroll
+        for (int j = 0; j < KP; ++j)
+#pragma unroll
+            for (int b = 0; b < NQ; ++b) {
+                const bool live = k0 + 256 * j < nblk;
+                const float fv = live ? __builtin_bit_cast(float, v[b][j]) : kNegInf;
+                const int fi = live ? (int)ix[b][j] : 0x7fffffff;
+                if (better(fv, fi, bv[b], bi[b])) { bv[b] = fv; bi[b] = fi; }
+            }
+    }
+#pragma unroll
+    for (int b = 0; b < NQ; ++b) {
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const float ov = shfl_xor(bv[b], m);
+            const int oi = shfl_xor(bi[b], m);
+            if (better(ov, oi, bv[b], bi[b])) { bv[b] = ov; bi[b] = oi; }
         }
-        block_best(bv, bi, red);
-        if (tid == 0) {
-            if (bi == 0x7fffffff) bi = 0;          // all-NaN scores: np.argmax would also answer 0
-            p.idx_out[b] = (long long)bi * p.idx_scale;
-            p.score_out[b] = bv;
-        }
+        if (lane == 0) { fin_v[wave * NQ + b] = bv[b]; fin_i[wave * NQ + b] = bi[b]; }
+    }
+    __syncthreads();
+    if (tid < NQ && tid < p.B) {
+        float v = fin_v[tid];
+        int ix = fin_i[tid];
+        for (int w = 1; w < 4; ++w)
+            if (better(fin_v[w * NQ + tid], fin_i[w * NQ + tid], v, ix)) { v = fin_v[w * NQ + tid]; ix = fin_i[w * NQ + tid]; }
+        if (ix == 0x7fffffff) ix = 0;              // all-NaN scores: np.argmax would also answer 0
+        p.idx_out[tid] = (long long)ix * p.idx_scale;
+        p.score_out[tid] = v;
     }
 }
 
 // ----------------------------------------------------------------- scan_stream
 // B <= 4, the reference's real usage (one crop per detection).  One launch does the
 // L2-normalisation AND the scan; the codebook is the only HBM stream:
-//   * every wave owns 32 consecutive rows and issues all 16 of its 1-KiB row-pair loads
-//     (16 B per lane, one 512-B row per half-wave) before it touches any of them, so the
-//     whole 47 MB codebook is in flight at once across the chip;
-//   * loads go through a bounds-checked buffer view (rows >= N read zeros): no branches,
-//     no early vmcnt waits;
-//   * while they fly, the wave normalises the <= 4 queries in registers;
-//   * each row's dot product is finished with 5 DPP adds (no LDS traffic); lanes 31 / 63
-//     keep the running (max, first row) for the even / odd rows of the wave.
-template <int NQ, bool UPRIGHT>
+//   * the <= 4 query rows are requested FIRST (16 B per lane), then every wave issues all 16 of its 1-KiB codebook
+//     loads -- 32 consecutive rows, one 512-B row per half-wave and load: half rs reads rows 16 rs ... 16 rs + 15 --
+//     before it touches any of them, so the whole 47 MB codebook is in flight at once across the chip; vmcnt counts in
+//     order, so the queries are normalised (replicated in every lane) while the rows still fly;
+//   * loads go through a bounds-checked buffer view (rows >= N read zeros): no branches, no early vmcnt waits;
+//   * per query: 16 x 4 fmas give the lane's share of its half-wave's 16 rows, half_wave_reduce_scatter16 sums them over
+//     the half-wave in 38 cross-lane instructions and leaves row (l >> 1) of the wave's 32 in lane l -- rows in lane
+//     order -- and wave_max_first_lane finds (max, first row) with one compare and a scalar bit search.  (Round 3 finished
+//     every (row, query) dot product with its own five-step DPP tree and kept a running best per lane: 80 cross-lane adds
+//     and 48 compare/select steps per query -- and, with the optional similarity store as a branch inside that loop, 64
+//     basic blocks whose DPP chains the compiler could not interleave: B = 4 took 23.5 us for the 47 MB that B = 1 streams
+//     in 13.3.)  WITH_CS: the similarity row is wanted as well (parity tests, the B <= 4 top-k path): the even lanes store
+//     their rows, 128 B contiguous per half-wave.
+// The same three helpers serve the scan phase of the persistent per-detection launch (detect_chain.h): same bits per row.
+template <int NQ>
+__device__ __forceinline__ void scan_normalise_queries(const f32x4 (&zv)[NQ], f32x4 (&qv)[NQ]) {
+    // tf.nn.l2_normalize(z, 1) (codebook.py:27), per query, replicated in every lane
+#pragma unroll
+    for (int b = 0; b < NQ; ++b) {
+        float ss = zv[b].x * zv[b].x;
+        ss = fmaf(zv[b].y, zv[b].y, ss);
+        ss = fmaf(zv[b].z, zv[b].z, ss);
+        ss = fmaf(zv[b].w, zv[b].w, ss);
+#pragma unroll
+        for (int m = 16; m >= 1; m >>= 1) ss += shfl_xor(ss, m);
+        const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
+        qv[b] = zv[b] * inv;
+    }
+}
+// rows [row0, row0 + 32) of this wave, clipped at row_end: lane (rs = l >> 5, kq = l & 31) requests columns 4 kq ... + 3 of rows row0 + 16 rs + u
+__device__ __forceinline__ void scan_issue32(const ScanArgs& p, const buffer_rsrc& ebuf, int row0, int row_end, f32x4 (&e)[16]) {
+    const int lane = threadIdx.x & 63, rs = lane >> 5, col = (lane & 31) * 4;
+    const bool col_ok = col < p.J;                               // J <= 128, J % 4 == 0
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        const int r = row0 + 16 * rs + u;
+        e[u] = buffer_load4(ebuf, (r < row_end && col_ok) ? (unsigned)(r * p.J + col) * 4u : kOobOffset);
+    }
+}
+// cosine of the wave's 32 rows with one query: lane l gets row row0 + (l >> 1)
+__device__ __forceinline__ float scan_scores32(const f32x4 (&e)[16], const f32x4& q) {
+    float d[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+        float t = e[u].x * q.x;
+        t = fmaf(e[u].y, q.y, t);
+        t = fmaf(e[u].z, q.z, t);
+        d[u] = fmaf(e[u].w, q.w, t);
+    }
+    return half_wave_reduce_scatter16(d);
+}
+
+template <int NQ, bool UPRIGHT, bool WITH_CS>
 __global__ __launch_bounds__(256) void scan_stream_kernel(const ScanArgs p) {
     AAE_DYN_SMEM(smem_raw);
     float* red_v = reinterpret_cast<float*>(smem_raw);           // [4][NQ]
     int* red_i = reinterpret_cast<int*>(red_v + 4 * NQ);         // [4][NQ]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rs = lane >> 5, kq = lane & 31;
-    const int col = kq * 4;
-    const bool col_ok = col < p.J;                               // J <= 128, J % 4 == 0
+    const int col = (lane & 31) * 4;
+    const bool col_ok = col < p.J;
     const int row_first = blockIdx.x * 128 + wave * 32;
 
+    f32x4 zv[NQ];
+#pragma unroll
+    for (int b = 0; b < NQ; ++b) {
+        zv[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (b < p.B && col_ok) zv[b] = *reinterpret_cast<const f32x4*>(p.z + (long long)b * p.J + col);
+    }
     const buffer_rsrc ebuf = make_buffer(p.E, p.e_bytes);
     f32x4 e[16];
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-        const int row = row_first + 2 * u + rs;
-        const bool ok = row < p.N && col_ok;
-        e[u] = buffer_load4(ebuf, ok ? (unsigned)(row * p.J + col) * 4u : kOobOffset);
-    }
+    scan_issue32(p, ebuf, row_first, p.N, e);
 
     if (p.tickets && blockIdx.x == 0) ticket_prepare_slot(p.tickets, p.nonce, gridDim.x);   // the block's loads are in flight; arrivals come microseconds later
 
-    // tf.nn.l2_normalize(z, 1) (codebook.py:27), per query, replicated in every lane
     f32x4 qv[NQ];
+    scan_normalise_queries<NQ>(zv, qv);
+
+    const int row = row_first + (lane >> 1);
+    bool cand = row < p.N;
+    if (UPRIGHT) cand = cand && (row % p.col_stride == 0);
 #pragma unroll
     for (int b = 0; b < NQ; ++b) {
-        f32x4 zv = {0.f, 0.f, 0.f, 0.f};
-        if (b < p.B && col_ok) zv = *reinterpret_cast<const f32x4*>(p.z + (long long)b * p.J + col);
-        float ss = zv.x * zv.x;
-        ss = fmaf(zv.y, zv.y, ss);
-        ss = fmaf(zv.z, zv.z, ss);
-        ss = fmaf(zv.w, zv.w, ss);
-#pragma unroll
-        for (int m = 16; m >= 1; m >>= 1) ss += shfl_xor(ss, m);
-        const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
-        qv[b] = zv * inv;
-    }
-
-    float best_v[NQ];
-    int best_i[NQ];
-#pragma unroll
-    for (int b = 0; b < NQ; ++b) { best_v[b] = kNegInf; best_i[b] = row_first + rs; }
-
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-        const int row = row_first + 2 * u + rs;
-        bool cand = row < p.N;
-        if (UPRIGHT) cand = cand && (row % p.col_stride == 0);
-#pragma unroll
-        for (int b = 0; b < NQ; ++b) {
-            float d = e[u].x * qv[b].x;
-            d = fmaf(e[u].y, qv[b].y, d);
-            d = fmaf(e[u].z, qv[b].z, d);
-            d = fmaf(e[u].w, qv[b].w, d);
-            d = half_wave_sum(d);                                // total valid in lanes 16-31 / 48-63
-            if (p.cs && kq == 31 && row < p.N && b < p.B) p.cs[(long long)b * p.N + row] = d;
-            if (cand && d > best_v[b]) { best_v[b] = d; best_i[b] = row; }
+        const float d = scan_scores32(e, qv[b]);
+        if (WITH_CS) {
+            if (!(lane & 1) && row < p.N && b < p.B) p.cs[(long long)b * p.N + row] = d;
         }
-    }
-    // lane 31: even rows, lane 63: odd rows -> lane 63 combines, then the 4 waves
-#pragma unroll
-    for (int b = 0; b < NQ; ++b) {
-        const float ov = shfl_xor(best_v[b], 32);
-        const int oi = shfl_xor(best_i[b], 32);
-        if (better(ov, oi, best_v[b], best_i[b])) { best_v[b] = ov; best_i[b] = oi; }
-        if (lane == 63) { red_v[wave * NQ + b] = best_v[b]; red_i[wave * NQ + b] = best_i[b]; }
+        int first;
+        const float m = wave_max_first_lane(cand ? d : kNegInf, first);
+        if (lane == 0) {
+            red_v[wave * NQ + b] = m;
+            red_i[wave * NQ + b] = (first >= 0 && m > kNegInf) ? row_first + (first >> 1) : 0x7fffffff;
+        }
     }
     __syncthreads();
     if (tid < NQ && tid < p.B) {
@@ -223,7 +278,7 @@ __global__ __launch_bounds__(256) void scan_stream_kernel(const ScanArgs p) {
             if (better(red_v[w * NQ + tid], red_i[w * NQ + tid], v, ix)) { v = red_v[w * NQ + tid]; ix = red_i[w * NQ + tid]; }
         scan_store_block_partial(p, tid, v, ix);
     }
-    if (p.tickets) scan_ticket_finish(p, red_v);
+    if (p.tickets) scan_ticket_finish<NQ>(p, red_v + 8 * NQ);
 }
 
 // ------------------------------------------------------------------- scan_gemv

@@ -119,8 +119,9 @@ __device__ __forceinline__ void conv_wavek_block(const ConvWaveKArgs& p, const i
                                                  const WaveKPrefetch& pf, const bool use_pf) {
     constexpr int COMBOS = MT * NT * 16;                       // accumulator registers per lane
     constexpr int T = 64 * WAVES;
-    constexpr int NF4 = 256 * MT * NT / T;                     // float4 pieces of the tile a thread finishes
-    static_assert((256 * MT * NT) % T == 0 && NF4 >= 1, "every thread finishes whole float4 pieces");
+    constexpr int PIECES = 256 * MT * NT;                      // float4 pieces of the tile
+    constexpr int NF4 = (PIECES + T - 1) / T;                  // ... a thread finishes (32 x 32 tiles on 8 waves: the first 256 threads one each, the rest none)
+    static_assert(PIECES % T == 0 || PIECES < T, "every finishing thread finishes whole float4 pieces");
 
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
@@ -240,13 +241,14 @@ __device__ __forceinline__ void conv_wavek_block(const ConvWaveKArgs& p, const i
         m = tm * (32 * MT) + 32 * mi + (q >> 3);
         n = tn * (32 * NT) + 32 * ni + 4 * (q & 7);
     };
+    const bool finisher = PIECES >= T || tid < PIECES;          // (uniform per wave: PIECES is a multiple of 64)
     f32x4 ep_bias[NF4];
 #pragma unroll
     for (int j = 0; j < NF4; ++j) {
         int m, n;
         piece_mn(j, m, n);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) ep_bias[j][e] = (n + e < p.Cout) ? p.bias[n + e] : 0.f;
+        for (int e = 0; e < 4; ++e) ep_bias[j][e] = (finisher && n + e < p.Cout) ? p.bias[n + e] : 0.f;
     }
     // (logical block 0, its first loads in flight) the tile words get this launch's nonce long before the first arrival
     if (p.gsplits > 1 && Lphys == 0)
@@ -275,7 +277,7 @@ __device__ __forceinline__ void conv_wavek_block(const ConvWaveKArgs& p, const i
     f32x4 v[NF4];
 #pragma unroll
     for (int j = 0; j < NF4; ++j) {
-        const int f = tid + T * j, sub = f >> 8, q = f & 255, row = q >> 3;
+        const int f = finisher ? tid + T * j : 0, sub = f >> 8, q = f & 255, row = q >> 3;
         const int at = (sub * 16 + (row & 3) + 4 * (row >> 3)) * 64 + 4 * (q & 7) + 32 * ((row >> 2) & 1);
         f32x4 s = lds_read4(red + at);
 #pragma unroll
@@ -288,10 +290,10 @@ __device__ __forceinline__ void conv_wavek_block(const ConvWaveKArgs& p, const i
     if (p.gsplits > 1 && !(ablate & 8)) {
         // this block's tile partial: one 16-B coherent store per piece, thread-linear (coalesced)
         const buffer_rsrc pbuf = make_buffer(p.partial, p.partial_bytes);
-        const unsigned tile_base = (unsigned)tile * (unsigned)p.gsplits * NF4 * T * 16u;
-        const unsigned mine = tile_base + (unsigned)g * NF4 * T * 16u + (unsigned)tid * 16u;
+        const unsigned tile_base = (unsigned)tile * (unsigned)p.gsplits * PIECES * 16u;
+        const unsigned mine = finisher ? tile_base + (unsigned)g * PIECES * 16u + (unsigned)tid * 16u : kOobBase;
 #pragma unroll
-        for (int j = 0; j < NF4; ++j) coherent_store4(pbuf, mine + j * T * 16u, v[j]);
+        for (int j = 0; j < NF4; ++j) coherent_store4(pbuf, finisher ? mine + j * T * 16u : kOobBase, v[j]);
         block_ticket_publish();
         stamp(4);                                               // partial stores complete (device scope)
         const bool last_block = block_ticket_take(p.tickets + tile, p.nonce, (unsigned)p.gsplits, (unsigned)g, flag);
@@ -303,15 +305,15 @@ __device__ __forceinline__ void conv_wavek_block(const ConvWaveKArgs& p, const i
         // time they cost more than the K loop); splits beyond gsplits read out of range = zeros.  Split order: the same
         // sum whichever block arrives last.
         constexpr int kBatch = 8;
-        const unsigned split_stride = NF4 * T * 16u;
+        const unsigned split_stride = PIECES * 16u;
         for (int sb = 0; sb < p.gsplits; sb += kBatch) {
             f32x4 t[kBatch][NF4];
 #pragma unroll
             for (int u = 0; u < kBatch; ++u)
 #pragma unroll
                 for (int j = 0; j < NF4; ++j)
-                    t[u][j] = coherent_load4(pbuf, sb + u < p.gsplits ? tile_base + (unsigned)(sb + u) * split_stride + (unsigned)tid * 16u + j * T * 16u
-                                                                      : kOobBase);
+                    t[u][j] = coherent_load4(pbuf, (finisher && sb + u < p.gsplits) ? tile_base + (unsigned)(sb + u) * split_stride + (unsigned)tid * 16u + j * T * 16u
+                                                                                    : kOobBase);
 #pragma unroll
             for (int u = 0; u < kBatch; ++u)
 #pragma unroll
@@ -326,7 +328,7 @@ __device__ __forceinline__ void conv_wavek_block(const ConvWaveKArgs& p, const i
     for (int j = 0; j < NF4; ++j) {
         int m, n;
         piece_mn(j, m, n);
-        if (m >= p.M || n >= p.Cout) continue;
+        if (!finisher || m >= p.M || n >= p.Cout) continue;
         f32x4 o = v[j] + ep_bias[j];
         if (p.relu) { o[0] = fmaxf(o[0], 0.f); o[1] = fmaxf(o[1], 0.f); o[2] = fmaxf(o[2], 0.f); o[3] = fmaxf(o[3], 0.f); }
         if (p.bn_scale) {                                       // (inference batch-norm after the ReLU: encoder.py:51-52)

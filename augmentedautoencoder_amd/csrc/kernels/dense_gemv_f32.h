@@ -6,6 +6,12 @@
 // batch element.  The chunks are added up (fixed order), with bias and the optional BN, either by
 // splitk_reduce_kernel in a second launch or -- TICKET = true, the default -- inside this launch by the last
 // block to arrive (block_ticket_arrive): one launch less on the per-detection path.
+// B >= 2 (round 4): ONE finishing block had to read chunks x B x Cout x 4 bytes of partials (512 KB at B = 4 of the default
+// net) at the ~100 GB/s a single block gets out of handed-off data, one batch row after the other: 13.3 us for the 16.8 MB
+// that B = 1 streams in 7.5.  Now the finish is a two-level tree that follows the two-level ticket: the last arriver of
+// each of the 16 chunk groups adds ITS group's chunk rows (chunks g, g + 16, ...: 8 KB x B) and publishes a group row; the
+// last of those 16 adds the group rows, bias and batch-norm.  Partials leave as 16-byte pieces (a 4-byte device-coherent
+// store costs about six times a 16-byte one per byte).  Fixed orders: the same bits whichever blocks arrive last.
 #pragma once
 
 namespace aae {
@@ -14,7 +20,7 @@ struct DenseGemvArgs {
     const float* x;        // [B][K]
     const float* wp;       // [K/4][CoutPad][4]
     unsigned wp_bytes;
-    float* partial;        // [chunks][B][Cout]
+    float* partial;        // [chunks][B][Cout] (+ [kGemvGroups][B][Cout] group rows behind them: the two-level finish)
     unsigned partial_bytes;
     int B, K, Cout, CoutPad;
     // TICKET mode: the last block of a column tile finishes z = sum(chunks) + bias [, BN]
@@ -28,6 +34,7 @@ struct DenseGemvArgs {
 };
 
 constexpr int kGemvChunk = 128;            // k per block = 32 slot rows: 64 KB of weights at CoutPad = 128
+constexpr int kGemvGroups = kTicketGroups; // chunk groups of the two-level finish (= the group words of a ticket slot)
 
 constexpr int kGemvTicketSmem = 8 * 128 * 4 + 16;                // the finishing block's 8 row-group sums + the ticket flag
 
@@ -89,17 +96,89 @@ __device__ __forceinline__ void dense_gemv_block(const DenseGemvArgs& p, const i
     }
     __syncthreads();
     const buffer_rsrc pbuf = make_buffer(p.partial, p.partial_bytes);
-    if (half == 0 && n < p.Cout) {
+    const bool tree = TICKET && MQ > 1 && nbx > (int)kTicketSingleLevelMax;      // two-level finish (the ticket has its group words)
+    if (!tree) {
+        if (half == 0 && n < p.Cout) {
 #pragma unroll
-        for (int m = 0; m < MQ; ++m)
-            if (m < p.B) {
-                const float sum = acc[m] + red[m * 128 + (tid & 127)];
-                const unsigned at = (unsigned)(((bx * p.B + m) * p.Cout + n) * 4);
-                if (TICKET) coherent_store1(pbuf, at, __builtin_bit_cast(uint32_t, sum));      // read back by another block of this launch
-                else p.partial[((long long)bx * p.B + m) * p.Cout + n] = sum;
-            }
+            for (int m = 0; m < MQ; ++m)
+                if (m < p.B) {
+                    const float sum = acc[m] + red[m * 128 + (tid & 127)];
+                    const unsigned at = (unsigned)(((bx * p.B + m) * p.Cout + n) * 4);
+                    if (TICKET) coherent_store1(pbuf, at, __builtin_bit_cast(uint32_t, sum));      // read back by another block of this launch
+                    else p.partial[((long long)bx * p.B + m) * p.Cout + n] = sum;
+                }
+        }
     }
     if constexpr (TICKET) {
+        if (tree) {
+            // ---- the chunk row of every batch element as 16-byte pieces: thread (m = tid / 32, n4 = tid % 32) ----------------
+            if (half == 0) {
+#pragma unroll
+                for (int m = 0; m < MQ; ++m) red[m * 128 + (tid & 127)] += acc[m];              // (own element: the k-half pair's sum)
+            }
+            __syncthreads();
+            const int pm = tid >> 5, pn = by * 128 + (tid & 31) * 4;
+            const bool piece = pm < p.B && pm < MQ && pn < p.Cout;                               // (Cout % 4 == 0: the host checks)
+            if (piece) coherent_store4(pbuf, (unsigned)(((bx * p.B + pm) * p.Cout + pn) * 4), *reinterpret_cast<const f32x4*>(red + pm * 128 + (tid & 31) * 4));
+            int* flag = reinterpret_cast<int*>(smem_raw + kGemvTicketSmem - 16);
+            unsigned long long* words = p.tickets + by * kTicketSlotWords;
+            const int groups = kGemvGroups, g = bx % groups, members = (nbx - g + groups - 1) / groups;
+            // level 1: the last arriver of chunk group g adds chunks g, g + groups, ... (in that order)
+            block_ticket_publish();
+            if (tid == 0) {
+                const bool last = ticket_count(words + (1 + g) * kTicketGroupStride, p.nonce) == (unsigned)members;
+                if (last) ticket_clear(words + (1 + g) * kTicketGroupStride);
+                *flag = last ? 1 : 0;
+            }
+            __syncthreads();
+            if (*flag == 0) return;
+            const unsigned group_base = (unsigned)nbx * (unsigned)(p.B * p.Cout) * 4u;          // group rows sit behind the chunk rows
+            {
+                f32x4 s = {0.f, 0.f, 0.f, 0.f};
+                constexpr int kInFlight = 16;
+                for (int j0 = 0; j0 < members; j0 += kInFlight) {
+                    f32x4 t[kInFlight];
+#pragma unroll
+                    for (int u = 0; u < kInFlight; ++u) {
+                        const int c = g + groups * (j0 + u);
+                        t[u] = coherent_load4(pbuf, (piece && j0 + u < members) ? (unsigned)(((c * p.B + pm) * p.Cout + pn) * 4) : kOobOffset);
+                    }
+#pragma unroll
+                    for (int u = 0; u < kInFlight; ++u) s += t[u];
+                }
+                if (piece) coherent_store4(pbuf, group_base + (unsigned)(((g * p.B + pm) * p.Cout + pn) * 4), s);
+            }
+            // level 2: the last of the group finishers adds the group rows in group order, then bias / ReLU / batch-norm
+            block_ticket_publish();
+            if (tid == 0) {
+                const bool last = ticket_count(words, p.nonce) == (unsigned)groups;
+                if (last) ticket_clear(words);
+                *flag = last ? 1 : 0;
+            }
+            __syncthreads();
+            if (*flag == 0) return;
+            f32x4 t[kGemvGroups];
+#pragma unroll
+            for (int u = 0; u < kGemvGroups; ++u)
+                t[u] = coherent_load4(pbuf, piece ? group_base + (unsigned)(((u * p.B + pm) * p.Cout + pn) * 4) : kOobOffset);
+            f32x4 e_bias = {0.f, 0.f, 0.f, 0.f}, e_sc = {1.f, 1.f, 1.f, 1.f}, e_sh = {0.f, 0.f, 0.f, 0.f};
+            if (piece) {
+                e_bias = *reinterpret_cast<const f32x4*>(p.bias + pn);
+                if (p.bn_scale) { e_sc = *reinterpret_cast<const f32x4*>(p.bn_scale + pn); e_sh = *reinterpret_cast<const f32x4*>(p.bn_shift + pn); }
+            }
+            f32x4 v = t[0];
+#pragma unroll
+            for (int u = 1; u < kGemvGroups; ++u) v += t[u];
+            v += e_bias;
+            if (p.relu) { v[0] = fmaxf(v[0], 0.f); v[1] = fmaxf(v[1], 0.f); v[2] = fmaxf(v[2], 0.f); v[3] = fmaxf(v[3], 0.f); }
+            if (p.bn_scale) v = v * e_sc + e_sh;
+            if (piece) {
+                const buffer_rsrc zbuf = make_buffer(p.out, (unsigned)(p.B * p.Cout * 4));
+                if (CHAIN) coherent_store4(zbuf, (unsigned)((pm * p.Cout + pn) * 4), v);
+                else *reinterpret_cast<f32x4*>(p.out + (long long)pm * p.Cout + pn) = v;
+            }
+            return;
+        }
         // The last of the nbx chunk blocks of this column tile adds the chunk rows: thread (group = tid / 32,
         // n4 = tid % 32) sums chunks group, group + 8, ... of four neighbouring columns (16-B loads, all of a batch
         // row's loads in flight), the 8 group sums meet in LDS and are added in group order -- one fixed tree,

@@ -26,7 +26,7 @@
 //   conv layer l = 2 ... L : conv_wavek_block<MT, NT, 4, 2, CHAIN> (wave-split-K implicit GEMM; split layers finish inside
 //                            the phase by the last block of a tile, no waiting)                    -> barrier
 //   dense                  : dense_gemv_block (weight-streaming GEMV, chunk rows added by the last block)  -> barrier
-//   scan                   : every wave streams its own contiguous range of codebook rows (two row pairs of 16 loads in
+//   scan                   : every wave streams its own contiguous range of codebook rows (two 32-row groups of 16 loads in
 //                            flight), block partial -> coherent store -> ticket -> the last block merges and answers.
 // Coherence: everything another block reads is stored device-coherently (sc1), every buffer is written once per launch and
 // never read before its barrier (device_intrinsics.h, grid barrier).  Residency: grid = min(CUs, 256) blocks of 256
@@ -65,34 +65,20 @@ __device__ __forceinline__ void chain_conv_phase(const ConvWaveKArgs& a, int blk
         conv_wavek_block<ChainShape<SHAPE>::MT, ChainShape<SHAPE>::NT, 4, 2, true>(a, L, nblk, red, flag, pf, have_pf && L == blk);
 }
 
-// codebook rows [row, row + 32) of this wave: 16 loads of two rows each (one 512-B row per half-wave), clipped at row_end
-__device__ __forceinline__ void chain_scan_issue(const ScanArgs& p, const buffer_rsrc& ebuf, int row, int row_end, f32x4 (&e)[16]) {
-    const int lane = threadIdx.x & 63, rs = lane >> 5, col = (lane & 31) * 4;
-    const bool col_ok = col < p.J;
-#pragma unroll
-    for (int u = 0; u < 16; ++u) {
-        const int r = row + 2 * u + rs;
-        e[u] = buffer_load4(ebuf, (r < row_end && col_ok) ? (unsigned)(r * p.J + col) * 4u : kOobOffset);
-    }
-}
-
+// scan phase: rows [row, row + 32) of a wave against the MQ queries -- scan_issue32 / scan_scores32 / wave_max_first_lane of
+// codebook_scan_f32.h, i.e. the same bits per row as the stand-alone stream scan; the running (max, first row) of a wave is
+// wave-uniform (rows arrive in ascending order: a later row replaces the best only when it is strictly larger)
 template <int NQ>
-__device__ __forceinline__ void chain_scan_consume(const ScanArgs& p, int row, int row_end, const f32x4 (&e)[16], const f32x4 (&qv)[NQ],
+__device__ __forceinline__ void chain_scan_consume(int row, int row_end, const f32x4 (&e)[16], const f32x4 (&qv)[NQ],
                                                    float (&best_v)[NQ], int (&best_i)[NQ]) {
-    const int rs = (threadIdx.x & 63) >> 5;
+    const int lane = threadIdx.x & 63;
+    const bool cand = row + (lane >> 1) < row_end;
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-        const int r = row + 2 * u + rs;
-        const bool cand = r < row_end;
-#pragma unroll
-        for (int b = 0; b < NQ; ++b) {
-            float d = e[u].x * qv[b].x;                          // the fma chain + DPP tree of scan_stream_kernel: same bits per row
-            d = fmaf(e[u].y, qv[b].y, d);
-            d = fmaf(e[u].z, qv[b].z, d);
-            d = fmaf(e[u].w, qv[b].w, d);
-            d = half_wave_sum(d);                                // total valid in lanes 16-31 / 48-63
-            if (cand && d > best_v[b]) { best_v[b] = d; best_i[b] = r; }
-        }
+    for (int b = 0; b < NQ; ++b) {
+        const float d = scan_scores32(e, qv[b]);
+        int first;
+        const float m = wave_max_first_lane(cand ? d : kNegInf, first);
+        if (first >= 0 && m > best_v[b]) { best_v[b] = m; best_i[b] = row + (first >> 1); }
     }
 }
 
@@ -157,7 +143,7 @@ __global__ __launch_bounds__(256, 1) void detect_chain_kernel(const DetectChainA
     f32x4 ea[16], eb[16];
     grid_barrier_arrive(p.barrier, (unsigned)G, (unsigned)blk, ++phase);
     stamp();
-    chain_scan_issue(s, ebuf, row_begin, row_end, ea);          // the first 64 KB of this block's rows fly while the barrier closes
+    scan_issue32(s, ebuf, row_begin, row_end, ea);              // the first 64 KB of this block's rows fly while the barrier closes
     if (blk == 0) ticket_prepare_slot(s.tickets, s.nonce, (unsigned)G);
     grid_barrier_wait(p.barrier, (unsigned)G, (unsigned)blk, phase);
     stamp();
@@ -166,40 +152,30 @@ __global__ __launch_bounds__(256, 1) void detect_chain_kernel(const DetectChainA
     const int kq = lane & 31, col = kq * 4;
     const bool col_ok = col < s.J;
     const buffer_rsrc zbuf = make_buffer(s.z, (unsigned)(s.B * s.J * 4));
-    f32x4 qv[MQ];
+    f32x4 zv[MQ], qv[MQ];
 #pragma unroll
     for (int b = 0; b < MQ; ++b) {
-        f32x4 zv = {0.f, 0.f, 0.f, 0.f};
-        if (b < s.B && col_ok) zv = coherent_load4(zbuf, (unsigned)((b * s.J + col) * 4));
-        float ss = zv.x * zv.x;
-        ss = fmaf(zv.y, zv.y, ss);
-        ss = fmaf(zv.z, zv.z, ss);
-        ss = fmaf(zv.w, zv.w, ss);
-#pragma unroll
-        for (int m = 16; m >= 1; m >>= 1) ss += shfl_xor(ss, m);
-        const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
-        qv[b] = zv * inv;
+        zv[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (b < s.B && col_ok) zv[b] = coherent_load4(zbuf, (unsigned)((b * s.J + col) * 4));
     }
+    scan_normalise_queries<MQ>(zv, qv);
     float best_v[MQ];
     int best_i[MQ];
 #pragma unroll
-    for (int b = 0; b < MQ; ++b) { best_v[b] = kNegInf; best_i[b] = row_begin + (lane >> 5); }
+    for (int b = 0; b < MQ; ++b) { best_v[b] = kNegInf; best_i[b] = 0x7fffffff; }
     for (int row = row_begin; row < row_end; row += 64) {
-        chain_scan_issue(s, ebuf, row + 32, row_end, eb);
-        chain_scan_consume<MQ>(s, row, row_end, ea, qv, best_v, best_i);
-        chain_scan_issue(s, ebuf, row + 64, row_end, ea);
-        chain_scan_consume<MQ>(s, row + 32, row_end, eb, qv, best_v, best_i);
+        scan_issue32(s, ebuf, row + 32, row_end, eb);
+        chain_scan_consume<MQ>(row, row_end, ea, qv, best_v, best_i);
+        scan_issue32(s, ebuf, row + 64, row_end, ea);
+        chain_scan_consume<MQ>(row + 32, row_end, eb, qv, best_v, best_i);
     }
-    // lane 31: even offsets, lane 63: odd offsets -> lane 63 combines, then the 4 waves, then the blocks (ticket)
+    // the 4 waves, then the blocks (ticket)
     float* red_v = red;                                          // [4][MQ]
     int* red_i = reinterpret_cast<int*>(red_v + 4 * MQ);
     __syncthreads();                                             // (the dense phase's LDS use is over)
+    if (lane == 0) {
 #pragma unroll
-    for (int b = 0; b < MQ; ++b) {
-        const float ov = shfl_xor(best_v[b], 32);
-        const int oi = shfl_xor(best_i[b], 32);
-        if (better(ov, oi, best_v[b], best_i[b])) { best_v[b] = ov; best_i[b] = oi; }
-        if (lane == 63) { red_v[wave * MQ + b] = best_v[b]; red_i[wave * MQ + b] = best_i[b]; }
+        for (int b = 0; b < MQ; ++b) { red_v[wave * MQ + b] = best_v[b]; red_i[wave * MQ + b] = best_i[b]; }
     }
     __syncthreads();
     if (tid < MQ && tid < s.B) {
@@ -210,7 +186,7 @@ __global__ __launch_bounds__(256, 1) void detect_chain_kernel(const DetectChainA
         scan_store_block_partial(s, tid, v, ix);
     }
     stamp();                                                     // this block's rows scanned
-    scan_ticket_finish(s, red_v + 32);
+    scan_ticket_finish<MQ>(s, red_v + 32);
     stamp();
 }
 

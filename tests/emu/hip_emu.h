@@ -324,6 +324,54 @@ inline float half_wave_sum(float v) {
     return v;
 }
 
+// device_intrinsics.h::half_wave_reduce_scatter16: the same tree, level by level (lane bit 4, 3, 2, 1, 0); at every level a
+// lane keeps the lower half of its quantities when that lane bit is 0, the upper half when it is 1, and adds its partner's
+// value of the same quantity.
+inline float reduce_scatter_levels(const float (&d)[16], const int* bits, int nbits, int last_bit) {
+    const int lane = lane_id();
+    float t[16];
+    for (int u = 0; u < 16; ++u) t[u] = d[u];
+    int n = 16;
+    for (int s = 0; s < nbits; ++s) {
+        const aae_emu::lane_slot* all = aae_emu::wave_exchange(t, 64);
+        const int bit = bits[s], half = n / 2, up = (lane & bit) ? half : 0;
+        float out[16];
+        for (int u = 0; u < half; ++u) {
+            float o;
+            memcpy(&o, &all[lane ^ bit][4 * (u + up)], 4);
+            out[u] = t[u + up] + o;
+        }
+        for (int u = 0; u < half; ++u) t[u] = out[u];
+        n = half;
+    }
+    if (last_bit) {
+        const aae_emu::lane_slot* all = aae_emu::wave_exchange(t, 4);
+        float o;
+        memcpy(&o, &all[lane ^ last_bit][0], 4);
+        t[0] += o;
+    }
+    return t[0];
+}
+inline float half_wave_reduce_scatter16(const float (&d)[16]) {
+    static const int bits[4] = {16, 8, 4, 2};
+    return reduce_scatter_levels(d, bits, 4, 1);
+}
+inline float row16_reduce_scatter16(const float (&d)[16]) {
+    static const int bits[4] = {8, 4, 2, 1};
+    return reduce_scatter_levels(d, bits, 4, 0);
+}
+inline float wave_max_first_lane(float v, int& first_lane) {
+    // device_intrinsics.h: NaNs rank as -inf, -0 as +0; lowest lane among the holders of the maximum
+    const float z = v + 0.f;
+    const float s = (z == z) ? z : -INFINITY;
+    const aae_emu::lane_slot* all = aae_emu::wave_exchange(&s, 4);
+    float m = -INFINITY;
+    for (int l = 0; l < 64; ++l) { float o; memcpy(&o, &all[l][0], 4); if (o > m) m = o; }
+    first_lane = 0;
+    for (int l = 63; l >= 0; --l) { float o; memcpy(&o, &all[l][0], 4); if (o == m) first_lane = l; }
+    return m;
+}
+
 }  // namespace aae
 
 // ---- the sliver of the HIP runtime API the host-side launch code uses ----

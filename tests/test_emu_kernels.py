@@ -261,6 +261,38 @@ def test_dense_layer_as_weight_streaming_gemv_for_tiny_batches(B):
     enc.close()
 
 
+@pytest.mark.parametrize('B', [2, 3, 4])
+def test_dense_gemv_two_level_finish_over_chunk_groups(B):
+    """More than 32 chunks and B >= 2: the GEMV's chunk rows are added by a two-level tree that follows the two-level ticket
+    (the last arriver of each of 16 chunk groups adds its group, the last group finisher adds the group rows + bias + BN).
+    64 chunks here (8 x 8 x 128 features); every block order must give the same bits, and those must agree with the oracle
+    and with the separate reduce launch within summation-order noise."""
+    cfg = EncoderConfig((32, 32, 3), [32, 128], [2, 2], 5, 128, batch_norm=True)
+    w = synth.make_weights(seed=21, shape=cfg.shape, num_filter=cfg.num_filter, strides=cfg.strides, latent=128, batch_norm=True)
+    x = synth.make_crops(B, seed=22, shape=cfg.shape)
+    z64 = ref.encoder_forward_np(ref.input_to_float(x), w, cfg.strides, True)
+    outs = []
+    try:
+        for order in (0, 1, 2):
+            eb.set_block_order(order)
+            enc = eb.EmuEncoder(w, cfg)
+            enc.set_option('detect_chain', 0)
+            z = enc.forward(x)
+            assert enc.labels()[-1].startswith('dense:dense_gemv_f32_ticket chunks=64'), enc.labels()
+            outs.append(z.copy())
+            enc.close()
+    finally:
+        eb.set_block_order(0)
+    assert np.abs(outs[0] - z64).max() / np.abs(z64).max() < 5e-6
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+    enc = eb.EmuEncoder(w, cfg)
+    enc.set_option('gemv_ticket', 0)
+    z2 = enc.forward(x)
+    assert enc.labels()[-1] == 'dense:splitk_reduce', enc.labels()
+    assert np.abs(outs[0] - z2).max() / np.abs(z64).max() < 2e-6
+    enc.close()
+
+
 @pytest.mark.parametrize('shape,filters,B', [
     ((40, 24, 3), [48, 32], 2),      # W*C = 72: dword staging, ragged last tile (240 px), Cout cut by the 32-channel wave tile
     ((24, 20, 1), [32, 32], 3),      # one input channel, W*C = 20, pl*C = 1 -> three lead floats
@@ -629,6 +661,22 @@ def test_wave_split_k_igemm_32x32_wave_tiles(B):
     cfg = EncoderConfig((16, 16, 3), [32, 96], [2, 2], 5, 128, True)
     labels = _run(cfg, B, 81, wavek=1, options={'wavek_tiny_max_tiles': 64})
     assert 'conv_wavek_f32_32x32_w4_d2' in labels[1], labels
+
+
+@pytest.mark.parametrize('order', [0, 2])
+@pytest.mark.parametrize('B', [1, 3])
+def test_wave_split_k_igemm_32x32_wave_tiles_on_eight_waves(B, order):
+    """Option wavek_tiny_waves = 8: the 32 x 32 wave tiles with two waves per SIMD (K cut eight ways inside a block; the 256
+    float4 pieces of a tile are finished by the first four waves).  With and without a cross-block K split, any block order."""
+    cfg = EncoderConfig((16, 16, 3), [32, 96], [2, 2], 5, 128, True)
+    eb.set_block_order(order)
+    try:
+        labels = _run(cfg, B, 81, wavek=1, options={'wavek_tiny_max_tiles': 64, 'wavek_tiny_waves': 8})
+        assert 'conv_wavek_f32_32x32_w8_d2' in labels[1], labels
+        labels = _run(cfg, B, 81, wavek=1, options={'wavek_tiny_max_tiles': 64, 'wavek_tiny_waves': 8, 'wavek_target_blocks': 2})
+        assert 'conv_wavek_f32_32x32_w8_d2_g1 ' in labels[1], labels
+    finally:
+        eb.set_block_order(0)
 
 
 def test_f32x3h_range_flag_on_the_emulated_kernels():
