@@ -142,6 +142,8 @@ struct aae_encoder {
                                            // measured: wins up to 64 tiles (B=1: 94 -> 87 us), loses from 128 on (twice the operand loads per MFMA)
     int wavek_target_blocks = 256;         // blocks a split layer is cut into (tiles x K splits): one per CU
     int wavek_waves = 4;                   // waves per block (4 | 8), each with its own K range
+    int wavek_pingpong = 0;                // 8-wave blocks: the two waves of a SIMD alternate load issue and MFMAs behind block barriers (conv_wavek_f32.h);
+                                           // measured SLOWER than free-running waves (B = 1: 95 vs 82 us): kept as an option with its measurement, off
     int wavek_tiny_waves = 4;              // ... of the 32 x 32 wave tiles (per-detection batches): 8 = two waves per SIMD, so that one wave's operand-load issue
                                            // (~250 cycles per slab in which its dependent MFMA chain stands still) runs under the other wave's MFMAs
     // measured per layer with rocprofv3 at B = 1 ... 8 (profiles/r09_small/variants_*.txt): depth 2 beats 3 by 0.5-1 us per launch
@@ -183,6 +185,10 @@ struct aae_codebook {
     // B <= 4, top-1 on a stream kernel: arg-max over the block partials inside the scan launch (last block to arrive)
     // instead of a separate argmax_reduce launch.  0: never (AAE_SCAN_STREAM_2L); otherwise always
     int scan_ticket = 1;
+    // fp32 stream scan (B <= 4): 0 = one 32-row batch per wave, the whole codebook requested at once (scan_stream_kernel); 1
+    // (AAE_SCAN_STREAM_WALK) = one block per CU walks the codebook with two batches in flight per wave (scan_stream_walk_kernel:
+    // measured level at B = 1, slower at B = 4 inside the fused query -- 18.4 vs 16.9 us)
+    int scan_walk = 0;
 };
 
 namespace aae_host {
@@ -661,7 +667,7 @@ static aae::ConvWaveKArgs wavek_args(const aae_encoder* enc, const Layer& L, con
     a.x = x; a.wp = L.wp; a.bias = L.bias; a.bn_scale = L.bn_scale; a.bn_shift = L.bn_shift; a.out = out;
     a.partial = partial; a.partial_bytes = (unsigned)w.partial_bytes; a.tickets = tickets; a.nonce = nonce;
     a.H = L.H; a.W = L.W; a.Cin = L.Cin; a.Ho = L.Ho; a.Wo = L.Wo; a.Cout = L.Cout; a.CoutPad = L.CoutPad;
-    a.KS = L.KS; a.S = L.S; a.pt = L.pt; a.pl = L.pl; a.M = M; a.relu = L.relu; a.ablate = enc->wavek_ablate;
+    a.KS = L.KS; a.S = L.S; a.pt = L.pt; a.pl = L.pl; a.M = M; a.relu = L.relu; a.ablate = enc->wavek_ablate; a.pingpong = enc->wavek_pingpong;
     a.timeline = (enc->wavek_timeline && tag >= 1 && tag <= 3 && w.num_mt * w.num_nt * w.gsplits <= 512)       // (the debug buffer holds 512 blocks per layer)
                      ? enc->wavek_timeline + (size_t)(tag - 1) * 512 * 8 : nullptr;
     a.x_bytes = (unsigned)((unsigned long long)(M / (L.Ho * L.Wo)) * L.H * L.W * L.Cin * sizeof(float));
@@ -1252,7 +1258,7 @@ static void launch_scan_mfma_t(const aae::ScanArgs& a, bool upright, int nblk, h
 // loop into 64 basic blocks and serialised the cross-lane reductions)
 template <int NQ>
 static void launch_scan_stream_t(const aae::ScanArgs& a, bool upright, int nblk, hipStream_t stream) {
-    const int smem = 8 * NQ * (int)sizeof(float) + aae::kScanTicketSmem;
+    const int smem = NQ * 128 * (int)sizeof(float) + aae::kScanTicketSmem;
     if (a.cs) {
         if (upright) AAE_LAUNCH((aae::scan_stream_kernel<NQ, true, true>), dim3(nblk), dim3(256), smem, stream, a);
         else AAE_LAUNCH((aae::scan_stream_kernel<NQ, false, true>), dim3(nblk), dim3(256), smem, stream, a);
@@ -1262,8 +1268,19 @@ static void launch_scan_stream_t(const aae::ScanArgs& a, bool upright, int nblk,
     }
 }
 template <int NQ>
-static void launch_scan_stream_bf16_t(const aae::ScanArgs& a, bool upright, int nblk, hipStream_t stream) {
+static void launch_scan_walk_t(const aae::ScanArgs& a, bool upright, int blocks, hipStream_t stream) {
     const int smem = 8 * NQ * (int)sizeof(float) + aae::kScanTicketSmem;
+    if (a.cs) {
+        if (upright) AAE_LAUNCH((aae::scan_stream_walk_kernel<NQ, true, true>), dim3(blocks), dim3(256), smem, stream, a);
+        else AAE_LAUNCH((aae::scan_stream_walk_kernel<NQ, false, true>), dim3(blocks), dim3(256), smem, stream, a);
+    } else {
+        if (upright) AAE_LAUNCH((aae::scan_stream_walk_kernel<NQ, true, false>), dim3(blocks), dim3(256), smem, stream, a);
+        else AAE_LAUNCH((aae::scan_stream_walk_kernel<NQ, false, false>), dim3(blocks), dim3(256), smem, stream, a);
+    }
+}
+template <int NQ>
+static void launch_scan_stream_bf16_t(const aae::ScanArgs& a, bool upright, int nblk, hipStream_t stream) {
+    const int smem = NQ * 256 * (int)sizeof(float) + aae::kScanTicketSmem;
     if (a.cs) {
         if (upright) AAE_LAUNCH((aae::scan_stream_bf16_kernel<NQ, true, true>), dim3(nblk), dim3(256), smem, stream, a);
         else AAE_LAUNCH((aae::scan_stream_bf16_kernel<NQ, false, true>), dim3(nblk), dim3(256), smem, stream, a);
@@ -1386,7 +1403,15 @@ static int run_scan(aae_codebook* cb, const float* z, int B, int col_stride, flo
         a.idx_out = reinterpret_cast<long long*>(fin->idx_out); a.score_out = fin->score_out; a.idx_scale = fin->idx_scale;
     }
     const bool upright = col_stride > 1;
-    if (s.stream) {
+    if (s.stream && cb->scan_walk) {
+        // one block per CU, never more blocks than 128-row groups (the partial buffers are sized for those)
+        const int blocks = std::min(cb->cu_count > 0 ? cb->cu_count : 256, s.nblk);
+        if (partial_rows) *partial_rows = blocks;
+        if (B == 1) launch_scan_walk_t<1>(a, upright, blocks, stream);
+        else if (B == 2) launch_scan_walk_t<2>(a, upright, blocks, stream);
+        else if (B == 3) launch_scan_walk_t<3>(a, upright, blocks, stream);
+        else launch_scan_walk_t<4>(a, upright, blocks, stream);
+    } else if (s.stream) {
         if (B == 1) launch_scan_stream_t<1>(a, upright, s.nblk, stream);
         else if (B == 2) launch_scan_stream_t<2>(a, upright, s.nblk, stream);
         else if (B == 3) launch_scan_stream_t<3>(a, upright, s.nblk, stream);
@@ -1601,7 +1626,8 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
     else if (!strcmp(name, "wavek_waves")) {
         if (value != 4 && value != 8) return fail(AAE_ERR_INVALID, "wavek_waves %d: 4 or 8", value);
         enc->wavek_waves = value;
-    } else if (!strcmp(name, "wavek_tiny_waves")) {
+    } else if (!strcmp(name, "wavek_pingpong")) enc->wavek_pingpong = value ? 1 : 0;
+    else if (!strcmp(name, "wavek_tiny_waves")) {
         if (value != 4 && value != 8) return fail(AAE_ERR_INVALID, "wavek_tiny_waves %d: 4 or 8", value);
         enc->wavek_tiny_waves = value;
     } else if (!strcmp(name, "wavek_depth")) {
@@ -1796,6 +1822,7 @@ int aae_codebook_prepare_upright(aae_codebook* cb, int col_stride, void* stream_
             cb->upright_copies.push_back({col_stride, sub});
         }
         sub->scan_mode = cb->scan_mode; sub->scan_ticket = cb->scan_ticket; sub->topk_prune = cb->topk_prune; sub->cu_count = cb->cu_count;
+        sub->scan_walk = cb->scan_walk;
         cb->upright = sub; cb->upright_stride = col_stride;
     }
     if (int rc = gather_upright_rows(cb, cb->upright, cb->upright_stride, stream)) return rc;
@@ -1825,12 +1852,15 @@ int aae_codebook_set_scan_mode(aae_codebook* cb, int mode) {
     using namespace aae_host;
     if (!cb) return fail(AAE_ERR_INVALID, "aae_codebook_set_scan_mode: null handle");
     if (mode != AAE_SCAN_AUTO && mode != AAE_SCAN_GEMV && mode != AAE_SCAN_MFMA && mode != AAE_SCAN_STREAM && mode != AAE_SCAN_STREAM_2L &&
-        mode != AAE_SCAN_AUTO_NO_PRUNE)
+        mode != AAE_SCAN_AUTO_NO_PRUNE && mode != AAE_SCAN_STREAM_WALK)
         return fail(AAE_ERR_INVALID, "scan mode %d", mode);
     cb->scan_ticket = mode == AAE_SCAN_STREAM_2L ? 0 : 1;
     cb->topk_prune = mode == AAE_SCAN_AUTO_NO_PRUNE ? 0 : 1;
-    cb->scan_mode = mode == AAE_SCAN_STREAM_2L ? AAE_SCAN_STREAM : (mode == AAE_SCAN_AUTO_NO_PRUNE ? AAE_SCAN_AUTO : mode);
-    for (auto& c : cb->upright_copies) { c.second->scan_mode = cb->scan_mode; c.second->scan_ticket = cb->scan_ticket; c.second->topk_prune = cb->topk_prune; }
+    cb->scan_walk = mode == AAE_SCAN_STREAM_WALK ? 1 : 0;
+    cb->scan_mode = (mode == AAE_SCAN_STREAM_2L || mode == AAE_SCAN_STREAM_WALK) ? AAE_SCAN_STREAM : (mode == AAE_SCAN_AUTO_NO_PRUNE ? AAE_SCAN_AUTO : mode);
+    for (auto& c : cb->upright_copies) {
+        c.second->scan_mode = cb->scan_mode; c.second->scan_ticket = cb->scan_ticket; c.second->topk_prune = cb->topk_prune; c.second->scan_walk = cb->scan_walk;
+    }
     return AAE_OK;
 }
 

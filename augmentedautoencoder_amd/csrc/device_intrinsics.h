@@ -229,6 +229,37 @@ __device__ __forceinline__ float wave_max_first_lane(float v, int& first_lane) {
     return __builtin_bit_cast(float, wk ^ ((wk >> 31) & 0x7fffffff));
 }
 
+// The same over NV values per lane, value j of lane l standing for position 64 j + l: largest value and the LOWEST position
+// that holds it (one key maximum, then one compare + bit search per slot, first slot with a hit wins).
+template <int NV>
+__device__ __forceinline__ float wave_max_first_position(const float (&v)[NV], int& first_pos) {
+    int key[NV];
+    int k = (int)0x80000000;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const float z = v[j] + 0.f;
+        const float s = (z == z) ? z : -__builtin_huge_valf();
+        const int b = __builtin_bit_cast(int, s);
+        key[j] = b ^ ((b >> 31) & 0x7fffffff);
+        k = key[j] > k ? key[j] : k;
+    }
+    k = dpp_max_step<0xB1, 0xF>(k);
+    k = dpp_max_step<0x4E, 0xF>(k);
+    k = dpp_max_step<0x141, 0xF>(k);
+    k = dpp_max_step<0x140, 0xF>(k);
+    k = dpp_max_step<0x142, 0xA>(k);
+    k = dpp_max_step<0x143, 0xC>(k);
+    const int wk = __builtin_amdgcn_readlane(k, 63);
+    first_pos = 0;
+    bool found = false;
+#pragma unroll
+    for (int j = 0; j < NV; ++j) {
+        const unsigned long long hit = __builtin_amdgcn_ballot_w64(key[j] == wk);
+        if (!found && hit) { first_pos = 64 * j + (int)__builtin_ctzll(hit); found = true; }     // (wave-uniform)
+    }
+    return __builtin_bit_cast(float, wk ^ ((wk >> 31) & 0x7fffffff));
+}
+
 // makes v available HERE (the compiler must finish the load that produces it before this point instead of
 // waiting in front of every later use in its own basic block)
 __device__ __forceinline__ float pin_value(float v) { asm volatile("" : "+v"(v)); return v; }
@@ -269,6 +300,11 @@ __device__ __forceinline__ void coherent_store4(buffer_rsrc r, uint32_t byte_off
 }
 __device__ __forceinline__ f32x4 coherent_load4(buffer_rsrc r, uint32_t byte_off) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, kCoherent));
+}
+__device__ __forceinline__ void coherent_store2(buffer_rsrc r, uint32_t byte_off, uint32_t v0, uint32_t v1) {
+    typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+    const u32x2_t v = {v0, v1};
+    __builtin_amdgcn_raw_buffer_store_b64(v, r, (int)byte_off, 0, kCoherent);
 }
 __device__ __forceinline__ void coherent_store1(buffer_rsrc r, uint32_t byte_off, uint32_t v) {
     __builtin_amdgcn_raw_buffer_store_b32(v, r, (int)byte_off, 0, kCoherent);

@@ -159,12 +159,11 @@ __global__ __launch_bounds__(256) void scan_bf16_kernel(const ScanBf16Args p) {
 // it touches any.  The bf16 elements are widened exactly (<< 16), the dot products are fp32 fma chains against the
 // fp32-normalised queries (no query splitting needed off the matrix cores); row16_reduce_scatter16 sums the 16 rows of a
 // group over its 16 lanes in 45 cross-lane instructions (16 separate four-step trees: 64) and leaves row l of the wave's
-// 64 in lane l, so (max, first row) is one wave_max_first_lane per query.
+// 64 in lane l; the block's scores meet in LDS and wave b finds (max, first row) of query b (scan_block_argmax_store).
 template <int NQ, bool UPRIGHT, bool WITH_CS>
 __global__ __launch_bounds__(256) void scan_stream_bf16_kernel(const ScanArgs p) {
     AAE_DYN_SMEM(smem_raw);
-    float* red_v = reinterpret_cast<float*>(smem_raw);           // [4][NQ]
-    int* red_i = reinterpret_cast<int*>(red_v + 4 * NQ);         // [4][NQ]
+    float* sc = reinterpret_cast<float*>(smem_raw);              // [NQ][256] scores of the block's rows
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int rs = lane >> 4, kq = lane & 15;                    // 16-lane group, 8-element column group
@@ -231,22 +230,11 @@ __global__ __launch_bounds__(256) void scan_stream_bf16_kernel(const ScanArgs p)
         if (WITH_CS) {
             if (row < p.N && b < p.B) p.cs[(long long)b * p.N + row] = dot;
         }
-        int first;
-        const float m = wave_max_first_lane(cand ? dot : kNegInf, first);
-        if (lane == 0) {
-            red_v[wave * NQ + b] = m;
-            red_i[wave * NQ + b] = (first >= 0 && m > kNegInf) ? row_first + first : 0x7fffffff;
-        }
+        sc[b * 256 + wave * 64 + lane] = cand ? dot : kNegInf;
     }
     __syncthreads();
-    if (tid < NQ && tid < p.B) {
-        float v = red_v[tid];
-        int ix = red_i[tid];
-        for (int w = 1; w < 4; ++w)
-            if (better(red_v[w * NQ + tid], red_i[w * NQ + tid], v, ix)) { v = red_v[w * NQ + tid]; ix = red_i[w * NQ + tid]; }
-        scan_store_block_partial(p, tid, v, ix);
-    }
-    if (p.tickets) scan_ticket_finish<NQ>(p, red_v + 8 * NQ);
+    scan_block_argmax_store<NQ, 256>(p, sc, blockIdx.x * 256);   // wave b: (max, first row) of query b over the block's 256 rows
+    if (p.tickets) scan_ticket_finish<NQ>(p, sc + NQ * 256);
 }
 
 }  // namespace aae

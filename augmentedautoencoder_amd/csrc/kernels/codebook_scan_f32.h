@@ -97,15 +97,43 @@ __device__ __forceinline__ void block_best(float& bv, int& bi, float* red) {
     __syncthreads();
 }
 
-// block partial (best score, best row) of query b: device-coherent when another block of this launch reads it back
-__device__ __forceinline__ void scan_store_block_partial(const ScanArgs& p, int b, float v, int ix) {
+// Block partials of a stream scan: thread 0 folds the four waves' (best score, best row) of every query and stores them.
+// In-launch finish (p.tickets): all queries of the block as 16-byte device-coherent pieces (score, row, score, row) at the
+// front of the block's row of p.pval -- one or two stores per block and, for the finishing block, one or two loads per
+// partial row instead of 2 NQ dword accesses each (round 3's form: at B = 4 the finish cost 6 us against 3 at B = 1,
+// tools/ubench/scan_stream_ablate.hip).  Separate reduce launch (no tickets): the [block][query] score and row arrays
+// argmax_reduce_kernel reads.
+template <int NQ>
+__device__ __forceinline__ void scan_store_block_partials(const ScanArgs& p, const float* red_v, const int* red_i) {
+    if (threadIdx.x != 0) return;
+    float v[NQ];
+    int ix[NQ];
+#pragma unroll
+    for (int b = 0; b < NQ; ++b) {
+        v[b] = red_v[b];
+        ix[b] = red_i[b];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (better(red_v[w * NQ + b], red_i[w * NQ + b], v[b], ix[b])) { v[b] = red_v[w * NQ + b]; ix[b] = red_i[w * NQ + b]; }
+    }
     if (p.tickets) {
-        const unsigned bytes = gridDim.x * (unsigned)p.Bstride * 4u, at = (blockIdx.x * (unsigned)p.Bstride + (unsigned)b) * 4u;
-        coherent_store1(make_buffer(p.pval, bytes), at, __builtin_bit_cast(uint32_t, v));
-        coherent_store1(make_buffer(p.pidx, bytes), at, (uint32_t)ix);
+        const buffer_rsrc pbuf = make_buffer(p.pval, gridDim.x * (unsigned)p.Bstride * 4u);
+#pragma unroll
+        for (int h = 0; h < (NQ + 1) / 2; ++h) {
+            u32x4 piece;
+            piece[0] = __builtin_bit_cast(uint32_t, v[2 * h]);
+            piece[1] = (uint32_t)ix[2 * h];
+            piece[2] = 2 * h + 1 < NQ ? __builtin_bit_cast(uint32_t, v[(2 * h + 1) % NQ]) : 0u;
+            piece[3] = 2 * h + 1 < NQ ? (uint32_t)ix[(2 * h + 1) % NQ] : 0u;
+            coherent_store4(pbuf, (blockIdx.x * (unsigned)p.Bstride + 4u * h) * 4u, __builtin_bit_cast(f32x4, piece));
+        }
     } else {
-        p.pval[(long long)blockIdx.x * p.Bstride + b] = v;
-        p.pidx[(long long)blockIdx.x * p.Bstride + b] = ix;
+#pragma unroll
+        for (int b = 0; b < NQ; ++b)
+            if (b < p.B) {
+                p.pval[(long long)blockIdx.x * p.Bstride + b] = v[b];
+                p.pidx[(long long)blockIdx.x * p.Bstride + b] = ix[b];
+            }
     }
 }
 
@@ -123,31 +151,31 @@ __device__ __forceinline__ void scan_ticket_finish(const ScanArgs& p, float* red
     float* fin_v = red + 16;                                     // [4][NQ]
     int* fin_i = reinterpret_cast<int*>(fin_v + 4 * NQ);         // [4][NQ]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nblk = (int)gridDim.x;
-    const buffer_rsrc vbuf = make_buffer(p.pval, (unsigned)nblk * p.Bstride * 4u);
-    const buffer_rsrc ibuf = make_buffer(p.pidx, (unsigned)nblk * p.Bstride * 4u);
+    const buffer_rsrc pbuf = make_buffer(p.pval, (unsigned)nblk * p.Bstride * 4u);
     float bv[NQ];
     int bi[NQ];
 #pragma unroll
     for (int b = 0; b < NQ; ++b) { bv[b] = kNegInf; bi[b] = 0x7fffffff; }
-    constexpr int KP = 3;                                        // partial rows per thread and round: 768 blocks = the 92232-row codebook in one round
+    constexpr int KP = 3;                                        // partial rows per thread and round: 768 blocks in one round
+    constexpr int PIECES = (NQ + 1) / 2;                         // 16-byte pieces (score, row, score, row) per partial row
     for (int k0 = tid; k0 < nblk; k0 += 256 * KP) {
-        uint32_t v[NQ][KP], ix[NQ][KP];
+        f32x4 t[KP][PIECES];
 #pragma unroll
         for (int j = 0; j < KP; ++j)
 #pragma unroll
-            for (int b = 0; b < NQ; ++b) {
+            for (int h = 0; h < PIECES; ++h) {
                 const int k = k0 + 256 * j;
-                const unsigned at = (k < nblk && b < p.B) ? (unsigned)(k * p.Bstride + b) * 4u : kOobOffset;
-                v[b][j] = coherent_load1(vbuf, at);
-                ix[b][j] = coherent_load1(ibuf, at);
+                t[j][h] = coherent_load4(pbuf, k < nblk ? (unsigned)(k * p.Bstride + 4 * h) * 4u : kOobOffset);
             }
 #pragma unroll
         for (int j = 0; j < KP; ++j)
 #pragma unroll
             for (int b = 0; b < NQ; ++b) {
                 const bool live = k0 + 256 * j < nblk;
-                const float fv = live ? __builtin_bit_cast(float, v[b][j]) : kNegInf;
-                const int fi = live ? (int)ix[b][j] : 0x7fffffff;
+                const u32x4 piece = __builtin_bit_cast(u32x4, t[j][b / 2]);      // (whole vector, then scalars: see device_intrinsics.h)
+                const uint32_t w0 = piece[0], w1 = piece[1], w2 = piece[2], w3 = piece[3];
+                const float fv = live ? __builtin_bit_cast(float, (b & 1) ? w2 : w0) : kNegInf;
+                const int fi = live ? (int)((b & 1) ? w3 : w1) : 0x7fffffff;
                 if (better(fv, fi, bv[b], bi[b])) { bv[b] = fv; bi[b] = fi; }
             }
     }
@@ -228,11 +256,35 @@ __device__ __forceinline__ float scan_scores32(const f32x4 (&e)[16], const f32x4
     return half_wave_reduce_scatter16(d);
 }
 
+// Arg-max of a block: every wave leaves the scores of its rows for every query in LDS ([NQ][ROWS], -inf where a row is no
+// candidate); after ONE barrier wave b finds (max, first row) of query b over the whole block -- one key maximum per query
+// and BLOCK instead of one per query and wave (at B = 4 the four per-wave searches cost as much as the whole reduce-scatter,
+// tools/ubench/scan_stream_ablate.hip) -- and its lane 0 stores the block partial: 8 device-coherent bytes (score, row) into
+// the query's slot of the packed partial row (in-launch finish) or the [block][query] arrays (separate reduce launch).
+template <int NQ, int ROWS>
+__device__ __forceinline__ void scan_block_argmax_store(const ScanArgs& p, const float* sc, int row_base) {
+    const int lane = threadIdx.x & 63, wave = wave_uniform(threadIdx.x >> 6);
+    if (wave >= NQ || wave >= p.B) return;                       // wave-uniform
+    float v[ROWS / 64];
+#pragma unroll
+    for (int j = 0; j < ROWS / 64; ++j) v[j] = sc[wave * ROWS + 64 * j + lane];
+    int first;
+    const float m = wave_max_first_position<ROWS / 64>(v, first);
+    if (lane != 0) return;
+    const int ix = m > kNegInf ? row_base + first : 0x7fffffff;
+    if (p.tickets)
+        coherent_store2(make_buffer(p.pval, gridDim.x * (unsigned)p.Bstride * 4u), (blockIdx.x * (unsigned)p.Bstride + 2u * wave) * 4u,
+                        __builtin_bit_cast(uint32_t, m), (uint32_t)ix);
+    else {
+        p.pval[(long long)blockIdx.x * p.Bstride + wave] = m;
+        p.pidx[(long long)blockIdx.x * p.Bstride + wave] = ix;
+    }
+}
+
 template <int NQ, bool UPRIGHT, bool WITH_CS>
 __global__ __launch_bounds__(256) void scan_stream_kernel(const ScanArgs p) {
     AAE_DYN_SMEM(smem_raw);
-    float* red_v = reinterpret_cast<float*>(smem_raw);           // [4][NQ]
-    int* red_i = reinterpret_cast<int*>(red_v + 4 * NQ);         // [4][NQ]
+    float* sc = reinterpret_cast<float*>(smem_raw);              // [NQ][128] scores of the block's rows
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = (lane & 31) * 4;
@@ -263,21 +315,87 @@ __global__ __launch_bounds__(256) void scan_stream_kernel(const ScanArgs p) {
         if (WITH_CS) {
             if (!(lane & 1) && row < p.N && b < p.B) p.cs[(long long)b * p.N + row] = d;
         }
-        int first;
-        const float m = wave_max_first_lane(cand ? d : kNegInf, first);
-        if (lane == 0) {
-            red_v[wave * NQ + b] = m;
-            red_i[wave * NQ + b] = (first >= 0 && m > kNegInf) ? row_first + (first >> 1) : 0x7fffffff;
-        }
+        if (!(lane & 1)) sc[b * 128 + wave * 32 + (lane >> 1)] = cand ? d : kNegInf;
     }
     __syncthreads();
-    if (tid < NQ && tid < p.B) {
-        float v = red_v[tid];
-        int ix = red_i[tid];
-        for (int w = 1; w < 4; ++w)
-            if (better(red_v[w * NQ + tid], red_i[w * NQ + tid], v, ix)) { v = red_v[w * NQ + tid]; ix = red_i[w * NQ + tid]; }
-        scan_store_block_partial(p, tid, v, ix);
+    scan_block_argmax_store<NQ, 128>(p, sc, blockIdx.x * 128);
+    if (p.tickets) scan_ticket_finish<NQ>(p, sc + NQ * 128);
+}
+
+// ------------------------------------------------------------ scan_stream_walk
+// The same query with compute UNDER the stream (round 4).  In scan_stream_kernel every wave owns exactly one 32-row batch
+// and the whole codebook is requested at t = 0: the memory system then serves 2884 waves round-robin, nearly every wave
+// receives its last row near the END of the 7.5 us stream, and all the arithmetic -- per wave ~130 vector instructions per
+// query -- runs after it, the waves of a SIMD one behind the other: B = 4 took 20.8 us for the bytes B = 1 streams in 12.8
+// although the instructions were already halved.  Here a block per CU walks the codebook: wave gw of nw takes batches gw,
+// gw + nw, gw + 2 nw, ... with TWO batches in flight (two 16-load register rings), scores batch i while batch i + 1 lands
+// and requests batch i + 2 into the ring it just freed; the running (max, first row) of a wave lives in scalar registers
+// (batches ascend: a later row wins only when strictly larger).  A third of the arithmetic is left behind the last byte
+// instead of all of it, the launch has 256 blocks instead of 721, and the in-launch finish merges 256 partials.
+// Same bits per row as scan_stream_kernel (scan_scores32), same tie rule.
+template <int NQ, bool UPRIGHT, bool WITH_CS>
+__device__ __forceinline__ void scan_walk_consume(const ScanArgs& p, int row0, const f32x4 (&e)[16], const f32x4 (&qv)[NQ], float (&best_v)[NQ], int (&best_i)[NQ]) {
+    const int lane = threadIdx.x & 63;
+    const int row = row0 + (lane >> 1);
+    bool cand = row < p.N;
+    if (UPRIGHT) cand = cand && (row % p.col_stride == 0);
+#pragma unroll
+    for (int b = 0; b < NQ; ++b) {
+        const float d = scan_scores32(e, qv[b]);
+        if (WITH_CS) {
+            if (!(lane & 1) && row < p.N && b < p.B) p.cs[(long long)b * p.N + row] = d;
+        }
+        int first;
+        const float m = wave_max_first_lane(cand ? d : kNegInf, first);
+        if (m > best_v[b]) { best_v[b] = m; best_i[b] = row0 + (first >> 1); }
     }
+}
+
+template <int NQ, bool UPRIGHT, bool WITH_CS>
+__global__ __launch_bounds__(256) void scan_stream_walk_kernel(const ScanArgs p) {
+    AAE_DYN_SMEM(smem_raw);
+    float* red_v = reinterpret_cast<float*>(smem_raw);           // [4][NQ]
+    int* red_i = reinterpret_cast<int*>(red_v + 4 * NQ);         // [4][NQ]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
+    const int col = (lane & 31) * 4;
+    const bool col_ok = col < p.J;
+    const int nbatch = (p.N + 31) >> 5;
+    const int gw = (int)blockIdx.x * 4 + wave, nw = (int)gridDim.x * 4;
+
+    f32x4 zv[NQ];
+#pragma unroll
+    for (int b = 0; b < NQ; ++b) {
+        zv[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (b < p.B && col_ok) zv[b] = *reinterpret_cast<const f32x4*>(p.z + (long long)b * p.J + col);
+    }
+    const buffer_rsrc ebuf = make_buffer(p.E, p.e_bytes);
+    f32x4 ea[16], eb[16];
+    // (a batch index beyond the codebook turns into rows >= N: every load out of range, no traffic)
+    scan_issue32(p, ebuf, gw < nbatch ? gw * 32 : p.N, p.N, ea);
+    scan_issue32(p, ebuf, gw + nw < nbatch ? (gw + nw) * 32 : p.N, p.N, eb);
+
+    if (p.tickets && blockIdx.x == 0) ticket_prepare_slot(p.tickets, p.nonce, gridDim.x);
+
+    f32x4 qv[NQ];
+    scan_normalise_queries<NQ>(zv, qv);
+
+    float best_v[NQ];
+    int best_i[NQ];
+#pragma unroll
+    for (int b = 0; b < NQ; ++b) { best_v[b] = kNegInf; best_i[b] = 0x7fffffff; }
+    for (int i = gw; i < nbatch; i += 2 * nw) {                   // wave-uniform trip count
+        scan_walk_consume<NQ, UPRIGHT, WITH_CS>(p, i * 32, ea, qv, best_v, best_i);
+        scan_issue32(p, ebuf, i + 2 * nw < nbatch ? (i + 2 * nw) * 32 : p.N, p.N, ea);
+        if (i + nw < nbatch) scan_walk_consume<NQ, UPRIGHT, WITH_CS>(p, (i + nw) * 32, eb, qv, best_v, best_i);
+        scan_issue32(p, ebuf, i + 3 * nw < nbatch ? (i + 3 * nw) * 32 : p.N, p.N, eb);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int b = 0; b < NQ; ++b) { red_v[wave * NQ + b] = best_v[b]; red_i[wave * NQ + b] = best_i[b]; }
+    }
+    __syncthreads();
+    scan_store_block_partials<NQ>(p, red_v, red_i);
     if (p.tickets) scan_ticket_finish<NQ>(p, red_v + 8 * NQ);
 }
 

@@ -49,6 +49,7 @@ struct ConvWaveKArgs {
     int relu;
     long long* timeline;         // optional [blocks][8] shader-clock stamps of wave 0 per phase (tools/ablate_wavek.py); nullptr in production
     int ablate;                  // timing experiments only (results are then wrong): 1 no A loads, 2 no B loads, 4 no MFMAs, 8 no cross-block hand-off
+    int pingpong;                // 8-wave blocks: the two waves of a SIMD alternate load issue and MFMAs, a block barrier between the half-steps
 };
 
 // Ticket preparation.  A launch whose blocks all arrive at a clean ticket word queue up behind the nonce install
@@ -253,14 +254,46 @@ __device__ __forceinline__ void conv_wavek_block(const ConvWaveKArgs& p, const i
     // (logical block 0, its first loads in flight) the tile words get this launch's nonce long before the first arrival
     if (p.gsplits > 1 && Lphys == 0)
         for (int w = tid; w < tiles; w += T) ticket_prepare_word(p.tickets + w, p.nonce);
-    for (int t = s0; t < s1; t += DEPTH) {
+    if (WAVES == 8 && DEPTH == 2 && !CHAIN && p.pingpong) {
+        // Two waves per SIMD (w and w + 4: tools/ubench/wave_simd_map.hip), made to ALTERNATE.  A wave's slab is ~300 cycles of
+        // address arithmetic + load issue, during which its dependent MFMA chain stands still, then 16 x 64 cycles of MFMAs.  Left
+        // alone, the two waves of a SIMD fall into step -- they share the matrix pipe, so they finish their MFMAs together and
+        // then both issue loads while the pipe idles: eight waves measured exactly like four (B = 1 conv2 20.1 vs 19.5 us).  With a
+        // block barrier between the half-steps one wave's load issue always sits under the other's MFMAs:
+        //     waves 0-3:  L(t+1) | M(t)   | L(t+2) | M(t+1) ...
+        //     waves 4-7:  M(t)   | L(t+1) | M(t+1) | L(t+2) ...
+        // Every wave runs the same number of half-steps (K ranges differ by at most one slab; a wave past its range issues
+        // out-of-range loads -- no traffic).  Same per-wave fma chains: the same values as the free-running loop.
+        const int nmax = (b1 - b0 + WAVES - 1) / WAVES;
+        // ONE loop body for both halves -- { L(t+1); barrier; M(t); barrier } -- the second half enters it one barrier late (and
+        // the first half pays that barrier back behind the loop).  (A first version branched on the half inside the loop: the
+        // compiler then kept the accumulators in VGPRs and copied all 16 across every join -- each copy waits for the MFMA that
+        // produced its source: conv2 at B = 1 24.7 us instead of 19.8.)  A stage past the wave's K range multiplies zeros.
+        if (wave >= WAVES / 2) block_barrier();
+        for (int t = 0; t < nmax; t += 2) {
 #pragma unroll
-        for (int d = 0; d < DEPTH; ++d) {
-            if (t + d < s1) {                                   // wave-uniform
+            for (int d = 0; d < 2; ++d) {
                 sched_fence();
-                load_stage((d + DEPTH - 1) % DEPTH, true);      // slab t + d + DEPTH - 1 (dead loads once past s1)
+                load_stage(d ^ 1, true);
                 sched_fence();
-                if (!(ablate & 4)) mfma_stage(d);
+                block_barrier();
+                sched_fence();
+                mfma_stage(d);
+                sched_fence();
+                block_barrier();
+            }
+        }
+        if (wave < WAVES / 2) block_barrier();
+    } else {
+        for (int t = s0; t < s1; t += DEPTH) {
+#pragma unroll
+            for (int d = 0; d < DEPTH; ++d) {
+                if (t + d < s1) {                                   // wave-uniform
+                    sched_fence();
+                    load_stage((d + DEPTH - 1) % DEPTH, true);      // slab t + d + DEPTH - 1 (dead loads once past s1)
+                    sched_fence();
+                    if (!(ablate & 4)) mfma_stage(d);
+                }
             }
         }
     }

@@ -178,13 +178,7 @@ __global__ __launch_bounds__(256, 1) void detect_chain_kernel(const DetectChainA
         for (int b = 0; b < MQ; ++b) { red_v[wave * MQ + b] = best_v[b]; red_i[wave * MQ + b] = best_i[b]; }
     }
     __syncthreads();
-    if (tid < MQ && tid < s.B) {
-        float v = red_v[tid];
-        int ix = red_i[tid];
-        for (int w = 1; w < 4; ++w)
-            if (better(red_v[w * MQ + tid], red_i[w * MQ + tid], v, ix)) { v = red_v[w * MQ + tid]; ix = red_i[w * MQ + tid]; }
-        scan_store_block_partial(s, tid, v, ix);
-    }
+    scan_store_block_partials<MQ>(s, red_v, red_i);
     stamp();                                                     // this block's rows scanned
     scan_ticket_finish<MQ>(s, red_v + 32);
     stamp();

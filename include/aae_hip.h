@@ -51,6 +51,8 @@ extern "C" {
 #define AAE_SCAN_STREAM_2L 4      /* the same stream kernel followed by a separate arg-max reduce launch (A/B, race screen) */
 #define AAE_SCAN_AUTO_NO_PRUNE 5  /* AUTO, but the top-k lists inside the query-resident scan take every candidate (no bound shared
                                      between the blocks): A/B of the pruning, same answers */
+#define AAE_SCAN_STREAM_WALK 6    /* STREAM with a block per compute unit walking the codebook, two 32-row batches in flight per wave,
+                                     instead of one batch per wave and the whole codebook requested at once: A/B, same answers */
 
 typedef struct aae_encoder aae_encoder;
 typedef struct aae_codebook aae_codebook;

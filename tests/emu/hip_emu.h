@@ -185,6 +185,10 @@ inline void coherent_store4(buffer_rsrc r, uint32_t byte_off, f32x4 v) {
     if ((uint64_t)byte_off + 16 <= r.bytes) memcpy(const_cast<unsigned char*>(r.base) + byte_off, &v, 16);
 }
 inline f32x4 coherent_load4(buffer_rsrc r, uint32_t byte_off) { return buffer_load4(r, byte_off); }
+inline void coherent_store2(buffer_rsrc r, uint32_t byte_off, uint32_t v0, uint32_t v1) {
+    const uint32_t v[2] = {v0, v1};
+    if ((uint64_t)byte_off + 8 <= r.bytes) memcpy(const_cast<unsigned char*>(r.base) + byte_off, v, 8);
+}
 inline void coherent_store1(buffer_rsrc r, uint32_t byte_off, uint32_t v) {
     if ((uint64_t)byte_off + 4 <= r.bytes) memcpy(const_cast<unsigned char*>(r.base) + byte_off, &v, 4);
 }
@@ -369,6 +373,21 @@ inline float wave_max_first_lane(float v, int& first_lane) {
     for (int l = 0; l < 64; ++l) { float o; memcpy(&o, &all[l][0], 4); if (o > m) m = o; }
     first_lane = 0;
     for (int l = 63; l >= 0; --l) { float o; memcpy(&o, &all[l][0], 4); if (o == m) first_lane = l; }
+    return m;
+}
+
+template <int NV>
+inline float wave_max_first_position(const float (&v)[NV], int& first_pos) {
+    // device_intrinsics.h: value j of lane l stands for position 64 j + l; NaNs rank as -inf, -0 as +0
+    float s[NV];
+    for (int j = 0; j < NV; ++j) { const float z = v[j] + 0.f; s[j] = (z == z) ? z : -INFINITY; }
+    const aae_emu::lane_slot* all = aae_emu::wave_exchange(s, 4 * NV);
+    float m = -INFINITY;
+    for (int l = 0; l < 64; ++l)
+        for (int j = 0; j < NV; ++j) { float o; memcpy(&o, &all[l][4 * j], 4); if (o > m) m = o; }
+    first_pos = 0;
+    for (int j = NV - 1; j >= 0; --j)
+        for (int l = 63; l >= 0; --l) { float o; memcpy(&o, &all[l][4 * j], 4); if (o == m) first_pos = 64 * j + l; }
     return m;
 }
 

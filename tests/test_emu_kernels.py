@@ -79,6 +79,7 @@ def test_generic_fallback_everything():
 
 @pytest.mark.parametrize('B,mode', [(1, _lib.AAE_SCAN_GEMV), (4, _lib.AAE_SCAN_GEMV), (3, _lib.AAE_SCAN_MFMA),
                                     (1, _lib.AAE_SCAN_STREAM), (2, _lib.AAE_SCAN_STREAM), (3, _lib.AAE_SCAN_AUTO),
+                                    (1, _lib.AAE_SCAN_STREAM_WALK), (4, _lib.AAE_SCAN_STREAM_WALK),
                                     (33, _lib.AAE_SCAN_AUTO), (70, _lib.AAE_SCAN_AUTO)])
 def test_codebook_scan_kernels(B, mode):
     N, J = 36 * 11 + 5, 128                                   # 401 rows: 3 full 128-row blocks + a partial one
@@ -103,6 +104,39 @@ def test_codebook_scan_kernels(B, mode):
         assert np.array_equal(ik, ref.topk_canonical(cs, 5))
         assert np.all(np.diff(sk, axis=1) <= 0)
     cb.close()
+
+
+@pytest.mark.parametrize('B', [1, 2, 3, 4])
+def test_walking_stream_scan_equals_the_one_batch_per_wave_form_bitwise(B):
+    """B <= 4: scan_stream_walk_kernel (a block per compute unit -- three on the emulator -- walks the codebook, two 32-row
+    batches in flight per wave, running best in scalar registers) against scan_stream_kernel (one batch per wave): indices,
+    scores and similarity rows bit for bit, with a ragged last batch, exact ties inside a batch, across the two batches a wave
+    has in flight and across waves, a zero latent (every score 0 -> row 0), and the upright stride."""
+    N, J = 36 * 60 + 7, 128                                   # 2167 rows = 68 batches: five or six per wave
+    E = synth.make_codebook(N, J, seed=17, planted_duplicates=0)
+    E[5] = E[36 * 40]                                         # twin rows far apart (different waves), close together (same batch) ...
+    E[36 * 40 + 3] = E[36 * 40 + 1]
+    E[36 * 20 + 384] = E[36 * 20]                             # ... and 12 batches apart: the two rings of one wave (12 waves on the emulator)
+    rows = [36 * 40, 36 * 40 + 3, 36 * 20 + 384, 100][:B]
+    z = np.stack([E[r] * (1.5 + i) for i, r in enumerate(rows)]).astype(np.float32)
+    if B == 4:
+        z[3] = 0.0
+    want = [5, 36 * 40 + 1, 36 * 20, 0][:B]
+    got = {}
+    for mode in (_lib.AAE_SCAN_STREAM_WALK, _lib.AAE_SCAN_AUTO):
+        cb = eb.EmuCodebook(E)
+        cb.set_mode(mode)
+        idx, score = cb.nn(z)
+        up, ups = cb.nn(z, col_stride=36)
+        got[mode] = (idx.copy(), score.copy(), cb.similarity(z).copy(), up.copy(), ups.copy())
+        cb.close()
+    a, b = got[_lib.AAE_SCAN_STREAM_WALK], got[_lib.AAE_SCAN_AUTO]
+    for u, v in zip(a, b):
+        assert np.array_equal(u, v)
+    assert a[0][:, 0].tolist() == want
+    cs64 = ref.cos_similarity(z, E)
+    assert np.abs(a[2] - cs64).max() < 2e-6
+    assert np.array_equal(a[3][:, 0], ref.nearest_indices_reference(a[2], 1, upright=True, num_cyclo=36))
 
 
 def test_small_latent_and_l2_normalize():
@@ -677,6 +711,28 @@ def test_wave_split_k_igemm_32x32_wave_tiles_on_eight_waves(B, order):
         assert 'conv_wavek_f32_32x32_w8_d2_g1 ' in labels[1], labels
     finally:
         eb.set_block_order(0)
+
+
+@pytest.mark.parametrize('tiny', [0, 64])
+def test_eight_wave_pingpong_schedule_is_bit_identical_to_the_free_running_loop(tiny):
+    """8-wave blocks: the two waves of a SIMD alternate load issue and MFMAs with a block barrier between the half-steps
+    (option wavek_pingpong; measured slower on MI355X, default off).  Same per-wave fma chains as the free-running loop: identical bits, for ragged K
+    ranges (25 slabs over 3 blocks x 8 waves: some waves get one slab, some two), 64 x 32 and 32 x 32 wave tiles."""
+    cfg = EncoderConfig((16, 16, 3), [32, 64], [2, 2], 5, 128)
+    w = synth.make_weights(seed=5, shape=cfg.shape, num_filter=cfg.num_filter, strides=cfg.strides, latent=128)
+    x = synth.make_crops(3, seed=6, shape=cfg.shape)
+    outs = []
+    for pp in (1, 0):
+        enc = eb.EmuEncoder(w, cfg)
+        for k, v in (('detect_chain', 0), ('wavek_waves', 8), ('wavek_tiny_waves', 8), ('wavek_tiny_max_tiles', tiny), ('wavek_pingpong', pp)):
+            enc.set_option(k, v)
+        z = enc.forward(x)
+        assert '_w8_d2' in enc.labels()[1], enc.labels()
+        outs.append((z.copy(), enc.activation(1).copy()))
+        enc.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    z64 = ref.encoder_forward_np(ref.input_to_float(x), w, cfg.strides, False)
+    assert np.abs(outs[0][0] - z64).max() / np.abs(z64).max() < 5e-6
 
 
 def test_f32x3h_range_flag_on_the_emulated_kernels():

@@ -25,7 +25,10 @@ if mode == 'noprep':       # every ticketed launch installs its own nonce (the a
     enc.set_option('ticket_prep', 0)
 for kv in (sys.argv[4].split(',') if len(sys.argv) > 4 else []):       # extra encoder options: name=value,name=value
     name, value = kv.split('=')
-    enc.set_option(name, int(value))
+    if name == 'scan_mode':                 # (a codebook option: AAE_SCAN_* of include/aae_hip.h)
+        cb.set_scan_mode(int(value))
+    else:
+        enc.set_option(name, int(value))
 x = torch.from_numpy(synth.make_crops(B, seed=3)).cuda()
 for _ in range(reps):
     if mode == 'old':

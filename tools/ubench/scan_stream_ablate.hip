@@ -1,0 +1,173 @@
+// Micro-benchmark (MI355X): where does the B <= 4 stream scan (92 232 x 128 fp32 rows) spend its time beyond the 47 MB stream?
+// The walking kernel of codebook_scan_f32.h rebuilt from its own helpers with parts of the per-batch arithmetic removed:
+//   ABL 0 full | 1 no wave arg-max | 2 no reduce-scatter (in-lane sum instead) | 3 neither | 4 loads only (one add per load)
+// and the grid / batches-in-flight varied.  Results of an ablated build are wrong by construction; only the time is looked at.
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -I augmentedautoencoder_amd/csrc -o build/ubench/scan_stream_ablate tools/ubench/scan_stream_ablate.hip
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include "device_intrinsics.h"
+#include "kernels/tile_f32.h"
+#include "kernels/codebook_scan_f32.h"
+
+#define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
+
+namespace aae {
+template <int NQ, int ABL>
+__device__ __forceinline__ void consume_abl(const ScanArgs& p, int row0, const f32x4 (&e)[16], const f32x4 (&qv)[NQ], float (&best_v)[NQ], int (&best_i)[NQ]) {
+    const int lane = threadIdx.x & 63;
+    const bool cand = row0 + (lane >> 1) < p.N;
+    if (ABL == 4) {
+        float s = 0.f;
+#pragma unroll
+        for (int u = 0; u < 16; ++u) s += e[u].x;
+#pragma unroll
+        for (int b = 0; b < NQ; ++b) best_v[b] += s;
+        return;
+    }
+#pragma unroll
+    for (int b = 0; b < NQ; ++b) {
+        float d;
+        if (ABL & 2) {
+            d = 0.f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                float t = e[u].x * qv[b].x;
+                t = fmaf(e[u].y, qv[b].y, t);
+                t = fmaf(e[u].z, qv[b].z, t);
+                d += fmaf(e[u].w, qv[b].w, t);
+            }
+        } else {
+            d = scan_scores32(e, qv[b]);
+        }
+        if (ABL & 1) {
+            best_v[b] += cand ? d : 0.f;
+        } else {
+            int first;
+            const float m = wave_max_first_lane(cand ? d : kNegInf, first);
+            if (m > best_v[b]) { best_v[b] = m; best_i[b] = row0 + (first >> 1); }
+        }
+    }
+}
+
+template <int NQ, int ABL>
+__global__ __launch_bounds__(256) void walk_abl_kernel(const ScanArgs p) {
+    AAE_DYN_SMEM(smem_raw);
+    float* red_v = reinterpret_cast<float*>(smem_raw);
+    int* red_i = reinterpret_cast<int*>(red_v + 4 * NQ);
+    const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
+    const int col = (lane & 31) * 4;
+    const int nbatch = (p.N + 31) >> 5;
+    const int gw = (int)blockIdx.x * 4 + wave, nw = (int)gridDim.x * 4;
+    f32x4 zv[NQ];
+#pragma unroll
+    for (int b = 0; b < NQ; ++b) zv[b] = *reinterpret_cast<const f32x4*>(p.z + (long long)b * p.J + col);
+    const buffer_rsrc ebuf = make_buffer(p.E, p.e_bytes);
+    f32x4 ea[16], eb[16];
+    scan_issue32(p, ebuf, gw < nbatch ? gw * 32 : p.N, p.N, ea);
+    scan_issue32(p, ebuf, gw + nw < nbatch ? (gw + nw) * 32 : p.N, p.N, eb);
+    if (p.tickets && blockIdx.x == 0) ticket_prepare_slot(p.tickets, p.nonce, gridDim.x);
+    f32x4 qv[NQ];
+    scan_normalise_queries<NQ>(zv, qv);
+    float best_v[NQ];
+    int best_i[NQ];
+#pragma unroll
+    for (int b = 0; b < NQ; ++b) { best_v[b] = kNegInf; best_i[b] = 0x7fffffff; }
+    for (int i = gw; i < nbatch; i += 2 * nw) {
+        consume_abl<NQ, ABL>(p, i * 32, ea, qv, best_v, best_i);
+        scan_issue32(p, ebuf, i + 2 * nw < nbatch ? (i + 2 * nw) * 32 : p.N, p.N, ea);
+        if (i + nw < nbatch) consume_abl<NQ, ABL>(p, (i + nw) * 32, eb, qv, best_v, best_i);
+        scan_issue32(p, ebuf, i + 3 * nw < nbatch ? (i + 3 * nw) * 32 : p.N, p.N, eb);
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int b = 0; b < NQ; ++b) { red_v[wave * NQ + b] = best_v[b]; red_i[wave * NQ + b] = best_i[b]; }
+    }
+    __syncthreads();
+    scan_store_block_partials<NQ>(p, red_v, red_i);
+    if (p.tickets) scan_ticket_finish<NQ>(p, red_v + 8 * NQ);
+}
+__global__ void trivial_kernel(float* o) { if (threadIdx.x == 0 && blockIdx.x == 0) o[0] = 1.f; }
+}  // namespace aae
+
+static unsigned g_nonce = 1;
+template <int NQ, int ABL>
+static int run(const char* what, aae::ScanArgs a, int blocks, bool ticket) {
+    const int smem = 8 * NQ * 4 + aae::kScanTicketSmem;
+    hipEvent_t e0, e1;
+    CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    unsigned long long* tk = a.tickets;
+    if (!ticket) a.tickets = nullptr;
+    const int reps = 200;
+    for (int w = 0; w < 10; ++w) { a.nonce = ++g_nonce; hipLaunchKernelGGL((aae::walk_abl_kernel<NQ, ABL>), dim3(blocks), dim3(256), smem, 0, a); }
+    CHECK(hipEventRecord(e0, 0));
+    for (int r = 0; r < reps; ++r) { a.nonce = ++g_nonce; hipLaunchKernelGGL((aae::walk_abl_kernel<NQ, ABL>), dim3(blocks), dim3(256), smem, 0, a); }
+    CHECK(hipEventRecord(e1, 0));
+    CHECK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    CHECK(hipEventElapsedTime(&ms, e0, e1));
+    printf("{\"what\": \"scan_stream_ablate\", \"NQ\": %d, \"ablate\": %d, \"variant\": \"%s\", \"blocks\": %d, \"ticket\": %d, \"us_per_launch\": %.2f}\n", NQ, ABL, what, blocks, ticket ? 1 : 0,
+           ms * 1000.f / reps);
+    a.tickets = tk;
+    return 0;
+}
+
+int main() {
+    hipDeviceProp_t prop;
+    CHECK(hipGetDeviceProperties(&prop, 0));
+    const int cus = prop.multiProcessorCount;
+    const int N = 92232, J = 128;
+    float* E; float* z; float* pval; int* pidx; unsigned long long* tickets; long long* idx; float* score;
+    CHECK(hipMalloc(&E, (size_t)N * J * 4));
+    CHECK(hipMalloc(&z, 4 * J * 4));
+    CHECK(hipMalloc(&pval, 4096 * 4 * 4));
+    CHECK(hipMalloc(&pidx, 4096 * 4 * 4));
+    CHECK(hipMalloc(&tickets, aae::kTicketSlotWords * 8));
+    CHECK(hipMalloc(&idx, 4 * 8));
+    CHECK(hipMalloc(&score, 4 * 4));
+    CHECK(hipMemset(tickets, 0, aae::kTicketSlotWords * 8));
+    {
+        const size_t n = (size_t)N * J;
+        float* h = (float*)malloc(n * 4);
+        unsigned s = 12345u;
+        for (size_t k = 0; k < n; ++k) { s = s * 1664525u + 1013904223u; h[k] = ((int)(s >> 8) % 2001 - 1000) * 1e-4f; }
+        CHECK(hipMemcpy(E, h, n * 4, hipMemcpyHostToDevice));
+        CHECK(hipMemcpy(z, h, 4 * J * 4, hipMemcpyHostToDevice));
+        free(h);
+    }
+    aae::ScanArgs a;
+    a.E = E; a.q = nullptr; a.qp = nullptr; a.pval = pval; a.pidx = pidx; a.cs = nullptr;
+    a.N = N; a.J = J; a.Jpad = 128; a.B = 4; a.Bpad = 32; a.Bstride = 32; a.col_stride = 1; a.z = z; a.e_bytes = (unsigned)((size_t)N * J * 4);
+    a.tickets = tickets; a.idx_out = idx; a.score_out = score; a.idx_scale = 1;
+    {   // launch floor: a trivial kernel back to back
+        hipEvent_t e0, e1; CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+        for (int w = 0; w < 10; ++w) hipLaunchKernelGGL(aae::trivial_kernel, dim3(256), dim3(256), 0, 0, score);
+        CHECK(hipEventRecord(e0, 0));
+        for (int r = 0; r < 200; ++r) hipLaunchKernelGGL(aae::trivial_kernel, dim3(256), dim3(256), 0, 0, score);
+        CHECK(hipEventRecord(e1, 0)); CHECK(hipEventSynchronize(e1));
+        float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
+        printf("{\"what\": \"trivial_kernel_period\", \"us_per_launch\": %.2f}\n", ms * 5.f);
+    }
+    for (int pass = 0; pass < 2; ++pass) {
+        a.B = 4;
+        if (run<4, 0>("full", a, cus, true)) return 1;
+        if (run<4, 1>("no wave arg-max", a, cus, true)) return 1;
+        if (run<4, 2>("no reduce-scatter", a, cus, true)) return 1;
+        if (run<4, 3>("fma only", a, cus, true)) return 1;
+        if (run<4, 4>("loads only", a, cus, true)) return 1;
+        if (run<4, 0>("full, no ticket finish", a, cus, false)) return 1;
+        if (run<4, 0>("full, 2 blocks per CU", a, 2 * cus, true)) return 1;
+        if (run<4, 0>("full, 721 blocks", a, 721, true)) return 1;
+        if (run<4, 4>("loads only, 721 blocks", a, 721, true)) return 1;
+        if (run<4, 4>("loads only, 2 blocks per CU", a, 2 * cus, true)) return 1;
+        a.B = 1;
+        if (run<1, 0>("full", a, cus, true)) return 1;
+        if (run<1, 3>("fma only", a, cus, true)) return 1;
+        if (run<1, 4>("loads only", a, cus, true)) return 1;
+        if (run<1, 4>("loads only, no ticket finish", a, cus, false)) return 1;
+        if (run<1, 0>("full, 2 blocks per CU", a, 2 * cus, true)) return 1;
+        if (run<1, 0>("full, 721 blocks", a, 721, true)) return 1;
+    }
+    return 0;
+}
