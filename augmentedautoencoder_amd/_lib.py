@@ -16,7 +16,7 @@ AAE_DTYPE_F32 = 1
 AAE_DTYPE_BF16 = 2
 AAE_MAX_LAYERS = 8
 AAE_SCAN_AUTO, AAE_SCAN_GEMV, AAE_SCAN_MFMA, AAE_SCAN_STREAM, AAE_SCAN_STREAM_2L, AAE_SCAN_AUTO_NO_PRUNE, AAE_SCAN_STREAM_WALK = 0, 1, 2, 3, 4, 5, 6
-AAE_ABI_VERSION = 1
+AAE_ABI_VERSION = 2
 
 LIB_NAME = 'libaae_hip.so'
 
@@ -26,10 +26,11 @@ EXPORTED_SYMBOLS = (
     'aae_encoder_create', 'aae_encoder_destroy', 'aae_encoder_set_option', 'aae_encoder_workspace_bytes', 'aae_encoder_forward',
     'aae_encoder_forward_timed', 'aae_encoder_kernel_label', 'aae_encoder_kernel_flops',
     'aae_encoder_activation_info', 'aae_encoder_debug_timeline', 'aae_encoder_x3h_saturated', 'aae_encoder_x3h_last_slot', 'aae_encoder_x3h_poll',
+    'aae_encoder_x3h_release_slot',
     'aae_encoder_split_precision_for_batch',
     'aae_codebook_create', 'aae_codebook_update', 'aae_codebook_destroy', 'aae_codebook_set_scan_mode',
     'aae_codebook_prepare_upright',
-    'aae_codebook_workspace_bytes', 'aae_codebook_nn', 'aae_encode_nn', 'aae_codebook_similarity', 'aae_l2_normalize',
+    'aae_codebook_workspace_bytes', 'aae_codebook_nn', 'aae_codebook_nn_timed', 'aae_encode_nn', 'aae_detect_nn', 'aae_codebook_similarity', 'aae_l2_normalize',
     'aae_crop_resize_u8', 'aae_pack_pairs', 'aae_unpack_pairs',
     'aae_decoder_create', 'aae_decoder_destroy', 'aae_decoder_workspace_bytes', 'aae_decoder_forward',
     'aae_decoder_forward_timed', 'aae_decoder_kernel_label', 'aae_decoder_kernel_flops', 'aae_decoder_activation_info',
@@ -94,6 +95,8 @@ def declare(lib):
     lib.aae_encoder_x3h_last_slot.argtypes = []
     lib.aae_encoder_x3h_poll.restype = c_int
     lib.aae_encoder_x3h_poll.argtypes = [c_void_p, POINTER(c_int), c_int, POINTER(c_int), c_void_p]
+    lib.aae_encoder_x3h_release_slot.restype = c_int
+    lib.aae_encoder_x3h_release_slot.argtypes = [c_void_p, c_int]
     lib.aae_encoder_debug_timeline.restype = c_int
     lib.aae_encoder_debug_timeline.argtypes = [c_void_p, POINTER(c_int64)]
     lib.aae_encoder_activation_info.restype = c_int
@@ -120,6 +123,11 @@ def declare(lib):
                                   c_void_p, c_size_t, c_void_p]
     lib.aae_codebook_nn.restype = c_int
     lib.aae_codebook_nn.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.aae_codebook_nn_timed.restype = c_int
+    lib.aae_codebook_nn_timed.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_int, POINTER(c_float)]
+    lib.aae_detect_nn.restype = c_int
+    lib.aae_detect_nn.argtypes = [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                                  c_void_p, c_size_t, c_void_p, c_size_t, c_void_p]
     lib.aae_codebook_similarity.restype = c_int
     lib.aae_codebook_similarity.argtypes = [c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]
     lib.aae_l2_normalize.restype = c_int

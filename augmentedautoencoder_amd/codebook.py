@@ -278,7 +278,9 @@ class Codebook(object):
         if depth_preds is None:
             num = np.array([np.linalg.norm(np.float32(r[2:])) for r in rb], dtype=np.float32)
             den = np.array([np.linalg.norm(np.float32(bb[2:])) for bb in predicted_bbs], dtype=np.float32)
-            z = (num / den) * K_diag_ratio * render_radius          # float32 quotient, then float64 products: as the scalar code
+            # float32 quotient, then float64 products, as the scalar code does it -- the cast is explicit so that NumPy 1.x's
+            # value-based casting (float32 array x float64 scalar -> float32) gives the same bits as NumPy 2's promotion
+            z = (num / den).astype(np.float64) * K_diag_ratio * render_radius
         else:
             z = np.array([float(d) for d in depth_preds], dtype=np.float64)
         cx_train = rb[:, 0] + rb[:, 2] / 2. - K_train[0, 2]

@@ -110,7 +110,9 @@ struct aae_encoder {
     // together when their results are consumed (aae_encoder_x3h_poll).
     int* x3h_sat = nullptr;                // device [kX3hRing + kX3hCaptured]
     std::atomic<unsigned long long> x3h_seq{0};
-    std::atomic<int> x3h_captured{0};
+    int x3h_captured = 0;                  // slots of the captured region handed out so far (under x3h_mu) ...
+    std::vector<int> x3h_free;             // ... and the ones given back (aae_encoder_x3h_release_slot)
+    std::mutex x3h_mu;
     std::vector<void*> allocations;
     std::vector<aae_host::KernelRecord> records;   // of the most recent completed forward (swapped in under rec_mu)
     std::mutex rec_mu;
@@ -1060,9 +1062,15 @@ static int forward_impl(aae_encoder* enc, const void* x, int x_dtype, int B, flo
         (void)hipStreamIsCapturing(stream, &capture);
         int slot;
         if (capture != hipStreamCaptureStatusNone) {
-            const int c = enc->x3h_captured.fetch_add(1, std::memory_order_relaxed);
-            if (c >= kX3hCaptured) return fail(AAE_ERR_UNSUPPORTED, "more than %d f32x3h forwards captured into HIP graphs on one encoder handle", kX3hCaptured);
-            slot = kX3hRing + c;
+            std::lock_guard<std::mutex> lk(enc->x3h_mu);
+            if (!enc->x3h_free.empty()) {
+                slot = enc->x3h_free.back();
+                enc->x3h_free.pop_back();
+            } else {
+                if (enc->x3h_captured >= kX3hCaptured)         // (nothing is consumed by the failing call)
+                    return fail(AAE_ERR_UNSUPPORTED, "more than %d f32x3h forwards live in HIP graphs on one encoder handle (aae_encoder_x3h_release_slot returns a destroyed graph's slot)", kX3hCaptured);
+                slot = kX3hRing + enc->x3h_captured++;
+            }
         } else {
             slot = (int)(enc->x3h_seq.fetch_add(1, std::memory_order_relaxed) % kX3hRing);
         }
@@ -1739,6 +1747,18 @@ int aae_encoder_x3h_poll(aae_encoder* enc, const int* slots, int n, int* flags_o
     return AAE_OK;
 }
 
+int aae_encoder_x3h_release_slot(aae_encoder* enc, int slot) {
+    using namespace aae_host;
+    if (!enc) return fail(AAE_ERR_INVALID, "aae_encoder_x3h_release_slot: null handle");
+    if (slot < kX3hRing || slot >= kX3hRing + kX3hCaptured) return fail(AAE_ERR_INVALID, "aae_encoder_x3h_release_slot: slot %d is not a captured forward's", slot);
+    std::lock_guard<std::mutex> lk(enc->x3h_mu);
+    if (slot >= kX3hRing + enc->x3h_captured || std::find(enc->x3h_free.begin(), enc->x3h_free.end(), slot) != enc->x3h_free.end())
+        return fail(AAE_ERR_INVALID, "aae_encoder_x3h_release_slot: slot %d is not in use", slot);
+    AAE_HIP_TRY(hipMemset(enc->x3h_sat + slot, 0, sizeof(int)));          // (the next owner starts from a lowered flag)
+    enc->x3h_free.push_back(slot);
+    return AAE_OK;
+}
+
 int aae_encoder_debug_timeline(aae_encoder* enc, long long* host_out) {
     using namespace aae_host;
     if (!enc || !host_out) return fail(AAE_ERR_INVALID, "aae_encoder_debug_timeline: null argument");
@@ -1927,6 +1947,29 @@ int aae_codebook_nn(aae_codebook* cb, const float* z, int B, int topk, int col_s
     return nn_impl(cb, z, B, topk, col_stride, idx_out, score_out, workspace, ws_bytes, stream, 0u);
 }
 
+int aae_codebook_nn_timed(aae_codebook* cb, const float* z, int B, int topk, int col_stride, int64_t* idx_out,
+                          float* score_out, void* workspace, size_t ws_bytes, void* stream_v, int reps, float* kernel_ms) {
+    using namespace aae_host;
+    if (!kernel_ms || reps < 1) return fail(AAE_ERR_INVALID, "aae_codebook_nn_timed: null output or reps < 1");
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    hipEvent_t e0, e1;
+    AAE_HIP_TRY(hipEventCreate(&e0));
+    AAE_HIP_TRY(hipEventCreate(&e1));
+    int rc = AAE_OK;
+    hipError_t e = hipEventRecord(e0, stream);
+    if (e == hipSuccess) {
+        for (int r = 0; r < reps && rc == AAE_OK; ++r) rc = nn_impl(cb, z, B, topk, col_stride, idx_out, score_out, workspace, ws_bytes, stream_v, 0u);
+        e = hipEventRecord(e1, stream);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        if (e == hipSuccess && rc == AAE_OK) e = hipEventElapsedTime(kernel_ms, e0, e1);
+        if (e == hipSuccess && rc == AAE_OK) *kernel_ms /= (float)reps;
+    }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    if (rc == AAE_OK && e != hipSuccess) rc = fail(AAE_ERR_RUNTIME, "aae_codebook_nn_timed: %s", hipGetErrorString(e));
+    return rc;
+}
+
 int aae_encode_nn(aae_encoder* enc, aae_codebook* cb, const void* x, int x_dtype, int B, int col_stride, float* z_out,
                   int64_t* idx_out, float* score_out, void* enc_workspace, size_t enc_ws_bytes, void* cb_workspace,
                   size_t cb_ws_bytes, void* stream) {
@@ -2028,6 +2071,17 @@ int aae_crop_resize_u8(const void* img, int H, int W, int C, const int32_t* boxe
                static_cast<hipStream_t>(stream_v), a);
     AAE_HIP_TRY(hipGetLastError());
     return AAE_OK;
+}
+
+int aae_detect_nn(aae_encoder* enc, aae_codebook* cb, const void* img, int H, int W, int C, const int32_t* boxes, int n,
+                  int col_stride, void* crops, float* z_out, int64_t* idx_out, float* score_out,
+                  void* enc_workspace, size_t enc_ws_bytes, void* cb_workspace, size_t cb_ws_bytes, void* stream) {
+    using namespace aae_host;
+    if (!enc || !cb || !crops) return fail(AAE_ERR_INVALID, "aae_detect_nn: null argument");
+    if (C != enc->desc.in_c) return fail(AAE_ERR_INVALID, "aae_detect_nn: image has %d channels, the encoder takes %d", C, enc->desc.in_c);
+    if (int rc = aae_crop_resize_u8(img, H, W, C, boxes, n, enc->desc.in_h, enc->desc.in_w, crops, stream)) return rc;
+    return aae_encode_nn(enc, cb, crops, AAE_DTYPE_U8, n, col_stride, z_out, idx_out, score_out, enc_workspace, enc_ws_bytes, cb_workspace,
+                         cb_ws_bytes, stream);
 }
 
 }  // extern "C"

@@ -160,14 +160,16 @@ class EncoderEngine(object):
     def _x3h_note(self, redo):
         """Called right after a forward / encode_nn C call: if it ran in f32x3h, remember its range-flag slot and how to
         redo it in exact fp32.  No synchronisation here; settle() looks at the flags."""
-        if not self.x3h_fallback or self.options.get('precision', 0) not in (1, 2):
+        if self.options.get('precision', 0) not in (1, 2):
             return
         slot = self.lib.aae_encoder_x3h_last_slot()
         if slot < 0:
             return
         torch = _torch()
         if torch.cuda.is_current_stream_capturing():
-            self._x3h_captured_slot = slot        # a graph owns this slot; CapturedNearestNeighbour polls it after each replay
+            self._x3h_captured_slot = slot        # a graph owns this slot until it is released (CapturedNearestNeighbour polls it after each replay)
+            return
+        if not self.x3h_fallback:
             return
         self._x3h_pending.append((slot, redo))
         if len(self._x3h_pending) >= 192:         # the ring has 256 slots: never let un-checked forwards share one
@@ -252,6 +254,42 @@ class EncoderEngine(object):
         z = self.encode(x)
         self.settle()
         return z
+
+    def detect_nn(self, codebook_engine, image, rows, n, col_stride, crops, z, idx, score):
+        """All `n` detections of this object in a frame in ONE C call (aae_detect_nn): crop + bilinear resize of the boxes
+        `rows` (int32 [n,5] x, y, w, h, size) out of `image` (uint8 [H,W,C]) into `crops`, encoder, top-1 codebook query.
+        Every argument is caller-owned storage that the per-frame loop reuses: image / rows on the device or in pinned host
+        memory (device-accessible), crops [>=n,h,w,c] uint8 / z [>=n,J] / score [>=n] device tensors, idx int64 [>=n] on the
+        device or pinned (a pinned tensor receives the indices without a copy back).  No checks beyond the C side's: the
+        estimator's staging code is the one caller.  Chunks of max_batch."""
+        torch = _torch()
+        cb = codebook_engine
+        H, W, C = int(image.shape[0]), int(image.shape[1]), int(image.shape[2])
+        cb.ensure_upright(col_stride, 1)
+        stream = _stream_ptr(torch)
+        rows_ptr, crops_ptr, z_ptr, idx_ptr, score_ptr = rows.data_ptr(), crops.data_ptr(), z.data_ptr(), idx.data_ptr(), score.data_ptr()
+        per_crop, J = int(crops[0].numel()), int(z.shape[1])
+        for a in range(0, n, self.max_batch):
+            m = min(self.max_batch, n - a)
+            nb_e = self.workspace_bytes(m)
+            nb_c = cb.workspace_bytes(m, 1)
+            _, ws_e = self.ws.get(nb_e)
+            _, ws_c = cb.ws.get(nb_c)
+            self._last_B = m
+            with _on_device(self.device):
+                rc = self.lib.aae_detect_nn(self.handle, cb.handle, ctypes.c_void_p(image.data_ptr()), H, W, C,
+                                            ctypes.c_void_p(rows_ptr + 20 * a), m, int(col_stride), ctypes.c_void_p(crops_ptr + per_crop * a),
+                                            ctypes.c_void_p(z_ptr + 4 * J * a), ctypes.c_void_p(idx_ptr + 8 * a), ctypes.c_void_p(score_ptr + 4 * a),
+                                            ctypes.c_void_p(ws_e), nb_e, ctypes.c_void_p(ws_c), nb_c, stream)
+            _lib.check(self.lib, rc, 'aae_detect_nn')
+
+            def redo(a=a, m=m):                   # (split precision, out of range: the chunk again in exact fp32, from its crops)
+                za, ia, sa = self.encode_nn(cb, crops[a:a + m], col_stride)
+                z[a:a + m] = za
+                score[a:a + m] = sa[:, 0]
+                idx[a:a + m].copy_(ia[:, 0])
+                torch.cuda.current_stream().synchronize()
+            self._x3h_note(redo)
 
     def encode_nn(self, codebook_engine, x, col_stride=1, out=None):
         """Encoder.z + the top-1 codebook query of a batch in one C call per chunk (aae_encode_nn): what
@@ -433,6 +471,25 @@ class CodebookEngine(object):
                                           ctypes.c_void_p(ws_ptr), nbytes, _stream_ptr(torch))
         _lib.check(self.lib, rc, 'aae_codebook_nn')
         return idx, score
+
+    def nn_timed(self, z, topk=1, col_stride=1, reps=100):
+        """nn() `reps` times back to back, queued from C between two HIP events: (idx, score, device milliseconds per query --
+        kernel(s) + dependent-launch gap, free of the per-call host cost of a Python loop)."""
+        torch = _torch()
+        z = self._z(z)
+        B = z.shape[0]
+        idx = torch.empty((B, topk), dtype=torch.int64, device=self.device)
+        score = torch.empty((B, topk), dtype=torch.float32, device=self.device)
+        self.ensure_upright(col_stride, topk)
+        nbytes = self.workspace_bytes(B, topk)
+        _, ws_ptr = self.ws.get(nbytes)
+        ms = ctypes.c_float(0.0)
+        with _on_device(self.device):
+            rc = self.lib.aae_codebook_nn_timed(self.handle, ctypes.c_void_p(z.data_ptr()), B, int(topk), int(col_stride),
+                                                ctypes.c_void_p(idx.data_ptr()), ctypes.c_void_p(score.data_ptr()),
+                                                ctypes.c_void_p(ws_ptr), nbytes, _stream_ptr(torch), int(reps), ctypes.byref(ms))
+        _lib.check(self.lib, rc, 'aae_codebook_nn_timed')
+        return idx, score, float(ms.value)
 
     def similarity(self, z):
         """Full cos_similarity [B,N] (codebook.py:50) on the device."""
@@ -682,14 +739,26 @@ class CapturedNearestNeighbour(object):
     forward's range flag (a host round trip) and, if it is up, by an eager exact-fp32 recomputation -- the same
     guarantee the eager path gives."""
 
-    def __init__(self, encoder_engine, codebook_engine, batch, in_dtype='uint8', topk=1, col_stride=1):
+    def __init__(self, encoder_engine, codebook_engine, batch, in_dtype='uint8', topk=1, col_stride=1, force_graph=False):
+        """force_graph: record and replay a graph also for the per-detection batches (B <= 4, top-1), where the fused eager call
+        -- ONE C call that queues the six launches -- is measured FASTER than a graph replay (81.8 vs 87.0 us at B = 1: a replay
+        costs the host 10-16 us, the C call 3-5): there the object keeps its interface (static input / output tensors) and
+        simply makes that call.  bench.py forces the graph to keep measuring it."""
         torch = _torch()
         self.enc, self.cb = encoder_engine, codebook_engine
         self.batch, self.topk, self.col_stride = int(batch), int(topk), int(col_stride)
         dt = torch.uint8 if in_dtype in ('uint8', torch.uint8) else torch.float32
         dev = encoder_engine.device
         self._x3h_slot = -1
+        self.graph = None
         self.x = torch.zeros((self.batch,) + tuple(encoder_engine.cfg.shape), dtype=dt, device=dev)
+        self.eager = self.batch <= 4 and self.topk == 1 and not force_graph
+        if self.eager:
+            self.z = torch.empty((self.batch, encoder_engine.cfg.latent_space_size), dtype=torch.float32, device=dev)
+            self.idx = torch.empty((self.batch, 1), dtype=torch.int64, device=dev)
+            self.score = torch.empty((self.batch, 1), dtype=torch.float32, device=dev)
+            self._ws = None
+            return
         # The graph bakes raw device addresses: its scratch memory must outlive it and must never be regrown by somebody
         # else.  So the capture runs on PRIVATE workspaces owned by this object (the engines' own grow-only buffers are
         # put back afterwards and may be reallocated by later eager calls with larger batches without touching the graph);
@@ -716,7 +785,23 @@ class CapturedNearestNeighbour(object):
             with torch.cuda.graph(self.graph):
                 self.z, self.idx, self.score = self._query()
             # split-precision capture: the recorded forward owns a range-flag slot of its own, looked at after every replay
-            self._x3h_slot = self.enc._x3h_captured_slot if self.enc.x3h_fallback else -1
+            self._owned_slot = self.enc._x3h_captured_slot
+            self._x3h_slot = self._owned_slot if self.enc.x3h_fallback else -1
+
+    def close(self):
+        """Drop the graph and give the range-flag slot of a split-precision capture back to the encoder (64 per handle)."""
+        self.graph = None
+        slot, self._owned_slot = getattr(self, '_owned_slot', -1), -1
+        self._x3h_slot = -1
+        if slot >= 0 and getattr(self.enc, 'handle', None):
+            _torch().cuda.synchronize(self.enc.device)          # (no replay may still be writing the flag)
+            _lib.check(self.enc.lib, self.enc.lib.aae_encoder_x3h_release_slot(self.enc.handle, int(slot)), 'aae_encoder_x3h_release_slot')
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
     def _query(self):
         if self.topk == 1:                               # one C call: conv1 prepares the ticket words of the later launches
@@ -738,6 +823,11 @@ class CapturedNearestNeighbour(object):
         if x.dtype != self.x.dtype:
             raise ValueError('captured for dtype %s, got %s' % (self.x.dtype, x.dtype))
         self.x.copy_(x, non_blocking=True)
+        if self.eager:
+            self.enc.encode_nn(self.cb, self.x, self.col_stride, out=(self.z, self.idx, self.score))
+            if self.enc._x3h_pending:
+                self.enc.settle()                # (split precision: the same checked result a replay gives)
+            return self.idx, self.score
         self.graph.replay()
         if self._x3h_slot >= 0 and self.enc._x3h_poll([self._x3h_slot])[0]:
             # f32x3h replay that left the fp16 pair range (one host round trip per replay in this mode -- the price of a
@@ -757,7 +847,11 @@ class CapturedNearestNeighbour(object):
 
 class StreamingNearestNeighbour(object):
     """Host-resident crop batches -> (idx, score) with the H2D copy of batch i+1 overlapped with
-    encode+scan of batch i: two device input buffers, a copy stream, event hand-offs.  The copy is
+    encode+scan of batch i: a ring of three device input buffers, a copy stream, event hand-offs.
+    (Three, not two: in split-precision mode the range flag of batch i is only read when batch i's results are fetched,
+    one iteration later, and a batch that left the fp16 pair range is then recomputed FROM ITS INPUT BUFFER -- which
+    must not have been handed to the next upload by then.  With three buffers the buffer of batch i is recycled for
+    batch i + 3, after batch i has been fetched and settled.)  The copy is
     issued straight from the caller's (pageable) array after the kernels of the previous batch
     have been queued -- the runtime's own bounce buffers move 12.6 MB in ~0.4 ms while the GPU is
     busy for ~8 ms; an extra staging copy into pinned memory measured 3.5x SLOWER end to end
@@ -772,11 +866,12 @@ class StreamingNearestNeighbour(object):
         dt = torch.uint8 if in_dtype in ('uint8', torch.uint8) else torch.float32
         dev = encoder_engine.device
         shape = (self.batch,) + tuple(encoder_engine.cfg.shape)
-        self.dev = [torch.empty(shape, dtype=dt, device=dev) for _ in range(2)]
+        self.slots = 3
+        self.dev = [torch.empty(shape, dtype=dt, device=dev) for _ in range(self.slots)]
         with _on_device(dev):
             self.copy_stream = torch.cuda.Stream()
-            self.copied = [torch.cuda.Event() for _ in range(2)]
-            self.consumed = [torch.cuda.Event() for _ in range(2)]
+            self.copied = [torch.cuda.Event() for _ in range(self.slots)]
+            self.consumed = [torch.cuda.Event() for _ in range(self.slots)]
 
     def _upload(self, slot, x):
         torch = _torch()
@@ -815,13 +910,13 @@ class StreamingNearestNeighbour(object):
             except StopIteration:
                 nxt = None
             if nxt is not None:
-                n_next = self._upload(slot ^ 1, nxt)                # overlaps the kernels just queued
+                n_next = self._upload((slot + 1) % self.slots, nxt)  # overlaps the kernels just queued; that buffer's batch was fetched (and settled) an iteration ago
             if pending is not None:
                 yield self._fetch(pending)
             pending = (idx, score)
             if nxt is None:
                 break
-            slot ^= 1
+            slot = (slot + 1) % self.slots
             n = n_next
         yield self._fetch(pending)
 
@@ -830,5 +925,10 @@ class StreamingNearestNeighbour(object):
         an affected batch has been recomputed in place (exact fp32) when this returns."""
         idx, score = pair[0].cpu(), pair[1].cpu()
         if self.enc.settle():
+            # recompute kernels were queued just now and read input buffers whose `consumed` events are older: no upload may
+            # overtake them
+            compute = _torch().cuda.current_stream()
+            for ev in self.consumed:
+                ev.record(compute)
             idx, score = pair[0].cpu(), pair[1].cpu()
         return idx.numpy(), score.numpy()

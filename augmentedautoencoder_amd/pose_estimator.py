@@ -54,8 +54,7 @@ class _FrameStage(object):
     def __init__(self, device):
         self.device = device
         self.img_host = self.img_dev = None
-        self.rows_host = self.rows_dev = None
-        self.crops = self.z = self.idx = self.score = self.idx_host = None
+        self.crops = self.z = self.score = self.idx_host = None
 
     @staticmethod
     def _grow(torch, old, n, dtype, device=None, pin=False):
@@ -64,25 +63,28 @@ class _FrameStage(object):
         n = max(int(n), 1)
         return torch.empty((n,), dtype=dtype, pin_memory=True) if pin else torch.empty((n,), dtype=dtype, device=device)
 
-    def upload_image(self, torch, frame):
-        """frame: uint8 [h,w,c] (any strides) -> contiguous device tensor [h,w,c], queued on the current stream"""
+    def upload_frame_and_rows(self, torch, frame, rows):
+        """frame uint8 [h,w,c] (any strides) and the int32 [total,5] box rows behind it in ONE pinned staging buffer and ONE
+        asynchronous copy (two copies cost two trips through the copy engine: ~8 us each in front of a 82 us query).
+        Returns the device views (image [h,w,c], rows [total,5])."""
         h, w, c = frame.shape
         n = h * w * c
-        self.img_host = self._grow(torch, self.img_host, n, torch.uint8, pin=True)
-        self.img_dev = self._grow(torch, self.img_dev, n, torch.uint8, self.device)
-        np.copyto(self.img_host.numpy()[:n].reshape(h, w, c), frame)
-        dev = self.img_dev[:n]
-        dev.copy_(self.img_host[:n], non_blocking=True)
-        return dev.view(h, w, c)
+        off = (n + 15) // 16 * 16
+        total = off + rows.nbytes
+        self.img_host = self._grow(torch, self.img_host, total, torch.uint8, pin=True)
+        self.img_dev = self._grow(torch, self.img_dev, total, torch.uint8, self.device)
+        host = self.img_host.numpy()
+        np.copyto(host[:n].reshape(h, w, c), frame)
+        host[off:total].view(np.int32)[:] = rows.reshape(-1)
+        self.img_dev[:total].copy_(self.img_host[:total], non_blocking=True)
+        return self.img_dev[:n].view(h, w, c), self.img_dev[off:total].view(torch.int32).view(-1, 5)
 
     def reserve(self, torch, total, latent, crop_shape):
-        """room for `total` detections of this frame: box rows, crops [total,h,w,c], latents, indices, scores"""
+        """room for `total` detections of this frame: crops [total,h,w,c], latents, scores (device), indices (pinned host: the
+        scan writes them there itself)"""
         per_crop = int(np.prod(crop_shape))
-        self.rows_host = self._grow(torch, self.rows_host, total * 5, torch.int32, pin=True)
-        self.rows_dev = self._grow(torch, self.rows_dev, total * 5, torch.int32, self.device)
         self.crops = self._grow(torch, self.crops, total * per_crop, torch.uint8, self.device)
         self.z = self._grow(torch, self.z, total * latent, torch.float32, self.device)
-        self.idx = self._grow(torch, self.idx, total, torch.int64, self.device)
         self.score = self._grow(torch, self.score, total, torch.float32, self.device)
         self.idx_host = self._grow(torch, self.idx_host, total, torch.int64, pin=True)
 
@@ -134,6 +136,7 @@ class AePoseEstimator(object):
             raise NotImplementedError('topk > 1 not implemented (as in the reference, ae_pose_estimator.py:36-39)')
         self._camPose, self._upright, self._topk = bool(camPose), bool(upright), int(topk)
         self.upload_union_only = True      # process(): upload the union rectangle of the boxes instead of the frame
+        self.geometry_chunk = 16           # process(): classes with more than 2 x this many detections go to the GPU in chunks of this size
         if self._camPose:
             self._process_requirements.append('camPose')
 
@@ -269,55 +272,60 @@ class AePoseEstimator(object):
         return poses
 
     def _process_staged(self, accepted, classes, frame, off_x, off_y, camK, device):
-        """The same on the GPU with everything queued before the first wait: frame (union rectangle) and box rows go through
-        pinned staging buffers, all classes' crop + encode + scan launches follow on the caller's stream, each class's indices
-        come back by an asynchronous copy with an event behind it -- the float64 geometry of class k then runs on the host
-        while the GPU is busy with class k + 1.  Nothing is allocated per frame; bit-identical to _process_plain."""
+        """The same on the GPU with everything queued before the first wait: frame (union rectangle) and box rows travel in ONE
+        pinned staging buffer and one copy, every class (in chunks when it has many detections) is ONE C call -- aae_detect_nn:
+        crop + resize, encoder, top-1 query -- whose indices are written straight into pinned host memory, with an event behind
+        it; the float64 geometry of chunk k then runs on the host while the GPU is busy with chunk k + 1.  Nothing is
+        allocated per frame; bit-identical to _process_plain."""
         import torch
-        from .engine import crop_resize_into
         stage = self.__dict__.setdefault('_stages', {}).get(device)
         if stage is None:
             stage = self._stages[device] = _FrameStage(device)
         crop_shapes = set((self.patch_sizes[c][1], self.patch_sizes[c][0]) for c in classes)
         if len(crop_shapes) != 1:
             return self._process_plain(accepted, classes, frame, off_x, off_y, camK)      # (objects trained at different crop sizes)
+        latent_sizes = set(int(self.all_codebooks[c]._encoder.latent_space_size) for c in classes)
+        if len(latent_sizes) != 1:
+            return self._process_plain(accepted, classes, frame, off_x, off_y, camK)      # (objects with different latent sizes: one staging row width does not fit all)
         oh, ow = crop_shapes.pop()
         C = int(frame.shape[2])
         total = len(accepted)
-        J = int(self.all_codebooks[classes[0]]._encoder.latent_space_size)
+        J = latent_sizes.pop()
         with torch.cuda.device(device):
-            image_dev = stage.upload_image(torch, frame)
             stage.reserve(torch, total, J, (oh, ow, C))
-            rows_host = stage.rows_host.numpy()[:total * 5].reshape(total, 5)
+            # box rows of all classes, class by class; classes with many detections are cut into chunks so that the host's
+            # float64 geometry of chunk k runs while the GPU works on chunk k + 1 (the geometry of the LAST chunk is all that
+            # stays exposed: 16 detections instead of a whole class)
+            rows_all = np.empty((total, 5), dtype=np.int32)
             groups, at = [], 0
             for clas in classes:
                 members = [(j, bb) for j, c, bb in accepted if c == clas]
                 n = len(members)
-                rows_host[at:at + n] = self.box_rows([[bb[0] - off_x, bb[1] - off_y, bb[2], bb[3]] for _, bb in members], self.pad_factors[clas])
-                groups.append((clas, members, at, n))
+                rows_all[at:at + n] = self.box_rows([[bb[0] - off_x, bb[1] - off_y, bb[2], bb[3]] for _, bb in members], self.pad_factors[clas])
+                step = n if n <= 2 * self.geometry_chunk else self.geometry_chunk
+                for a in range(0, n, step):
+                    groups.append((clas, members[a:a + step], at + a, min(step, n - a)))
                 at += n
-            stage.rows_dev[:total * 5].copy_(stage.rows_host[:total * 5], non_blocking=True)
-            rows_dev = stage.rows_dev[:total * 5].view(total, 5)
+            image_dev, rows_dev = stage.upload_frame_and_rows(torch, frame, rows_all)
             crops_all = stage.crops[:total * oh * ow * C].view(total, oh, ow, C)
-            z_all, idx_all, score_all = stage.z[:total * J].view(total, J), stage.idx[:total].view(total, 1), stage.score[:total].view(total, 1)
+            z_all = stage.z[:total * J].view(total, J)
             events = []
             for clas, members, a, n in groups:
                 codebook = self.all_codebooks[clas]
-                eng = codebook._encoder.engine
-                crop_resize_into(image_dev, rows_dev[a:a + n], crops_all[a:a + n])
                 stride = int(codebook._dataset._kw['num_cyclo']) if self._upright else 1
-                eng.encode_nn(codebook.engine, crops_all[a:a + n], stride, out=(z_all[a:a + n], idx_all[a:a + n], score_all[a:a + n]))
-                stage.idx_host[a:a + n].copy_(stage.idx[a:a + n], non_blocking=True)
+                # ONE C call per chunk: crop + resize, encoder, top-1 query; the indices land in pinned host memory directly
+                codebook._encoder.engine.detect_nn(codebook.engine, image_dev, rows_dev[a:a + n], n, stride, crops_all[a:a + n], z_all[a:a + n],
+                                                   stage.idx_host[a:a + n], stage.score[a:a + n])
                 ev = torch.cuda.Event()
                 ev.record()
                 events.append(ev)
             poses = {}
+            idx_host = stage.idx_host.numpy()
             for (clas, members, a, n), ev in zip(groups, events):
                 ev.synchronize()
                 codebook = self.all_codebooks[clas]
-                if codebook._encoder.engine.settle():             # (split precision, out of range: recomputed in fp32, in place)
-                    stage.idx_host[a:a + n].copy_(stage.idx[a:a + n])
-                idcs = stage.idx_host.numpy()[a:a + n].copy()
+                codebook._encoder.engine.settle()                  # (split precision, out of range: recomputed in fp32, indices rewritten in place)
+                idcs = idx_host[a:a + n].copy()
                 Rs, ts = codebook.poses_from_indices(idcs, [bb for _, bb in members], camK, self.all_train_args[clas])
                 for k, (j, _) in enumerate(members):
                     poses[j] = (clas, Rs[k], ts[k])

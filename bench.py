@@ -261,10 +261,12 @@ def main():
         dom_flops = per[dom['kernel']][1]
         achieved = dom_flops / (dom['ms'] * 1e-3) / 1e12
         peak = PEAK_F32_TFLOPS if precision == 'f32' else PEAK_X3H_TFLOPS
-        traffic = None
+        traffic, traffic_src = None, None
         try:      # HBM-side bytes per launch from the committed rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE)
             with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
-                traffic = json.load(f).get(precision, {}).get(dom['kernel'].split(':')[0])
+                tj = json.load(f)
+            traffic = tj.get(precision, {}).get(dom['kernel'].split(':')[0])
+            traffic_src = tj.get(precision + '_source')
         except Exception:
             traffic = None
         return {
@@ -272,8 +274,8 @@ def main():
             'ms_per_step': round(elapsed / args.steps * 1e3, 4),
             'roofline': {'bound': 'mfma', 'kernel': dom['kernel'], 'achieved': round(achieved, 2), 'peak': round(peak, 1),
                          'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4), 'traffic': traffic,
-                         'traffic_source': 'profiles/traffic.json (rocprofv3 PMC passes of an earlier run of this command: 2*FETCH_SIZE + WRITE_SIZE; '
-                                           'not measured in this run)' if traffic is not None else None,
+                         'traffic_source': ('profiles/traffic.json <- ' + (traffic_src or 'rocprofv3 PMC passes of an earlier run of this command: 2*FETCH_SIZE + WRITE_SIZE') +
+                                            '; a committed measurement, not taken in this run (PMC collection needs the profiler)') if traffic is not None else None,
                          'flops_per_launch': dom_flops, 'avg_ms': dom['ms']},
             'encoder_tflops': round(cfg.flops_per_crop() * B / (sum(k['ms'] for k in kernels) * 1e-3) / 1e12, 2),
             'kernels': kernels,
@@ -342,11 +344,12 @@ def main():
         for b in (1, 2, 4):
             xb = x[:b].contiguous()
             eager = time_us(lambda: enc.encode_nn(cb, xb, 1), 200)
-            cap = CapturedNearestNeighbour(enc, cb, b)
+            cap = CapturedNearestNeighbour(enc, cb, b, force_graph=True)     # (the object itself makes the eager call at B <= 4: it is faster)
             graph = time_us(lambda: cap.graph.replay(), 200)
             _, recs = enc.encode_timed(xb)
             lat['B%d' % b] = {'encode+nn_us': round(eager, 2), 'graph_replay_us': round(graph, 2), 'crops_per_s': round(b / eager * 1e6, 1),
                               'launches': len(recs) if any(l.startswith('chain:') for l, _, _ in recs) else len(recs) + 1}
+            cap.close()
             del cap
         lat['note'] = ('fused aae_encode_nn: conv1, three wave-split-K convolutions, dense GEMV, stream scan -- each split reduction finished '
                        'inside its own launch; floor of this chain = 27 us of fp32 MFMA work (4.28 GFLOP at 157 TF) + 107 MB of weights/codebook.  '
@@ -382,6 +385,12 @@ def main():
             ts.sort()
             return ts[len(ts) // 2]
         solo1 = single_call_us(lambda: cb.nn(z1, 1, 1))
+        # device time per single-launch query, measured HERE: 100 launches queued from C between two HIP events (kernel +
+        # dependent-launch gap; the Python loops above pay more host time per call than this kernel runs)
+        cb.nn_timed(z1, 1, 1, reps=20)
+        ks = sorted(cb.nn_timed(z1, 1, 1, reps=100)[2] * 1e3 for _ in range(9))
+        kernel_med, kernel_min = ks[len(ks) // 2], ks[0]
+        k256 = sorted(cb.nn_timed(z, 1, 1, reps=50)[2] * 1e3 for _ in range(5))[2]
         scan_traffic = None
         try:
             with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
@@ -390,9 +399,13 @@ def main():
             scan_traffic = None
         extras['scan'] = {
             'single_call_between_events_us': round(solo1, 2),
-            'kernel_us': (scan_traffic or {}).get('kernel_us_avg'), 'kernel_us_min': (scan_traffic or {}).get('kernel_us_min'),
+            'kernel_period_us': round(kernel_med, 2), 'kernel_period_us_min': round(kernel_min, 2),
+            'kernel_period_GBps': round(cb_bytes / kernel_med / 1e3, 1), 'kernel_period_frac': round(cb_bytes / kernel_med / 1e3 / PEAK_HBM_GBPS, 3),
+            'B256_kernel_period_us': round(k256, 2),
+            'kernel_period_source': 'this run: 100 queries queued back to back from C between two HIP events on the launch stream (aae_codebook_nn_timed): '
+                                    'kernel + dependent-launch gap per query, median / min of 9 such runs; rocprofv3 kernel durations: profiles/',
             'traffic': (scan_traffic or {}).get('hbm_side_bytes_warm'), 'traffic_cold': (scan_traffic or {}).get('hbm_side_bytes_cold'),
-            'kernel_and_traffic_source': 'profiles/traffic.json <- profiles/r11_small (rocprofv3 --stats and PMC passes of tools/prof_mix.py, an earlier run: not measured in this one)',
+            'traffic_source': (scan_traffic or {}).get('source', 'profiles/traffic.json (rocprofv3 PMC passes of tools/prof_mix.py: not measured in this run)'),
 
             'codebook_bytes': cb_bytes, 'peak_GBps': PEAK_HBM_GBPS,
             'B1_whole_call_warm_us': round(warm1, 2), 'B1_warm_GBps': round(cb_bytes / warm1 / 1e3, 1), 'B1_warm_frac': round(cb_bytes / warm1 / 1e3 / PEAK_HBM_GBPS, 3),
@@ -401,9 +414,9 @@ def main():
             'note': 'whole aae_codebook_nn call = ONE launch at B <= 4 (normalise + stream + arg-max hand-off inside the scan kernel); whole_call = '
                     'back-to-back calls on one stream (consecutive launches overlap: a call can cost less than the duration of its own kernel); '
                     'single_call_between_events = one call between its own HIP events on an idle stream (median; includes the host launch latency); '
-                    'kernel_us / traffic = the committed rocprofv3 figures.  warm: the 47 MB codebook stays in the 256 MB Infinity Cache between calls '
-                    '(algorithmic bytes, not HBM bytes); cold: 8 codebook copies visited in turn, so every call streams from HBM.  '
-                    'B=256 is MFMA-bound (crossover B~39).  Kernel-only durations: profiles/ (rocprofv3 --kernel-trace --stats)'}
+                    'kernel_period = queries queued from C between two events (no per-call host cost); traffic = the committed rocprofv3 PMC figures.  warm: the 47 MB codebook stays in the '
+                    '256 MB Infinity Cache between calls (algorithmic bytes, not HBM bytes); cold: 8 codebook copies visited in turn, so every call streams from HBM.  '
+                    'B=256 is MFMA-bound (crossover B~39).  Kernel-only durations under rocprofv3: profiles/'}
         # ---- BASELINE config 3: ae_embed -- encode 92232 views (codebook.py:190-219), encoder only, inputs resident
         c3 = {}
         for bs in ((64, 256) if args.full_extras else (256,)):

@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define AAE_ABI_VERSION 1
+#define AAE_ABI_VERSION 2
 
 #define AAE_OK 0
 #define AAE_ERR_INVALID (-1)      /* bad argument                                  */
@@ -178,6 +178,9 @@ int aae_encoder_x3h_saturated(aae_encoder* enc, int* flag_out, void* stream);
  * slots at once. */
 int aae_encoder_x3h_last_slot(void);
 int aae_encoder_x3h_poll(aae_encoder* enc, const int* slots, int n, int* flags_out, void* stream);
+/* A forward recorded into a HIP graph owns its slot (one of 64) until the owner of the graph gives it back: call this when
+ * the graph is destroyed (the Python mirror: CapturedNearestNeighbour.close()).  Slots of eager forwards need no release. */
+int aae_encoder_x3h_release_slot(aae_encoder* enc, int slot);
 
 /* 1 when a forward of batch B on this handle runs in f32x3h (precision 1, or precision 2 and a large enough batch):
  * the layer outputs in the workspace are then fp16 (hi, lo) pairs instead of fp32 (aae_encoder_activation_info). */
@@ -219,6 +222,14 @@ size_t aae_codebook_workspace_bytes(const aae_codebook* cb, int B, int topk);
 int aae_codebook_nn(aae_codebook* cb, const float* z, int B, int topk, int col_stride,
                     int64_t* idx_out, float* score_out, void* workspace, size_t ws_bytes, void* stream);
 
+/* The same query `reps` times back to back, queued from C between two HIP events on `stream`: *period_ms = device time per
+ * query = its kernel(s) + the dependent-launch gap, without the caller's per-call host cost (a Python loop spends longer per
+ * call than the 12 us kernel of the B = 1 query takes).  bench.py's `scan.kernel_period_us`, measured in the run that
+ * reports it.  (One call between two events on an idle stream measures the events' own latency more than the kernel.)
+ * Waits for the second event. */
+int aae_codebook_nn_timed(aae_codebook* cb, const float* z, int B, int topk, int col_stride,
+                          int64_t* idx_out, float* score_out, void* workspace, size_t ws_bytes, void* stream, int reps, float* period_ms);
+
 /* aae_encoder_forward followed by aae_codebook_nn(topk = 1) on `stream` in ONE call: what
  * Codebook.nearest_rotation(session, x) does per detection (auto_pose/ae/codebook.py:55-68,
  * m3_interface/ae_pose_estimator.py:143-170).  Same results as the two calls, bit for bit.  For B <= 4 the query is
@@ -257,6 +268,16 @@ int aae_unpack_pairs(const int64_t* gathered, const int32_t* owner, int n, int r
  * size = int(max(h, w) * pad_factor); out: device uint8 [D,out_h,out_w,C]. */
 int aae_crop_resize_u8(const void* img, int H, int W, int C, const int32_t* boxes, int D,
                        int out_h, int out_w, void* out, void* stream);
+
+/* All detections of ONE object class of a frame in one call: aae_crop_resize_u8 into `crops` (device scratch
+ * [n, in_h, in_w, in_c] uint8, the encoder's input shape) followed by aae_encode_nn on them -- what
+ * AePoseEstimator.process does per detected box (m3_interface/ae_pose_estimator.py:143-170: extract_square_patch,
+ * cv2.resize, one session.run, np.argmax), for n boxes, without a host round trip per launch.  img / boxes / idx_out /
+ * score_out may be device memory or device-accessible pinned host memory (a result written straight into pinned memory
+ * needs no copy back, an image read from it no upload).  Same results as the two calls. */
+int aae_detect_nn(aae_encoder* enc, aae_codebook* cb, const void* img, int H, int W, int C, const int32_t* boxes, int n,
+                  int col_stride, void* crops, float* z_out, int64_t* idx_out, float* score_out,
+                  void* enc_workspace, size_t enc_ws_bytes, void* cb_workspace, size_t cb_ws_bytes, void* stream);
 
 /* ---- Decoder ("next" row N4): auto_pose/ae/decoder.py:36-84 (Decoder.x), inference only ---------
  * Decoder(reconstruction_target, latent_code, num_filters, kernel_size, strides, ...) as

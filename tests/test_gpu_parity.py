@@ -312,6 +312,18 @@ def test_realistic_full_size_codebook_built_by_the_encoder(default_model):
         Z[a:a + 1024] = eng.encode(src.torch_batch(Rs[a:a + 1024], eng.device))
     E = ref.normalize_codebook(Z.cpu().numpy())
     twins = sum(bool(np.array_equal(E[r], E[r + 35])) for r in range(0, N, 36))
+    # BASELINE config 3 across the whole row range: a strided sample of 2048 of the 92232 HIP-encoded rows against
+    # the same views through the fp64 oracle encoder + float64 normalisation (codebook.py:190-219)
+    sample = np.arange(0, N, 45)[:2048]
+    assert sample[-1] > N - 200
+    z_s = np.concatenate([ref.encoder_forward_torch(ref.input_to_float(src.torch_batch(Rs[sample[a:a + 256]], eng.device).cpu().numpy()),
+                                                    weights, STRIDES, False, 'float64') for a in range(0, len(sample), 256)])
+    E_s = z_s / np.linalg.norm(z_s, axis=1, keepdims=True)
+    row_err = np.abs(E[sample].astype(np.float64) - E_s).max(axis=1)
+    codebook_row_err = float(row_err.max())
+    report.record('codebook_rows', 'codebook rows built by the HIP encoder (2048 of 92232, stride 45) vs fp64 oracle rows', max_abs_err=codebook_row_err,
+                  worst_row=int(sample[int(np.argmax(row_err))]))
+    assert codebook_row_err <= 1e-6, 'codebook row error %.3e at row %d' % (codebook_row_err, sample[int(np.argmax(row_err))])
     cb = CodebookEngine(E)
     rng = np.random.default_rng(2025)
     B = 256
@@ -367,6 +379,7 @@ def test_realistic_full_size_codebook_built_by_the_encoder(default_model):
         'codebook': '92232 x 128 fp32, rows = HIP encoder over SyntheticViewSource(seed 1) views of the reference viewsphere, float64 normalise',
         'queries': '256 views 0.3-6 deg off a codebook rotation + N(0, 3) pixel noise, B=256 in one chunk',
         'exact_twin_pairs_in_codebook': int(twins), 'max_cosine_abs_err_256xN': cos_err,
+        'codebook_rows_vs_oracle_max_abs_err_2048_rows_stride_45': codebook_row_err,
         'flips_total': int(flips), 'flips_at_2e-6': int(np.sum(wrong & (raw_gap >= STRICT_GAP_TOL))), 'flips_at_2e-5': int(np.sum(wrong & (raw_gap >= GAP_TOL))),
         'min_gap_raw': float(raw_gap.min()), 'min_gap_without_exact_twin': float(gap.min()), 'median_gap_without_exact_twin': float(np.median(gap)),
         'queries_with_gap_below_1e-4': int(np.sum(gap < 1e-4)), 'queries_with_gap_below_2e-5': int(np.sum(gap < GAP_TOL)),
@@ -642,7 +655,8 @@ def test_captured_graph_and_streaming_pipelines_equal_the_eager_calls():
     # a captured graph owns its scratch memory: later eager calls that regrow the engines' workspaces (bigger batch,
     # top-k buffers) or ask for the upright copy of another stride must not disturb its replays
     x1 = synth.make_crops(1, seed=990)
-    cap_up = CapturedNearestNeighbour(enc, cb, 1, col_stride=36)
+    cap_up = CapturedNearestNeighbour(enc, cb, 1, col_stride=36, force_graph=True)     # (B <= 4 makes the fused eager call unless a graph is asked for)
+    assert cap_up.graph is not None and CapturedNearestNeighbour(enc, cb, 1).graph is None
     want_i, want_s = cb.nn(enc.encode(x1), 1, 36)
     want_i, want_s = want_i.clone(), want_s.clone()
     big = synth.make_crops(96, seed=991)
@@ -1066,6 +1080,45 @@ def test_object_sharded_and_row_sharded_paths_run_through_rccl_at_world_size_one
         dist.destroy_process_group()
 
 
+def test_eight_objects_in_one_process_mixed_batch_against_the_per_object_oracle():
+    """BASELINE config 4 in the layout the reference actually runs (m3_interface/ae_pose_estimator.py:61-78: N independent
+    AAEs in ONE process): 8 objects = 8 weight sets + 8 codebooks (seeds 2024 + i / 7 + i) on one GPU,
+    ShardedPoseEngine with an explicit world size of 1 (every object local, no collective), one mixed batch of 256 crops
+    with labels integers(0, 8).  Every answer against the fp64 oracle OF ITS OBJECT: cosine within 1e-5, tie-aware index."""
+    import torch
+    from augmentedautoencoder_amd.dist import ShardedPoseEngine
+    from augmentedautoencoder_amd.engine import CodebookEngine, EncoderEngine, pack_pairs, unpack_pairs
+    from augmentedautoencoder_amd.weights import EncoderConfig
+    dev = torch.device('cuda', 0)
+    n_obj, B = 8, 256
+    weights = [synth.make_weights(seed=2024 + o) for o in range(n_obj)]
+    books = [synth.make_codebook(92232, 128, seed=7 + o, planted_duplicates=8) for o in range(n_obj)]
+    objs = [(EncoderEngine(EncoderConfig(), weights[o], max_batch=64), CodebookEngine(books[o])) for o in range(n_obj)]
+    try:
+        labels = np.random.default_rng(0).integers(0, n_obj, B)
+        crops_host = synth.make_crops(B, seed=4321)
+        crops = torch.from_numpy(crops_host).to(dev)
+        spe = ShardedPoseEngine(lambda o, c: objs[o][0].encode_nn(objs[o][1], c, 1)[1:], world_size=1, rank=0, device=dev,
+                                pack_pairs=pack_pairs, unpack_pairs=unpack_pairs)
+        assert spe.world_size == 1 and not spe._gather
+        idx, score = spe.infer(crops, labels)
+        idx, score = idx.cpu().numpy().copy(), score.cpu().numpy().copy()
+        idx2, score2 = spe.infer({o: crops[torch.from_numpy(np.flatnonzero(labels == o)).to(dev)] for o in range(n_obj)}, labels)
+        assert np.array_equal(idx, idx2.cpu().numpy()) and np.array_equal(score, score2.cpu().numpy())     # pre-routed buckets, cached plan
+        assert (idx >= 0).all()
+        flips = 0
+        for o in range(n_obj):
+            pos = np.flatnonzero(labels == o)
+            z64 = ref.encoder_forward_torch(ref.input_to_float(crops_host[pos]), weights[o], STRIDES, False, 'float64')
+            cs64 = ref.cos_similarity(z64, books[o])
+            assert np.abs(score[pos] - cs64.max(axis=1)).max() <= COS_TOL, o
+            flips += _check_indices(idx[pos], cs64, where='8 objects in one process, object %d (%d crops)' % (o, len(pos)))
+    finally:
+        for e, c in objs:
+            e.close()
+            c.close()
+
+
 def test_f32x3h_adversarial_ranges_and_the_saturation_fallback():
     """Opt-in f32x3h mode outside the comfortable glorot regime (same tolerances as everywhere: layers and latents
     within 2e-5 of the fp64 oracle relative to the layer's largest value):
@@ -1175,7 +1228,7 @@ def test_f32x3h_adversarial_ranges_and_the_saturation_fallback():
             _, i1, s1 = enc.encode_nn(cbe, crops, 1)
             assert enc.settle() == 1 and torch.equal(i1, i32) and torch.equal(s1, s32)
             # a HIP graph captured in split-precision mode: every replay looks at the recorded forward's own flag
-            cap = CapturedNearestNeighbour(enc, cbe, 4)
+            cap = CapturedNearestNeighbour(enc, cbe, 4, force_graph=True)
             before = enc.x3h_fallbacks
             ic, sc = cap(crops)
             assert cap._x3h_slot >= 256 and enc.x3h_fallbacks == before + 1 and torch.equal(ic, i32) and torch.equal(sc, s32)
@@ -1183,6 +1236,17 @@ def test_f32x3h_adversarial_ranges_and_the_saturation_fallback():
             assert enc.x3h_fallbacks == before + 1
             _, id1, sd1 = enc.encode_nn(cbe, dark, 1)
             assert enc.settle() == 0 and torch.equal(ic, id1) and torch.equal(sc, sd1)
+            # a destroyed graph gives its slot back: far more captures than the 64 slots of a handle, one after the other
+            first_slot = cap._owned_slot
+            cap.close()
+            for _ in range(70):
+                c2 = CapturedNearestNeighbour(enc, cbe, 4, force_graph=True)
+                assert c2._owned_slot == first_slot
+                c2.close()
+            # ... and the eager form of the same object (the default at B <= 4) gives the same checked answers
+            ce = CapturedNearestNeighbour(enc, cbe, 4)
+            ie, se = ce(crops)
+            assert ce.graph is None and torch.equal(ie, i32) and torch.equal(se, s32)
             cbe.close()
         enc.close()
 

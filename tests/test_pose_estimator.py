@@ -259,6 +259,15 @@ def test_process_on_gpu_full_size_two_objects():
     camK = np.array([[1075.65, 0, 320.0], [0, 1073.9, 240.0], [0, 0, 1]])
     got = est.process(dets, img, camK, mm=True)
     assert len(got) == 12
+    # classes cut into chunks (one aae_detect_nn call + event each, geometry of chunk k under the kernels of chunk k + 1) and
+    # the whole frame instead of the boxes' union rectangle: the same poses, bit for bit
+    est.geometry_chunk = 2
+    chunked = est.process(dets, img, camK, mm=True)
+    est.geometry_chunk, est.upload_union_only = 16, False
+    whole = est.process(dets, img, camK, mm=True)
+    est.upload_union_only = True
+    for a, b, c in zip(got, chunked, whole):
+        assert a.name == b.name == c.name and np.array_equal(a.trafo, b.trafo) and np.array_equal(a.trafo, c.trafo)
     K_train = np.array(_parse_K('[1075.65, 0, 720/2, 0, 1073.90, 540/2, 0, 0, 1]')).reshape(3, 3)
     for g, box in zip(got, dets):
         c = max(box.classes, key=box.classes.get)

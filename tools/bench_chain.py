@@ -41,7 +41,7 @@ for B in (1, 2, 3, 4):
         enc.set_option('detect_chain', chain)
         eager = time_us(lambda: enc.encode_nn(cb, xb, 1), reps)
         enc_only = time_us(lambda: enc.encode(xb), reps)
-        cap = CapturedNearestNeighbour(enc, cb, B)
+        cap = CapturedNearestNeighbour(enc, cb, B, force_graph=True)
         graph = time_us(lambda: cap.graph.replay(), reps)
         del cap
         row['chain' if chain else 'six_launches'] = {'eager_us': round(eager, 2), 'graph_replay_us': round(graph, 2), 'encoder_only_us': round(enc_only, 2)}

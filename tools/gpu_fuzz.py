@@ -52,6 +52,8 @@ def main():
         opts['x3h_wide256_min_blocks'] = int(rng.choice([1, 256]))               # ... also on grids that do not fill the chip
         opts['planner_cost_model'] = int(rng.integers(0, 2))                     # per-layer kernel choice by estimated time (5 <= B < 256)
         opts['detect_chain'] = int(rng.integers(0, 2))                           # B <= 4: conv2 ... scan as one persistent launch where it applies
+        opts['wavek_tiny_waves'] = int(rng.choice([4, 8]))                       # 32 x 32 wave tiles on eight waves ...
+        opts['wavek_pingpong'] = int(rng.integers(0, 2))                         # ... and the barrier-paced schedule of the 8-wave blocks
         for k, v in opts.items():
             enc.set_option(k, v)
         precision = int(rng.integers(0, 2)) if cfg.shape[2] in (1, 3) and all(f % 32 == 0 for f in filters) else 0
@@ -77,6 +79,8 @@ def main():
             dtype = str(rng.choice(['f32', 'bf16']))
             E = synth.make_codebook(N, 128, seed=case, planted_duplicates=min(8, N // 72))
             cb = CodebookEngine(E, dtype=dtype)
+            if rng.integers(0, 2):
+                cb.set_scan_mode(6)                        # AAE_SCAN_STREAM_WALK: the walking form of the fp32 stream scan (B <= 4)
             cs = cb.similarity(z).cpu().numpy()
             from augmentedautoencoder_amd.weights import bf16_bits_to_f32, to_bf16_bits
             Eo = bf16_bits_to_f32(to_bf16_bits(E)) if dtype == 'bf16' else E

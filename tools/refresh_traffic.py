@@ -1,0 +1,40 @@
+#!/usr/bin/env python
+"""profiles/traffic.json <- the round's own PMC passes.  Usage:
+    python tools/refresh_traffic.py <pmc_summary.json of the default bench> [<pmc_summary.json of tools/prof_mix.py>] --tag r12
+The fp32 entries (conv2 / conv3 / conv4 at B = 256) come from the kernels `conv_igemm_f32_kernel<false, true, false, L, true, *>`
+(L = 1, 2, 3) of the first summary, the `scan` entry (B = 1 stream scan) from the second when given.  bench.py copies the dominant
+kernel's entry into roofline.traffic and names this file's `source` as where it came from."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag = 'r12'
+argv = list(sys.argv[1:])
+if '--tag' in argv:
+    i = argv.index('--tag')
+    tag = argv[i + 1]
+    del argv[i:i + 2]
+args = argv
+path = os.path.join(ROOT, 'profiles', 'traffic.json')
+t = json.load(open(path))
+main = json.load(open(args[0]))
+changed = {}
+for name, layer in (('conv2', 1), ('conv3', 2), ('conv4', 3)):
+    rows = [v for k, v in main.items() if k.startswith('conv_igemm_f32_kernel<false, true, false, %d, true' % layer) and 'hbm_side_bytes' in v]
+    if rows:
+        best = max(rows, key=lambda v: v.get('dispatches_seen', 0))
+        t['f32'][name] = int(round(best['hbm_side_bytes'], -5))
+        changed[name] = t['f32'][name]
+t['f32_source'] = 'profiles/%s/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the default bench command in round %s: 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 per launch)' % (tag, tag)
+if len(args) > 1:
+    mix = json.load(open(args[1]))
+    rows = [(k, v) for k, v in mix.items() if k.startswith('scan_stream') and '<1,' in k and 'hbm_side_bytes' in v]
+    if rows:
+        k, v = max(rows, key=lambda kv: kv[1].get('dispatches_seen', 0))
+        t['scan']['hbm_side_bytes_warm'] = int(round(v['hbm_side_bytes'], -4))
+        t['scan']['kernel_us_under_pmc_warm'] = round(v['avg_ns_under_pmc'] / 1e3, 2)
+        t['scan']['source'] = 'profiles/%s_small/pmc_summary.json, kernel %s (rocprofv3 PMC passes of tools/prof_mix.py in round %s; not measured in the bench run)' % (tag, k, tag)
+        changed['scan'] = t['scan']['hbm_side_bytes_warm']
+json.dump(t, open(path, 'w'), indent=1)
+print('traffic.json updated:', changed)
