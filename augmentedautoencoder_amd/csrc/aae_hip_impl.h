@@ -144,6 +144,8 @@ struct aae_encoder {
                                            // measured: wins up to 64 tiles (B=1: 94 -> 87 us), loses from 128 on (twice the operand loads per MFMA)
     int wavek_target_blocks = 256;         // blocks a split layer is cut into (tiles x K splits): one per CU
     int wavek_waves = 4;                   // waves per block (4 | 8), each with its own K range
+    int wavek_spread = 1;                  // 64 x 64 wave tiles (four accumulators): next-slab loads between the MFMAs instead of a burst in front of them (conv_wavek_f32.h):
+                                           // conv2 at B = 8 128 -> 115 us, B = 24 encoder 910 -> 830 us; measured neutral-to-worse with two accumulators (64 x 32), not used there
     int wavek_pingpong = 0;                // 8-wave blocks: the two waves of a SIMD alternate load issue and MFMAs behind block barriers (conv_wavek_f32.h);
                                            // measured SLOWER than free-running waves (B = 1: 95 vs 82 us): kept as an option with its measurement, off
     int wavek_tiny_waves = 4;              // ... of the 32 x 32 wave tiles (per-detection batches): 8 = two waves per SIMD, so that one wave's operand-load issue
@@ -391,7 +393,8 @@ static int wavek_gsplits(const aae_encoder* enc, int tiles, int slabs, int waves
 constexpr double kSlabUs = 16.0 * 64.0 / 2400.0;
 
 static double wavek_cost_us(const aae_encoder* enc, int tiles, int g, int slabs, int mt, int nt) {
-    static const double eff[3] = {0.71, 0.72, 0.88}, fixed[3] = {0.0, 0.0, 5.0};
+    static const double eff_burst[3] = {0.71, 0.72, 0.88}, eff_spread[3] = {0.71, 0.72, 0.96}, fixed[3] = {0.0, 0.0, 5.0};
+    const double* eff = enc->wavek_spread ? eff_spread : eff_burst;          // (64 x 64 tiles with the spread schedule: +9 % measured, round 4)
     const int shape = mt == 1 ? 0 : (nt == 1 ? 1 : 2);
     const int cus = enc->wavek_target_blocks > 0 ? enc->wavek_target_blocks : 256;
     return (double)ceil_div(tiles * g, cus) * (ceil_div(slabs, 4 * g) + 4) * (mt * nt) * kSlabUs / eff[shape] + fixed[shape] + (g > 1 ? 3.0 : 0.0);
@@ -644,22 +647,22 @@ static int launch_igemm(aae_encoder* enc, const Layer& L, const float* x, int M,
 }
 
 // wave-split-K igemm (conv_wavek_f32.h): small M -- the per-detection batches
-template <int MT, int NT, int WAVES, int DEPTH>
+template <int MT, int NT, int WAVES, int DEPTH, bool SPREAD = false>
 static void launch_wavek_t(const aae::ConvWaveKArgs& a, int tag, int nblk, hipStream_t stream) {
     constexpr int smem = aae::conv_wavek_smem<MT, NT, WAVES>();
     // TAG only makes the symbol unique per encoder layer (separate rows in rocprofv3 --stats)
     if (tag == 1) {
-        (void)hipFuncSetAttribute((const void*)aae::conv_wavek_f32_kernel<MT, NT, WAVES, DEPTH, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        AAE_LAUNCH((aae::conv_wavek_f32_kernel<MT, NT, WAVES, DEPTH, 1>), dim3(nblk), dim3(64 * WAVES), smem, stream, a);
+        (void)hipFuncSetAttribute((const void*)aae::conv_wavek_f32_kernel<MT, NT, WAVES, DEPTH, 1, SPREAD>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        AAE_LAUNCH((aae::conv_wavek_f32_kernel<MT, NT, WAVES, DEPTH, 1, SPREAD>), dim3(nblk), dim3(64 * WAVES), smem, stream, a);
     } else if (tag == 2) {
-        (void)hipFuncSetAttribute((const void*)aae::conv_wavek_f32_kernel<MT, NT, WAVES, DEPTH, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        AAE_LAUNCH((aae::conv_wavek_f32_kernel<MT, NT, WAVES, DEPTH, 2>), dim3(nblk), dim3(64 * WAVES), smem, stream, a);
+        (void)hipFuncSetAttribute((const void*)aae::conv_wavek_f32_kernel<MT, NT, WAVES, DEPTH, 2, SPREAD>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        AAE_LAUNCH((aae::conv_wavek_f32_kernel<MT, NT, WAVES, DEPTH, 2, SPREAD>), dim3(nblk), dim3(64 * WAVES), smem, stream, a);
     } else if (tag == 3) {
-        (void)hipFuncSetAttribute((const void*)aae::conv_wavek_f32_kernel<MT, NT, WAVES, DEPTH, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        AAE_LAUNCH((aae::conv_wavek_f32_kernel<MT, NT, WAVES, DEPTH, 3>), dim3(nblk), dim3(64 * WAVES), smem, stream, a);
+        (void)hipFuncSetAttribute((const void*)aae::conv_wavek_f32_kernel<MT, NT, WAVES, DEPTH, 3, SPREAD>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        AAE_LAUNCH((aae::conv_wavek_f32_kernel<MT, NT, WAVES, DEPTH, 3, SPREAD>), dim3(nblk), dim3(64 * WAVES), smem, stream, a);
     } else {
-        (void)hipFuncSetAttribute((const void*)aae::conv_wavek_f32_kernel<MT, NT, WAVES, DEPTH, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        AAE_LAUNCH((aae::conv_wavek_f32_kernel<MT, NT, WAVES, DEPTH, 0>), dim3(nblk), dim3(64 * WAVES), smem, stream, a);
+        (void)hipFuncSetAttribute((const void*)aae::conv_wavek_f32_kernel<MT, NT, WAVES, DEPTH, 0, SPREAD>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        AAE_LAUNCH((aae::conv_wavek_f32_kernel<MT, NT, WAVES, DEPTH, 0, SPREAD>), dim3(nblk), dim3(64 * WAVES), smem, stream, a);
     }
 }
 
@@ -669,7 +672,7 @@ static aae::ConvWaveKArgs wavek_args(const aae_encoder* enc, const Layer& L, con
     a.x = x; a.wp = L.wp; a.bias = L.bias; a.bn_scale = L.bn_scale; a.bn_shift = L.bn_shift; a.out = out;
     a.partial = partial; a.partial_bytes = (unsigned)w.partial_bytes; a.tickets = tickets; a.nonce = nonce;
     a.H = L.H; a.W = L.W; a.Cin = L.Cin; a.Ho = L.Ho; a.Wo = L.Wo; a.Cout = L.Cout; a.CoutPad = L.CoutPad;
-    a.KS = L.KS; a.S = L.S; a.pt = L.pt; a.pl = L.pl; a.M = M; a.relu = L.relu; a.ablate = enc->wavek_ablate; a.pingpong = enc->wavek_pingpong;
+    a.KS = L.KS; a.S = L.S; a.pt = L.pt; a.pl = L.pl; a.M = M; a.relu = L.relu; a.ablate = enc->wavek_ablate; a.pingpong = enc->wavek_pingpong; a.spread = enc->wavek_spread;
     a.timeline = (enc->wavek_timeline && tag >= 1 && tag <= 3 && w.num_mt * w.num_nt * w.gsplits <= 512)       // (the debug buffer holds 512 blocks per layer)
                      ? enc->wavek_timeline + (size_t)(tag - 1) * 512 * 8 : nullptr;
     a.x_bytes = (unsigned)((unsigned long long)(M / (L.Ho * L.Wo)) * L.H * L.W * L.Cin * sizeof(float));
@@ -686,7 +689,7 @@ static int launch_wavek(aae_encoder* enc, const Layer& L, const WaveKPlan& w, co
     const int key = (w.MT == 1 ? 1000 : 0) + w.NT * 100 + w.waves * 10 + w.depth;
     switch (key) {
         case 243: launch_wavek_t<2, 2, 4, 3>(a, tag, nblk, stream); break;
-        case 242: launch_wavek_t<2, 2, 4, 2>(a, tag, nblk, stream); break;
+        case 242: if (a.spread) launch_wavek_t<2, 2, 4, 2, true>(a, tag, nblk, stream); else launch_wavek_t<2, 2, 4, 2>(a, tag, nblk, stream); break;
         case 282: launch_wavek_t<2, 2, 8, 2>(a, tag, nblk, stream); break;
         case 143: launch_wavek_t<2, 1, 4, 3>(a, tag, nblk, stream); break;
         case 142: launch_wavek_t<2, 1, 4, 2>(a, tag, nblk, stream); break;
@@ -1635,6 +1638,7 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
         if (value != 4 && value != 8) return fail(AAE_ERR_INVALID, "wavek_waves %d: 4 or 8", value);
         enc->wavek_waves = value;
     } else if (!strcmp(name, "wavek_pingpong")) enc->wavek_pingpong = value ? 1 : 0;
+    else if (!strcmp(name, "wavek_spread")) enc->wavek_spread = value ? 1 : 0;
     else if (!strcmp(name, "wavek_tiny_waves")) {
         if (value != 4 && value != 8) return fail(AAE_ERR_INVALID, "wavek_tiny_waves %d: 4 or 8", value);
         enc->wavek_tiny_waves = value;

@@ -50,6 +50,7 @@ struct ConvWaveKArgs {
     long long* timeline;         // optional [blocks][8] shader-clock stamps of wave 0 per phase (tools/ablate_wavek.py); nullptr in production
     int ablate;                  // timing experiments only (results are then wrong): 1 no A loads, 2 no B loads, 4 no MFMAs, 8 no cross-block hand-off
     int pingpong;                // 8-wave blocks: the two waves of a SIMD alternate load issue and MFMAs, a block barrier between the half-steps
+    int spread;                  // wave tiles with >= 2 accumulators: the operand loads of the next slab issue one per q-step BETWEEN the MFMAs of this one
 };
 
 // Ticket preparation.  A launch whose blocks all arrive at a clean ticket word queue up behind the nonce install
@@ -115,7 +116,7 @@ __device__ __forceinline__ void conv_wavek_prefetch_b(const ConvWaveKArgs& p, in
 // (row & 3) + 4 (row >> 3), lanes 4 (q % 8) + 32 ((row >> 2) & 1) ... + 3 -- so the cross-wave sum reads one ds_read_b128
 // per wave, conflict-free, and the row leaves as ONE 16-byte store instead of four 4-byte ones (a 4-byte sc1 store costs
 // about six times a 16-byte one per byte).  Sums run in wave order, then split order: the bits do not depend on who finishes.
-template <int MT, int NT, int WAVES, int DEPTH, bool CHAIN>
+template <int MT, int NT, int WAVES, int DEPTH, bool CHAIN, bool SPREAD = false>
 __device__ __forceinline__ void conv_wavek_block(const ConvWaveKArgs& p, const int Lphys, const int nblk, float* red, int* flag,
                                                  const WaveKPrefetch& pf, const bool use_pf) {
     constexpr int COMBOS = MT * NT * 16;                       // accumulator registers per lane
@@ -254,7 +255,51 @@ __device__ __forceinline__ void conv_wavek_block(const ConvWaveKArgs& p, const i
     // (logical block 0, its first loads in flight) the tile words get this launch's nonce long before the first arrival
     if (p.gsplits > 1 && Lphys == 0)
         for (int w = tid; w < tiles; w += T) ticket_prepare_word(p.tickets + w, p.nonce);
-    if (WAVES == 8 && DEPTH == 2 && !CHAIN && p.pingpong) {
+    if constexpr (SPREAD && MT * NT >= 2 && DEPTH == 2) {
+        // Spread schedule (wave tiles with two or four accumulators).  The burst form below issues the ~100 instructions that
+        // address and request the next slab in one piece, fenced in front of the slab's 64 (32) MFMAs: for ~450 cycles per slab
+        // the matrix pipe of a one-wave-per-SIMD block has nothing to do (64 x 64 tiles: 0.70 of the MFMA peak at B = 4).
+        // Consecutive MFMAs of a q-step go to DIFFERENT accumulators, so an instruction placed between them costs next to nothing
+        // (it issues while the pipe is busy with the MFMA just sent): here the address arithmetic of slab t + 1 follows the first
+        // q-step of slab t and its MT + NT loads of k-group c follow one per q-step of group c.  Same MFMA order per accumulator:
+        // bit-identical results.  (With ONE accumulator every MFMA depends on its predecessor and anything between two of them
+        // costs a full dependent-issue bubble: the 32 x 32 tiles keep the burst.)
+        for (int t = s0; t < s1; t += 2) {
+#pragma unroll
+            for (int d = 0; d < 2; ++d) {
+                if (t + d < s1) {                               // wave-uniform
+                    const int dn = d ^ 1;
+                    unsigned ao[MT], bo = 0;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            sched_fence();
+#pragma unroll
+                            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                                for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = mfma_32x32x2(fa[d][mi][c][q], fb[d][ni][c][q], acc[mi][ni]);
+                            sched_fence();
+                            if (c == 0 && q == 0) {             // addresses of slab t + d + 1 (dead once past s1: out of range, no traffic)
+                                const bool live = t_load < s1;
+                                const unsigned tap_off = (unsigned)(((kh * pW + kw) * pCin + cc * 32) * 4);
+#pragma unroll
+                                for (int mi = 0; mi < MT; ++mi) {
+                                    const bool ok = live && a_ok[mi] && (unsigned)(a_ih0[mi] + kh) < (unsigned)pH && (unsigned)(a_iw0[mi] + kw) < (unsigned)pW;
+                                    ao[mi] = ok ? a_off[mi] + tap_off : kOobBase;
+                                }
+                                bo = live ? bw_off + (unsigned)t_load * bw_slab : kOobBase;
+                                ++t_load;
+                                if (++kw == pKS) { kw = 0; if (++kh == pKS) { kh = 0; ++cc; } }
+                            }
+                            if (q < MT) fa[dn][q < MT ? q : 0][c] = buffer_load4(xbuf, ao[q < MT ? q : 0] + 32u * c);
+                            else if (q - MT < NT) fb[dn][q - MT < NT ? q - MT : 0][c] = buffer_load4(wbuf, bo == kOobBase ? kOobBase : bo + c * bw_group + 512u * (q - MT));
+                        }
+                    }
+                }
+            }
+        }
+    } else if (WAVES == 8 && DEPTH == 2 && !CHAIN && p.pingpong) {
         // Two waves per SIMD (w and w + 4: tools/ubench/wave_simd_map.hip), made to ALTERNATE.  A wave's slab is ~300 cycles of
         // address arithmetic + load issue, during which its dependent MFMA chain stands still, then 16 x 64 cycles of MFMAs.  Left
         // alone, the two waves of a SIMD fall into step -- they share the matrix pipe, so they finish their MFMAs together and
@@ -388,13 +433,13 @@ __device__ __forceinline__ void conv_wavek_block(const ConvWaveKArgs& p, const i
 // (64 x 64 wave tiles: two blocks per CU asked for -- 209 instead of 288 registers, no spills -- so that the second round of a
 // 257 ... 512-tile layer overlaps the first: conv2 at B = 7 / 8 118.6 / 120.6 -> 112.9 / 114.6 us; the smaller tiles lose 8 % under the
 // same bound and keep the whole register file)
-template <int MT, int NT, int WAVES, int DEPTH, int TAG = 0>
+template <int MT, int NT, int WAVES, int DEPTH, int TAG = 0, bool SPREAD = false>
 __global__ __launch_bounds__(64 * WAVES, (MT * NT == 4 && WAVES == 4 && DEPTH == 2 ? 2 : 1)) void conv_wavek_f32_kernel(const ConvWaveKArgs p) {
     AAE_DYN_SMEM(smem_raw);
     float* red = reinterpret_cast<float*>(smem_raw);           // [WAVES][COMBOS][64]
     int* flag = reinterpret_cast<int*>(red + WAVES * MT * NT * 16 * 64);
     WaveKPrefetch none;
-    conv_wavek_block<MT, NT, WAVES, DEPTH, false>(p, (int)blockIdx.x, p.num_mt * p.num_nt * p.gsplits, red, flag, none, false);
+    conv_wavek_block<MT, NT, WAVES, DEPTH, false, SPREAD>(p, (int)blockIdx.x, p.num_mt * p.num_nt * p.gsplits, red, flag, none, false);
 }
 
 }  // namespace aae

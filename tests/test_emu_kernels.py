@@ -713,6 +713,28 @@ def test_wave_split_k_igemm_32x32_wave_tiles_on_eight_waves(B, order):
         eb.set_block_order(0)
 
 
+@pytest.mark.parametrize('narrow', [0])
+def test_spread_load_schedule_is_bit_identical_to_the_burst(narrow):
+    """Option wavek_spread (default on): 64 x 64 wave tiles (four accumulators) issue the operand loads of the next slab one per
+    q-step between the MFMAs of the current one instead of as a burst in front of them.  Same MFMA order per accumulator:
+    identical bits, with ragged K ranges and a cross-block split."""
+    cfg = EncoderConfig((16, 16, 3), [32, 64], [2, 2], 5, 128)
+    w = synth.make_weights(seed=5, shape=cfg.shape, num_filter=cfg.num_filter, strides=cfg.strides, latent=128)
+    x = synth.make_crops(5, seed=6, shape=cfg.shape)
+    outs = []
+    for spread in (1, 0):
+        enc = eb.EmuEncoder(w, cfg)
+        for k, v in (('detect_chain', 0), ('planner_cost_model', 0), ('wavek_tiny_max_tiles', 0), ('wavek_narrow_max_tiles', narrow), ('wavek_spread', spread)):
+            enc.set_option(k, v)
+        z = enc.forward(x)
+        assert ('conv_wavek_f32_64x32_w4_d2' if narrow else 'conv_wavek_f32_64x64_w4_d2') in enc.labels()[1], enc.labels()
+        outs.append((z.copy(), enc.activation(1).copy()))
+        enc.close()
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1])
+    z64 = ref.encoder_forward_np(ref.input_to_float(x), w, cfg.strides, False)
+    assert np.abs(outs[0][0] - z64).max() / np.abs(z64).max() < 5e-6
+
+
 @pytest.mark.parametrize('tiny', [0, 64])
 def test_eight_wave_pingpong_schedule_is_bit_identical_to_the_free_running_loop(tiny):
     """8-wave blocks: the two waves of a SIMD alternate load issue and MFMAs with a block barrier between the half-steps
