@@ -144,8 +144,9 @@ struct aae_encoder {
                                            // measured: wins up to 64 tiles (B=1: 94 -> 87 us), loses from 128 on (twice the operand loads per MFMA)
     int wavek_target_blocks = 256;         // blocks a split layer is cut into (tiles x K splits): one per CU
     int wavek_waves = 4;                   // waves per block (4 | 8), each with its own K range
-    int wavek_spread = 1;                  // 64 x 64 wave tiles (four accumulators): next-slab loads between the MFMAs instead of a burst in front of them (conv_wavek_f32.h):
-                                           // conv2 at B = 8 128 -> 115 us, B = 24 encoder 910 -> 830 us; measured neutral-to-worse with two accumulators (64 x 32), not used there
+    int wavek_spread = 3;                  // bit 0: 64 x 64 wave tiles (four accumulators): next-slab loads between the MFMAs instead of a burst in front of them (conv_wavek_f32.h):
+                                           // conv2 at B = 8 128 -> 115 us, B = 24 encoder 910 -> 830 us; measured neutral-to-worse for 64 x 32 tiles, not used there.
+                                           // bit 1: 32 x 32 tiles with a second accumulator for the odd q-steps (two fma chains, added once): B = 1 80.2 -> 78.0 us
     int wavek_pingpong = 0;                // 8-wave blocks: the two waves of a SIMD alternate load issue and MFMAs behind block barriers (conv_wavek_f32.h);
                                            // measured SLOWER than free-running waves (B = 1: 95 vs 82 us): kept as an option with its measurement, off
     int wavek_tiny_waves = 4;              // ... of the 32 x 32 wave tiles (per-detection batches): 8 = two waves per SIMD, so that one wave's operand-load issue
@@ -394,7 +395,7 @@ constexpr double kSlabUs = 16.0 * 64.0 / 2400.0;
 
 static double wavek_cost_us(const aae_encoder* enc, int tiles, int g, int slabs, int mt, int nt) {
     static const double eff_burst[3] = {0.71, 0.72, 0.88}, eff_spread[3] = {0.71, 0.72, 0.96}, fixed[3] = {0.0, 0.0, 5.0};
-    const double* eff = enc->wavek_spread ? eff_spread : eff_burst;          // (64 x 64 tiles with the spread schedule: +9 % measured, round 4)
+    const double* eff = (enc->wavek_spread & 1) ? eff_spread : eff_burst;          // (64 x 64 tiles with the spread schedule: +9 % measured, round 4)
     const int shape = mt == 1 ? 0 : (nt == 1 ? 1 : 2);
     const int cus = enc->wavek_target_blocks > 0 ? enc->wavek_target_blocks : 256;
     return (double)ceil_div(tiles * g, cus) * (ceil_div(slabs, 4 * g) + 4) * (mt * nt) * kSlabUs / eff[shape] + fixed[shape] + (g > 1 ? 3.0 : 0.0);
@@ -689,11 +690,11 @@ static int launch_wavek(aae_encoder* enc, const Layer& L, const WaveKPlan& w, co
     const int key = (w.MT == 1 ? 1000 : 0) + w.NT * 100 + w.waves * 10 + w.depth;
     switch (key) {
         case 243: launch_wavek_t<2, 2, 4, 3>(a, tag, nblk, stream); break;
-        case 242: if (a.spread) launch_wavek_t<2, 2, 4, 2, true>(a, tag, nblk, stream); else launch_wavek_t<2, 2, 4, 2>(a, tag, nblk, stream); break;
+        case 242: if (a.spread & 1) launch_wavek_t<2, 2, 4, 2, true>(a, tag, nblk, stream); else launch_wavek_t<2, 2, 4, 2>(a, tag, nblk, stream); break;
         case 282: launch_wavek_t<2, 2, 8, 2>(a, tag, nblk, stream); break;
         case 143: launch_wavek_t<2, 1, 4, 3>(a, tag, nblk, stream); break;
         case 142: launch_wavek_t<2, 1, 4, 2>(a, tag, nblk, stream); break;
-        case 1142: launch_wavek_t<1, 1, 4, 2>(a, tag, nblk, stream); break;
+        case 1142: if (a.spread & 2) launch_wavek_t<1, 1, 4, 2, true>(a, tag, nblk, stream); else launch_wavek_t<1, 1, 4, 2>(a, tag, nblk, stream); break;
         case 1143: launch_wavek_t<1, 1, 4, 3>(a, tag, nblk, stream); break;
         case 182: launch_wavek_t<2, 1, 8, 2>(a, tag, nblk, stream); break;
         case 1182: launch_wavek_t<1, 1, 8, 2>(a, tag, nblk, stream); break;
@@ -961,6 +962,7 @@ static bool chain_eligible(const aae_encoder* enc, int B, const std::vector<Wave
     const size_t nl = enc->layers.size();
     if (!enc->detect_chain || B > 4 || nl != (size_t)aae::kChainConv + 1 || enc->compact_workspace || !dense_gemv_ticket) return false;
     if (enc->wavek_ablate || (enc->wavek_timeline && !enc->chain_timeline)) return false;   // (profiling aids of the stand-alone launches)
+    if (enc->wavek_spread != 3) return false;                  // (the phases are compiled with the default schedules)
     for (size_t li = 1; li < nl; ++li) {
         const WaveKPlan& w = plans[li];
         if (!w.use || w.waves != 4 || w.depth != 2 || enc->layers[li].Cout % 4 != 0) return false;
@@ -1638,7 +1640,7 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
         if (value != 4 && value != 8) return fail(AAE_ERR_INVALID, "wavek_waves %d: 4 or 8", value);
         enc->wavek_waves = value;
     } else if (!strcmp(name, "wavek_pingpong")) enc->wavek_pingpong = value ? 1 : 0;
-    else if (!strcmp(name, "wavek_spread")) enc->wavek_spread = value ? 1 : 0;
+    else if (!strcmp(name, "wavek_spread")) enc->wavek_spread = value & 3;       // bit 0: 64 x 64 tiles, bit 1: 32 x 32 tiles (two accumulator chains)
     else if (!strcmp(name, "wavek_tiny_waves")) {
         if (value != 4 && value != 8) return fail(AAE_ERR_INVALID, "wavek_tiny_waves %d: 4 or 8", value);
         enc->wavek_tiny_waves = value;

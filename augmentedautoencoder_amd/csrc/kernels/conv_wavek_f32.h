@@ -209,6 +209,15 @@ __device__ __forceinline__ void conv_wavek_block(const ConvWaveKArgs& p, const i
         for (int ni = 0; ni < NT; ++ni)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[mi][ni][r] = 0.f;
+    // 32 x 32 wave tile in the spread form: a second accumulator takes the odd q-steps, so that consecutive MFMAs are independent and
+    // the next slab's loads can sit between them (the two chains are added once, behind the K loop: a different -- fixed --
+    // summation order than the one-chain form)
+    constexpr bool TWIN = SPREAD && MT * NT == 1 && DEPTH == 2;
+    f32x16 acc_odd;
+    if (TWIN) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_odd[r] = 0.f;
+    }
 
     auto mfma_stage = [&](int d) {
 #pragma unroll
@@ -255,7 +264,7 @@ __device__ __forceinline__ void conv_wavek_block(const ConvWaveKArgs& p, const i
     // (logical block 0, its first loads in flight) the tile words get this launch's nonce long before the first arrival
     if (p.gsplits > 1 && Lphys == 0)
         for (int w = tid; w < tiles; w += T) ticket_prepare_word(p.tickets + w, p.nonce);
-    if constexpr (SPREAD && MT * NT >= 2 && DEPTH == 2) {
+    if constexpr (SPREAD && DEPTH == 2) {
         // Spread schedule (wave tiles with two or four accumulators).  The burst form below issues the ~100 instructions that
         // address and request the next slab in one piece, fenced in front of the slab's 64 (32) MFMAs: for ~450 cycles per slab
         // the matrix pipe of a one-wave-per-SIMD block has nothing to do (64 x 64 tiles: 0.70 of the MFMA peak at B = 4).
@@ -275,10 +284,13 @@ __device__ __forceinline__ void conv_wavek_block(const ConvWaveKArgs& p, const i
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             sched_fence();
+                            if (TWIN && (q & 1)) acc_odd = mfma_32x32x2(fa[d][0][c][q], fb[d][0][c][q], acc_odd);
+                            else {
 #pragma unroll
-                            for (int mi = 0; mi < MT; ++mi)
+                                for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
-                                for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = mfma_32x32x2(fa[d][mi][c][q], fb[d][ni][c][q], acc[mi][ni]);
+                                    for (int ni = 0; ni < NT; ++ni) acc[mi][ni] = mfma_32x32x2(fa[d][mi][c][q], fb[d][ni][c][q], acc[mi][ni]);
+                            }
                             sched_fence();
                             if (c == 0 && q == 0) {             // addresses of slab t + d + 1 (dead once past s1: out of range, no traffic)
                                 const bool live = t_load < s1;
@@ -292,7 +304,10 @@ __device__ __forceinline__ void conv_wavek_block(const ConvWaveKArgs& p, const i
                                 ++t_load;
                                 if (++kw == pKS) { kw = 0; if (++kh == pKS) { kh = 0; ++cc; } }
                             }
-                            if (q < MT) fa[dn][q < MT ? q : 0][c] = buffer_load4(xbuf, ao[q < MT ? q : 0] + 32u * c);
+                            if (TWIN) {                         // (one A and one B load per k-group: behind the even q-steps)
+                                if (q == 0) fa[dn][0][c] = buffer_load4(xbuf, ao[0] + 32u * c);
+                                if (q == 2) fb[dn][0][c] = buffer_load4(wbuf, bo == kOobBase ? kOobBase : bo + c * bw_group);
+                            } else if (q < MT) fa[dn][q < MT ? q : 0][c] = buffer_load4(xbuf, ao[q < MT ? q : 0] + 32u * c);
                             else if (q - MT < NT) fb[dn][q - MT < NT ? q - MT : 0][c] = buffer_load4(wbuf, bo == kOobBase ? kOobBase : bo + c * bw_group + 512u * (q - MT));
                         }
                     }
@@ -343,6 +358,10 @@ __device__ __forceinline__ void conv_wavek_block(const ConvWaveKArgs& p, const i
         }
     }
 
+    if (TWIN) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][0][r] += acc_odd[r];
+    }
     stamp(2);                                                   // K loop done (MFMA results may still be in the pipe)
     // ---- the WAVES partial tiles meet in LDS, lane-linear (conflict-free), and are added in wave order ----------
 #pragma unroll

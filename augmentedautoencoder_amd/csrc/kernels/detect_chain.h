@@ -62,7 +62,7 @@ template <int SHAPE>
 __device__ __forceinline__ void chain_conv_phase(const ConvWaveKArgs& a, int blk, int G, float* red, int* flag, const WaveKPrefetch& pf, bool have_pf) {
     const int nblk = a.num_mt * a.num_nt * a.gsplits;
     for (int L = blk; L < nblk; L += G)
-        conv_wavek_block<ChainShape<SHAPE>::MT, ChainShape<SHAPE>::NT, 4, 2, true>(a, L, nblk, red, flag, pf, have_pf && L == blk);
+        conv_wavek_block<ChainShape<SHAPE>::MT, ChainShape<SHAPE>::NT, 4, 2, true, SHAPE != 1>(a, L, nblk, red, flag, pf, have_pf && L == blk);     // (the schedules of the stand-alone launches at their defaults: spread for 32 x 32 and 64 x 64 tiles)
 }
 
 // scan phase: rows [row, row + 32) of a wave against the MQ queries -- scan_issue32 / scan_scores32 / wave_max_first_lane of

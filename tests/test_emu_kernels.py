@@ -735,6 +735,18 @@ def test_spread_load_schedule_is_bit_identical_to_the_burst(narrow):
     assert np.abs(outs[0][0] - z64).max() / np.abs(z64).max() < 5e-6
 
 
+@pytest.mark.parametrize('B', [1, 3])
+def test_spread_schedule_of_the_32x32_tiles_with_two_accumulator_chains(B):
+    """wavek_spread bit 1: the 32 x 32 wave tile takes its odd q-steps into a second accumulator (consecutive MFMAs independent,
+    the next slab's loads between them); the two chains are added behind the K loop -- another fixed summation order, so the
+    check is the oracle's tolerance, layer by layer, with a partial M tile and a cross-block split."""
+    cfg = EncoderConfig((16, 16, 3), [32, 96], [2, 2], 5, 128, True)
+    labels = _run(cfg, B, 81, wavek=1, options={'wavek_tiny_max_tiles': 64, 'wavek_spread': 3})
+    assert 'conv_wavek_f32_32x32_w4_d2' in labels[1], labels
+    labels = _run(cfg, B, 81, wavek=1, options={'wavek_tiny_max_tiles': 64, 'wavek_spread': 3, 'wavek_target_blocks': 2})
+    assert 'conv_wavek_f32_32x32_w4_d2_g1 ' in labels[1], labels
+
+
 @pytest.mark.parametrize('tiny', [0, 64])
 def test_eight_wave_pingpong_schedule_is_bit_identical_to_the_free_running_loop(tiny):
     """8-wave blocks: the two waves of a SIMD alternate load issue and MFMAs with a block barrier between the half-steps
