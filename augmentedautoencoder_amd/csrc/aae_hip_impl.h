@@ -417,7 +417,10 @@ static WaveKPlan plan_wavek(const aae_encoder* enc, const Layer& L, long long M,
     WaveKPlan w;
     if (!enc->wavek || split || L.kind != KIND_IGEMM) return w;
     const long long tiles22 = ((M + 63) / 64) * (L.CoutPad / 64);
-    const bool by_cost = enc->planner_cost_model && L.index >= 0 && M / ((long long)L.Ho * L.Wo) >= 5 && enc->wavek_waves != 8;
+    // (5 <= B < 256: at the headline batch every layer keeps its measured choice -- the big igemm tiles; conv4 would cost the same
+    //  on 64 x 64 wave tiles, 1.542 vs 1.547 ms, profiles/r12)
+    const long long batch_of = L.index >= 0 ? M / ((long long)L.Ho * L.Wo) : M;
+    const bool by_cost = enc->planner_cost_model && L.index >= 0 && batch_of >= 5 && batch_of < 256 && enc->wavek_waves != 8;
     if (tiles22 > kWaveKTileCap || (!by_cost && tiles22 > enc->wavek_max_tiles)) return w;
     const unsigned long long x_bytes = (unsigned long long)(M / (L.Ho * L.Wo)) * L.H * L.W * L.Cin * sizeof(float);
     if (x_bytes >= 0xFFFFFF00ull) return w;
@@ -425,7 +428,7 @@ static WaveKPlan plan_wavek(const aae_encoder* enc, const Layer& L, long long M,
     w.waves = enc->wavek_waves == 8 ? 8 : 4;
     w.depth = (enc->wavek_depth == 2 || w.waves == 8) ? 2 : 3;    // 8 waves share the register file two per SIMD: two slabs in flight each
     const long long batch = L.index >= 0 ? M / ((long long)L.Ho * L.Wo) : M;
-    if (enc->planner_cost_model && L.index >= 0 && batch >= 5 && w.waves == 4) {
+    if (by_cost && w.waves == 4) {
         // conv layers of batches beyond the per-detection regime: cheapest of {igemm, wave-split-K 32 x 32 | 64 x 32 | 64 x 64} by estimate
         const int slabs = (int)(L.K() / 32);
         double best = igemm_cost_us(enc, L, M);

@@ -10,12 +10,12 @@ mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
 CMD="python $GRAFT_REPO_ROOT/tools/prof_mix.py $REPS $OPTS"
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o mix -- $CMD > $OUT/trace.log 2>&1
+timeout -s KILL 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o mix -- $CMD > $OUT/trace.log 2>&1
 echo "trace rc=$?" > $OUT/pmc_status.txt
 i=0
 for SET in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE SQ_BUSY_CYCLES"; do
   i=$((i+1))
-  timeout 300 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $OUT/pmc$i -o mix -- $CMD > $OUT/pmc$i.log 2>&1
+  timeout -s KILL 300 rocprofv3 --pmc $SET --kernel-trace --output-format csv -d $OUT/pmc$i -o mix -- $CMD > $OUT/pmc$i.log 2>&1
   echo "pmc$i [$SET] rc=$?" >> $OUT/pmc_status.txt
 done
 cd $GRAFT_REPO_ROOT
