@@ -427,7 +427,6 @@ static WaveKPlan plan_wavek(const aae_encoder* enc, const Layer& L, long long M,
     w.use = true;
     w.waves = enc->wavek_waves == 8 ? 8 : 4;
     w.depth = (enc->wavek_depth == 2 || w.waves == 8) ? 2 : 3;    // 8 waves share the register file two per SIMD: two slabs in flight each
-    const long long batch = L.index >= 0 ? M / ((long long)L.Ho * L.Wo) : M;
     if (by_cost && w.waves == 4) {
         // conv layers of batches beyond the per-detection regime: cheapest of {igemm, wave-split-K 32 x 32 | 64 x 32 | 64 x 64} by estimate
         const int slabs = (int)(L.K() / 32);

@@ -314,7 +314,7 @@ __device__ __forceinline__ void conv_wavek_block(const ConvWaveKArgs& p, const i
                 }
             }
         }
-    } else if (WAVES == 8 && DEPTH == 2 && !CHAIN && p.pingpong) {
+    } else if (WAVES == 8 && DEPTH == 2 && MT * NT == 1 && !CHAIN && p.pingpong) {     // (kept for the 32 x 32 tiles only: beside the free-running loop it made the 64 x 64 / 8-wave form spill)
         // Two waves per SIMD (w and w + 4: tools/ubench/wave_simd_map.hip), made to ALTERNATE.  A wave's slab is ~300 cycles of
         // address arithmetic + load issue, during which its dependent MFMA chain stands still, then 16 x 64 cycles of MFMAs.  Left
         // alone, the two waves of a SIMD fall into step -- they share the matrix pipe, so they finish their MFMAs together and

@@ -747,11 +747,11 @@ def test_spread_schedule_of_the_32x32_tiles_with_two_accumulator_chains(B):
     assert 'conv_wavek_f32_32x32_w4_d2_g1 ' in labels[1], labels
 
 
-@pytest.mark.parametrize('tiny', [0, 64])
+@pytest.mark.parametrize('tiny', [64])
 def test_eight_wave_pingpong_schedule_is_bit_identical_to_the_free_running_loop(tiny):
     """8-wave blocks: the two waves of a SIMD alternate load issue and MFMAs with a block barrier between the half-steps
     (option wavek_pingpong; measured slower on MI355X, default off).  Same per-wave fma chains as the free-running loop: identical bits, for ragged K
-    ranges (25 slabs over 3 blocks x 8 waves: some waves get one slab, some two), 64 x 32 and 32 x 32 wave tiles."""
+    ranges (25 slabs over 3 blocks x 8 waves: some waves get one slab, some two); 32 x 32 wave tiles (the only form that keeps the schedule)."""
     cfg = EncoderConfig((16, 16, 3), [32, 64], [2, 2], 5, 128)
     w = synth.make_weights(seed=5, shape=cfg.shape, num_filter=cfg.num_filter, strides=cfg.strides, latent=128)
     x = synth.make_crops(3, seed=6, shape=cfg.shape)
