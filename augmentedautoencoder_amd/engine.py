@@ -78,6 +78,26 @@ class _Workspace(object):
         return self.buf.numel() - (-self.buf.data_ptr()) % 256
 
 
+def share_workspaces(engines):
+    """Engines that only ever run one after the other on one stream -- the N objects of one pose estimator
+    (m3_interface/ae_pose_estimator.py:61-78 keeps N encoders + N codebooks in one process) -- can scratch in the SAME device
+    memory: N x 973 MB of encoder workspace at batch 256 become one (7.8 GB -> 1 GB for eight objects).  `engines`: objects with
+    a `.ws` scratch buffer and a `.device`, all of one kind (encoders, or codebooks: one call uses an encoder's and a codebook's
+    workspace at the same time, so the two kinds never share).  Nothing in a workspace outlives a call (the ticket words at its
+    front are nonce-tagged per launch), so sharing changes no result; engines used CONCURRENTLY on several streams must keep
+    their own."""
+    pools = {}
+    for e in engines:
+        ws = getattr(e, 'ws', None)
+        if e is None or ws is None or not hasattr(e, 'device'):
+            continue
+        key = (type(e), str(e.device))
+        if key in pools:
+            e.ws = pools[key]
+        else:
+            pools[key] = ws
+
+
 class EncoderEngine(object):
     """Owns one aae_encoder handle (device weights) -- the stand-in for the encoder
     part of the TF graph + session of the reference."""

@@ -134,6 +134,14 @@ class AePoseEstimator(object):
                 self._register(k, codebooks[k], train_args[k])
         if topk > 1:
             raise NotImplementedError('topk > 1 not implemented (as in the reference, ae_pose_estimator.py:36-39)')
+        # the objects of one estimator run one after the other on one stream: they scratch in the same device memory
+        # (one encoder workspace -- 973 MB at batch 256 -- instead of one per object)
+        try:
+            from .engine import share_workspaces
+            share_workspaces([getattr(getattr(c, '_encoder', None), 'engine', None) for c in self.all_codebooks.values()])
+            share_workspaces([getattr(c, 'engine', None) for c in self.all_codebooks.values()])
+        except ImportError:
+            pass
         self._camPose, self._upright, self._topk = bool(camPose), bool(upright), int(topk)
         self.upload_union_only = True      # process(): upload the union rectangle of the boxes instead of the frame
         self.geometry_chunk = 16           # process(): classes with more than 2 x this many detections go to the GPU in chunks of this size

@@ -248,6 +248,8 @@ def test_process_on_gpu_full_size_two_objects():
         cb.assign_obj_bbs(bbs)
         codebooks[name], train_args[name], info[name] = cb, targs, (w, E, bbs, ds)
     est = AePoseEstimator(codebooks=codebooks, train_args=train_args)
+    # the objects of one estimator scratch in the same device memory (one encoder workspace instead of one per object)
+    assert codebooks['obj_a']._encoder.engine.ws is codebooks['obj_b']._encoder.engine.ws and codebooks['obj_a'].engine.ws is codebooks['obj_b'].engine.ws
     img = _scene(9, 480, 640)
     rng = np.random.default_rng(2)
     dets, raw = [], []

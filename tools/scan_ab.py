@@ -11,6 +11,8 @@ from augmentedautoencoder_amd.engine import CodebookEngine
 
 tag = sys.argv[1] if len(sys.argv) > 1 else 'x'
 cb = CodebookEngine(synth.make_codebook(92232, 128, seed=7))
+if len(sys.argv) > 2:
+    cb.set_scan_mode(int(sys.argv[2]))
 z = torch.randn(4, 128, device='cuda')
 
 
@@ -32,3 +34,10 @@ for b in (1, 2, 4):
     zb = z[:b].contiguous()
     out['B%d' % b] = [round(time_us(lambda: cb.nn(zb, 1, 1), 400), 2) for _ in range(5)]
 print(json.dumps(out))
+if hasattr(cb, 'nn_timed'):
+    out2 = {'tag': tag + ' queued from C (aae_codebook_nn_timed, 200 reps)'}
+    for b in (1, 2, 4):
+        zb = z[:b].contiguous()
+        cb.nn_timed(zb, 1, 1, reps=20)
+        out2['B%d' % b] = [round(cb.nn_timed(zb, 1, 1, reps=200)[2] * 1e3, 2) for _ in range(5)]
+    print(json.dumps(out2))
