@@ -1612,7 +1612,21 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
     else if (!strcmp(name, "wavek_balance")) enc->wavek_balance = value ? 1 : 0;
     else if (!strcmp(name, "planner_cost_model")) enc->planner_cost_model = value ? 1 : 0;
     else if (!strcmp(name, "ticket_prep")) enc->ticket_prep = value ? 1 : 0;
-    else if (!strcmp(name, "detect_chain")) enc->detect_chain = value ? 1 : 0;
+    else if (!strcmp(name, "detect_chain")) {
+        if (value) {
+            // the persistent launch's grid barrier needs EVERY block resident: refuse the option unless the runtime confirms that one
+            // 256-thread block with the chain's LDS footprint fits a compute unit and the device's CU count is known (a plain launch
+            // of an over-sized grid would spin until its bounded wait traps).  A CU mask smaller than the device is not detectable
+            // from here: the option stays opt-in.
+            if (enc->cu_count <= 0) return fail(AAE_ERR_UNSUPPORTED, "detect_chain: the device's compute-unit count is unknown");
+            int per_cu = 0;
+            const hipError_t e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)aae::detect_chain_kernel<1, 0, 0, 0>, 256, aae::kChainSmem);
+            if (e != hipSuccess || per_cu < 1)
+                return fail(AAE_ERR_UNSUPPORTED, "detect_chain: the runtime does not confirm residency of the persistent launch (%s, %d blocks per CU)",
+                            e == hipSuccess ? "ok" : hipGetErrorString(e), per_cu);
+        }
+        enc->detect_chain = value ? 1 : 0;
+    }
     else if (!strcmp(name, "detect_chain_blocks")) enc->detect_chain_blocks = value < 1 ? 1 : (value > aae_host::kChainMaxBlocks ? aae_host::kChainMaxBlocks : value);
     else if (!strcmp(name, "compact_workspace")) enc->compact_workspace = value ? 1 : 0;
     else if (!strcmp(name, "chain_timeline")) {

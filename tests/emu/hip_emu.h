@@ -422,6 +422,7 @@ inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
 inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
 inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
+inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* n, const void*, int, size_t) { *n = 1; return hipSuccess; }
 enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
 
 #define AAE_LAUNCH(kernel, grid, block, smem, stream, ...) \
