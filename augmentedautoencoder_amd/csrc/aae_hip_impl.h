@@ -127,7 +127,8 @@ struct aae_encoder {
     int igemm_breg_min_blocks = 768;       // ... with the 32 KB footprint only for grids of at least this many blocks
     int igemm_breg_wide = 1;               // BREG conv2/conv3: 128 x 256 block tiles (each wave 64 x 128) when the layer is wide enough (+0.9 %)
     int igemm_breg_wide_min_blocks = 512;
-    int dense_gemv = 1;                    // B <= 4: dense layer as a weight-streaming GEMV instead of a split-K MFMA tile
+    int dense_gemv = 1;                    // B <= dense_gemv_max_batch: dense layer as a weight-streaming GEMV instead of a split-K MFMA tile
+    int dense_gemv_max_batch = 8;          // (1 ... 8; 4 = rounds 2-3: beyond it the wave-split-K MFMA tile, 15 us at any mid batch)
     int igemm_breg = 1;                    // conv layers: weight fragments straight from global memory to registers (A-only LDS-DMA, 32 KB LDS)
     int igemm_dma = 1;                     // fp32 igemm operand slabs by LDS-DMA (buffer_load ... lds); 0 = register-staged variant
     int x3h_wide_min_blocks = 0;           // > 0: f32x3h conv layers use 256x128 tiles (8 waves) when that still yields this many blocks; measured neutral (+-1.5 %), off by default
@@ -194,6 +195,9 @@ struct aae_codebook {
     // (AAE_SCAN_STREAM_WALK) = one block per CU walks the codebook with two batches in flight per wave (scan_stream_walk_kernel:
     // measured level at B = 1, slower at B = 4 inside the fused query -- 18.4 vs 16.9 us)
     int scan_walk = 0;
+    // B > 4, top-1 on the query-resident kernel: 1 = the scan normalises the raw latent codes in its prologue (one launch less);
+    // 0 (AAE_SCAN_AUTO_PACKED) = l2norm_pack launch in front, the scan reads the packed planes -- identical bits
+    int scan_fused_norm = 1;
 };
 
 namespace aae_host {
@@ -538,7 +542,7 @@ static Workspace plan_workspace(const aae_encoder* enc, int B) {
         const size_t bytes = splits > 1 ? (size_t)splits * B * enc->dense.Cout * sizeof(float) : 0;
         if (bytes > partial) partial = bytes;
     }
-    if (B <= 4 && enc->dense.kind == KIND_IGEMM) {           // the GEMV form of the dense layer: one partial row per 128-k chunk
+    if (B <= aae::kGemvMaxBatch && enc->dense.kind == KIND_IGEMM) {   // the GEMV form of the dense layer: one partial row per 128-k chunk
         const size_t gemv = gemv_partial_bytes(enc->dense, B);
         if (gemv > partial) partial = gemv;
     }
@@ -884,7 +888,10 @@ static int launch_generic(aae_encoder* enc, const Layer& L, const void* x, bool 
     return tm.mark();
 }
 
-// dense layer at B <= 4: weight-streaming GEMV + the fixed-order chunk reduction
+// dense layer at B <= 8: weight-streaming GEMV + the fixed-order chunk reduction
+static int gemv_max_batch(const aae_encoder* enc) {
+    return enc->dense_gemv_max_batch < 1 ? 1 : (enc->dense_gemv_max_batch > aae::kGemvMaxBatch ? aae::kGemvMaxBatch : enc->dense_gemv_max_batch);
+}
 static bool gemv_uses_ticket(const aae_encoder* enc, const Layer& D) {
     return enc->gemv_ticket && D.Cout % 4 == 0 && D.CoutPad / 128 <= kGemvTicketSlots;
 }
@@ -903,8 +910,8 @@ static int launch_dense_gemv(aae_encoder* enc, const Layer& D, const float* x, i
     aae::DenseGemvArgs a = gemv_args(D, x, B, partial);
     const int chunks = ceil_div(a.K, aae::kGemvChunk);
     const dim3 grid(chunks, D.CoutPad / 128);
-    const int MQ = B <= 2 ? B : (B == 3 ? 3 : 4);
-    int smem = 2 * MQ * aae::kGemvChunk * (int)sizeof(float);
+    const int MQ = B <= 4 ? B : 8;
+    int smem = 2 * MQ * aae::kGemvChunk * (int)sizeof(float) + 16;
     const bool ticket = tickets && gemv_uses_ticket(enc, D);
     char label[96];
     if (ticket) {
@@ -915,7 +922,8 @@ static int launch_dense_gemv(aae_encoder* enc, const Layer& D, const float* x, i
         if (MQ == 1) AAE_LAUNCH((aae::dense_gemv_f32_kernel<1, true>), grid, dim3(256), smem, stream, a);
         else if (MQ == 2) AAE_LAUNCH((aae::dense_gemv_f32_kernel<2, true>), grid, dim3(256), smem, stream, a);
         else if (MQ == 3) AAE_LAUNCH((aae::dense_gemv_f32_kernel<3, true>), grid, dim3(256), smem, stream, a);
-        else AAE_LAUNCH((aae::dense_gemv_f32_kernel<4, true>), grid, dim3(256), smem, stream, a);
+        else if (MQ == 4) AAE_LAUNCH((aae::dense_gemv_f32_kernel<4, true>), grid, dim3(256), smem, stream, a);
+        else AAE_LAUNCH((aae::dense_gemv_f32_kernel<8, true>), grid, dim3(256), smem, stream, a);
         snprintf(label, sizeof(label), "dense:dense_gemv_f32_ticket chunks=%d M=%d N=%d K=%d", chunks, B, D.Cout, a.K);
         note_kernel({label, 2.0 * B * (double)D.K() * D.Cout});
         AAE_HIP_TRY(hipGetLastError());
@@ -925,7 +933,8 @@ static int launch_dense_gemv(aae_encoder* enc, const Layer& D, const float* x, i
     if (MQ == 1) AAE_LAUNCH((aae::dense_gemv_f32_kernel<1>), grid, dim3(256), smem, stream, a);
     else if (MQ == 2) AAE_LAUNCH((aae::dense_gemv_f32_kernel<2>), grid, dim3(256), smem, stream, a);
     else if (MQ == 3) AAE_LAUNCH((aae::dense_gemv_f32_kernel<3>), grid, dim3(256), smem, stream, a);
-    else AAE_LAUNCH((aae::dense_gemv_f32_kernel<4>), grid, dim3(256), smem, stream, a);
+    else if (MQ == 4) AAE_LAUNCH((aae::dense_gemv_f32_kernel<4>), grid, dim3(256), smem, stream, a);
+    else AAE_LAUNCH((aae::dense_gemv_f32_kernel<8>), grid, dim3(256), smem, stream, a);
     snprintf(label, sizeof(label), "dense:dense_gemv_f32 chunks=%d M=%d N=%d K=%d", chunks, B, D.Cout, a.K);
     note_kernel({label, 2.0 * B * (double)D.K() * D.Cout});
     AAE_HIP_TRY(hipGetLastError());
@@ -1109,7 +1118,7 @@ static int forward_impl(aae_encoder* enc, const void* x, int x_dtype, int B, flo
         const bool first_mfma = li == 0 && L.kind == KIND_FIRST_MFMA;
         if (!first_mfma && L.kind == KIND_IGEMM && !(li == 0 && cur_u8)) plans[li] = plan_wavek(enc, L, (long long)B * L.Ho * L.Wo, false);
     }
-    const bool dense_gemv = D.kind == KIND_IGEMM && B <= 4 && enc->dense_gemv && D.K() % aae::kGemvChunk == 0;
+    const bool dense_gemv = D.kind == KIND_IGEMM && B <= gemv_max_batch(enc) && enc->dense_gemv && D.K() % aae::kGemvChunk == 0;
     const bool gemv_ticket = dense_gemv && gemv_uses_ticket(enc, D);
     if (!dense_gemv && D.kind == KIND_IGEMM && enc->wavek_dense) plans[nl] = plan_wavek(enc, D, B, false);
     aae::TicketPrep prep;
@@ -1305,14 +1314,15 @@ static void launch_scan_stream_bf16_t(const aae::ScanArgs& a, bool upright, int 
     }
 }
 
-template <bool BF16, int K, int RH>
+template <bool BF16, int K, int RH, bool NORM = false>
 static void launch_scan_resident_t(const aae::ScanResidentArgs& a, dim3 grid, hipStream_t stream) {
-    (void)hipFuncSetAttribute((const void*)aae::scan_resident_kernel<BF16, K, RH>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kScanResidentSmem);
-    AAE_LAUNCH((aae::scan_resident_kernel<BF16, K, RH>), grid, dim3(aae::kScanResidentThreads), aae::kScanResidentSmem, stream, a);
+    (void)hipFuncSetAttribute((const void*)aae::scan_resident_kernel<BF16, K, RH, NORM>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kScanResidentSmem);
+    AAE_LAUNCH((aae::scan_resident_kernel<BF16, K, RH, NORM>), grid, dim3(aae::kScanResidentThreads), aae::kScanResidentSmem, stream, a);
 }
 template <bool BF16, int RH>
 static void launch_scan_resident_k(const aae::ScanResidentArgs& a, dim3 grid, hipStream_t stream) {
-    if (a.k <= 1) launch_scan_resident_t<BF16, 0, RH>(a, grid, stream);
+    if (a.k <= 1 && a.z) launch_scan_resident_t<BF16, 0, RH, true>(a, grid, stream);      // the block normalises its own queries
+    else if (a.k <= 1) launch_scan_resident_t<BF16, 0, RH>(a, grid, stream);
     else if (a.k <= 2) launch_scan_resident_t<BF16, 2, RH>(a, grid, stream);    // list slots: the smallest instantiated K >= k
     else if (a.k <= 4) launch_scan_resident_t<BF16, 4, RH>(a, grid, stream);
     else if (a.k == 5) launch_scan_resident_t<BF16, 5, RH>(a, grid, stream);
@@ -1321,10 +1331,11 @@ static void launch_scan_resident_k(const aae::ScanResidentArgs& a, dim3 grid, hi
 
 // topk == 1: block partials (pval, pidx) for argmax_reduce_kernel; topk 2..8: candidate lists for topk_merge_kernel
 static int launch_scan_resident(const aae_codebook* cb, const void* qp, int B, const ScanPlan& s, unsigned char* base, hipStream_t stream,
-                                int topk = 1) {
+                                int topk = 1, const float* raw_z = nullptr) {
     aae::ScanResidentArgs a;
     a.E = cb->E; a.e_bytes = (unsigned)((size_t)cb->N * cb->J * (cb->dtype == AAE_DTYPE_BF16 ? 2 : 4));
     a.qp = qp;
+    a.z = raw_z;
     a.pval = reinterpret_cast<float*>(base + s.pval_off);
     a.pidx = reinterpret_cast<int*>(base + s.pidx_off);
     a.N = cb->N; a.B = B; a.Bpad = s.Bpad; a.Bstride = s.Bstride; a.tiles_per_block = s.res_tiles_per_block;
@@ -1351,6 +1362,8 @@ static int run_scan(aae_codebook* cb, const float* z, int B, int col_stride, flo
     float* qp = reinterpret_cast<float*>(base + s.qp_off);
     const bool resident = s.resident_ok && cs_out == nullptr && col_stride == 1;
     if (partial_rows) *partial_rows = resident ? s.res_blocks : s.nblk;
+    // arg-max on the query-resident kernel: the scan normalises the queries itself (no l2norm_pack launch in front)
+    if (resident && topk == 1 && cb->scan_fused_norm && ((uintptr_t)z & 15) == 0) return launch_scan_resident(cb, nullptr, B, s, base, stream, 1, z);
     if (cb->dtype == AAE_DTYPE_BF16 && s.stream) {
         aae::ScanArgs a;
         a.z = z; a.e_bytes = (unsigned)((size_t)cb->N * cb->J * 2);
@@ -1605,6 +1618,7 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
     else if (!strcmp(name, "igemm_dma")) enc->igemm_dma = value ? 1 : 0;
     else if (!strcmp(name, "igemm_breg")) enc->igemm_breg = value ? 1 : 0;
     else if (!strcmp(name, "dense_gemv")) enc->dense_gemv = value ? 1 : 0;
+    else if (!strcmp(name, "dense_gemv_max_batch")) enc->dense_gemv_max_batch = value;
     else if (!strcmp(name, "gemv_ticket")) enc->gemv_ticket = value ? 1 : 0;
     else if (!strcmp(name, "wavek")) enc->wavek = value ? 1 : 0;
     else if (!strcmp(name, "wavek_dense")) enc->wavek_dense = value ? 1 : 0;
@@ -1864,7 +1878,7 @@ int aae_codebook_prepare_upright(aae_codebook* cb, int col_stride, void* stream_
             cb->upright_copies.push_back({col_stride, sub});
         }
         sub->scan_mode = cb->scan_mode; sub->scan_ticket = cb->scan_ticket; sub->topk_prune = cb->topk_prune; sub->cu_count = cb->cu_count;
-        sub->scan_walk = cb->scan_walk;
+        sub->scan_walk = cb->scan_walk; sub->scan_fused_norm = cb->scan_fused_norm;
         cb->upright = sub; cb->upright_stride = col_stride;
     }
     if (int rc = gather_upright_rows(cb, cb->upright, cb->upright_stride, stream)) return rc;
@@ -1894,14 +1908,17 @@ int aae_codebook_set_scan_mode(aae_codebook* cb, int mode) {
     using namespace aae_host;
     if (!cb) return fail(AAE_ERR_INVALID, "aae_codebook_set_scan_mode: null handle");
     if (mode != AAE_SCAN_AUTO && mode != AAE_SCAN_GEMV && mode != AAE_SCAN_MFMA && mode != AAE_SCAN_STREAM && mode != AAE_SCAN_STREAM_2L &&
-        mode != AAE_SCAN_AUTO_NO_PRUNE && mode != AAE_SCAN_STREAM_WALK)
+        mode != AAE_SCAN_AUTO_NO_PRUNE && mode != AAE_SCAN_STREAM_WALK && mode != AAE_SCAN_AUTO_PACKED)
         return fail(AAE_ERR_INVALID, "scan mode %d", mode);
     cb->scan_ticket = mode == AAE_SCAN_STREAM_2L ? 0 : 1;
     cb->topk_prune = mode == AAE_SCAN_AUTO_NO_PRUNE ? 0 : 1;
     cb->scan_walk = mode == AAE_SCAN_STREAM_WALK ? 1 : 0;
-    cb->scan_mode = (mode == AAE_SCAN_STREAM_2L || mode == AAE_SCAN_STREAM_WALK) ? AAE_SCAN_STREAM : (mode == AAE_SCAN_AUTO_NO_PRUNE ? AAE_SCAN_AUTO : mode);
+    cb->scan_fused_norm = mode == AAE_SCAN_AUTO_PACKED ? 0 : 1;
+    cb->scan_mode = (mode == AAE_SCAN_STREAM_2L || mode == AAE_SCAN_STREAM_WALK) ? AAE_SCAN_STREAM
+                    : ((mode == AAE_SCAN_AUTO_NO_PRUNE || mode == AAE_SCAN_AUTO_PACKED) ? AAE_SCAN_AUTO : mode);
     for (auto& c : cb->upright_copies) {
         c.second->scan_mode = cb->scan_mode; c.second->scan_ticket = cb->scan_ticket; c.second->topk_prune = cb->topk_prune; c.second->scan_walk = cb->scan_walk;
+        c.second->scan_fused_norm = cb->scan_fused_norm;
     }
     return AAE_OK;
 }

@@ -60,11 +60,15 @@ __device__ __forceinline__ f32x16 mfma_32x32x16_bf16(u32x4 a, u32x4 b, f32x16 c)
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 // fp32 -> three bf16 terms (round-to-nearest-even each): v = t0 + t1 + t2 to fp32 accuracy.
-__device__ __forceinline__ unsigned short bf16_rn(float v) {
-    unsigned u = __builtin_bit_cast(unsigned, v);
-    u += 0x7FFFu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
+// (the conversion is one instruction on gfx950, v_cvt_pk_bf16_f32 -- two values at a time; as integer arithmetic on the bit
+//  pattern it was four per value)
+__device__ __forceinline__ unsigned bf16_rn_pack2(float lo, float hi) {
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t v = {lo, hi};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
+__device__ __forceinline__ unsigned short bf16_rn(float v) { return (unsigned short)(bf16_rn_pack2(v, 0.f) & 0xFFFFu); }
 __device__ __forceinline__ float bf16_to_f32(unsigned short h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
 __device__ __forceinline__ void split_bf16x3(float v, unsigned short& t0, unsigned short& t1, unsigned short& t2) {
     t0 = bf16_rn(v);

@@ -44,6 +44,9 @@ struct ScanResidentArgs {
     // top-k pruning across blocks (optional): [kPruneReplicas][Bpad][kPruneGroups] score keys, reset by the normalise kernel in front of the
     // scan; block b raises word b % kPruneGroups of a query to the best score it has seen for it
     int* prune = nullptr;
+    // NORM = true (arg-max form): the raw latent codes [B][128] fp32 (16-byte aligned) -- the block normalises its own queries,
+    // no l2norm_pack launch in front of the scan; qp is not read then
+    const float* z = nullptr;
 #ifdef AAE_SCAN_COUNT
     int* dbg = nullptr;         // [32 steps][2]: accumulator tiles that passed the pretest, value slots that ran the insertion
 #endif
@@ -82,7 +85,81 @@ constexpr int kScanResidentSmem = kScanResidentStages * kScanResidentTileFloats 
 // finished accumulators and the LDS fragment reads sit between the MFMAs of the next ones (below).  Same MFMA order per
 // accumulator: bit-identical scores and indices.  (A running maximum per accumulator position -- 3 instead of 5 vector
 // instructions per value -- was tried for the arg-max: 128 more registers at four accumulator tiles, 300 spilled: dropped.)
-template <bool BF16, int K = 0, int RH = 2>
+// NORM: the query fragments come straight from the raw latent codes.  Lane (i, h) of a wave holds 64 of the 128 elements of
+// query q0 + i -- exactly the fragments it multiplies -- and the norm is added up in the order of l2norm_pack_kernel (element
+// j and j + 64 by one fma chain, then the butterfly over j % 64 with masks 32 ... 1): the steps of that butterfly that pair
+// elements of the same lane are plain adds, the one that pairs the lane halves is an exchange with lane ^ 32.  Same sum, same
+// 1 / sqrt, same products: the fragments have the bits the packed planes had (tests/test_emu_kernels.py compares them).
+// Every block repeats this for its queries (128 KB of hot L2 reads and ~200 vector instructions per wave against a kernel of
+// 40 us); what it buys is the launch in front: config 5 arg-max 53 -> 50 us, the B = 5 ... 256 calls 3 us each.
+// (two steps: the raw pieces are requested in front of the first codebook tiles, the arithmetic runs while those are in flight)
+template <bool BF16>
+__device__ __forceinline__ void scan_resident_load_raw(const float* z, const int query, const bool real, const int h, f32x4 (&zs)[16]) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c) {   // fp32: slot 2c + h (4 elements); bf16: slot 2s + h = pieces 2s, 2s + 1 (8 elements), c = 2s + piece
+        const int piece = BF16 ? (2 * (c >> 1) + h) * 2 + (c & 1) : 2 * c + h;       // 16-byte piece of the query row
+        zs[c] = real ? *reinterpret_cast<const f32x4*>(z + (long long)query * 128 + piece * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+}
+template <bool BF16>
+__device__ __forceinline__ void scan_resident_normalise(const f32x4 (&zs)[16], f32x4 (&bq)[BF16 ? 8 * kBf16QueryTerms : 16]) {
+    // no fused multiply-adds the packing kernel does not have: there the product z * inv is rounded before the first bf16 term is
+    // taken off it (on the GPU the contracted form changed the second term's last bit in a few elements per batch)
+#pragma clang fp contract(off)
+    // element j of the row sits in (register r, component e) with j % 64 = 8 r' ... : the first 8 registers hold j < 64, register
+    // r + 8 the partner j + 64 of register r (fp32: j = 8 c + 4 h + e; bf16: j = 16 s + 8 h + 4 (c & 1) + e, c = 2 s + (c & 1))
+    f32x4 t[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[r][e] = fmaf(zs[r + 8][e], zs[r + 8][e], fmaf(zs[r][e], zs[r][e], 0.f));
+    float ss;
+    if (BF16) {
+        // j % 64 = 16 (s & 3) + 8 h + 4 (c & 1) + e, register r = 2 (s & 3) + (c & 1): masks 32, 16 pair registers r ^ 4, r ^ 2;
+        // mask 8 the lane halves; mask 4 registers r ^ 1; masks 2, 1 components
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[r] += t[r + 4];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) t[r] += t[r + 2];
+#pragma unroll
+        for (int r = 0; r < 2; ++r)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) t[r][e] += shfl_xor(t[r][e], 32);
+        t[0] += t[1];
+    } else {
+        // j % 64 = 8 c + 4 h + e, register r = c: masks 32, 16, 8 pair registers r ^ 4, r ^ 2, r ^ 1; mask 4 the lane halves
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[r] += t[r + 4];
+#pragma unroll
+        for (int r = 0; r < 2; ++r) t[r] += t[r + 2];
+        t[0] += t[1];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) t[0][e] += shfl_xor(t[0][e], 32);
+    }
+    ss = (t[0][0] + t[0][2]) + (t[0][1] + t[0][3]);
+    const float inv = 1.0f / sqrtf(fmaxf(ss, 1e-12f));
+    if (BF16) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {
+            // the first two terms of split_bf16x3, two elements per conversion: t0 = bf16(v), t1 = bf16(v - t0)
+            static_assert(kBf16QueryTerms == 2, "the fused normalisation forms two bf16 terms per element");
+            u32x4 w0, w1;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const float v_lo = zs[2 * s + (d >> 1)][(2 * d) & 3] * inv, v_hi = zs[2 * s + (d >> 1)][(2 * d + 1) & 3] * inv;
+                w0[d] = bf16_rn_pack2(v_lo, v_hi);
+                w1[d] = bf16_rn_pack2(v_lo - __builtin_bit_cast(float, w0[d] << 16), v_hi - __builtin_bit_cast(float, w0[d] & 0xFFFF0000u));
+            }
+            bq[s] = __builtin_bit_cast(f32x4, w0);
+            bq[8 + s] = __builtin_bit_cast(f32x4, w1);
+        }
+    } else {
+#pragma unroll
+        for (int c = 0; c < 16; ++c) bq[c] = zs[c] * inv;
+    }
+}
+
+template <bool BF16, int K = 0, int RH = 2, bool NORM = false>
 __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(const ScanResidentArgs p) {
     constexpr int kTileRows = BF16 ? 128 : 64;
     constexpr int kMi = (BF16 ? 4 : 2) / RH;       // 32-row accumulator tiles per wave
@@ -104,7 +181,10 @@ __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(con
 
     // this wave's query fragments, for good
     f32x4 bq[BF16 ? 8 * kBf16QueryTerms : 16];
-    if (active) {
+    [[maybe_unused]] f32x4 zraw[16];                      // (NORM only; dead otherwise)
+    if (NORM) {
+        if (active) scan_resident_load_raw<BF16>(p.z, query, query < p.B, h, zraw);
+    } else if (active) {
         if (BF16) {
             const unsigned short* qp3 = reinterpret_cast<const unsigned short*>(p.qp);
             const long long qplane = (long long)16 * p.Bpad * 8;
@@ -276,6 +356,9 @@ __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(con
     // tile t (vmcnt counts in issue order: the four of tile t + 1 stay in flight), the barrier covers the other waves'.
     dma(tile0, Et);
     dma(tile0 + 1, Et + kScanResidentTileFloats);
+    if constexpr (NORM) {
+        if (active) scan_resident_normalise<BF16>(zraw, bq);
+    }
     int img = 0;
     const bool prune = K > 0 && p.prune != nullptr;
     if (K > 0 && tid < QB) tau[tid] = kNegInf;                 // (in place at the first barrier)

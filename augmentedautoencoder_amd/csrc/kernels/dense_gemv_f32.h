@@ -1,4 +1,4 @@
-// Dense layer for tiny batches (B <= 4: the reference's per-detection usage): z = flatten(x) . W + b as a
+// Dense layer for tiny batches (B <= 8; B <= 4 is the reference's per-detection usage): z = flatten(x) . W + b as a
 // weight-streaming GEMV (/root/reference/auto_pose/ae/encoder.py:58-68).  At M <= 4 a 128 x 128 MFMA tile is
 // 97 % padding and the layer is the 16.8 MB read of W: each block streams a 128-k chunk of the packed weights
 // [K/4][CoutPad][4] -- thread n reads 16 B = four consecutive k of ITS output column, 2 KB contiguous per
@@ -37,6 +37,10 @@ constexpr int kGemvChunk = 128;            // k per block = 32 slot rows: 64 KB 
 constexpr int kGemvGroups = kTicketGroups; // chunk groups of the two-level finish (= the group words of a ticket slot)
 
 constexpr int kGemvTicketSmem = 8 * 128 * 4 + 16;                // the finishing block's 8 row-group sums + the ticket flag
+constexpr int kGemvMaxBatch = 8;                                 // batch rows one block carries (MQ): 8 KB of LDS for the activation chunk + half sums
+// the ticket flag sits behind whatever the block keeps in LDS: xs + red (2 x MQ x 512 B) or the 8 row-group sums (4 KB)
+template <int MQ>
+constexpr int gemv_flag_offset() { return 2 * MQ * kGemvChunk * 4 > 8 * 128 * 4 ? 2 * MQ * kGemvChunk * 4 : 8 * 128 * 4; }
 
 // this thread's 16 weight pieces of chunk bx, column tile by (all in flight at once; out of range = zeros, no traffic)
 __device__ __forceinline__ void dense_gemv_load_weights(const DenseGemvArgs& p, int bx, int by, bool live, f32x4 (&w)[16]) {
@@ -120,7 +124,7 @@ __device__ __forceinline__ void dense_gemv_block(const DenseGemvArgs& p, const i
             const int pm = tid >> 5, pn = by * 128 + (tid & 31) * 4;
             const bool piece = pm < p.B && pm < MQ && pn < p.Cout;                               // (Cout % 4 == 0: the host checks)
             if (piece) coherent_store4(pbuf, (unsigned)(((bx * p.B + pm) * p.Cout + pn) * 4), *reinterpret_cast<const f32x4*>(red + pm * 128 + (tid & 31) * 4));
-            int* flag = reinterpret_cast<int*>(smem_raw + kGemvTicketSmem - 16);
+            int* flag = reinterpret_cast<int*>(smem_raw + gemv_flag_offset<MQ>());
             unsigned long long* words = p.tickets + by * kTicketSlotWords;
             const int groups = kGemvGroups, g = bx % groups, members = (nbx - g + groups - 1) / groups;
             // level 1: the last arriver of chunk group g adds chunks g, g + groups, ... (in that order)
@@ -184,7 +188,7 @@ __device__ __forceinline__ void dense_gemv_block(const DenseGemvArgs& p, const i
         // row's loads in flight), the 8 group sums meet in LDS and are added in group order -- one fixed tree,
         // whichever block happens to finish last.  (Needs Cout % 4 == 0; the host checks.)
         float* gsum = reinterpret_cast<float*>(smem_raw);        // [8][128] (xs / red are dead by now)
-        int* flag = reinterpret_cast<int*>(gsum + 8 * 128);
+        int* flag = reinterpret_cast<int*>(smem_raw + gemv_flag_offset<MQ>());
         __syncthreads();
         if (!block_ticket_arrive(p.tickets + by * kTicketSlotWords, p.nonce, nbx, bx, flag)) return;
         const int group = tid >> 5, n4 = by * 128 + (tid & 31) * 4;

@@ -53,6 +53,8 @@ extern "C" {
                                      between the blocks): A/B of the pruning, same answers */
 #define AAE_SCAN_STREAM_WALK 6    /* STREAM with a block per compute unit walking the codebook, two 32-row batches in flight per wave,
                                      instead of one batch per wave and the whole codebook requested at once: A/B, same answers */
+#define AAE_SCAN_AUTO_PACKED 7    /* AUTO, but the top-1 query-resident scan (B > 4) reads queries normalised and packed by a
+                                     launch in front instead of normalising the raw codes in its own prologue: A/B, same answers */
 
 typedef struct aae_encoder aae_encoder;
 typedef struct aae_codebook aae_codebook;

@@ -132,12 +132,14 @@ inline f32x16 mfma_32x32x16_f16(u32x4 a, u32x4 b, f32x16 c) {
     }
     return d;
 }
-inline unsigned short bf16_rn(float v) {
+inline unsigned short bf16_rn(float v) {             // v_cvt_pk_bf16_f32: round to nearest even, a NaN stays a (quiet) NaN
     unsigned u;
     memcpy(&u, &v, 4);
+    if ((u & 0x7FFFFFFFu) > 0x7F800000u) return (unsigned short)((u >> 16) | 0x0040u);
     u += 0x7FFFu + ((u >> 16) & 1u);
     return (unsigned short)(u >> 16);
 }
+inline unsigned bf16_rn_pack2(float lo, float hi) { return (unsigned)bf16_rn(lo) | ((unsigned)bf16_rn(hi) << 16); }
 inline float bf16_to_f32(unsigned short h) {
     const unsigned u = (unsigned)h << 16;
     float f;

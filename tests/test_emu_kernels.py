@@ -276,18 +276,25 @@ def test_wide_block_tile_of_the_weights_to_registers_variant_is_bit_identical():
         enc.close()
 
 
-@pytest.mark.parametrize('B', [1, 2, 3, 4, 5])
+@pytest.mark.parametrize('B', [1, 2, 3, 4, 5, 7, 8, 9])
 def test_dense_layer_as_weight_streaming_gemv_for_tiny_batches(B):
-    """B <= 4: dense_gemv_f32_kernel (+ the fixed-order chunk reduction) instead of a padded MFMA tile; B = 5 stays
-    on the MFMA path.  Both against the fp64 oracle, and against each other within fp32 summation-order noise."""
+    """B <= 8: dense_gemv_f32_kernel (+ the fixed-order chunk reduction) instead of a padded MFMA tile (B = 5 ... 8 on the
+    8-row form of the block); B = 9 stays on the MFMA path, and so does B = 5 with dense_gemv_max_batch = 4.  Both against
+    the fp64 oracle, and against each other within fp32 summation-order noise."""
     cfg = EncoderConfig((16, 16, 3), [32, 64], [2, 2], 5, 128)
     w = synth.make_weights(seed=12, shape=cfg.shape, num_filter=cfg.num_filter, strides=cfg.strides, latent=128)
     x = synth.make_crops(B, seed=13, shape=cfg.shape)
     enc = eb.split_k_small_batches(eb.EmuEncoder(w, cfg))
     z = enc.forward(x)
-    assert any('dense_gemv' in l for l in enc.labels()) == (B <= 4)
+    assert any('dense_gemv' in l for l in enc.labels()) == (B <= 8)
     z64 = ref.encoder_forward_np(ref.input_to_float(x), w, cfg.strides, False)
     assert np.abs(z - z64).max() / np.abs(z64).max() < 5e-6
+    if B > 4:
+        enc.set_option('dense_gemv_max_batch', 4)
+        z4 = enc.forward(x)
+        assert not any('dense_gemv' in l for l in enc.labels())
+        assert np.abs(z - z4).max() / np.abs(z64).max() < 2e-6
+        enc.set_option('dense_gemv_max_batch', 8)
     enc.set_option('dense_gemv', 0)
     z_mfma = enc.forward(x)
     assert not any('dense_gemv' in l for l in enc.labels())
@@ -295,7 +302,7 @@ def test_dense_layer_as_weight_streaming_gemv_for_tiny_batches(B):
     enc.close()
 
 
-@pytest.mark.parametrize('B', [2, 3, 4])
+@pytest.mark.parametrize('B', [2, 3, 4, 6, 8])
 def test_dense_gemv_two_level_finish_over_chunk_groups(B):
     """More than 32 chunks and B >= 2: the GEMV's chunk rows are added by a two-level tree that follows the two-level ticket
     (the last arriver of each of 16 chunk groups adds its group, the last group finisher adds the group rows + bias + BN).
@@ -402,6 +409,11 @@ def test_query_resident_scan_equals_the_tile_resident_kernels_bitwise(dtype, N, 
     cb.set_mode(_lib.AAE_SCAN_MFMA)                         # forces the tile-resident MFMA kernel
     idx_t, sc_t = cb.nn(z)
     assert np.array_equal(idx_r, idx_t) and np.array_equal(sc_r, sc_t)
+    # AUTO normalises the raw codes in the scan's prologue (norm added up in l2norm_pack_kernel's order); AUTO_PACKED runs
+    # that kernel in front and reads its packed planes: the same fragments, the same bits
+    cb.set_mode(_lib.AAE_SCAN_AUTO_PACKED)
+    idx_p, sc_p = cb.nn(z)
+    assert np.array_equal(idx_r, idx_p) and np.array_equal(sc_r, sc_p)
     cs = cb.similarity(z)
     assert np.array_equal(idx_r[:, 0], np.argmax(cs, axis=1)) and np.array_equal(sc_r[:, 0], cs.max(axis=1))
     cb.close()
@@ -507,9 +519,9 @@ def test_wave_split_k_results_do_not_depend_on_block_arrival_order():
 def test_wave_split_k_igemm_wide_tiles_several_m_tiles_and_dense(narrow):
     """conv2: M = 5*8*8 = 320 rows = 5 M tiles of 64 (no partial), N = 64, 25 slabs; narrow = 0 forces 64 x 64 wave
     tiles (5 tiles, K split over 5 blocks x 4 waves -> waves with a single slab), 16 keeps the 64 x 32 form.
-    B = 5 > 4: the dense layer (M = 5, K = 4096 = 128 slabs) also runs on the wave-split-K kernel."""
+    B = 5 with the GEMV held to B <= 4: the dense layer (M = 5, K = 4096 = 128 slabs) also runs on the wave-split-K kernel."""
     cfg = EncoderConfig((32, 32, 3), [32, 64], [2, 2], 5, 128, True)
-    labels = _run(cfg, 5, 61, wavek=1, options={'wavek_narrow_max_tiles': narrow, 'wavek_tiny_max_tiles': 0})
+    labels = _run(cfg, 5, 61, wavek=1, options={'wavek_narrow_max_tiles': narrow, 'wavek_tiny_max_tiles': 0, 'dense_gemv_max_batch': 4})
     assert ('conv_wavek_f32_64x64' if narrow == 0 else 'conv_wavek_f32_64x32') in labels[1], labels
     assert labels[2].startswith('dense:conv_wavek_f32_64x') and len(labels) == 3, labels
 

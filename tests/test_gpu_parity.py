@@ -603,6 +603,17 @@ def test_config5_large_bf16_codebook_topk():
     idxk, sck = cb.nn(z, K, 1)
     idxk, sck = idxk.cpu().numpy(), sck.cpu().numpy()
     assert idxk.shape == (B, K) and np.array_equal(idxk[:, 0], idx1) and np.all(np.diff(sck, axis=1) <= 0)
+    # the arg-max scan normalises the raw codes in its own prologue, the top-k scan reads the planes l2norm_pack wrote (and so does
+    # the arg-max under AAE_SCAN_AUTO_PACKED): the same query fragments, bit for bit -> the same scores
+    assert np.array_equal(sck[:, 0], sc1)
+    from augmentedautoencoder_amd import _lib
+    for Bq in (B, 130, 9):
+        cb.set_scan_mode(_lib.AAE_SCAN_AUTO_PACKED)
+        ip, sp = cb.nn(z[:Bq], 1, 1)
+        cb.set_scan_mode(_lib.AAE_SCAN_AUTO)
+        ia, sa = cb.nn(z[:Bq], 1, 1)
+        assert bool((ip == ia).all()) and bool((sp == sa).all()), Bq
+        assert np.array_equal(sa[:, 0].cpu().numpy(), sc1[:Bq])
     assert np.array_equal(idx1[:8], np.array(dup) - 35)
     assert np.array_equal(idxk[:8, 1], np.array(dup))          # ... and the twin itself comes second
     Bo = 24
@@ -887,7 +898,9 @@ def test_small_batch_wave_split_k_path_matches_fp64_oracle(default_model, B, cha
         assert len(labels) == 5 and labels[0].startswith('conv1:conv_first_f32') and labels[4].startswith('dense:dense_gemv_f32_ticket'), labels
         assert all(':conv_wavek_f32_' in l for l in labels[1:4]), labels
     else:                                                       # B >= 5: family and tile shape per layer by the planner's cost model
-        assert all((':conv_wavek_f32_' in l) or (':conv_igemm_f32' in l) or l.endswith(':splitk_reduce') for l in labels[1:]), labels
+        assert all((':conv_wavek_f32_' in l) or (':conv_igemm_f32' in l) or l.endswith(':splitk_reduce') for l in labels[1:-1]), labels
+        # (the dense layer: the GEMV up to B = 8 -- the 8-row form of its block --, the wave-split-K tile beyond)
+        assert labels[-1].startswith('dense:dense_gemv_f32_ticket' if B <= 8 else 'dense:conv_wavek_f32_'), labels
     z64, acts = ref.encoder_forward_torch(ref.input_to_float(crops), weights, STRIDES, False, 'float64', return_activations=True)
     for i, a in enumerate(acts):
         _check_layer(enc.engine.activation(i).cpu().numpy(), a, 'small batch B=%d layer %d' % (B, i))
