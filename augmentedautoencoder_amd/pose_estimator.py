@@ -144,9 +144,25 @@ class AePoseEstimator(object):
             pass
         self._camPose, self._upright, self._topk = bool(camPose), bool(upright), int(topk)
         self.upload_union_only = True      # process(): upload the union rectangle of the boxes instead of the frame
-        self.geometry_chunk = 16           # process(): classes with more than 2 x this many detections go to the GPU in chunks of this size
+        self.geometry_chunk = 16           # process(): classes with more than 2 x this many detections go to the GPU in chunks (_chunk_sizes), the last of this size
         if self._camPose:
             self._process_requirements.append('camPose')
+
+    def _chunk_sizes(self, n):
+        """How the n detections of one class go to the GPU: up to 2 x geometry_chunk in one call; more as a LAST chunk of
+        geometry_chunk (only its float64 geometry stays exposed behind the GPU work) behind chunks three times the size of
+        their successor (a large batch costs the encoder less per crop: 31 us at B = 48 against 35 at 16; the geometry of a
+        chunk runs under the GPU time of its successors), the first one taking the remainder: 64 -> 48 + 16, 256 -> 48 + 144 + 48 + 16."""
+        c = self.geometry_chunk
+        if n <= 2 * c:
+            return [n] if n > 0 else []
+        sizes, left, cur = [c], n - c, 3 * c
+        while left > 0:
+            take = left if left <= cur + c else cur        # (no sliver in front: a remainder of at most one chunk joins its neighbour)
+            sizes.append(take)
+            left -= take
+            cur *= 3
+        return sizes[::-1]
 
     def _register(self, clas_name, codebook, targs):
         self.all_codebooks[clas_name] = codebook
@@ -310,9 +326,10 @@ class AePoseEstimator(object):
                 members = [(j, bb) for j, c, bb in accepted if c == clas]
                 n = len(members)
                 rows_all[at:at + n] = self.box_rows([[bb[0] - off_x, bb[1] - off_y, bb[2], bb[3]] for _, bb in members], self.pad_factors[clas])
-                step = n if n <= 2 * self.geometry_chunk else self.geometry_chunk
-                for a in range(0, n, step):
-                    groups.append((clas, members[a:a + step], at + a, min(step, n - a)))
+                a = 0
+                for step in self._chunk_sizes(n):
+                    groups.append((clas, members[a:a + step], at + a, step))
+                    a += step
                 at += n
             image_dev, rows_dev = stage.upload_frame_and_rows(torch, frame, rows_all)
             crops_all = stage.crops[:total * oh * ow * C].view(total, oh, ow, C)

@@ -396,3 +396,23 @@ def _args_for_format_test():
     args = configparser.ConfigParser()
     args.read_string('[Dataset]\nPAD_FACTOR: 1.2\nW: 128\nH: 128\n')
     return args
+
+
+def test_detection_chunks_cover_every_count_and_end_in_a_small_chunk():
+    """process() sends the detections of a class to the GPU in chunks whose float64 geometry runs under the kernels of the
+    chunks behind them: every detection exactly once, large chunks first (cheaper per crop), the last one geometry_chunk."""
+    from augmentedautoencoder_amd.pose_estimator import AePoseEstimator
+
+    class Shell(object):
+        geometry_chunk = 16
+
+    for n in list(range(0, 200)) + [255, 256, 257, 1000, 4097]:
+        sizes = AePoseEstimator._chunk_sizes(Shell, n)
+        assert sum(sizes) == n and all(s > 0 for s in sizes), (n, sizes)
+        if n <= 32:
+            assert sizes == ([n] if n else [])
+        else:
+            assert sizes[-1] == 16, (n, sizes)
+            # every chunk behind the first is three times its successor; the first takes what is left (at most that + one chunk)
+            assert all(a == 3 * b for a, b in zip(sizes[1:-1], sizes[2:])) and (len(sizes) < 2 or sizes[0] <= 3 * sizes[1] + 16), (n, sizes)
+    assert AePoseEstimator._chunk_sizes(Shell, 64) == [48, 16] and AePoseEstimator._chunk_sizes(Shell, 256) == [48, 144, 48, 16]
