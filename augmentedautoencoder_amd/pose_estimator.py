@@ -53,6 +53,7 @@ class _FrameStage(object):
 
     def __init__(self, device):
         self.device = device
+        self.direct_rows = 8                # frames with up to this many boxes are read by the crop kernel in place (no H2D copy)
         self.img_host = self.img_dev = None
         self.crops = self.z = self.score = self.idx_host = None
 
@@ -76,6 +77,11 @@ class _FrameStage(object):
         host = self.img_host.numpy()
         np.copyto(host[:n].reshape(h, w, c), frame)
         host[off:total].view(np.int32)[:] = rows.reshape(-1)
+        if len(rows) <= self.direct_rows:
+            # a few boxes: the crop kernel reads its pixels and the rows straight out of the pinned buffer (device-accessible) --
+            # it touches the boxes only, not the rectangle around them, and a trip through the copy engine costs ~10 us in front of
+            # the query (1 detection 188 -> 172 us, 4: 345 -> 338, 8: level; 16 and more: the copy wins, 64: 2.78 vs 2.82 ms)
+            return self.img_host[:n].view(h, w, c), self.img_host[off:total].view(torch.int32).view(-1, 5)
         self.img_dev[:total].copy_(self.img_host[:total], non_blocking=True)
         return self.img_dev[:n].view(h, w, c), self.img_dev[off:total].view(torch.int32).view(-1, 5)
 

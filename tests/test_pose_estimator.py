@@ -270,6 +270,18 @@ def test_process_on_gpu_full_size_two_objects():
     est.upload_union_only = True
     for a, b, c in zip(got, chunked, whole):
         assert a.name == b.name == c.name and np.array_equal(a.trafo, b.trafo) and np.array_equal(a.trafo, c.trafo)
+    # frames with few boxes are not copied to the device at all: the crop kernel reads the pinned staging buffer in place
+    for stage in getattr(est, '_stages', {}).values():
+        stage.direct_rows = 64
+    in_place = est.process(dets, img, camK, mm=True)
+    few = est.process(dets[:5], img, camK, mm=True)
+    for stage in getattr(est, '_stages', {}).values():
+        stage.direct_rows = 0
+    few_copied = est.process(dets[:5], img, camK, mm=True)
+    for stage in getattr(est, '_stages', {}).values():
+        stage.direct_rows = 8
+    assert all(np.array_equal(a.trafo, b.trafo) for a, b in zip(got, in_place)) and len(few) == 5
+    assert all(a.name == b.name and np.array_equal(a.trafo, b.trafo) for a, b in zip(few, few_copied))
     K_train = np.array(_parse_K('[1075.65, 0, 720/2, 0, 1073.90, 540/2, 0, 0, 1]')).reshape(3, 3)
     for g, box in zip(got, dets):
         c = max(box.classes, key=box.classes.get)
