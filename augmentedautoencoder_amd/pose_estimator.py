@@ -240,7 +240,7 @@ class AePoseEstimator(object):
                 print('%s not contained in config class_names %s' % (pred_clas, list(self.class_2_encoder.keys())))
                 continue
             box_xywh = [box.xmin * W, box.ymin * H, (box.xmax - box.xmin) * W, (box.ymax - box.ymin) * H]
-            if np.any(np.array(box_xywh) < 0):
+            if box_xywh[0] < 0 or box_xywh[1] < 0 or box_xywh[2] < 0 or box_xywh[3] < 0:
                 print('invalid bb', box_xywh)
                 continue
             accepted.append((j, pred_clas, box_xywh))
@@ -321,7 +321,8 @@ class AePoseEstimator(object):
         C = int(frame.shape[2])
         total = len(accepted)
         J = latent_sizes.pop()
-        with torch.cuda.device(device):
+        from .engine import _on_device
+        with _on_device(device):                      # (torch.cuda.device costs ~8 us per entry even when the device is current already)
             stage.reserve(torch, total, J, (oh, ow, C))
             # box rows of all classes, class by class; classes with many detections are cut into chunks so that the host's
             # float64 geometry of chunk k runs while the GPU works on chunk k + 1 (the geometry of the LAST chunk is all that
