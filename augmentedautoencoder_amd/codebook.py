@@ -204,7 +204,19 @@ class Codebook(object):
         idcs = np.atleast_1d(self.nearest_rotation(session, x, top_n=top_n, upright=upright, return_idcs=True))
         return self.pose_from_indices(idcs, predicted_bb, K_test, train_args, depth_pred=depth_pred)
 
-    def pose_from_indices(self, idcs, predicted_bb, K_test, train_args, depth_pred=None):
+    def pose_prepare(self, predicted_bb, K_test, train_args, depth_pred=None):
+        """The part of pose_from_indices that does not depend on the matched rows -- the estimator computes it while the GPU is
+        still busy with the query and passes it back as ``prepared``.  Same expressions, same operands: same bits."""
+        K_train, render_radius = self._train_geometry_of(train_args)
+        K_diag_ratio = np.sqrt(K_test[0, 0] ** 2 + K_test[1, 1] ** 2) / np.sqrt(K_train[0, 0] ** 2 + K_train[1, 1] ** 2)
+        if self.embed_obj_bbs_values is None:
+            self.embed_obj_bbs_values = self.embed_obj_bbs_value()
+        pred_diag = np.linalg.norm(np.float32(predicted_bb[2:])) if depth_pred is None else None
+        cx_test = predicted_bb[0] + predicted_bb[2] / 2 - K_test[0, 2]
+        cy_test = predicted_bb[1] + predicted_bb[3] / 2 - K_test[1, 2]
+        return K_train, render_radius, K_diag_ratio, pred_diag, cx_test, cy_test
+
+    def pose_from_indices(self, idcs, predicted_bb, K_test, train_args, depth_pred=None, prepared=None):
         """The geometry half of auto_pose6d (codebook.py:82-129) for already-matched codebook
         rows -- what the batched estimator calls after one encode+scan over all detections."""
         idcs = np.atleast_1d(idcs)
@@ -213,24 +225,20 @@ class Codebook(object):
 
         # [Dataset] K / RADIUS are parsed once per config (the per-detection estimator flow calls this for every box; the
         # parse was 40 % of the call, the two configparser lookups another 10 us)
-        K_train, render_radius = self._train_geometry_of(train_args)
-        K_diag_ratio = np.sqrt(K_test[0, 0] ** 2 + K_test[1, 1] ** 2) / np.sqrt(K_train[0, 0] ** 2 + K_train[1, 1] ** 2)
-
-        if self.embed_obj_bbs_values is None:
-            self.embed_obj_bbs_values = self.embed_obj_bbs_value()
+        if prepared is None:
+            prepared = self.pose_prepare(predicted_bb, K_test, train_args, depth_pred)
+        K_train, render_radius, K_diag_ratio, pred_diag, cx_test, cy_test = prepared
 
         ts_est = np.empty((top_n, 3))
         for i, idx in enumerate(idcs):
             rendered_bb = self.embed_obj_bbs_values[idx].squeeze()
             if depth_pred is None:
-                diag_ratio = np.linalg.norm(np.float32(rendered_bb[2:])) / np.linalg.norm(np.float32(predicted_bb[2:]))
+                diag_ratio = np.linalg.norm(np.float32(rendered_bb[2:])) / pred_diag
                 z = diag_ratio * K_diag_ratio * render_radius
             else:
                 z = depth_pred
             cx_train = rendered_bb[0] + rendered_bb[2] / 2. - K_train[0, 2]
             cy_train = rendered_bb[1] + rendered_bb[3] / 2. - K_train[1, 2]
-            cx_test = predicted_bb[0] + predicted_bb[2] / 2 - K_test[0, 2]
-            cy_test = predicted_bb[1] + predicted_bb[3] / 2 - K_test[1, 2]
             tx = cx_test * z / K_test[0, 0] - cx_train * render_radius / K_train[0, 0]
             ty = cy_test * z / K_test[1, 1] - cy_train * render_radius / K_train[1, 1]
             ts_est[i] = (tx, ty, z)
@@ -252,7 +260,22 @@ class Codebook(object):
             cache[id(train_args)] = hit
         return hit[1], hit[2]
 
-    def poses_from_indices(self, idcs, predicted_bbs, K_test, train_args, depth_preds=None):
+    def poses_prepare(self, predicted_bbs, K_test, train_args, depth_preds=None):
+        """The part of poses_from_indices that does not depend on the matched rows (see pose_prepare)."""
+        n = len(predicted_bbs)
+        if n < 4 or not _batch_geometry_matches_scalar():
+            return [self.pose_prepare(bb, K_test, train_args, None if depth_preds is None else depth_preds[k]) for k, bb in enumerate(predicted_bbs)]
+        K_train, render_radius = self._train_geometry_of(train_args)
+        K_diag_ratio = np.sqrt(K_test[0, 0] ** 2 + K_test[1, 1] ** 2) / np.sqrt(K_train[0, 0] ** 2 + K_train[1, 1] ** 2)
+        if self.embed_obj_bbs_values is None:
+            self.embed_obj_bbs_values = self.embed_obj_bbs_value()
+        pb = np.array([[float(v) for v in bb] for bb in predicted_bbs], dtype=np.float64).reshape(n, 4)
+        den = None if depth_preds is not None else np.array([np.linalg.norm(np.float32(bb[2:])) for bb in predicted_bbs], dtype=np.float32)
+        cx_test = pb[:, 0] + pb[:, 2] / 2 - K_test[0, 2]
+        cy_test = pb[:, 1] + pb[:, 3] / 2 - K_test[1, 2]
+        return K_train, render_radius, K_diag_ratio, den, cx_test, cy_test
+
+    def poses_from_indices(self, idcs, predicted_bbs, K_test, train_args, depth_preds=None, prepared=None):
         """pose_from_indices for n detections of one object at once: idcs [n] (top-1 rows), predicted_bbs [n][4] ->
         (Rs [n,3,3], ts [n,3]), every number bit-identical to n scalar calls (codebook.py:84-129).  Array arithmetic is used
         only where NumPy gives the same bits for an element of an array as for a scalar: + - * / sqrt and the ufuncs arctan /
@@ -264,20 +287,18 @@ class Codebook(object):
         if n == 0:
             return np.empty((0, 3, 3)), np.empty((0, 3))
         if n < 4 or not _batch_geometry_matches_scalar():          # (a handful of detections: the array form's fixed cost, ~45 us, exceeds 28 us per scalar call)
-            out = [self.pose_from_indices([int(i)], bb, K_test, train_args, depth_pred=None if depth_preds is None else depth_preds[k])
+            out = [self.pose_from_indices([int(i)], bb, K_test, train_args, depth_pred=None if depth_preds is None else depth_preds[k],
+                                          prepared=None if prepared is None else prepared[k])
                    for k, (i, bb) in enumerate(zip(idcs, predicted_bbs))]
             return np.concatenate([r for r, _ in out], axis=0), np.concatenate([t for _, t in out], axis=0)
         Rs_est = self._dataset.viewsphere_for_embedding[idcs]      # fancy index -> copy
-        K_train, render_radius = self._train_geometry_of(train_args)
-        K_diag_ratio = np.sqrt(K_test[0, 0] ** 2 + K_test[1, 1] ** 2) / np.sqrt(K_train[0, 0] ** 2 + K_train[1, 1] ** 2)
-        if self.embed_obj_bbs_values is None:
-            self.embed_obj_bbs_values = self.embed_obj_bbs_value()
+        # (predicted boxes keep their Python-float arithmetic -- x + w / 2 ...: float64 arrays of the same values give the same bits)
+        if prepared is None:
+            prepared = self.poses_prepare(predicted_bbs, K_test, train_args, depth_preds)
+        K_train, render_radius, K_diag_ratio, den, cx_test, cy_test = prepared
         rb = self.embed_obj_bbs_values[idcs]                       # [n,4] int32
-        # predicted boxes keep their Python-float arithmetic (x + w / 2 ...): float64 arrays of the same values give the same bits
-        pb = np.array([[float(v) for v in bb] for bb in predicted_bbs], dtype=np.float64).reshape(n, 4)
         if depth_preds is None:
             num = np.array([np.linalg.norm(np.float32(r[2:])) for r in rb], dtype=np.float32)
-            den = np.array([np.linalg.norm(np.float32(bb[2:])) for bb in predicted_bbs], dtype=np.float32)
             # float32 quotient, then float64 products, as the scalar code does it -- the cast is explicit so that NumPy 1.x's
             # value-based casting (float32 array x float64 scalar -> float32) gives the same bits as NumPy 2's promotion
             z = (num / den).astype(np.float64) * K_diag_ratio * render_radius
@@ -285,8 +306,6 @@ class Codebook(object):
             z = np.array([float(d) for d in depth_preds], dtype=np.float64)
         cx_train = rb[:, 0] + rb[:, 2] / 2. - K_train[0, 2]
         cy_train = rb[:, 1] + rb[:, 3] / 2. - K_train[1, 2]
-        cx_test = pb[:, 0] + pb[:, 2] / 2 - K_test[0, 2]
-        cy_test = pb[:, 1] + pb[:, 3] / 2 - K_test[1, 2]
         tx = cx_test * z / K_test[0, 0] - cx_train * render_radius / K_train[0, 0]
         ty = cy_test * z / K_test[1, 1] - cy_train * render_radius / K_train[1, 1]
         ts_est = np.stack([tx, ty, z], axis=1)

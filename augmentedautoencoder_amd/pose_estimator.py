@@ -150,6 +150,7 @@ class AePoseEstimator(object):
             pass
         self._camPose, self._upright, self._topk = bool(camPose), bool(upright), int(topk)
         self.upload_union_only = True      # process(): upload the union rectangle of the boxes instead of the frame
+        self.poll_results = True           # process(): watch the pinned index buffer instead of waiting on an event per chunk (exact fp32 only)
         self.geometry_chunk = 16           # process(): classes with more than 2 x this many detections go to the GPU in chunks (_chunk_sizes), the last of this size
         if self._camPose:
             self._process_requirements.append('camPose')
@@ -342,23 +343,46 @@ class AePoseEstimator(object):
             crops_all = stage.crops[:total * oh * ow * C].view(total, oh, ow, C)
             z_all = stage.z[:total * J].view(total, J)
             events = []
+            idx_host = stage.idx_host.numpy()
+            # exact fp32 (the default): the host learns that a chunk is done from the indices themselves -- the scan's last block
+            # stores them into pinned host memory, the host watches the sentinel it put there disappear.  An event behind the
+            # chunk costs a signal + wake-up on top (~8 us per frame with one detection).  Split precision keeps the events: a
+            # chunk that left the fp16 range is recomputed on the stream first (settle()).
+            poll = self.poll_results and all(self.all_codebooks[c]._encoder.engine.options.get('precision', 0) == 0 for c in classes)
+            if poll:
+                idx_host[:total] = -1
             for clas, members, a, n in groups:
                 codebook = self.all_codebooks[clas]
                 stride = int(codebook._dataset._kw['num_cyclo']) if self._upright else 1
                 # ONE C call per chunk: crop + resize, encoder, top-1 query; the indices land in pinned host memory directly
                 codebook._encoder.engine.detect_nn(codebook.engine, image_dev, rows_dev[a:a + n], n, stride, crops_all[a:a + n], z_all[a:a + n],
                                                    stage.idx_host[a:a + n], stage.score[a:a + n])
-                ev = torch.cuda.Event()
-                ev.record()
-                events.append(ev)
+                if poll:
+                    events.append(None)
+                else:
+                    ev = torch.cuda.Event()
+                    ev.record()
+                    events.append(ev)
             poses = {}
-            idx_host = stage.idx_host.numpy()
-            for (clas, members, a, n), ev in zip(groups, events):
-                ev.synchronize()
+            # while the GPU works: the part of the float64 geometry that does not depend on the matched rows
+            prepared = [self.all_codebooks[clas].poses_prepare([bb for _, bb in members], camK, self.all_train_args[clas])
+                        for clas, members, _, _ in groups]
+            for (clas, members, a, n), ev, prep in zip(groups, events, prepared):
                 codebook = self.all_codebooks[clas]
-                codebook._encoder.engine.settle()                  # (split precision, out of range: recomputed in fp32, indices rewritten in place)
+                if ev is None:
+                    chunk = idx_host[a:a + n]
+                    spins = 0
+                    while chunk.min() < 0:                         # (one 8-byte store per index; every index of the chunk must have landed)
+                        spins += 1
+                        if spins > 2000000:                        # ~seconds: the GPU work behind this chunk failed -- let the runtime report it
+                            torch.cuda.current_stream().synchronize()
+                            if chunk.min() < 0:
+                                raise RuntimeError('aae_detect_nn: the indices of a chunk never arrived')
+                else:
+                    ev.synchronize()
+                    codebook._encoder.engine.settle()              # (split precision, out of range: recomputed in fp32, indices rewritten in place)
                 idcs = idx_host[a:a + n].copy()
-                Rs, ts = codebook.poses_from_indices(idcs, [bb for _, bb in members], camK, self.all_train_args[clas])
+                Rs, ts = codebook.poses_from_indices(idcs, [bb for _, bb in members], camK, self.all_train_args[clas], prepared=prep)
                 for k, (j, _) in enumerate(members):
                     poses[j] = (clas, Rs[k], ts[k])
         return poses

@@ -185,6 +185,13 @@ def test_batched_pose_geometry_equals_the_per_detection_calls(recorded_codebook)
         for i in range(n):
             R, t = cb.pose_from_indices([idcs[i]], bbs[i], G['K_test'], args, depth_pred=None if depths is None else depths[i])
             assert np.array_equal(Rb[i], R[0]) and np.array_equal(tb[i], t[0]), i
+        # the row-independent half computed ahead of time (the estimator does it while the GPU is busy): the same bits, in the
+        # array form and in the per-detection form (fewer than four detections)
+        Rp, tp = cb.poses_from_indices(idcs, bbs, G['K_test'], args, depth_preds=depths, prepared=cb.poses_prepare(bbs, G['K_test'], args, depths))
+        assert np.array_equal(Rp, Rb) and np.array_equal(tp, tb)
+        d3 = None if depths is None else depths[:3]
+        R3, t3 = cb.poses_from_indices(idcs[:3], bbs[:3], G['K_test'], args, depth_preds=d3, prepared=cb.poses_prepare(bbs[:3], G['K_test'], args, d3))
+        assert np.array_equal(R3, Rb[:3]) and np.array_equal(t3, tb[:3])
     boxes = [[rng.uniform(-5, 2000), rng.uniform(-5, 1100), rng.uniform(0.2, 900), rng.uniform(0.2, 700)] for _ in range(200)]
     for pad in (1.2, 1.0, 1.5):
         want = np.array([list(np.array(bb).astype(np.int32)) + [int(np.maximum(np.array(bb).astype(np.int32)[3], np.array(bb).astype(np.int32)[2]) * pad)]
