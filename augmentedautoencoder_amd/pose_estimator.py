@@ -155,21 +155,33 @@ class AePoseEstimator(object):
         if self._camPose:
             self._process_requirements.append('camPose')
 
-    def _chunk_sizes(self, n):
-        """How the n detections of one class go to the GPU: up to 2 x geometry_chunk in one call; more as a LAST chunk of
-        geometry_chunk (only its float64 geometry stays exposed behind the GPU work) behind chunks three times the size of
-        their successor (a large batch costs the encoder less per crop: 31 us at B = 48 against 35 at 16; the geometry of a
-        chunk runs under the GPU time of its successors), the first one taking the remainder: 64 -> 48 + 16, 256 -> 48 + 144 + 48 + 16."""
+    def _chunk_plan(self, counts):
+        """How the detections of a frame go to the GPU: ``counts`` = detections per class in launch order -> chunk sizes per
+        class.  A chunk's float64 geometry (~10 us per detection) runs on the host while the GPU works on everything queued
+        behind it (~33 us per crop), so a chunk may be three times as large as what follows it -- large chunks cost the
+        encoder less per crop (31 us at B = 48 against 35 at 16) -- and only the geometry of the very last chunk stays
+        exposed: it is geometry_chunk detections, or the whole last class when that has at most twice as many.  Chunks never
+        span classes (one encoder per object).  64 of one class -> 48 + 16; 256 -> 192 + 48 + 16; 43 + 21 of two classes ->
+        one chunk each."""
         c = self.geometry_chunk
-        if n <= 2 * c:
-            return [n] if n > 0 else []
-        sizes, left, cur = [c], n - c, 3 * c
-        while left > 0:
-            take = left if left <= cur + c else cur        # (no sliver in front: a remainder of at most one chunk joins its neighbour)
-            sizes.append(take)
-            left -= take
-            cur *= 3
-        return sizes[::-1]
+        plan = [[] for _ in counts]
+        behind = 0
+        for ci in range(len(counts) - 1, -1, -1):
+            left, sizes = int(counts[ci]), []
+            while left > 0:
+                if behind < c:                                # (nothing, or less than a chunk, behind it: the end of the frame)
+                    take = left if left <= 2 * c else c
+                else:
+                    take = left if left <= 3 * behind + c else 3 * behind     # (no sliver in front: a remainder of at most one chunk joins its neighbour)
+                sizes.append(take)
+                left -= take
+                behind += take
+            plan[ci] = sizes[::-1]
+        return plan
+
+    def _chunk_sizes(self, n):
+        """_chunk_plan for the detections of a single class"""
+        return self._chunk_plan([n])[0]
 
     def _register(self, clas_name, codebook, targs):
         self.all_codebooks[clas_name] = codebook
@@ -330,12 +342,13 @@ class AePoseEstimator(object):
             # stays exposed: 16 detections instead of a whole class)
             rows_all = np.empty((total, 5), dtype=np.int32)
             groups, at = [], 0
-            for clas in classes:
-                members = [(j, bb) for j, c, bb in accepted if c == clas]
+            by_class = [[(j, bb) for j, c, bb in accepted if c == clas] for clas in classes]
+            plan = self._chunk_plan([len(m) for m in by_class])
+            for clas, members, sizes in zip(classes, by_class, plan):
                 n = len(members)
                 rows_all[at:at + n] = self.box_rows([[bb[0] - off_x, bb[1] - off_y, bb[2], bb[3]] for _, bb in members], self.pad_factors[clas])
                 a = 0
-                for step in self._chunk_sizes(n):
+                for step in sizes:
                     groups.append((clas, members[a:a + step], at + a, step))
                     a += step
                 at += n

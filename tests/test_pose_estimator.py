@@ -411,20 +411,31 @@ def _args_for_format_test():
 
 
 def test_detection_chunks_cover_every_count_and_end_in_a_small_chunk():
-    """process() sends the detections of a class to the GPU in chunks whose float64 geometry runs under the kernels of the
-    chunks behind them: every detection exactly once, large chunks first (cheaper per crop), the last one geometry_chunk."""
+    """process() sends the detections of a frame to the GPU in chunks whose float64 geometry runs under the kernels of the
+    chunks behind them: every detection exactly once, chunks at most three times what follows them (+ a remainder), never
+    across classes, the very last one geometry_chunk detections (or a whole small class)."""
     from augmentedautoencoder_amd.pose_estimator import AePoseEstimator
 
     class Shell(object):
         geometry_chunk = 16
+        _chunk_plan = AePoseEstimator._chunk_plan
 
-    for n in list(range(0, 200)) + [255, 256, 257, 1000, 4097]:
-        sizes = AePoseEstimator._chunk_sizes(Shell, n)
-        assert sum(sizes) == n and all(s > 0 for s in sizes), (n, sizes)
-        if n <= 32:
-            assert sizes == ([n] if n else [])
-        else:
-            assert sizes[-1] == 16, (n, sizes)
-            # every chunk behind the first is three times its successor; the first takes what is left (at most that + one chunk)
-            assert all(a == 3 * b for a, b in zip(sizes[1:-1], sizes[2:])) and (len(sizes) < 2 or sizes[0] <= 3 * sizes[1] + 16), (n, sizes)
-    assert AePoseEstimator._chunk_sizes(Shell, 64) == [48, 16] and AePoseEstimator._chunk_sizes(Shell, 256) == [48, 144, 48, 16]
+    sh = Shell()
+    rng = np.random.default_rng(3)
+    cases = [[n] for n in list(range(0, 200)) + [255, 256, 257, 1000, 4097]] + [list(rng.integers(0, 120, rng.integers(2, 6))) for _ in range(300)]
+    for counts in cases:
+        plan = sh._chunk_plan(counts)
+        assert len(plan) == len(counts)
+        flat = []
+        for n, sizes in zip(counts, plan):
+            assert sum(sizes) == n and all(s > 0 for s in sizes), (counts, plan)
+            flat += sizes
+        if not flat:
+            continue
+        assert flat[-1] <= 32, (counts, plan)
+        behind = 0
+        for s in flat[::-1]:
+            assert s <= (32 if behind < 16 else 3 * behind + 16), (counts, plan)
+            behind += s
+    assert AePoseEstimator._chunk_sizes(sh, 64) == [48, 16] and AePoseEstimator._chunk_sizes(sh, 256) == [192, 48, 16]
+    assert sh._chunk_plan([43, 21]) == [[43], [21]] and sh._chunk_plan([21, 43]) == [[21], [27, 16]] and sh._chunk_plan([300, 2]) == [[230, 54, 16], [2]]

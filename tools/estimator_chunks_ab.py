@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""AePoseEstimator.process on a 1080p frame, D detections of two classes: the chunk sizes of _chunk_sizes (large first, the last one
-geometry_chunk) against equal chunks of geometry_chunk (the form of the first half of round 4), A B A B on one box."""
+"""AePoseEstimator.process on a 1080p frame, D detections of two classes: the chunk plan of _chunk_plan (large chunks first, each at most three times what follows it,
+the last one geometry_chunk) against equal chunks of geometry_chunk (the form of the first half of round 4), A B A B on one box."""
 import configparser
 import json
 import os
@@ -36,12 +36,12 @@ est = AePoseEstimator(codebooks=books, train_args={'obj_a': targs, 'obj_b': targ
 rng = np.random.default_rng(0)
 img = rng.integers(0, 256, (1080, 1920, 3), dtype=np.uint8)
 camK = np.array([[1075.65, 0, 960.0], [0, 1073.9, 540.0], [0, 0, 1]])
-graded = AePoseEstimator._chunk_sizes
+graded = AePoseEstimator._chunk_plan
 
 
-def equal(self, n):
+def equal(self, counts):
     c = self.geometry_chunk
-    return ([n] if n else []) if n <= 2 * c else [min(c, n - a) for a in range(0, n, c)]
+    return [([n] if n else []) if n <= 2 * c else [min(c, n - a) for a in range(0, n, c)] for n in counts]
 
 
 for D in (48, 64, 128, 256):
@@ -53,7 +53,7 @@ for D in (48, 64, 128, 256):
     poses = {}
     for rnd in range(3):
         for key, fn in (('graded_ms', graded), ('equal_ms', equal)):
-            AePoseEstimator._chunk_sizes = fn
+            AePoseEstimator._chunk_plan = fn
             for _ in range(3):
                 got = est.process(dets, img, camK)
             torch.cuda.synchronize()
