@@ -198,6 +198,7 @@ struct aae_codebook {
     // B > 4, top-1 on the query-resident kernel: 1 = the scan normalises the raw latent codes in its prologue (one launch less);
     // 0 (AAE_SCAN_AUTO_PACKED) = l2norm_pack launch in front, the scan reads the packed planes -- identical bits
     int scan_fused_norm = 1;
+    int scan_rh4 = 1;      // B <= 32, top-1 on the query-resident kernel: rows of a tile over four waves per query group (AAE_SCAN_AUTO_RH2: 0 = two, A/B)
 };
 
 namespace aae_host {
@@ -1232,11 +1233,14 @@ static ScanPlan plan_scan(const aae_codebook* cb, int B, int topk) {
     // 0.024 ms, B=32 0.036 -> 0.024, B=256 0.106 -> 0.063; bf16 4x codebook B=32 0.083 -> 0.034, B=256 0.25 -> 0.078
     s.resident_ok = false; s.res_tiles_per_block = 0; s.res_blocks = 0; s.res_rh = 2;
     if (cb->scan_mode == AAE_SCAN_AUTO && cb->J == 128 && !s.stream && !s.gemv && B > 4) {
-        const int tile_rows = cb->dtype == AAE_DTYPE_BF16 ? 128 : 64;
+        // B > 128: 256 queries per block, every wave all rows of a tile (the codebook streamed once per 256 queries);
+        // B <= 32, arg-max: FOUR waves share the rows of a tile for the one query group (with two, two of the CU's four matrix pipes sat
+        // idle: 20.7 us per query of the 47 MB default codebook at any B <= 32, now 15.8; with two query groups -- 33 ... 64 queries -- all
+        // eight waves are busy either way and the 128-row fp32 tiles in two LDS images measured slower, 23.3 against 21.3)
+        s.res_rh = s.Bpad > 128 ? 1 : ((B <= 32 && topk == 1 && cb->scan_rh4) ? 4 : 2);
+        const int tile_rows = (cb->dtype == AAE_DTYPE_BF16 || s.res_rh == 4) ? 128 : 64;
         const int ntiles = ceil_div(cb->N, tile_rows);
-        // B > 128: 256 queries per block, every wave all rows of a tile (the codebook streamed once per 256 queries)
-        s.res_rh = s.Bpad > 128 ? 1 : 2;
-        const int qchunks = ceil_div(s.Bpad, s.res_rh == 1 ? 256 : 128);
+        const int qchunks = ceil_div(s.Bpad, 256 / s.res_rh);
         int row_blocks = (cb->cu_count > 0 ? cb->cu_count : 256) / qchunks;
         if (row_blocks < 1) row_blocks = 1;
         s.res_tiles_per_block = ceil_div(ntiles, row_blocks);
@@ -1316,8 +1320,9 @@ static void launch_scan_stream_bf16_t(const aae::ScanArgs& a, bool upright, int 
 
 template <bool BF16, int K, int RH, bool NORM = false>
 static void launch_scan_resident_t(const aae::ScanResidentArgs& a, dim3 grid, hipStream_t stream) {
-    (void)hipFuncSetAttribute((const void*)aae::scan_resident_kernel<BF16, K, RH, NORM>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kScanResidentSmem);
-    AAE_LAUNCH((aae::scan_resident_kernel<BF16, K, RH, NORM>), grid, dim3(aae::kScanResidentThreads), aae::kScanResidentSmem, stream, a);
+    constexpr int smem = aae::scan_resident_smem<BF16, RH>();
+    (void)hipFuncSetAttribute((const void*)aae::scan_resident_kernel<BF16, K, RH, NORM>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+    AAE_LAUNCH((aae::scan_resident_kernel<BF16, K, RH, NORM>), grid, dim3(aae::kScanResidentThreads), smem, stream, a);
 }
 template <bool BF16, int RH>
 static void launch_scan_resident_k(const aae::ScanResidentArgs& a, dim3 grid, hipStream_t stream) {
@@ -1339,7 +1344,7 @@ static int launch_scan_resident(const aae_codebook* cb, const void* qp, int B, c
     a.pval = reinterpret_cast<float*>(base + s.pval_off);
     a.pidx = reinterpret_cast<int*>(base + s.pidx_off);
     a.N = cb->N; a.B = B; a.Bpad = s.Bpad; a.Bstride = s.Bstride; a.tiles_per_block = s.res_tiles_per_block;
-    const dim3 grid(s.res_blocks, ceil_div(s.Bpad, s.res_rh == 1 ? 256 : 128));
+    const dim3 grid(s.res_blocks, ceil_div(s.Bpad, 256 / s.res_rh));
     a.k = topk > 1 ? topk : 0;
     if (topk > 1) {
         a.cand_v = reinterpret_cast<float*>(base + s.cand_off);
@@ -1347,7 +1352,12 @@ static int launch_scan_resident(const aae_codebook* cb, const void* qp, int B, c
         if (cb->topk_prune) a.prune = reinterpret_cast<int*>(base + s.prune_off);      // (reset by the normalise kernel in front)
     }
     const bool bf16 = cb->dtype == AAE_DTYPE_BF16;
-    if (bf16 && s.res_rh == 1) launch_scan_resident_k<true, 1>(a, grid, stream);
+    if (s.res_rh == 4) {                           // (arg-max only: plan_scan)
+        if (bf16 && a.z) launch_scan_resident_t<true, 0, 4, true>(a, grid, stream);
+        else if (bf16) launch_scan_resident_t<true, 0, 4>(a, grid, stream);
+        else if (a.z) launch_scan_resident_t<false, 0, 4, true>(a, grid, stream);
+        else launch_scan_resident_t<false, 0, 4>(a, grid, stream);
+    } else if (bf16 && s.res_rh == 1) launch_scan_resident_k<true, 1>(a, grid, stream);
     else if (bf16) launch_scan_resident_k<true, 2>(a, grid, stream);
     else if (s.res_rh == 1) launch_scan_resident_k<false, 1>(a, grid, stream);
     else launch_scan_resident_k<false, 2>(a, grid, stream);
@@ -1878,7 +1888,7 @@ int aae_codebook_prepare_upright(aae_codebook* cb, int col_stride, void* stream_
             cb->upright_copies.push_back({col_stride, sub});
         }
         sub->scan_mode = cb->scan_mode; sub->scan_ticket = cb->scan_ticket; sub->topk_prune = cb->topk_prune; sub->cu_count = cb->cu_count;
-        sub->scan_walk = cb->scan_walk; sub->scan_fused_norm = cb->scan_fused_norm;
+        sub->scan_walk = cb->scan_walk; sub->scan_fused_norm = cb->scan_fused_norm; sub->scan_rh4 = cb->scan_rh4;
         cb->upright = sub; cb->upright_stride = col_stride;
     }
     if (int rc = gather_upright_rows(cb, cb->upright, cb->upright_stride, stream)) return rc;
@@ -1908,17 +1918,18 @@ int aae_codebook_set_scan_mode(aae_codebook* cb, int mode) {
     using namespace aae_host;
     if (!cb) return fail(AAE_ERR_INVALID, "aae_codebook_set_scan_mode: null handle");
     if (mode != AAE_SCAN_AUTO && mode != AAE_SCAN_GEMV && mode != AAE_SCAN_MFMA && mode != AAE_SCAN_STREAM && mode != AAE_SCAN_STREAM_2L &&
-        mode != AAE_SCAN_AUTO_NO_PRUNE && mode != AAE_SCAN_STREAM_WALK && mode != AAE_SCAN_AUTO_PACKED)
+        mode != AAE_SCAN_AUTO_NO_PRUNE && mode != AAE_SCAN_STREAM_WALK && mode != AAE_SCAN_AUTO_PACKED && mode != AAE_SCAN_AUTO_RH2)
         return fail(AAE_ERR_INVALID, "scan mode %d", mode);
     cb->scan_ticket = mode == AAE_SCAN_STREAM_2L ? 0 : 1;
     cb->topk_prune = mode == AAE_SCAN_AUTO_NO_PRUNE ? 0 : 1;
     cb->scan_walk = mode == AAE_SCAN_STREAM_WALK ? 1 : 0;
     cb->scan_fused_norm = mode == AAE_SCAN_AUTO_PACKED ? 0 : 1;
+    cb->scan_rh4 = mode == AAE_SCAN_AUTO_RH2 ? 0 : 1;
     cb->scan_mode = (mode == AAE_SCAN_STREAM_2L || mode == AAE_SCAN_STREAM_WALK) ? AAE_SCAN_STREAM
-                    : ((mode == AAE_SCAN_AUTO_NO_PRUNE || mode == AAE_SCAN_AUTO_PACKED) ? AAE_SCAN_AUTO : mode);
+                    : ((mode == AAE_SCAN_AUTO_NO_PRUNE || mode == AAE_SCAN_AUTO_PACKED || mode == AAE_SCAN_AUTO_RH2) ? AAE_SCAN_AUTO : mode);
     for (auto& c : cb->upright_copies) {
         c.second->scan_mode = cb->scan_mode; c.second->scan_ticket = cb->scan_ticket; c.second->topk_prune = cb->topk_prune; c.second->scan_walk = cb->scan_walk;
-        c.second->scan_fused_norm = cb->scan_fused_norm;
+        c.second->scan_fused_norm = cb->scan_fused_norm; c.second->scan_rh4 = cb->scan_rh4;
     }
     return AAE_OK;
 }

@@ -53,12 +53,20 @@ struct ScanResidentArgs {
 };
 
 constexpr int kScanResidentThreads = 512;
-constexpr int kScanResidentTileFloats = 8192;                               // 32 KB
-constexpr int kScanResidentStages = 3;                                      // LDS images of the codebook stream: one in use, two in flight
 // queries one block owns: 8 waves = RH row parts x (8 / RH) groups of 32 queries
 template <int RH>
 constexpr int scan_resident_queries() { return 32 * (8 / RH); }
-constexpr int kScanResidentSmem = kScanResidentStages * kScanResidentTileFloats * 4 + 2 * 2 * 256 * 4;
+// Geometry of the codebook stream.  A row tile is 32 KB -- 64 fp32 rows / 128 bf16 rows -- in three LDS images (one in use, two in
+// flight), except fp32 with RH = 4 (at most 64 queries per block): there a tile is 128 rows = 64 KB in two images (one in flight), so
+// that FOUR waves have a 32-row MFMA tile of their own per query group instead of two.
+template <bool BF16, int RH>
+constexpr int scan_resident_tile_rows() { return BF16 ? 128 : (RH == 4 ? 128 : 64); }
+template <bool BF16, int RH>
+constexpr int scan_resident_tile_floats() { return scan_resident_tile_rows<BF16, RH>() * (BF16 ? 64 : 128); }
+template <bool BF16, int RH>
+constexpr int scan_resident_stages() { return scan_resident_tile_floats<BF16, RH>() > 8192 ? 2 : 3; }
+template <bool BF16, int RH>
+constexpr int scan_resident_smem() { return scan_resident_stages<BF16, RH>() * scan_resident_tile_floats<BF16, RH>() * 4 + 2 * 2 * 256 * 4; }
 
 // K == 0: arg-max (one partial per row block and query).  K > 0: top-k for k <= K WITHOUT the [B][N] similarity matrix:
 // every lane keeps the K best (score, row) pairs of the rows it sees, sorted; a new score enters in front of the first
@@ -161,22 +169,26 @@ __device__ __forceinline__ void scan_resident_normalise(const f32x4 (&zs)[16], f
 
 template <bool BF16, int K = 0, int RH = 2, bool NORM = false>
 __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(const ScanResidentArgs p) {
-    constexpr int kTileRows = BF16 ? 128 : 64;
-    constexpr int kMi = (BF16 ? 4 : 2) / RH;       // 32-row accumulator tiles per wave
+    constexpr int kTileRows = scan_resident_tile_rows<BF16, RH>();
+    constexpr int kMi = kTileRows / (32 * RH);     // 32-row accumulator tiles per wave
     constexpr int kSlots = BF16 ? 16 : 32;         // 16-byte pieces per codebook row
     constexpr int kRowBytes = kSlots * 16;
+    constexpr int kTileFloats = scan_resident_tile_floats<BF16, RH>();
+    constexpr int kStages = scan_resident_stages<BF16, RH>();
+    constexpr int kPieces = kTileFloats / (4 * 64 * 8);                    // LDS-DMA instructions per wave and tile (4 or 8)
     constexpr int QB = scan_resident_queries<RH>();
+    static_assert(kMi >= 1 && RH * kMi * 32 == kTileRows, "row parts x accumulator tiles cover the row tile");
     AAE_DYN_SMEM(smem_raw);
-    float* Et = reinterpret_cast<float*>(smem_raw);                        // [kScanResidentStages][32 KB]
-    float* red_v = Et + kScanResidentStages * kScanResidentTileFloats;     // [RH row parts][QB queries]
+    float* Et = reinterpret_cast<float*>(smem_raw);                        // [kStages][tile]
+    float* red_v = Et + kStages * kTileFloats;                             // [RH row parts][QB queries]
     int* red_i = reinterpret_cast<int*>(red_v + 2 * 256);
     float* tau = red_v;                                                    // top-k: [QB] pruning bound per query of the block
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
-    const int rh = RH == 2 ? (wave & 1) : 0, qg = RH == 2 ? (wave >> 1) : wave;
+    const int rh = wave % RH, qg = wave / RH;
     const int q0 = blockIdx.y * QB + qg * 32;
-    const bool active = q0 < p.Bpad;               // wave-uniform
+    const bool active = q0 < p.Bpad && q0 < p.B;   // wave-uniform (a query group of padding only has nothing to do)
     const int query = q0 + i;
 
     // this wave's query fragments, for good
@@ -210,10 +222,10 @@ __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(con
     // of that row.  Rows past N lie beyond the buffer's size: the hardware delivers zeros.
     const buffer_rsrc ebuf = make_buffer(p.E, p.e_bytes);
     constexpr int kAblate = AAE_SCAN_RESIDENT_ABLATE;
-    unsigned dma_off[4];
+    unsigned dma_off[kPieces];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int pos = (wave * 4 + j) * 64 + lane;
+    for (int j = 0; j < kPieces; ++j) {
+        const int pos = (wave * kPieces + j) * 64 + lane;
         const int r = pos / kSlots, ps = pos % kSlots;
         dma_off[j] = (unsigned)(r * kRowBytes + ((ps ^ (r & 15)) << 4));
     }
@@ -221,7 +233,7 @@ __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(con
         if (kAblate & 8) return;
         const unsigned tile_off = (unsigned)t * (unsigned)(kTileRows * kRowBytes);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) lds_dma16(ebuf, t < tile1 ? tile_off + dma_off[j] : kOobOffset, img + (wave * 4 + j) * 256);
+        for (int j = 0; j < kPieces; ++j) lds_dma16(ebuf, t < tile1 ? tile_off + dma_off[j] : kOobOffset, img + (wave * kPieces + j) * 256);
     };
 
     // arg-max state: running (best score, first row) of this lane
@@ -355,7 +367,7 @@ __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(con
     // has passed that barrier, so nobody reads it any more.  One barrier per tile; a wave waits only for its OWN pieces of
     // tile t (vmcnt counts in issue order: the four of tile t + 1 stay in flight), the barrier covers the other waves'.
     dma(tile0, Et);
-    dma(tile0 + 1, Et + kScanResidentTileFloats);
+    if (kStages == 3) dma(tile0 + 1, Et + kTileFloats);
     if constexpr (NORM) {
         if (active) scan_resident_normalise<BF16>(zraw, bq);
     }
@@ -376,8 +388,8 @@ __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(con
     // longer (the bound arrives a step later) -- 92.7 against 91.6 us.
     constexpr unsigned kPublishSteps = 0x96u, kRefreshSteps = 0x12fu;      // after steps {1, 2, 4, 7} / at the end of steps {0, 1, 2, 3, 5, 8}
     for (int t = tile0; t < tile1; ++t) {
-        const float* Eb = Et + img * kScanResidentTileFloats;
-        wait_dma_keep_and_lds<4>();
+        const float* Eb = Et + img * kTileFloats;
+        wait_dma_keep_and_lds<(kStages - 2) * kPieces>();      // (two images: nothing else is in flight at this point)
         block_barrier();                                       // image of tile t complete
         [[maybe_unused]] const int step = t - tile0;
 #ifdef AAE_SCAN_COUNT
@@ -392,8 +404,8 @@ __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(con
             for (int w4 = 0; w4 < kPruneGroups / 4; ++w4)      // (whole-vector casts: a bit_cast of one element indexed by a loop
                 pw[w4] = __builtin_bit_cast(u32x4, coherent_load4(pb, (unsigned)(rq * kPruneGroups + w4 * 4) * 4u));   // variable picked element 0 under clang -O2)
         };
-        dma(t + 2, Et + (img == 0 ? 2 : img - 1) * kScanResidentTileFloats);
-        img = img == 2 ? 0 : img + 1;
+        dma(t + kStages - 1, Et + (img == 0 ? kStages - 1 : img - 1) * kTileFloats);      // into the image tile t - 1 was read from
+        img = img == kStages - 1 ? 0 : img + 1;
         if constexpr (K > 0) {
             if (active) {
                 tau_l = tau[qg * 32 + i];                      // (a bound of any age is valid)
@@ -492,10 +504,12 @@ __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(con
     if (tid < QB && qout < p.B) {
         float v = red_v[tid];
         int ix = red_i[tid];
-        if (RH == 2 && better(red_v[QB + tid], red_i[QB + tid], v, ix)) {
-            v = red_v[QB + tid];
-            ix = red_i[QB + tid];
-        }
+#pragma unroll
+        for (int part = 1; part < RH; ++part)                  // row parts in ascending row order
+            if (better(red_v[part * QB + tid], red_i[part * QB + tid], v, ix)) {
+                v = red_v[part * QB + tid];
+                ix = red_i[part * QB + tid];
+            }
         p.pval[(long long)blockIdx.x * p.Bstride + qout] = v;
         p.pidx[(long long)blockIdx.x * p.Bstride + qout] = ix;
     }

@@ -55,6 +55,8 @@ extern "C" {
                                      instead of one batch per wave and the whole codebook requested at once: A/B, same answers */
 #define AAE_SCAN_AUTO_PACKED 7    /* AUTO, but the top-1 query-resident scan (B > 4) reads queries normalised and packed by a
                                      launch in front instead of normalising the raw codes in its own prologue: A/B, same answers */
+#define AAE_SCAN_AUTO_RH2 8       /* AUTO, but the top-1 query-resident scan of at most 32 queries splits the rows of a tile over two waves
+                                     per query group (rounds 2-3) instead of four: A/B, same answers */
 
 typedef struct aae_encoder aae_encoder;
 typedef struct aae_codebook aae_codebook;

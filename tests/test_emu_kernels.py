@@ -395,7 +395,7 @@ def test_few_split_reduce_kernel_matches_the_grouped_one_bitwise(precision, bn):
 
 
 @pytest.mark.parametrize('dtype,N,B', [('f32', 1000, 40), ('f32', 700, 130), ('f32', 520, 5), ('bf16', 1100, 70), ('bf16', 640, 129), ('bf16', 400, 9),
-                                       ('bf16', 1100, 200), ('f32', 1000, 256)])
+                                       ('bf16', 1100, 200), ('f32', 1000, 256), ('f32', 2300, 32), ('f32', 130, 17), ('bf16', 900, 31), ('f32', 1500, 20)])
 def test_query_resident_scan_equals_the_tile_resident_kernels_bitwise(dtype, N, B):
     """Batches (B > 4, top-1, stride 1) keep the queries in registers and stream the codebook through LDS
     (codebook_scan_resident.h).  Same per-accumulator MFMA order as the tile-resident kernels -> the same bits:
@@ -414,6 +414,10 @@ def test_query_resident_scan_equals_the_tile_resident_kernels_bitwise(dtype, N, 
     cb.set_mode(_lib.AAE_SCAN_AUTO_PACKED)
     idx_p, sc_p = cb.nn(z)
     assert np.array_equal(idx_r, idx_p) and np.array_equal(sc_r, sc_p)
+    # at most 32 queries: four waves per query group share the rows of a tile (fp32: 128-row tiles in two LDS images); AUTO_RH2 = two
+    cb.set_mode(_lib.AAE_SCAN_AUTO_RH2)
+    idx_2, sc_2 = cb.nn(z)
+    assert np.array_equal(idx_r, idx_2) and np.array_equal(sc_r, sc_2)
     cs = cb.similarity(z)
     assert np.array_equal(idx_r[:, 0], np.argmax(cs, axis=1)) and np.array_equal(sc_r[:, 0], cs.max(axis=1))
     cb.close()
