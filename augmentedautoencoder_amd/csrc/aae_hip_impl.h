@@ -145,6 +145,9 @@ struct aae_encoder {
                                            // measured: wins up to 64 tiles (B=1: 94 -> 87 us), loses from 128 on (twice the operand loads per MFMA)
     int wavek_target_blocks = 256;         // blocks a split layer is cut into (tiles x K splits): one per CU
     int wavek_waves = 4;                   // waves per block (4 | 8), each with its own K range
+    int wavek_tail_split = 1;              // planner by cost: tiles beyond the last full round of whole tiles are cut in K (wavek_tail_split())
+    int wavek_force_tail_tiles = 0;        // tests: cut the last n tiles of every un-split wave-split-K layer ...
+    int wavek_force_tail_g = 2;            // ... this many ways
     int wavek_spread = 3;                  // bit 0: 64 x 64 wave tiles (four accumulators): next-slab loads between the MFMAs instead of a burst in front of them (conv_wavek_f32.h):
                                            // conv2 at B = 8 128 -> 115 us, B = 24 encoder 910 -> 830 us; measured neutral-to-worse for 64 x 32 tiles, not used there.
                                            // bit 1: 32 x 32 tiles with a second accumulator for the odd q-steps (two fma chains, added once): B = 1 80.2 -> 78.0 us
@@ -357,7 +360,9 @@ struct WaveKPlan {
     bool use = false;
     int MT = 2, NT = 2, waves = 4, depth = 3;
     int num_mt = 0, num_nt = 0, gsplits = 1;
+    int tail_tiles = 0, tail_g = 1;        // the last tail_tiles tiles cut tail_g ways in K (gsplits == 1 then): conv_wavek_f32.h
     size_t partial_bytes = 0;
+    int blocks() const { return (num_mt * num_nt - tail_tiles) * gsplits + tail_tiles * tail_g; }
 };
 
 // Does a forward of batch B run in f32x3h?  precision 1: always.  precision 2 ("where it is faster"): only when the first
@@ -406,6 +411,31 @@ static double wavek_cost_us(const aae_encoder* enc, int tiles, int g, int slabs,
     return (double)ceil_div(tiles * g, cus) * (ceil_div(slabs, 4 * g) + 4) * (mt * nt) * kSlabUs / eff[shape] + fixed[shape] + (g > 1 ? 3.0 : 0.0);
 }
 
+// Tail split.  `tiles` whole tiles (no K split) leave the last round of blocks partly empty whenever tiles is not a multiple of
+// what the chip runs at once: 576 tiles of 64 x 64 at B = 9 cost three tile times on 256 CUs, B = 12 is slower than B = 16.  The
+// tiles beyond the last full round (a round = one tile per CU) can be cut g ways in K instead -- smaller blocks that fill every CU:
+//     t = [full rounds * (slabs / 4 + fill) + ceil(tail * g / CUs) * (slabs / (4 g) + fill)] * tile time per slab / efficiency
+// Returns the best g (1 = leave the layer alone) and its estimate.
+static int wavek_tail_split(const aae_encoder* enc, int tiles, int slabs, int waves, int mt, int nt, int* tail_tiles, double* cost) {
+    static const double eff_burst[3] = {0.71, 0.72, 0.88}, eff_spread[3] = {0.71, 0.72, 0.96}, fixed[3] = {0.0, 0.0, 5.0};
+    const double* eff = (enc->wavek_spread & 1) ? eff_spread : eff_burst;
+    const int shape = mt == 1 ? 0 : (nt == 1 ? 1 : 2);
+    const int cus = enc->wavek_target_blocks > 0 ? enc->wavek_target_blocks : 256;
+    const int tail = tiles % cus, full_rounds = tiles / cus;
+    *tail_tiles = 0;
+    *cost = wavek_cost_us(enc, tiles, 1, slabs, mt, nt);
+    if (!enc->wavek_tail_split || tail == 0 || full_rounds == 0 || tail > kLayerTicketWords) return 1;
+    const int gmax = std::min(slabs / (2 * waves), (int)aae::kTicketSingleLevelMax);
+    const double per_slab = (mt * nt) * kSlabUs / eff[shape];
+    int best = 1;
+    for (int g = 2; g <= gmax && g <= 16; ++g) {
+        const double c = ((double)full_rounds * (ceil_div(slabs, 4) + 4) + (double)ceil_div(tail * g, cus) * (ceil_div(slabs, 4 * g) + 4)) * per_slab + fixed[shape] + 3.0;
+        if (c < 0.97 * *cost) { *cost = c; best = g; }
+    }
+    if (best > 1) *tail_tiles = tail;
+    return best;
+}
+
 static double igemm_cost_us(const aae_encoder* enc, const Layer& L, long long M) {
     const int mt = ceil_div((int)M, 128), nt = L.CoutPad / 128, slabs = (int)(L.K() / 32);
     int s, per;
@@ -418,7 +448,22 @@ static double igemm_cost_us(const aae_encoder* enc, const Layer& L, long long M)
     return (double)ceil_div(blocks, cus) * (ceil_div(slabs, s) + 2) * (4 * kSlabUs) / 0.86 + (s > 1 ? 10.0 : 0.0) + 5.0;
 }
 
+static WaveKPlan plan_wavek_core(const aae_encoder* enc, const Layer& L, long long M, bool split);
 static WaveKPlan plan_wavek(const aae_encoder* enc, const Layer& L, long long M, bool split) {
+    WaveKPlan w = plan_wavek_core(enc, L, M, split);
+    if (w.use && enc->wavek_force_tail_tiles > 0 && w.gsplits == 1 && w.tail_tiles == 0) {       // (tests)
+        const int tiles = w.num_mt * w.num_nt, slabs = (int)(L.K() / 32);
+        const int gmax = std::min(slabs / (2 * w.waves), (int)aae::kTicketSingleLevelMax);
+        const int g = std::min(enc->wavek_force_tail_g, gmax);
+        if (g >= 2) {
+            w.tail_tiles = std::min(std::min(enc->wavek_force_tail_tiles, tiles), kLayerTicketWords);
+            w.tail_g = g;
+            w.partial_bytes = (size_t)w.blocks() * (w.MT * w.NT * 16) * 64 * sizeof(float);
+        }
+    }
+    return w;
+}
+static WaveKPlan plan_wavek_core(const aae_encoder* enc, const Layer& L, long long M, bool split) {
     WaveKPlan w;
     if (!enc->wavek || split || L.kind != KIND_IGEMM) return w;
     const long long tiles22 = ((M + 63) / 64) * (L.CoutPad / 64);
@@ -442,7 +487,12 @@ static WaveKPlan plan_wavek(const aae_encoder* enc, const Layer& L, long long M,
             const long long tiles = ((M + 32 * sh[0] - 1) / (32 * sh[0])) * (long long)(L.CoutPad / (32 * sh[1]));
             if (tiles > (1 << 20)) continue;
             const int g = wavek_gsplits(enc, (int)tiles, slabs, w.waves);
-            const double c = wavek_cost_us(enc, (int)tiles, g, slabs, sh[0], sh[1]);
+            double c = wavek_cost_us(enc, (int)tiles, g, slabs, sh[0], sh[1]);
+            if (g == 1) {                                        // whole tiles: the part beyond the last full round may be cut in K
+                int tt;
+                double ct;
+                if (wavek_tail_split(enc, (int)tiles, slabs, w.waves, sh[0], sh[1], &tt, &ct) > 1) c = ct;
+            }
             if (c < best) { best = c; best_mt = sh[0]; best_nt = sh[1]; }
         }
         if (best_mt == 0) { w.use = false; return w; }           // the 128-row igemm (+ reduce launch) is estimated faster
@@ -451,7 +501,11 @@ static WaveKPlan plan_wavek(const aae_encoder* enc, const Layer& L, long long M,
         w.num_nt = L.CoutPad / (32 * w.NT);
         const int tiles = w.num_mt * w.num_nt;
         w.gsplits = wavek_gsplits(enc, tiles, slabs, w.waves);
-        if (w.gsplits > 1) w.partial_bytes = (size_t)tiles * w.gsplits * (w.MT * w.NT * 16) * 64 * sizeof(float);
+        if (w.gsplits == 1) {
+            double ct;
+            w.tail_g = wavek_tail_split(enc, tiles, slabs, w.waves, w.MT, w.NT, &w.tail_tiles, &ct);
+        }
+        if (w.gsplits > 1 || w.tail_tiles > 0) w.partial_bytes = (size_t)w.blocks() * (w.MT * w.NT * 16) * 64 * sizeof(float);
         return w;
     }
     w.NT = tiles22 <= enc->wavek_narrow_max_tiles ? 1 : 2;
@@ -681,19 +735,20 @@ static aae::ConvWaveKArgs wavek_args(const aae_encoder* enc, const Layer& L, con
     a.partial = partial; a.partial_bytes = (unsigned)w.partial_bytes; a.tickets = tickets; a.nonce = nonce;
     a.H = L.H; a.W = L.W; a.Cin = L.Cin; a.Ho = L.Ho; a.Wo = L.Wo; a.Cout = L.Cout; a.CoutPad = L.CoutPad;
     a.KS = L.KS; a.S = L.S; a.pt = L.pt; a.pl = L.pl; a.M = M; a.relu = L.relu; a.ablate = enc->wavek_ablate; a.pingpong = enc->wavek_pingpong; a.spread = enc->wavek_spread;
-    a.timeline = (enc->wavek_timeline && tag >= 1 && tag <= 3 && w.num_mt * w.num_nt * w.gsplits <= 512)       // (the debug buffer holds 512 blocks per layer)
+    a.timeline = (enc->wavek_timeline && tag >= 1 && tag <= 3 && w.blocks() <= 512)       // (the debug buffer holds 512 blocks per layer)
                      ? enc->wavek_timeline + (size_t)(tag - 1) * 512 * 8 : nullptr;
     a.x_bytes = (unsigned)((unsigned long long)(M / (L.Ho * L.Wo)) * L.H * L.W * L.Cin * sizeof(float));
     a.slabs_total = (int)(L.K() / 32);
     a.wp_bytes = (unsigned)((unsigned long long)a.slabs_total * 8ull * L.CoutPad * 16ull);
     a.num_mt = w.num_mt; a.num_nt = w.num_nt; a.gsplits = w.gsplits;
+    a.tail_tiles = w.tail_tiles; a.tail_gsplits = w.tail_g;
     return a;
 }
 
 static int launch_wavek(aae_encoder* enc, const Layer& L, const WaveKPlan& w, const float* x, int M, float* out, float* partial,
                         unsigned long long* tickets, unsigned nonce, hipStream_t stream, Timer& tm, const char* name, int tag) {
     const aae::ConvWaveKArgs a = wavek_args(enc, L, w, x, M, out, partial, tickets, nonce, tag);
-    const int nblk = w.num_mt * w.num_nt * w.gsplits;
+    const int nblk = w.blocks();
     const int key = (w.MT == 1 ? 1000 : 0) + w.NT * 100 + w.waves * 10 + w.depth;
     switch (key) {
         case 243: launch_wavek_t<2, 2, 4, 3>(a, tag, nblk, stream); break;
@@ -707,9 +762,10 @@ static int launch_wavek(aae_encoder* enc, const Layer& L, const WaveKPlan& w, co
         case 1182: launch_wavek_t<1, 1, 8, 2>(a, tag, nblk, stream); break;
         default: return fail(AAE_ERR_RUNTIME, "%s: no wave-split-K instantiation for NT=%d waves=%d depth=%d", name, w.NT, w.waves, w.depth);
     }
-    char label[112];
-    snprintf(label, sizeof(label), "%s:conv_wavek_f32_%dx%d_w%d_d%d_g%d M=%d N=%d K=%lld", name, 32 * w.MT, 32 * w.NT, w.waves, w.depth,
-             w.gsplits, M, L.Cout, L.K());
+    char label[128], tail[24] = "";
+    if (w.tail_tiles > 0) snprintf(tail, sizeof(tail), "t%dx%d", w.tail_tiles, w.tail_g);       // (e.g. g1t64x4: the last 64 tiles cut four ways)
+    snprintf(label, sizeof(label), "%s:conv_wavek_f32_%dx%d_w%d_d%d_g%d%s M=%d N=%d K=%lld", name, 32 * w.MT, 32 * w.NT, w.waves, w.depth,
+             w.gsplits, tail, M, L.Cout, L.K());
     note_kernel({label, 2.0 * (double)M * (double)L.K() * (double)L.Cout});
     AAE_HIP_TRY(hipGetLastError());
     return tm.mark();
@@ -1130,9 +1186,9 @@ static int forward_impl(aae_encoder* enc, const void* x, int x_dtype, int B, flo
         return true;
     };
     for (size_t li = 0; li <= nl; ++li)
-        if (plans[li].use && plans[li].gsplits > 1) {
+        if (plans[li].use && (plans[li].gsplits > 1 || plans[li].tail_tiles > 0)) {
             nonces[li] = next_nonce();
-            add_prep(layer_tickets(li), plans[li].num_mt * plans[li].num_nt, nonces[li]);
+            add_prep(layer_tickets(li), plans[li].tail_tiles > 0 ? plans[li].tail_tiles : plans[li].num_mt * plans[li].num_nt, nonces[li]);
         }
     unsigned gemv_nonce = 0;
     if (gemv_ticket) {
@@ -1629,6 +1685,9 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
     else if (!strcmp(name, "igemm_breg")) enc->igemm_breg = value ? 1 : 0;
     else if (!strcmp(name, "dense_gemv")) enc->dense_gemv = value ? 1 : 0;
     else if (!strcmp(name, "dense_gemv_max_batch")) enc->dense_gemv_max_batch = value;
+    else if (!strcmp(name, "wavek_tail_split")) enc->wavek_tail_split = value ? 1 : 0;
+    else if (!strcmp(name, "wavek_force_tail_tiles")) enc->wavek_force_tail_tiles = value < 0 ? 0 : value;
+    else if (!strcmp(name, "wavek_force_tail_g")) enc->wavek_force_tail_g = value < 2 ? 2 : value;
     else if (!strcmp(name, "gemv_ticket")) enc->gemv_ticket = value ? 1 : 0;
     else if (!strcmp(name, "wavek")) enc->wavek = value ? 1 : 0;
     else if (!strcmp(name, "wavek_dense")) enc->wavek_dense = value ? 1 : 0;

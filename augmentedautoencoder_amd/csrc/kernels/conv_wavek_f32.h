@@ -46,6 +46,12 @@ struct ConvWaveKArgs {
     int M;                       // B*Ho*Wo
     int slabs_total;             // KS*KS*Cin/32
     int num_mt, num_nt, gsplits;
+    // Tail split (batches whose tile count is not a multiple of what the chip holds at once): the LAST tail_tiles tiles of the
+    // layer are cut tail_gsplits ways in K while the tiles in front of them are whole (gsplits == 1 then), so that the last,
+    // partly filled round of blocks is made of SMALLER blocks that fill every CU: 576 tiles of 64 x 64 on 512 block slots cost
+    // three tile times as 512 + 64 whole tiles, 2.3 as 512 whole + 64 x 4 quarter blocks.  0 = off.  Tickets and partials of the
+    // tail tiles are indexed from the first tail tile (at most kLayerTicketWords of them).
+    int tail_tiles = 0, tail_gsplits = 1;
     int relu;
     long long* timeline;         // optional [blocks][8] shader-clock stamps of wave 0 per phase (tools/ablate_wavek.py); nullptr in production
     int ablate;                  // timing experiments only (results are then wrong): 1 no A loads, 2 no B loads, 4 no MFMAs, 8 no cross-block hand-off
@@ -135,14 +141,23 @@ __device__ __forceinline__ void conv_wavek_block(const ConvWaveKArgs& p, const i
     const int pH = p.H, pW = p.W, pCin = p.Cin, pKS = p.KS;
     const int ablate = CHAIN ? 0 : p.ablate;                    // (timing experiments exist for the stand-alone launches only)
     const int tiles = p.num_mt * p.num_nt;
-    const int L = xcd_remap(Lphys, nblk);
-    const int tm = L % p.num_mt;                               // M tiles of one (N tile, K split) are neighbours: they share its weights in L2
-    const int tn = (L / p.num_mt) % p.num_nt;
-    const int g = L / tiles;
-    const int tile = tn * p.num_mt + tm;
+    // logical block -> (tile, K part g of gs).  Head tiles [0, head): gsplits parts each, part-major; tail tiles: tail_gsplits parts.
+    // Head and tail are remapped to the XCDs separately (each XCD gets a contiguous chunk of BOTH), and the tail blocks -- the
+    // small ones -- are the last to be dispatched: they fill in behind the whole tiles.
+    const int head = tiles - p.tail_tiles, head_blocks = head * p.gsplits;
+    const bool in_tail = Lphys >= head_blocks;
+    const int Lr = in_tail ? xcd_remap(Lphys - head_blocks, nblk - head_blocks) : xcd_remap(Lphys, head_blocks);
+    const int span = in_tail ? p.tail_tiles : head;
+    const int g = Lr / span;
+    const int tile = (in_tail ? head : 0) + (Lr - g * span);
+    const int gs = in_tail ? p.tail_gsplits : p.gsplits;
+    const int tm = tile % p.num_mt;                            // M tiles of one (N tile, K split) are neighbours: they share its weights in L2
+    const int tn = tile / p.num_mt;
+    const int slot0 = in_tail ? head_blocks + (tile - head) * p.tail_gsplits : tile * p.gsplits;    // first partial slot of the tile
+    const int ticket_word = p.tail_tiles > 0 ? tile - head : tile;
     // K ranges: block g of the tile walks slabs [b0, b1), its wave w the w-th part of that; sizes differ by at most one slab
-    const int b0 = (int)((long long)g * p.slabs_total / p.gsplits);
-    const int b1 = (int)((long long)(g + 1) * p.slabs_total / p.gsplits);
+    const int b0 = (int)((long long)g * p.slabs_total / gs);
+    const int b1 = (int)((long long)(g + 1) * p.slabs_total / gs);
     const int s0 = b0 + wave * (b1 - b0) / WAVES;
     const int s1 = b0 + (wave + 1) * (b1 - b0) / WAVES;
 
@@ -262,8 +277,8 @@ __device__ __forceinline__ void conv_wavek_block(const ConvWaveKArgs& p, const i
         for (int e = 0; e < 4; ++e) ep_bias[j][e] = (finisher && n + e < p.Cout) ? p.bias[n + e] : 0.f;
     }
     // (logical block 0, its first loads in flight) the tile words get this launch's nonce long before the first arrival
-    if (p.gsplits > 1 && Lphys == 0)
-        for (int w = tid; w < tiles; w += T) ticket_prepare_word(p.tickets + w, p.nonce);
+    if ((p.gsplits > 1 || p.tail_tiles > 0) && Lphys == 0)
+        for (int w = tid; w < (p.tail_tiles > 0 ? p.tail_tiles : tiles); w += T) ticket_prepare_word(p.tickets + w, p.nonce);
     if constexpr (SPREAD && DEPTH == 2) {
         // Spread schedule (wave tiles with two or four accumulators).  The burst form below issues the ~100 instructions that
         // address and request the next slab in one piece, fenced in front of the slab's 64 (32) MFMAs: for ~450 cycles per slab
@@ -384,16 +399,16 @@ __device__ __forceinline__ void conv_wavek_block(const ConvWaveKArgs& p, const i
     __syncthreads();                                            // (CHAIN: the next work item of this block reuses red)
 
     stamp(3);                                                   // cross-wave sum done
-    if (p.gsplits > 1 && !(ablate & 8)) {
+    if (gs > 1 && !(ablate & 8)) {
         // this block's tile partial: one 16-B coherent store per piece, thread-linear (coalesced)
         const buffer_rsrc pbuf = make_buffer(p.partial, p.partial_bytes);
-        const unsigned tile_base = (unsigned)tile * (unsigned)p.gsplits * PIECES * 16u;
+        const unsigned tile_base = (unsigned)slot0 * PIECES * 16u;
         const unsigned mine = finisher ? tile_base + (unsigned)g * PIECES * 16u + (unsigned)tid * 16u : kOobBase;
 #pragma unroll
         for (int j = 0; j < NF4; ++j) coherent_store4(pbuf, finisher ? mine + j * T * 16u : kOobBase, v[j]);
         block_ticket_publish();
         stamp(4);                                               // partial stores complete (device scope)
-        const bool last_block = block_ticket_take(p.tickets + tile, p.nonce, (unsigned)p.gsplits, (unsigned)g, flag);
+        const bool last_block = block_ticket_take(p.tickets + ticket_word, p.nonce, (unsigned)gs, (unsigned)g, flag);
         stamp(5);                                               // ticket taken
         if (!last_block) return;
 #pragma unroll
@@ -403,13 +418,13 @@ __device__ __forceinline__ void conv_wavek_block(const ConvWaveKArgs& p, const i
         // sum whichever block arrives last.
         constexpr int kBatch = 8;
         const unsigned split_stride = PIECES * 16u;
-        for (int sb = 0; sb < p.gsplits; sb += kBatch) {
+        for (int sb = 0; sb < gs; sb += kBatch) {
             f32x4 t[kBatch][NF4];
 #pragma unroll
             for (int u = 0; u < kBatch; ++u)
 #pragma unroll
                 for (int j = 0; j < NF4; ++j)
-                    t[u][j] = coherent_load4(pbuf, (finisher && sb + u < p.gsplits) ? tile_base + (unsigned)(sb + u) * split_stride + (unsigned)tid * 16u + j * T * 16u
+                    t[u][j] = coherent_load4(pbuf, (finisher && sb + u < gs) ? tile_base + (unsigned)(sb + u) * split_stride + (unsigned)tid * 16u + j * T * 16u
                                                                                     : kOobBase);
 #pragma unroll
             for (int u = 0; u < kBatch; ++u)
@@ -458,7 +473,7 @@ __global__ __launch_bounds__(64 * WAVES, (MT * NT == 4 && WAVES == 4 && DEPTH ==
     float* red = reinterpret_cast<float*>(smem_raw);           // [WAVES][COMBOS][64]
     int* flag = reinterpret_cast<int*>(red + WAVES * MT * NT * 16 * 64);
     WaveKPrefetch none;
-    conv_wavek_block<MT, NT, WAVES, DEPTH, false, SPREAD>(p, (int)blockIdx.x, p.num_mt * p.num_nt * p.gsplits, red, flag, none, false);
+    conv_wavek_block<MT, NT, WAVES, DEPTH, false, SPREAD>(p, (int)blockIdx.x, (int)gridDim.x, red, flag, none, false);
 }
 
 }  // namespace aae

@@ -878,3 +878,45 @@ def test_f32x3h_256x256_tile_kernel_is_bit_identical(shape, B, filters, bn):
     z64 = ref.encoder_forward_np(ref.input_to_float(x), w, cfg.strides, bn)
     assert np.abs(z1 - z64).max() / np.abs(z64).max() < 2e-5       # the latent tolerance of the GPU parity tests
     enc.close()
+
+
+@pytest.mark.parametrize('order', [0, 1, 2])
+@pytest.mark.parametrize('shape_opts,tail,g', [({'wavek_narrow_max_tiles': 0, 'wavek_tiny_max_tiles': 0}, 3, 2),      # 64 x 64 wave tiles
+                                               ({'wavek_narrow_max_tiles': 1 << 20, 'wavek_tiny_max_tiles': 0}, 4, 3),  # 64 x 32
+                                               ({'wavek_narrow_max_tiles': 1 << 20, 'wavek_tiny_max_tiles': 1 << 20}, 7, 3)])   # 32 x 32
+def test_wave_split_k_tail_tiles_cut_in_k(shape_opts, tail, g, order):
+    """Mid-size batches whose tile count does not fill the last round of blocks: the LAST `tail` tiles of a layer are cut `g` ways
+    in K (their partials meet through the ticket of the tile, indexed from the first tail tile), the tiles in front of them stay
+    whole -- one launch, head and tail remapped to the XCDs separately.  Every layer against the fp64 oracle (inside _run), the
+    label names the cut, any block order gives the same bits, and the untouched head tiles have the bits of the un-cut layer."""
+    cfg = EncoderConfig((32, 32, 3), [32, 64], [2, 2], 5, 128, True)
+    opts = dict(shape_opts, wavek_max_tiles=1 << 12, wavek_target_blocks=1, wavek_force_tail_tiles=tail, wavek_force_tail_g=g, dense_gemv_max_batch=4)
+    eb.set_block_order(order)
+    try:
+        labels = _run(cfg, 6, 91, wavek=1, options=opts)
+        assert '_g1t%dx%d ' % (tail, g) in labels[1], labels
+    finally:
+        eb.set_block_order(0)
+
+
+def test_wave_split_k_tail_split_leaves_the_head_tiles_bitwise_alone():
+    cfg = EncoderConfig((32, 32, 3), [32, 64], [2, 2], 5, 128, True)
+    w = synth.make_weights(seed=5, shape=cfg.shape, num_filter=cfg.num_filter, strides=cfg.strides, latent=128, batch_norm=True)
+    x = synth.make_crops(6, seed=6, shape=cfg.shape)
+    outs = []
+    for tail in (0, 5):
+        enc = eb.EmuEncoder(w, cfg)
+        for k, v in {'planner_cost_model': 0, 'wavek_max_tiles': 1 << 12, 'wavek_target_blocks': 1, 'wavek_narrow_max_tiles': 0, 'wavek_tiny_max_tiles': 0,
+                     'wavek_force_tail_tiles': tail, 'wavek_force_tail_g': 3}.items():
+            enc.set_option(k, v)
+        enc.forward(x)
+        assert ('t5x3' in enc.labels()[1]) == (tail == 5), enc.labels()
+        outs.append(enc.activation(1).copy())                  # conv2 output [B, Ho, Wo, C]
+        enc.close()
+    a, b = (o.reshape(-1, o.shape[-1]) for o in outs)          # rows = output pixels; 64-row M tiles, 64-column N tiles
+    tiles_m = -(-a.shape[0] // 64)
+    tiles = tiles_m * (a.shape[1] // 64)
+    same = [bool(np.array_equal(a[(t % tiles_m) * 64:(t % tiles_m + 1) * 64, (t // tiles_m) * 64:(t // tiles_m + 1) * 64],
+                                b[(t % tiles_m) * 64:(t % tiles_m + 1) * 64, (t // tiles_m) * 64:(t // tiles_m + 1) * 64])) for t in range(tiles)]
+    assert all(same[:tiles - 5]), same                        # head tiles: the same fma chains
+    assert np.abs(a - b).max() / np.abs(a).max() < 2e-6       # tail tiles: another (fixed) summation order

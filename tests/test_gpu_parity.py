@@ -915,12 +915,14 @@ def test_small_batch_wave_split_k_path_matches_fp64_oracle(default_model, B, cha
     assert np.array_equal(idx_f.cpu().numpy(), idx.cpu().numpy()) and np.array_equal(score_f.cpu().numpy(), score.cpu().numpy())
 
 
-@pytest.mark.parametrize('B', [5, 6, 10, 24, 48, 96])
+@pytest.mark.parametrize('B', [5, 6, 8, 9, 10, 12, 16, 24, 48, 96])
 def test_planner_by_cost_model_batches_match_fp64_oracle(default_model, B):
     """Mid-size batches (the reference embeds in batches of 64, train_template.cfg:61): each conv layer runs whichever of the
     128-row igemm / wave-split-K 32x32 | 64x32 | 64x64 the planner estimates fastest (plan_wavek, fitted to
-    profiles/r11/planner_sweep_*.jsonl).  Every layer, the latents and the indices against the fp64 oracle, the labels of the
-    chosen kernels recorded; the threshold planner (option off) must agree to rounding."""
+    profiles/r11/planner_sweep_*.jsonl); where whole tiles leave the last round of blocks partly empty the tiles of that round
+    are cut in K (label ..._g1t<tiles>x<parts>: B = 9 and 12 of the default net, none at 8 and 16 where the tile counts fit).
+    Every layer, the latents and the indices against the fp64 oracle, the labels of the chosen kernels recorded; the threshold
+    planner (option off) and the planner without the tail cut must agree to rounding."""
     weights, enc, cb, E, _ = default_model
     eng = enc.engine
     crops = synth.make_crops(B, seed=2500 + B)
@@ -934,6 +936,18 @@ def test_planner_by_cost_model_batches_match_fp64_oracle(default_model, B):
     idx, score = cb.engine.nn(z, 1, 1)
     _check_indices(idx[:, 0].cpu().numpy(), cs64, where='cost-model plan B=%d' % B)
     report.record('planner', 'B=%d' % B, kernels=labels)
+    cut = [l for l in labels if '_g1t' in l]
+    if B in (9, 12):
+        assert cut and all('conv_wavek_f32_' in l for l in cut), labels
+    if B in (8, 16):
+        assert not cut and all('conv_wavek_f32_64x64' in l for l in labels[1:3]), labels
+    eng.set_option('wavek_tail_split', 0)
+    try:
+        z_whole, recs_whole = eng.encode_timed(crops)
+    finally:
+        eng.set_option('wavek_tail_split', 1)
+    assert not any('_g1t' in l for l, _, _ in recs_whole)
+    assert float((z_whole - z).abs().max() / z.abs().max()) < 1e-5
     eng.set_option('planner_cost_model', 0)
     try:
         z_thr, recs_thr = eng.encode_timed(crops)
