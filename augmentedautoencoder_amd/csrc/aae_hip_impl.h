@@ -535,7 +535,11 @@ static WaveKPlan plan_wavek_core(const aae_encoder* enc, const Layer& L, long lo
     const int slabs = (int)(L.K() / 32);
     const int g = wavek_gsplits(enc, tiles, slabs, w.waves);
     w.gsplits = g;
-    if (g > 1) w.partial_bytes = (size_t)tiles * g * (w.MT * w.NT * 16) * 64 * sizeof(float);
+    if (g == 1 && L.index >= 0) {                                // (B = 3 of the default net: 384 tiles of 64 x 32 on 256 CUs)
+        double ct;
+        w.tail_g = wavek_tail_split(enc, tiles, slabs, w.waves, w.MT, w.NT, &w.tail_tiles, &ct);
+    }
+    if (g > 1 || w.tail_tiles > 0) w.partial_bytes = (size_t)w.blocks() * (w.MT * w.NT * 16) * 64 * sizeof(float);
     return w;
 }
 
@@ -1033,7 +1037,7 @@ static bool chain_eligible(const aae_encoder* enc, int B, const std::vector<Wave
     if (enc->wavek_spread != 3) return false;                  // (the phases are compiled with the default schedules)
     for (size_t li = 1; li < nl; ++li) {
         const WaveKPlan& w = plans[li];
-        if (!w.use || w.waves != 4 || w.depth != 2 || enc->layers[li].Cout % 4 != 0) return false;
+        if (!w.use || w.waves != 4 || w.depth != 2 || w.tail_tiles > 0 || enc->layers[li].Cout % 4 != 0) return false;
         if (!((w.MT == 1 && w.NT == 1) || (w.MT == 2 && w.NT == 1) || (w.MT == 2 && w.NT == 2))) return false;
     }
     if (enc->dense.Cout % 4 != 0) return false;
