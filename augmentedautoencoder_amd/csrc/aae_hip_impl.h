@@ -145,6 +145,8 @@ struct aae_encoder {
                                            // measured: wins up to 64 tiles (B=1: 94 -> 87 us), loses from 128 on (twice the operand loads per MFMA)
     int wavek_target_blocks = 256;         // blocks a split layer is cut into (tiles x K splits): one per CU
     int wavek_waves = 4;                   // waves per block (4 | 8), each with its own K range
+    int planner_cost_batch3 = 1;           // ... and at B = 3
+    int planner_cost_min_batch = 5;        // planner by cost from this batch on (below: the measured thresholds of the per-detection path)
     int wavek_tail_split = 1;              // planner by cost: tiles beyond the last full round of whole tiles are cut in K (wavek_tail_split())
     int wavek_force_tail_tiles = 0;        // tests: cut the last n tiles of every un-split wave-split-K layer ...
     int wavek_force_tail_g = 2;            // ... this many ways
@@ -470,7 +472,10 @@ static WaveKPlan plan_wavek_core(const aae_encoder* enc, const Layer& L, long lo
     // (5 <= B < 256: at the headline batch every layer keeps its measured choice -- the big igemm tiles; conv4 would cost the same
     //  on 64 x 64 wave tiles, 1.542 vs 1.547 ms, profiles/r12)
     const long long batch_of = L.index >= 0 ? M / ((long long)L.Ho * L.Wo) : M;
-    const bool by_cost = enc->planner_cost_model && L.index >= 0 && batch_of >= 5 && batch_of < 256 && enc->wavek_waves != 8;
+    // (B = 3 too: its layers are 0.75 / 1.5 rounds under the thresholds of the per-detection path -- 174 -> 160 us with the estimate and
+    //  the tail split; B = 2 and 4 fill their rounds exactly and measured equal / 1 % slower under the estimate: they keep the thresholds)
+    const bool by_cost = enc->planner_cost_model && L.index >= 0 && (batch_of >= enc->planner_cost_min_batch || (batch_of == 3 && enc->planner_cost_batch3)) &&
+                         batch_of < 256 && enc->wavek_waves != 8;
     if (tiles22 > kWaveKTileCap || (!by_cost && tiles22 > enc->wavek_max_tiles)) return w;
     const unsigned long long x_bytes = (unsigned long long)(M / (L.Ho * L.Wo)) * L.H * L.W * L.Cin * sizeof(float);
     if (x_bytes >= 0xFFFFFF00ull) return w;
@@ -1690,6 +1695,8 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
     else if (!strcmp(name, "dense_gemv")) enc->dense_gemv = value ? 1 : 0;
     else if (!strcmp(name, "dense_gemv_max_batch")) enc->dense_gemv_max_batch = value;
     else if (!strcmp(name, "wavek_tail_split")) enc->wavek_tail_split = value ? 1 : 0;
+    else if (!strcmp(name, "planner_cost_min_batch")) enc->planner_cost_min_batch = value < 1 ? 1 : value;
+    else if (!strcmp(name, "planner_cost_batch3")) enc->planner_cost_batch3 = value ? 1 : 0;
     else if (!strcmp(name, "wavek_force_tail_tiles")) enc->wavek_force_tail_tiles = value < 0 ? 0 : value;
     else if (!strcmp(name, "wavek_force_tail_g")) enc->wavek_force_tail_g = value < 2 ? 2 : value;
     else if (!strcmp(name, "gemv_ticket")) enc->gemv_ticket = value ? 1 : 0;

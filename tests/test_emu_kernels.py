@@ -603,6 +603,7 @@ def test_persistent_detect_chain_equals_the_stand_alone_launches(shapes, order):
         E = synth.make_codebook(36 * 9 + 7, 128, seed=8, planted_duplicates=9)
         enc, cb = eb.EmuEncoder(w, cfg), eb.EmuCodebook(E)
         enc.set_option('wavek_balance', 0)
+        enc.set_option('planner_cost_batch3', 0)     # (the shape sequences below are steered through the thresholds)
         for k, v in opts.items():
             enc.set_option(k, v)
         x = synth.make_crops(B, seed=40 + B, shape=cfg.shape)

@@ -892,11 +892,15 @@ def test_small_batch_wave_split_k_path_matches_fp64_oracle(default_model, B, cha
         enc.engine.set_option('detect_chain', 0)
     assert np.array_equal(zf.cpu().numpy(), z.cpu().numpy())
     labels = [l for l, _, _ in recs]
-    if B <= 4 and chain:
+    if B <= 4 and chain and B != 3:
         assert len(labels) == 2 and labels[0].startswith('conv1:conv_first_f32') and labels[1].startswith('chain:detect_chain_f32 B=%d blocks=256 shapes=' % B), labels
     elif B <= 4:
+        # (B = 3 is planned by estimated time since round 4 -- tiles beyond a full round of blocks cut in K --: a plan the persistent
+        #  launch is not compiled for, so the option falls back to the six launches there)
         assert len(labels) == 5 and labels[0].startswith('conv1:conv_first_f32') and labels[4].startswith('dense:dense_gemv_f32_ticket'), labels
         assert all(':conv_wavek_f32_' in l for l in labels[1:4]), labels
+        if B == 3:
+            assert any('_g1t' in l for l in labels[1:4]), labels
     else:                                                       # B >= 5: family and tile shape per layer by the planner's cost model
         assert all((':conv_wavek_f32_' in l) or (':conv_igemm_f32' in l) or l.endswith(':splitk_reduce') for l in labels[1:-1]), labels
         # (the dense layer: the GEMV up to B = 8 -- the 8-row form of its block --, the wave-split-K tile beyond)
