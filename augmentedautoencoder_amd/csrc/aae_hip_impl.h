@@ -145,6 +145,9 @@ struct aae_encoder {
                                            // measured: wins up to 64 tiles (B=1: 94 -> 87 us), loses from 128 on (twice the operand loads per MFMA)
     int wavek_target_blocks = 256;         // blocks a split layer is cut into (tiles x K splits): one per CU
     int wavek_waves = 4;                   // waves per block (4 | 8), each with its own K range
+    int wavek_g_boost = 2;                 // planner by cost (B = 3, B >= 5): layers that split K split it for this many blocks per CU (two co-resident
+                                           // blocks hide each other's load stalls: B = 5 236 -> 226 us, 8: 316 -> 309, 16: 560 -> 552; the per-detection
+                                           // batches B = 1, 2, 4 measured 4-10 % SLOWER that way and keep one block per CU)
     int planner_cost_batch3 = 1;           // ... and at B = 3
     int planner_cost_min_batch = 5;        // planner by cost from this batch on (below: the measured thresholds of the per-detection path)
     int wavek_tail_split = 1;              // planner by cost: tiles beyond the last full round of whole tiles are cut in K (wavek_tail_split())
@@ -381,8 +384,8 @@ static bool runs_split(const aae_encoder* enc, int B) {
 
 // K splits of a wave-split-K layer of `tiles` output tiles: one block per CU, never a second round of blocks; every wave keeps
 // at least two slabs; one ticket word per tile
-static int wavek_gsplits(const aae_encoder* enc, int tiles, int slabs, int waves) {
-    int g = enc->wavek_target_blocks / tiles;
+static int wavek_gsplits(const aae_encoder* enc, int tiles, int slabs, int waves, int boost = 1) {
+    int g = enc->wavek_target_blocks * boost / tiles;
     const int gmax = slabs / (2 * waves);
     if (g > gmax) g = gmax;
     if (g > (int)aae::kTicketSingleLevelMax) g = (int)aae::kTicketSingleLevelMax;
@@ -491,7 +494,7 @@ static WaveKPlan plan_wavek_core(const aae_encoder* enc, const Layer& L, long lo
         for (const auto& sh : shapes) {
             const long long tiles = ((M + 32 * sh[0] - 1) / (32 * sh[0])) * (long long)(L.CoutPad / (32 * sh[1]));
             if (tiles > (1 << 20)) continue;
-            const int g = wavek_gsplits(enc, (int)tiles, slabs, w.waves);
+            const int g = wavek_gsplits(enc, (int)tiles, slabs, w.waves, enc->wavek_g_boost);
             double c = wavek_cost_us(enc, (int)tiles, g, slabs, sh[0], sh[1]);
             if (g == 1) {                                        // whole tiles: the part beyond the last full round may be cut in K
                 int tt;
@@ -505,7 +508,7 @@ static WaveKPlan plan_wavek_core(const aae_encoder* enc, const Layer& L, long lo
         w.num_mt = (int)((M + 32 * w.MT - 1) / (32 * w.MT));
         w.num_nt = L.CoutPad / (32 * w.NT);
         const int tiles = w.num_mt * w.num_nt;
-        w.gsplits = wavek_gsplits(enc, tiles, slabs, w.waves);
+        w.gsplits = wavek_gsplits(enc, tiles, slabs, w.waves, enc->wavek_g_boost);
         if (w.gsplits == 1) {
             double ct;
             w.tail_g = wavek_tail_split(enc, tiles, slabs, w.waves, w.MT, w.NT, &w.tail_tiles, &ct);
@@ -1697,6 +1700,7 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
     else if (!strcmp(name, "wavek_tail_split")) enc->wavek_tail_split = value ? 1 : 0;
     else if (!strcmp(name, "planner_cost_min_batch")) enc->planner_cost_min_batch = value < 1 ? 1 : value;
     else if (!strcmp(name, "planner_cost_batch3")) enc->planner_cost_batch3 = value ? 1 : 0;
+    else if (!strcmp(name, "wavek_g_boost")) enc->wavek_g_boost = value < 1 ? 1 : (value > 4 ? 4 : value);
     else if (!strcmp(name, "wavek_force_tail_tiles")) enc->wavek_force_tail_tiles = value < 0 ? 0 : value;
     else if (!strcmp(name, "wavek_force_tail_g")) enc->wavek_force_tail_g = value < 2 ? 2 : value;
     else if (!strcmp(name, "gemv_ticket")) enc->gemv_ticket = value ? 1 : 0;
