@@ -417,23 +417,6 @@ def main():
                     'kernel_period = queries queued from C between two events (no per-call host cost); traffic = the committed rocprofv3 PMC figures.  warm: the 47 MB codebook stays in the '
                     '256 MB Infinity Cache between calls (algorithmic bytes, not HBM bytes); cold: 8 codebook copies visited in turn, so every call streams from HBM.  '
                     'B=256 is MFMA-bound (crossover B~39).  Kernel-only durations under rocprofv3: profiles/'}
-        # ---- BASELINE config 3: ae_embed -- encode 92232 views (codebook.py:190-219), encoder only, inputs resident
-        c3 = {}
-        for bs in ((64, 256) if args.full_extras else (256,)):
-            bs = min(bs, B)
-            xb = x[:bs].contiguous()
-            nb = -(-N_ROWS // bs)
-            enc.encode(xb)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(nb):
-                enc.encode(xb)
-            torch.cuda.synchronize()
-            dt = time.perf_counter() - t0
-            c3['batch%d' % bs] = {'seconds': round(dt, 3), 'crops_per_s': round(nb * bs / dt, 1), 'batches': nb}
-        c3['note'] = ('92232 synthetic views in batches of 256, fp32, the float64 normalise on the host is not timed; the reference batch size 64 '
-                      '(train_template.cfg:61) is timed with --full-extras: 31.6 k crops/s = 2.92 s (profiles/r09)')
-        extras['config3'] = c3
         # ---- BASELINE config 5: 4x codebook in bf16, B = 256, arg-max and top-5
         N5 = 368928
         E5 = synth.make_codebook(N5, 128, seed=11, planted_duplicates=0)
@@ -454,6 +437,23 @@ def main():
                                      'candidates below a bound the blocks publish to each other are dropped (same answers as the unpruned lists and the similarity-matrix path: tests + tools/soak_prune.py)'}
         cb5.close()
         del E5
+        # ---- BASELINE config 3: ae_embed -- encode 92232 views (codebook.py:190-219), encoder only, inputs resident
+        c3 = {}
+        for bs in ((64, 256) if args.full_extras else (256,)):
+            bs = min(bs, B)
+            xb = x[:bs].contiguous()
+            nb = -(-N_ROWS // bs)
+            enc.encode(xb)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(nb):
+                enc.encode(xb)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            c3['batch%d' % bs] = {'seconds': round(dt, 3), 'crops_per_s': round(nb * bs / dt, 1), 'batches': nb}
+        c3['note'] = ('92232 synthetic views in batches of 256, fp32, the float64 normalise on the host is not timed; the reference batch size 64 '
+                      '(train_template.cfg:61) is timed with --full-extras: 31.6 k crops/s = 2.92 s (profiles/r09)')
+        extras['config3'] = c3
         # ---- PCIe-inclusive: host uint8 batches, H2D of batch i+1 overlapped with compute of batch i
         host = [synth.make_crops(B, seed=100 + i) for i in range(4)]
         sp = StreamingNearestNeighbour(enc, cb, B)

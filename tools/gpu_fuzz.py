@@ -33,7 +33,7 @@ def main():
         cfg = EncoderConfig((H, W, C), filters, strides, 5, latent, bn)
         if cfg.flatten_size % 32 or cfg.flatten_size > 262144:
             continue
-        B = int(rng.choice([1, 2, 3, 4, 5, 7, 16, 33, 64, 100, 129, 256]))
+        B = int(rng.choice([1, 2, 3, 4, 5, 7, 9, 12, 16, 33, 64, 100, 129, 256]))
         if B * max(a * b * c for a, b, _, _, _, c in [(s[3], s[4], 0, 0, 0, s[5]) for s in cfg.layer_shapes()]) > 6e7:
             B = min(B, 8)
         w = synth.make_weights(seed=case, shape=cfg.shape, num_filter=filters, strides=strides, latent=latent, batch_norm=bn)
@@ -54,6 +54,14 @@ def main():
         opts['detect_chain'] = int(rng.integers(0, 2))                           # B <= 4: conv2 ... scan as one persistent launch where it applies
         opts['wavek_tiny_waves'] = int(rng.choice([4, 8]))                       # 32 x 32 wave tiles on eight waves ...
         opts['wavek_pingpong'] = int(rng.integers(0, 2))                         # ... and the barrier-paced schedule of the 8-wave blocks
+        # round 4, second half: tiles beyond the last full round cut in K (by the estimate, or forced on any un-split layer), K splits
+        # sized for 1 ... 3 blocks per CU, the dense GEMV up to 8 rows, B = 3 under the estimate
+        opts['wavek_tail_split'] = int(rng.integers(0, 2))
+        opts['wavek_force_tail_tiles'] = int(rng.choice([0, 0, 1, 5, 40, 200]))
+        opts['wavek_force_tail_g'] = int(rng.choice([2, 3, 5, 8]))
+        opts['wavek_g_boost'] = int(rng.choice([1, 2, 3]))
+        opts['dense_gemv_max_batch'] = int(rng.choice([4, 8]))
+        opts['planner_cost_batch3'] = int(rng.integers(0, 2))
         for k, v in opts.items():
             enc.set_option(k, v)
         precision = int(rng.integers(0, 2)) if cfg.shape[2] in (1, 3) and all(f % 32 == 0 for f in filters) else 0
@@ -79,8 +87,9 @@ def main():
             dtype = str(rng.choice(['f32', 'bf16']))
             E = synth.make_codebook(N, 128, seed=case, planted_duplicates=min(8, N // 72))
             cb = CodebookEngine(E, dtype=dtype)
-            if rng.integers(0, 2):
-                cb.set_scan_mode(6)                        # AAE_SCAN_STREAM_WALK: the walking form of the fp32 stream scan (B <= 4)
+            # AAE_SCAN_AUTO, or one of its A/B forms: the walking stream scan (B <= 4), packed-query planes instead of the in-scan
+            # normalisation, two instead of four waves per query group (B <= 32)
+            cb.set_scan_mode(int(rng.choice([0, 0, 6, 7, 8])))
             cs = cb.similarity(z).cpu().numpy()
             from augmentedautoencoder_amd.weights import bf16_bits_to_f32, to_bf16_bits
             Eo = bf16_bits_to_f32(to_bf16_bits(E)) if dtype == 'bf16' else E
