@@ -145,6 +145,9 @@ struct aae_encoder {
                                            // measured: wins up to 64 tiles (B=1: 94 -> 87 us), loses from 128 on (twice the operand loads per MFMA)
     int wavek_target_blocks = 256;         // blocks a split layer is cut into (tiles x K splits): one per CU
     int wavek_waves = 4;                   // waves per block (4 | 8), each with its own K range
+    int wavek_eff64x32_pct = 75;           // cost model: efficiency of the 64 x 32 wave tile, per cent (0.72 in round 3's fit; with the tail cut it
+                                           // wins more often than that predicted: 74 ... 76 takes conv4 at B = 24 from 198 to 175 us and changes
+                                           // nothing else at B = 5 ... 48, 78 and more start to lose at B = 5, 6, 28)
     int wavek_g_boost = 2;                 // planner by cost (B = 3, B >= 5): layers that split K split it for this many blocks per CU (two co-resident
                                            // blocks hide each other's load stalls: B = 5 236 -> 226 us, 8: 316 -> 309, 16: 560 -> 552; the per-detection
                                            // batches B = 1, 2, 4 measured 4-10 % SLOWER that way and keep one block per CU)
@@ -409,7 +412,8 @@ static int wavek_gsplits(const aae_encoder* enc, int tiles, int slabs, int waves
 constexpr double kSlabUs = 16.0 * 64.0 / 2400.0;
 
 static double wavek_cost_us(const aae_encoder* enc, int tiles, int g, int slabs, int mt, int nt) {
-    static const double eff_burst[3] = {0.71, 0.72, 0.88}, eff_spread[3] = {0.71, 0.72, 0.96}, fixed[3] = {0.0, 0.0, 5.0};
+    const double eff_burst[3] = {0.71, enc->wavek_eff64x32_pct / 100.0, 0.88}, eff_spread[3] = {0.71, enc->wavek_eff64x32_pct / 100.0, 0.96};
+    static const double fixed[3] = {0.0, 0.0, 5.0};
     const double* eff = (enc->wavek_spread & 1) ? eff_spread : eff_burst;          // (64 x 64 tiles with the spread schedule: +9 % measured, round 4)
     const int shape = mt == 1 ? 0 : (nt == 1 ? 1 : 2);
     const int cus = enc->wavek_target_blocks > 0 ? enc->wavek_target_blocks : 256;
@@ -422,7 +426,8 @@ static double wavek_cost_us(const aae_encoder* enc, int tiles, int g, int slabs,
 //     t = [full rounds * (slabs / 4 + fill) + ceil(tail * g / CUs) * (slabs / (4 g) + fill)] * tile time per slab / efficiency
 // Returns the best g (1 = leave the layer alone) and its estimate.
 static int wavek_tail_split(const aae_encoder* enc, int tiles, int slabs, int waves, int mt, int nt, int* tail_tiles, double* cost) {
-    static const double eff_burst[3] = {0.71, 0.72, 0.88}, eff_spread[3] = {0.71, 0.72, 0.96}, fixed[3] = {0.0, 0.0, 5.0};
+    const double eff_burst[3] = {0.71, enc->wavek_eff64x32_pct / 100.0, 0.88}, eff_spread[3] = {0.71, enc->wavek_eff64x32_pct / 100.0, 0.96};
+    static const double fixed[3] = {0.0, 0.0, 5.0};
     const double* eff = (enc->wavek_spread & 1) ? eff_spread : eff_burst;
     const int shape = mt == 1 ? 0 : (nt == 1 ? 1 : 2);
     const int cus = enc->wavek_target_blocks > 0 ? enc->wavek_target_blocks : 256;
@@ -1700,6 +1705,7 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
     else if (!strcmp(name, "wavek_tail_split")) enc->wavek_tail_split = value ? 1 : 0;
     else if (!strcmp(name, "planner_cost_min_batch")) enc->planner_cost_min_batch = value < 1 ? 1 : value;
     else if (!strcmp(name, "planner_cost_batch3")) enc->planner_cost_batch3 = value ? 1 : 0;
+    else if (!strcmp(name, "wavek_eff64x32_pct")) enc->wavek_eff64x32_pct = value < 30 ? 30 : (value > 100 ? 100 : value);
     else if (!strcmp(name, "wavek_g_boost")) enc->wavek_g_boost = value < 1 ? 1 : (value > 4 ? 4 : value);
     else if (!strcmp(name, "wavek_force_tail_tiles")) enc->wavek_force_tail_tiles = value < 0 ? 0 : value;
     else if (!strcmp(name, "wavek_force_tail_g")) enc->wavek_force_tail_g = value < 2 ? 2 : value;
