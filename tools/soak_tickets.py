@@ -30,9 +30,9 @@ def main():
     rng = np.random.default_rng(1)
     pool = torch.from_numpy(synth.make_crops(256, seed=77)).cuda()
     bad, checks, t0 = 0, 0, time.time()
-    per_B = {1: 0, 2: 0, 3: 0, 4: 0, 6: 0}
+    per_B = {1: 0, 2: 0, 3: 0, 4: 0, 6: 0, 9: 0, 12: 0}       # (3, 6, 9, 12: layers whose last tiles are cut in K -- tickets indexed from the first cut tile)
     for it in range(queries):
-        B = int(rng.choice([1, 1, 1, 2, 3, 4, 6]))
+        B = int(rng.choice([1, 1, 1, 2, 3, 4, 6, 9, 12]))
         sel = torch.from_numpy(rng.choice(256, B, replace=False)).cuda()
         x = pool[sel] ^ int(rng.integers(0, 256))                    # new pixels every query
         if it % 40 == 0:
