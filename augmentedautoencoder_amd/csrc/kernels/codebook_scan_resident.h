@@ -83,6 +83,9 @@ constexpr int scan_resident_smem() { return scan_resident_stages<BF16, RH>() * s
 // is about the 8th best of 30 000 rows; one value slot in 60 still has a candidate.  The words are read without any
 // ordering -- whatever has been published so far is a valid bound -- so the result does not depend on timing.
 //
+// RH = 4 (B <= 32, arg-max; round 4): ONE query group per block and four waves that share the rows of a tile -- with RH = 2 a batch of
+// at most 32 queries kept two of a CU's four matrix pipes idle (20.7 -> 15.8 us per query of the 92 232-row fp32 codebook); fp32 rows
+// then come in 128-row tiles = 64 KB, held in two LDS images instead of three.
 // RH = 2 (B <= 128): wave (rh, qg) accumulates half the rows of a tile for query group qg -- four query groups per block.
 // RH = 1 (B > 128): every wave takes ALL rows of a tile for its own query group -- eight groups = 256 queries per block, so
 // the codebook is streamed ONCE for 256 queries instead of once per 128 (config 5, B = 256: 189 -> 94 MB per scan; the kernel

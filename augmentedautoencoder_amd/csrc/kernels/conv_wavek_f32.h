@@ -22,6 +22,9 @@
 //     the last of the gsplits blocks re-reads all partials in split order, applies bias / ReLU / BN and stores the
 //     outputs.  Fixed orders everywhere -> run-to-run bit-identical results; 8x fewer partial bytes than the
 //     128 x 128 split-K and no second launch.
+//   * mid-size batches (round 4): when whole tiles leave the last round of blocks partly empty, the tiles of that round alone are
+//     cut in K (tail_tiles / tail_gsplits below) -- smaller blocks, dispatched last, that fill every CU; their partials meet
+//     through the same tickets.
 // K order inside a slab and the (c, q) MFMA pairing are those of tile_f32.h, so each wave's partial is the same
 // k-ordered fma chain the large kernel would compute over that K range.
 #pragma once
