@@ -596,6 +596,8 @@ def test_persistent_detect_chain_equals_the_stand_alone_launches(shapes, order):
     shape sequence), grids of 1, 2 and 3 resident blocks (work items walked grid-stride; the K splits of one tile on different
     blocks or on the same one), any interleaving of the blocks, workspaces full of garbage, with batch-norm."""
     B, filters, opts = _CHAIN_CASES[shapes]
+    if shapes == '210' and order == 1:
+        pytest.skip('the largest case runs in ascending and scrambled block order only (CPU suite time)')
     eb.set_block_order(order)
     try:
         cfg = EncoderConfig((16, 16, 3), filters, [2, 2, 2, 1], 5, 128, True)

@@ -83,7 +83,7 @@ def test_nearest_and_topk_selection_under_heavy_ties(seed, N, k, B):
     cb.close()
 
 
-@settings(max_examples=6, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.too_slow])
+@settings(max_examples=4, deadline=None, derandomize=True, suppress_health_check=[HealthCheck.too_slow])
 @given(st.integers(0, 10 ** 6))
 def test_random_small_encoders_on_the_emulated_kernels(seed):
     """Random [Network] shapes through the emulated HIP kernels (first-layer MFMA kernel, implicit GEMM in its
