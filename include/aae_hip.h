@@ -112,8 +112,8 @@ void aae_encoder_destroy(aae_encoder* enc);
  *                        per CU); "igemm_breg_min_blocks" (768): smaller grids keep the 64 KB footprint;
  *   "igemm_breg_wide" (1): ... with 128x256 block tiles for layers whose padded Cout is a multiple of 256 and
  *                        whose grid stays >= 512 blocks;
- *   "dense_gemv" (1): batches of <= 4 run the dense layer as a weight-streaming GEMV instead of a padded
- *                        matrix-core tile (same value up to fp32 summation order);
+ *   "dense_gemv" (1): batches of <= "dense_gemv_max_batch" (8; 4 in rounds 2-3) run the dense layer as a weight-streaming GEMV
+ *                        instead of a padded matrix-core tile (same value up to fp32 summation order);
  *   "x3h_wide_min_blocks" (0): > 0 lets f32x3h conv layers use 256x128 tiles when that still yields this
  *                        many blocks (measured neutral);
  *   "x3h_wide256" (1), "x3h_wide256_min_blocks" (256): f32x3h conv layers with Cout % 256 == 0 whose grid
@@ -132,7 +132,12 @@ void aae_encoder_destroy(aae_encoder* enc);
  *                        in its last round of blocks) -- defaults set from per-layer rocprofv3 sweeps;
  *   "planner_cost_model" (1): B >= 5: each conv layer runs the implicit-GEMM family and wave-tile shape with the smallest ESTIMATED time
  *                        (block-count rounds x slabs x MFMA time / fitted efficiency, plan_wavek) instead of the tile-count thresholds above
- *                        ("wavek_max_tiles" etc. then steer B <= 4 and the dense layer only); B = 24 / 40 / 96 gain 14 / 17 / 6 %;
+ *                        ("wavek_max_tiles" etc. then steer B = 1, 2, 4 and the dense layer only; B = 3: "planner_cost_batch3" (1));
+ *                        B = 24 / 40 / 96 gain 14 / 17 / 6 %;
+ *   "wavek_tail_split" (1): where whole tiles leave the last round of blocks partly empty, the tiles of that round are cut in K inside
+ *                        the launch (kernel label ..._g1t<tiles>x<parts>; B = 9 438 -> 369 us, B = 12 504 -> 439); "wavek_g_boost" (2): layers
+ *                        the estimate splits in K are split for this many blocks per CU; "wavek_eff64x32_pct" (75): a constant of the estimate;
+ *                        "wavek_force_tail_tiles" / "wavek_force_tail_g": tests -- cut the last n tiles of every un-split layer g ways;
  *   "detect_chain" (0), "detect_chain_blocks" (256): B <= 4 of a four-layer encoder as conv1 + ONE persistent launch (conv2 ... dense,
  *                        in aae_encode_nn also the scan; grid barriers between the phases) -- bit-identical to the stand-alone launches and,
  *                        measured on MI355X, slower than them (92 vs 82 us at B = 1): opt-in, kept for the record and for other parts;
@@ -141,7 +146,8 @@ void aae_encoder_destroy(aae_encoder* enc);
  *                        runs one block per 32-pixel group for batches of at most that many 128-pixel tiles;
  *   "compact_workspace" (0): two alternating activation buffers instead of one per layer (layer outputs not inspectable);
  *   "wavek_ablate", "wavek_timeline": profiling aids (tools/ablate_wavek.py); results are wrong while wavek_ablate != 0.
- * All variants selected by these knobs are bit-identical to each other (tests/test_gpu_parity.py). */
+ * All variants selected by these knobs are bit-identical to each other or differ by fp32 summation order only (split-K forms, the
+ * GEMV, a cut tail tile); every one is held to the fp64 oracle by tests/test_gpu_parity.py and tools/gpu_fuzz.py. */
 int aae_encoder_set_option(aae_encoder* enc, const char* name, int value);
 
 size_t aae_encoder_workspace_bytes(const aae_encoder* enc, int B);
