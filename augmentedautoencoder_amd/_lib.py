@@ -16,7 +16,7 @@ AAE_DTYPE_F32 = 1
 AAE_DTYPE_BF16 = 2
 AAE_MAX_LAYERS = 8
 AAE_SCAN_AUTO, AAE_SCAN_GEMV, AAE_SCAN_MFMA, AAE_SCAN_STREAM, AAE_SCAN_STREAM_2L, AAE_SCAN_AUTO_NO_PRUNE, AAE_SCAN_STREAM_WALK = 0, 1, 2, 3, 4, 5, 6
-AAE_SCAN_AUTO_PACKED, AAE_SCAN_AUTO_RH2 = 7, 8
+AAE_SCAN_AUTO_PACKED, AAE_SCAN_AUTO_RH2, AAE_SCAN_AUTO_FIN = 7, 8, 9
 AAE_ABI_VERSION = 2
 
 LIB_NAME = 'libaae_hip.so'

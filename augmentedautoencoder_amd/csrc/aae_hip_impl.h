@@ -209,6 +209,7 @@ struct aae_codebook {
     // B > 4, top-1 on the query-resident kernel: 1 = the scan normalises the raw latent codes in its prologue (one launch less);
     // 0 (AAE_SCAN_AUTO_PACKED) = l2norm_pack launch in front, the scan reads the packed planes -- identical bits
     int scan_fused_norm = 1;
+    int scan_resident_fin = 0;   // AAE_SCAN_AUTO_FIN: the B <= 32 resident scan answers inside its launch (ticket finish) instead of an argmax_reduce launch
     int scan_rh4 = 1;      // B <= 32, top-1 on the query-resident kernel: rows of a tile over four waves per query group (AAE_SCAN_AUTO_RH2: 0 = two, A/B)
 };
 
@@ -1409,7 +1410,7 @@ static void launch_scan_resident_k(const aae::ScanResidentArgs& a, dim3 grid, hi
 
 // topk == 1: block partials (pval, pidx) for argmax_reduce_kernel; topk 2..8: candidate lists for topk_merge_kernel
 static int launch_scan_resident(const aae_codebook* cb, const void* qp, int B, const ScanPlan& s, unsigned char* base, hipStream_t stream,
-                                int topk = 1, const float* raw_z = nullptr) {
+                                int topk = 1, const float* raw_z = nullptr, const ScanTicketOut* fin = nullptr) {
     aae::ScanResidentArgs a;
     a.E = cb->E; a.e_bytes = (unsigned)((size_t)cb->N * cb->J * (cb->dtype == AAE_DTYPE_BF16 ? 2 : 4));
     a.qp = qp;
@@ -1419,6 +1420,10 @@ static int launch_scan_resident(const aae_codebook* cb, const void* qp, int B, c
     a.N = cb->N; a.B = B; a.Bpad = s.Bpad; a.Bstride = s.Bstride; a.tiles_per_block = s.res_tiles_per_block;
     const dim3 grid(s.res_blocks, ceil_div(s.Bpad, 256 / s.res_rh));
     a.k = topk > 1 ? topk : 0;
+    if (fin && topk == 1 && grid.y == 1) {           // the last row block to arrive answers (no argmax_reduce launch)
+        a.tickets = reinterpret_cast<unsigned long long*>(base + s.ticket_off); a.nonce = fin->nonce ? fin->nonce : next_nonce();
+        a.idx_out = reinterpret_cast<long long*>(fin->idx_out); a.score_out = fin->score_out; a.idx_scale = fin->idx_scale;
+    }
     if (topk > 1) {
         a.cand_v = reinterpret_cast<float*>(base + s.cand_off);
         a.cand_i = reinterpret_cast<int*>(base + s.cand_off + align_up((size_t)B * s.cand_chunks * topk * sizeof(float), 256));
@@ -1446,7 +1451,8 @@ static int run_scan(aae_codebook* cb, const float* z, int B, int col_stride, flo
     const bool resident = s.resident_ok && cs_out == nullptr && col_stride == 1;
     if (partial_rows) *partial_rows = resident ? s.res_blocks : s.nblk;
     // arg-max on the query-resident kernel: the scan normalises the queries itself (no l2norm_pack launch in front)
-    if (resident && topk == 1 && cb->scan_fused_norm && ((uintptr_t)z & 15) == 0) return launch_scan_resident(cb, nullptr, B, s, base, stream, 1, z);
+    const ScanTicketOut* rfin = (resident && topk == 1 && s.res_rh == 4) ? fin : nullptr;     // (nn_impl passes fin for these only when the mode asks)
+    if (resident && topk == 1 && cb->scan_fused_norm && ((uintptr_t)z & 15) == 0) return launch_scan_resident(cb, nullptr, B, s, base, stream, 1, z, rfin);
     if (cb->dtype == AAE_DTYPE_BF16 && s.stream) {
         aae::ScanArgs a;
         a.z = z; a.e_bytes = (unsigned)((size_t)cb->N * cb->J * 2);
@@ -1473,7 +1479,7 @@ static int run_scan(aae_codebook* cb, const float* z, int B, int col_stride, flo
         if (resident && topk > 1 && cb->topk_prune) n.prune = reinterpret_cast<int*>(base + s.prune_off);
         AAE_LAUNCH((aae::l2norm_pack_bf16x3_kernel), dim3(ceil_div(s.Bpad, 4)), dim3(256), 0, stream, n);
         AAE_HIP_TRY(hipGetLastError());
-        if (resident) return launch_scan_resident(cb, n.qp3, B, s, base, stream, topk);
+        if (resident) return launch_scan_resident(cb, n.qp3, B, s, base, stream, topk, nullptr, rfin);
         aae::ScanBf16Args a;
         a.E = reinterpret_cast<const unsigned short*>(cb->E);
         a.e_bytes = (unsigned)((size_t)cb->N * cb->J * 2);
@@ -1499,7 +1505,7 @@ static int run_scan(aae_codebook* cb, const float* z, int B, int col_stride, flo
         AAE_LAUNCH((aae::l2norm_pack_kernel), dim3(ceil_div(n.Bpad, 4)), dim3(256), 0, stream, n);
         AAE_HIP_TRY(hipGetLastError());
     }
-    if (resident) return launch_scan_resident(cb, qp, B, s, base, stream, topk);
+    if (resident) return launch_scan_resident(cb, qp, B, s, base, stream, topk, nullptr, rfin);
 
     aae::ScanArgs a;
     a.z = z; a.e_bytes = (unsigned)((size_t)cb->N * cb->J * sizeof(float));
@@ -1968,7 +1974,7 @@ int aae_codebook_prepare_upright(aae_codebook* cb, int col_stride, void* stream_
             cb->upright_copies.push_back({col_stride, sub});
         }
         sub->scan_mode = cb->scan_mode; sub->scan_ticket = cb->scan_ticket; sub->topk_prune = cb->topk_prune; sub->cu_count = cb->cu_count;
-        sub->scan_walk = cb->scan_walk; sub->scan_fused_norm = cb->scan_fused_norm; sub->scan_rh4 = cb->scan_rh4;
+        sub->scan_walk = cb->scan_walk; sub->scan_fused_norm = cb->scan_fused_norm; sub->scan_rh4 = cb->scan_rh4; sub->scan_resident_fin = cb->scan_resident_fin;
         cb->upright = sub; cb->upright_stride = col_stride;
     }
     if (int rc = gather_upright_rows(cb, cb->upright, cb->upright_stride, stream)) return rc;
@@ -1998,18 +2004,19 @@ int aae_codebook_set_scan_mode(aae_codebook* cb, int mode) {
     using namespace aae_host;
     if (!cb) return fail(AAE_ERR_INVALID, "aae_codebook_set_scan_mode: null handle");
     if (mode != AAE_SCAN_AUTO && mode != AAE_SCAN_GEMV && mode != AAE_SCAN_MFMA && mode != AAE_SCAN_STREAM && mode != AAE_SCAN_STREAM_2L &&
-        mode != AAE_SCAN_AUTO_NO_PRUNE && mode != AAE_SCAN_STREAM_WALK && mode != AAE_SCAN_AUTO_PACKED && mode != AAE_SCAN_AUTO_RH2)
+        mode != AAE_SCAN_AUTO_NO_PRUNE && mode != AAE_SCAN_STREAM_WALK && mode != AAE_SCAN_AUTO_PACKED && mode != AAE_SCAN_AUTO_RH2 && mode != AAE_SCAN_AUTO_FIN)
         return fail(AAE_ERR_INVALID, "scan mode %d", mode);
     cb->scan_ticket = mode == AAE_SCAN_STREAM_2L ? 0 : 1;
     cb->topk_prune = mode == AAE_SCAN_AUTO_NO_PRUNE ? 0 : 1;
     cb->scan_walk = mode == AAE_SCAN_STREAM_WALK ? 1 : 0;
     cb->scan_fused_norm = mode == AAE_SCAN_AUTO_PACKED ? 0 : 1;
     cb->scan_rh4 = mode == AAE_SCAN_AUTO_RH2 ? 0 : 1;
+    cb->scan_resident_fin = mode == AAE_SCAN_AUTO_FIN ? 1 : 0;
     cb->scan_mode = (mode == AAE_SCAN_STREAM_2L || mode == AAE_SCAN_STREAM_WALK) ? AAE_SCAN_STREAM
-                    : ((mode == AAE_SCAN_AUTO_NO_PRUNE || mode == AAE_SCAN_AUTO_PACKED || mode == AAE_SCAN_AUTO_RH2) ? AAE_SCAN_AUTO : mode);
+                    : ((mode == AAE_SCAN_AUTO_NO_PRUNE || mode == AAE_SCAN_AUTO_PACKED || mode == AAE_SCAN_AUTO_RH2 || mode == AAE_SCAN_AUTO_FIN) ? AAE_SCAN_AUTO : mode);
     for (auto& c : cb->upright_copies) {
         c.second->scan_mode = cb->scan_mode; c.second->scan_ticket = cb->scan_ticket; c.second->topk_prune = cb->topk_prune; c.second->scan_walk = cb->scan_walk;
-        c.second->scan_fused_norm = cb->scan_fused_norm; c.second->scan_rh4 = cb->scan_rh4;
+        c.second->scan_fused_norm = cb->scan_fused_norm; c.second->scan_rh4 = cb->scan_rh4; c.second->scan_resident_fin = cb->scan_resident_fin;
     }
     return AAE_OK;
 }
@@ -2048,7 +2055,9 @@ static int nn_impl(aae_codebook* cb, const float* z, int B, int topk, int col_st
     // B <= 4, top-1 on a stream kernel: the last block to arrive merges the block partials -- the query is one launch
     ScanTicketOut fin;
     fin.idx_out = idx_out; fin.score_out = score_out; fin.idx_scale = idx_scale; fin.nonce = prepared_nonce;
-    const bool one_launch = topk == 1 && s.stream && cb->scan_ticket != 0;
+    // (opt-in, AAE_SCAN_AUTO_FIN: the same for the query-resident scan of at most 32 queries -- one row of row blocks)
+    const bool resident_fin = topk == 1 && cb->scan_resident_fin && s.resident_ok && s.res_rh == 4 && col_stride == 1;
+    const bool one_launch = topk == 1 && ((s.stream && cb->scan_ticket != 0) || resident_fin);
     if (int rc = run_scan(cb, z, B, col_stride, cs, s, base, stream, &partial_rows, one_launch ? &fin : nullptr, s.topk_fused ? topk : 1)) return rc;
     if (one_launch) return AAE_OK;
     if (topk == 1) {

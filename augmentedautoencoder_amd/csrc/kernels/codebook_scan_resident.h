@@ -47,6 +47,13 @@ struct ScanResidentArgs {
     // NORM = true (arg-max form): the raw latent codes [B][128] fp32 (16-byte aligned) -- the block normalises its own queries,
     // no l2norm_pack launch in front of the scan; qp is not read then
     const float* z = nullptr;
+    // arg-max form, gridDim.y == 1 (opt-in, AAE_SCAN_AUTO_FIN): when tickets != nullptr the last row block to arrive merges the block
+    // partials itself and writes (index, score) -- no argmax_reduce launch behind the scan
+    unsigned long long* tickets = nullptr;   // kTicketSlotWords words
+    unsigned nonce = 0;
+    long long* idx_out = nullptr;            // [B] int64
+    float* score_out = nullptr;              // [B]
+    int idx_scale = 1;
 #ifdef AAE_SCAN_COUNT
     int* dbg = nullptr;         // [32 steps][2]: accumulator tiles that passed the pretest, value slots that ran the insertion
 #endif
@@ -503,6 +510,84 @@ __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(con
         if (h == 0) { red_v[rh * QB + qg * 32 + i] = bv; red_i[rh * QB + qg * 32 + i] = bi; }
     }
     __syncthreads();
+    if constexpr (K == 0) {
+        if (p.tickets != nullptr) {                            // (block-uniform)
+            // ---- in-launch finish.  This block's partial row leaves as 16-byte device-coherent pieces (four queries each, scores in
+            // pval, rows in pidx); the last block to arrive reads every block's pieces -- all of a thread's loads in flight at once --
+            // and merges them with the tie rule of argmax_reduce_kernel (higher score, then lower row: a total order, so the grouping
+            // of the merge does not matter).
+            constexpr int Q4 = QB / 4;                         // pieces per partial row
+            const int nblk = (int)gridDim.x;
+            const buffer_rsrc vbuf = make_buffer(p.pval, (unsigned)nblk * (unsigned)p.Bstride * 4u);
+            const buffer_rsrc ibuf = make_buffer(p.pidx, (unsigned)nblk * (unsigned)p.Bstride * 4u);
+            if (tid < Q4) {
+                f32x4 pv;
+                u32x4 pi;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int q = 4 * tid + e;
+                    float v = red_v[q];
+                    int ix = red_i[q];
+#pragma unroll
+                    for (int part = 1; part < RH; ++part)
+                        if (better(red_v[part * QB + q], red_i[part * QB + q], v, ix)) { v = red_v[part * QB + q]; ix = red_i[part * QB + q]; }
+                    const bool real = q < p.B && (q >> 5) * 32 < p.B;            // (a query group of padding only wrote nothing into red_v)
+                    pv[e] = real ? v : kNegInf;
+                    pi[e] = real ? (uint32_t)ix : 0x7fffffffu;
+                }
+                const bool in_row = 4 * tid < p.Bstride;
+                coherent_store4(vbuf, in_row ? (unsigned)(blockIdx.x * p.Bstride + 4 * tid) * 4u : kOobOffset, pv);
+                coherent_store4(ibuf, in_row ? (unsigned)(blockIdx.x * p.Bstride + 4 * tid) * 4u : kOobOffset, __builtin_bit_cast(f32x4, pi));
+            }
+            int* flag = red_i + 2 * 256 - 4;                   // (the tail of the reduction area: red_i holds RH * QB = 256 entries)
+            if (!block_ticket_arrive(p.tickets, p.nonce, (unsigned)nblk, blockIdx.x, flag)) return;
+            constexpr int PARTS = kScanResidentThreads / Q4;   // 32 (QB = 64) ... 8 (QB = 256)
+            constexpr int KP = 8;                              // partial rows per thread and round: 256 row blocks in one round at QB = 64
+            const int q4 = tid % Q4, part = tid / Q4;
+            float bvq[4];
+            int biq[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { bvq[e] = kNegInf; biq[e] = 0x7fffffff; }
+            for (int k0 = part; k0 < nblk; k0 += PARTS * KP) {
+                f32x4 tv[KP], ti[KP];
+#pragma unroll
+                for (int j = 0; j < KP; ++j) {
+                    const int k = k0 + PARTS * j;
+                    const unsigned at = (k < nblk && 4 * q4 < p.Bstride) ? (unsigned)(k * p.Bstride + 4 * q4) * 4u : kOobOffset;
+                    tv[j] = coherent_load4(vbuf, at);
+                    ti[j] = coherent_load4(ibuf, at);
+                }
+#pragma unroll
+                for (int j = 0; j < KP; ++j) {
+                    const bool live = k0 + PARTS * j < nblk && 4 * q4 < p.Bstride;
+                    const u32x4 iw = __builtin_bit_cast(u32x4, ti[j]);
+                    const uint32_t i0 = iw[0], i1 = iw[1], i2 = iw[2], i3 = iw[3];
+                    const float fv[4] = {tv[j][0], tv[j][1], tv[j][2], tv[j][3]};
+                    const int fi[4] = {(int)i0, (int)i1, (int)i2, (int)i3};
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (live && better(fv[e], fi[e], bvq[e], biq[e])) { bvq[e] = fv[e]; biq[e] = fi[e]; }
+                }
+            }
+            wait_dma_and_lds();                                // (the zero pieces of the tiles past the end may still be landing in Et)
+            __syncthreads();
+            float* fin_v = Et;                                 // [PARTS][QB]
+            int* fin_i = reinterpret_cast<int*>(Et + PARTS * QB);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { fin_v[part * QB + 4 * q4 + e] = bvq[e]; fin_i[part * QB + 4 * q4 + e] = biq[e]; }
+            __syncthreads();
+            if (tid < QB && tid < p.B) {
+                float v = fin_v[tid];
+                int ix = fin_i[tid];
+                for (int w = 1; w < PARTS; ++w)
+                    if (better(fin_v[w * QB + tid], fin_i[w * QB + tid], v, ix)) { v = fin_v[w * QB + tid]; ix = fin_i[w * QB + tid]; }
+                if (ix == 0x7fffffff) ix = 0;                  // all-NaN scores: np.argmax would also answer 0
+                p.idx_out[tid] = (long long)ix * p.idx_scale;
+                p.score_out[tid] = v;
+            }
+            return;
+        }
+    }
     const int qout = blockIdx.y * QB + tid;
     if (tid < QB && qout < p.B) {
         float v = red_v[tid];

@@ -57,6 +57,9 @@ extern "C" {
                                      launch in front instead of normalising the raw codes in its own prologue: A/B, same answers */
 #define AAE_SCAN_AUTO_RH2 8       /* AUTO, but the top-1 query-resident scan of at most 32 queries splits the rows of a tile over two waves
                                      per query group (rounds 2-3) instead of four: A/B, same answers */
+#define AAE_SCAN_AUTO_FIN 9       /* AUTO, and the top-1 query-resident scan of at most 32 queries answers inside its own launch (the last
+                                     row block to arrive merges the block partials: the stream scan's ticket finish) instead of an arg-max
+                                     reduce launch behind it: opt-in, same answers */
 
 typedef struct aae_encoder aae_encoder;
 typedef struct aae_codebook aae_codebook;

@@ -418,6 +418,19 @@ def test_query_resident_scan_equals_the_tile_resident_kernels_bitwise(dtype, N, 
     cb.set_mode(_lib.AAE_SCAN_AUTO_RH2)
     idx_2, sc_2 = cb.nn(z)
     assert np.array_equal(idx_r, idx_2) and np.array_equal(sc_r, sc_2)
+    # opt-in: at most 32 queries answered inside the scan launch by the last row block to arrive (any arrival order)
+    try:
+        for order in (0, 1, 2):
+            eb.set_block_order(order)
+            cb.set_mode(_lib.AAE_SCAN_AUTO_FIN)
+            idx_f, sc_f = cb.nn(z)
+            assert np.array_equal(idx_r, idx_f) and np.array_equal(sc_r, sc_f), order
+            idx_u, _ = cb.nn(z, 1, 36)                     # (upright without a compacted copy: the masked tile-resident kernels)
+            cb.set_mode(_lib.AAE_SCAN_AUTO)
+            assert np.array_equal(idx_u, cb.nn(z, 1, 36)[0])
+    finally:
+        eb.set_block_order(0)
+        cb.set_mode(_lib.AAE_SCAN_AUTO)
     cs = cb.similarity(z)
     assert np.array_equal(idx_r[:, 0], np.argmax(cs, axis=1)) and np.array_equal(sc_r[:, 0], cs.max(axis=1))
     cb.close()
@@ -568,6 +581,11 @@ def test_fused_encode_nn_prepares_every_ticket_and_equals_the_two_calls(B, strid
         cb.set_mode(_lib.AAE_SCAN_STREAM)          # single-launch scan without preparation: the install path
         i2, s2 = cb.nn(z0, 1, stride)
         assert np.array_equal(i2, i0) and np.array_equal(s2, s0)
+        cb.set_mode(_lib.AAE_SCAN_AUTO_FIN)        # (B > 4: the query-resident scan answering inside its launch, stand-alone and fused)
+        i3, s3 = cb.nn(z0, 1, stride)
+        z4, i4, s4 = eb.encode_nn(enc, cb, x, stride)
+        assert np.array_equal(i3, i0) and np.array_equal(s3, s0) and np.array_equal(z4, z0) and np.array_equal(i4, i0) and np.array_equal(s4, s0)
+        cb.set_mode(_lib.AAE_SCAN_AUTO)
         cs = cb.similarity(z0)
         want = ref.nearest_indices_reference(cs, 1, upright=True, num_cyclo=36) if stride > 1 else np.argmax(cs, axis=1)
         assert np.array_equal(i0[:, 0], want)
