@@ -145,9 +145,10 @@ struct aae_encoder {
                                            // measured: wins up to 64 tiles (B=1: 94 -> 87 us), loses from 128 on (twice the operand loads per MFMA)
     int wavek_target_blocks = 256;         // blocks a split layer is cut into (tiles x K splits): one per CU
     int wavek_waves = 4;                   // waves per block (4 | 8), each with its own K range
-    int wavek_eff64x32_pct = 75;           // cost model: efficiency of the 64 x 32 wave tile, per cent (0.72 in round 3's fit; with the tail cut it
-                                           // wins more often than that predicted: 74 ... 76 takes conv4 at B = 24 from 198 to 175 us and changes
-                                           // nothing else at B = 5 ... 48, 78 and more start to lose at B = 5, 6, 28)
+    int wavek_eff64x32_pct = 74;           // cost model: efficiency of the 64 x 32 wave tile, per cent (0.72 in round 3's fit; with the tail cut it
+                                           // wins more often than that predicted: 74 takes conv4 at B = 24 from 198 to 175 us and changes nothing
+                                           // else at B = 5 ... 48; 75 also moves conv4 at B = 6 to a 64 x 32 tile that is 5 us slower, 78 and more
+                                           // lose at B = 5, 28 as well)
     int wavek_g_boost = 2;                 // planner by cost (B = 3, B >= 5): layers that split K split it for this many blocks per CU (two co-resident
                                            // blocks hide each other's load stalls: B = 5 236 -> 226 us, 8: 316 -> 309, 16: 560 -> 552; the per-detection
                                            // batches B = 1, 2, 4 measured 4-10 % SLOWER that way and keep one block per CU)

@@ -139,7 +139,7 @@ void aae_encoder_destroy(aae_encoder* enc);
  *                        B = 24 / 40 / 96 gain 14 / 17 / 6 %;
  *   "wavek_tail_split" (1): where whole tiles leave the last round of blocks partly empty, the tiles of that round are cut in K inside
  *                        the launch (kernel label ..._g1t<tiles>x<parts>; B = 9 438 -> 369 us, B = 12 504 -> 439); "wavek_g_boost" (2): layers
- *                        the estimate splits in K are split for this many blocks per CU; "wavek_eff64x32_pct" (75): a constant of the estimate;
+ *                        the estimate splits in K are split for this many blocks per CU; "wavek_eff64x32_pct" (74): a constant of the estimate;
  *                        "wavek_force_tail_tiles" / "wavek_force_tail_g": tests -- cut the last n tiles of every un-split layer g ways;
  *   "detect_chain" (0), "detect_chain_blocks" (256): B <= 4 of a four-layer encoder as conv1 + ONE persistent launch (conv2 ... dense,
  *                        in aae_encode_nn also the scan; grid barriers between the phases) -- bit-identical to the stand-alone launches and,
