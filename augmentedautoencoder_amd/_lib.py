@@ -17,7 +17,7 @@ AAE_DTYPE_BF16 = 2
 AAE_MAX_LAYERS = 8
 AAE_SCAN_AUTO, AAE_SCAN_GEMV, AAE_SCAN_MFMA, AAE_SCAN_STREAM, AAE_SCAN_STREAM_2L, AAE_SCAN_AUTO_NO_PRUNE, AAE_SCAN_STREAM_WALK = 0, 1, 2, 3, 4, 5, 6
 AAE_SCAN_AUTO_PACKED, AAE_SCAN_AUTO_RH2, AAE_SCAN_AUTO_FIN = 7, 8, 9
-AAE_ABI_VERSION = 2
+AAE_ABI_VERSION = 3
 
 LIB_NAME = 'libaae_hip.so'
 
@@ -33,6 +33,7 @@ EXPORTED_SYMBOLS = (
     'aae_codebook_prepare_upright',
     'aae_codebook_workspace_bytes', 'aae_codebook_nn', 'aae_codebook_nn_timed', 'aae_encode_nn', 'aae_detect_nn', 'aae_codebook_similarity', 'aae_l2_normalize',
     'aae_crop_resize_u8', 'aae_pack_pairs', 'aae_unpack_pairs',
+    'aae_multi_workspace_bytes', 'aae_multi_rows', 'aae_encode_nn_multi', 'aae_codebook_nn_multi', 'aae_detect_nn_multi', 'aae_multi_last_launches',
     'aae_decoder_create', 'aae_decoder_destroy', 'aae_decoder_workspace_bytes', 'aae_decoder_forward',
     'aae_decoder_forward_timed', 'aae_decoder_kernel_label', 'aae_decoder_kernel_flops', 'aae_decoder_activation_info',
 )
@@ -62,6 +63,11 @@ class DecoderDesc(Structure):
         ('batch_norm', c_int32),
         ('bn_eps', c_float),
     ]
+
+
+class MultiItem(Structure):
+    """aae_multi_item: (encoder handle, codebook handle, detections of that object in the frame, col_stride)"""
+    _fields_ = [('enc', c_void_p), ('cb', c_void_p), ('n', c_int32), ('col_stride', c_int32)]
 
 
 def declare(lib):
@@ -135,6 +141,19 @@ def declare(lib):
     lib.aae_l2_normalize.argtypes = [c_void_p, c_int, c_int, c_void_p, c_void_p]
     lib.aae_crop_resize_u8.restype = c_int
     lib.aae_crop_resize_u8.argtypes = [c_void_p, c_int, c_int, c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
+    lib.aae_multi_workspace_bytes.restype = c_size_t
+    lib.aae_multi_workspace_bytes.argtypes = [POINTER(MultiItem), c_int, c_int]
+    lib.aae_multi_rows.restype = c_int
+    lib.aae_multi_rows.argtypes = [POINTER(MultiItem), c_int]
+    lib.aae_encode_nn_multi.restype = c_int
+    lib.aae_encode_nn_multi.argtypes = [POINTER(MultiItem), c_int, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.aae_codebook_nn_multi.restype = c_int
+    lib.aae_codebook_nn_multi.argtypes = [POINTER(MultiItem), c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]
+    lib.aae_detect_nn_multi.restype = c_int
+    lib.aae_detect_nn_multi.argtypes = [POINTER(MultiItem), c_int, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                        c_void_p, c_size_t, c_void_p]
+    lib.aae_multi_last_launches.restype = c_int
+    lib.aae_multi_last_launches.argtypes = []
 
     lib.aae_decoder_create.restype = c_int
     lib.aae_decoder_create.argtypes = [POINTER(DecoderDesc), POINTER(c_void_p), c_int, POINTER(c_void_p)]

@@ -21,6 +21,7 @@
 
 #include "../../include/aae_hip.h"
 #include "kernels/tile_f32.h"
+#include "kernels/multi_launch.h"
 #include "kernels/conv_igemm_f32.h"
 #include "kernels/conv_wavek_f32.h"
 #include "kernels/conv_igemm_x3h.h"
@@ -915,11 +916,8 @@ static void launch_first_t(const aae::ConvFirstArgs& a, bool u8, bool planes, di
     }
 }
 
-static int launch_first(aae_encoder* enc, const Layer& L, const void* x, bool u8, int B, float* out, bool planes,
-                        hipStream_t stream, Timer& tm, const aae::TicketPrep* prep = nullptr) {
-    aae::ConvFirstArgs a;
-    if (prep) a.prep = *prep;
-    else a.prep.n = 0;
+// arguments of the first-layer kernel for a batch of B crops; returns the number of tile runs (blocks along grid.x)
+static int first_core_args(const aae_encoder* enc, const Layer& L, const void* x, bool u8, int B, float* out, bool planes, aae::ConvFirstCore& a) {
     a.x = x; a.lut = enc->lut; a.w = L.w_hwio; a.bias = L.bias; a.bn_scale = L.bn_scale; a.bn_shift = L.bn_shift;
     a.out = out; a.H = L.H; a.W = L.W; a.Ho = L.Ho; a.Wo = L.Wo; a.Cout = L.Cout;
     a.S = L.S; a.pt = L.pt; a.pl = L.pl; a.relu = L.relu;
@@ -934,7 +932,16 @@ static int launch_first(aae_encoder* enc, const Layer& L, const void* x, bool u8
     if (tpb < 1) tpb = 1;
     if (tpb > enc->first_max_tiles_per_block) tpb = enc->first_max_tiles_per_block;
     a.tiles_per_block = tpb;
-    const dim3 grid(ceil_div(a.total_tiles, tpb) + (a.prep.n > 0 ? 1 : 0), ceil_div(L.Cout, 128));    // + the ticket-preparation block
+    return ceil_div(a.total_tiles, tpb);
+}
+
+static int launch_first(aae_encoder* enc, const Layer& L, const void* x, bool u8, int B, float* out, bool planes,
+                        hipStream_t stream, Timer& tm, const aae::TicketPrep* prep = nullptr) {
+    aae::ConvFirstArgs a;
+    if (prep) a.prep = *prep;
+    else a.prep.n = 0;
+    const int runs = first_core_args(enc, L, x, u8, B, out, planes, a);
+    const dim3 grid(runs + (a.prep.n > 0 ? 1 : 0), ceil_div(L.Cout, 128));    // + the ticket-preparation block
     // per-detection batches: the four 32-pixel groups of every tile go to four blocks (10.6 -> ? us at B = 1)
     const bool group_split = !planes && a.total_tiles <= enc->first_group_split_max_tiles;
     if (L.Cin == 3) launch_first_t<5, 3>(a, u8, planes, grid, L.first_smem, stream, group_split);
@@ -2226,4 +2233,5 @@ int aae_detect_nn(aae_encoder* enc, aae_codebook* cb, const void* img, int H, in
 
 }  // extern "C"
 
+#include "aae_multi_impl.h"
 #include "aae_decoder_impl.h"

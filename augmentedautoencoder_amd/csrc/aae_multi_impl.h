@@ -1,0 +1,422 @@
+// Host side of the grouped multi-object query (include/aae_hip.h: aae_encode_nn_multi, aae_detect_nn_multi,
+// aae_codebook_nn_multi): a frame's detections of SEVERAL object classes -- each class its own encoder weights and its own
+// codebook, as /root/reference/auto_pose/m3_interface/ae_pose_estimator.py:61-78 keeps them -- answered with one launch per
+// LAYER instead of one six-launch chain per class (:143-170 runs one session.run per box).  Included at the end of
+// aae_hip_impl.h; kernels: kernels/multi_launch.h and the *_multi_kernel forms beside the per-object kernels.
+//
+// Which items are grouped.  An item (object, n detections) joins a group when its per-object call would run the
+// per-detection chain -- conv1 in the one-block-per-pixel-group form, every later conv layer on the wave-split-K kernel
+// (4 waves, 2 slabs in flight), the dense layer as the ticketed GEMV, the fp32 stream scan with its in-launch finish --
+// i.e. n <= 4 of the reference network at the default options.  Items of one group share the batch n and the network shape
+// (so that one kernel instantiation serves all of them); each keeps ITS launch plan -- tiles, K splits, tail cut -- and gets
+// its own slice of the workspace (activations, partials, ticket words), so the answers are the per-object calls' bit for bit.
+// Everything else (larger n, bf16 codebooks, split precision, other networks or options) is answered by the per-object
+// path inside the same call, one item after the other in a shared slice.
+#pragma once
+
+namespace aae_host {
+
+struct MultiItemPlan {
+    bool grouped = false;
+    int n = 0, row0 = 0;                       // detections of the item, its first row in the concatenated inputs / outputs
+    size_t enc_off = 0, enc_bytes = 0, cb_off = 0, cb_bytes = 0;     // grouped items: own workspace slices
+    Workspace ws;
+    std::vector<WaveKPlan> plans;              // per conv layer (grouped items)
+    ScanPlan sp;
+    const aae_codebook* eff = nullptr;         // the codebook the scan runs over (the compacted upright copy when col_stride > 1)
+    int idx_scale = 1;
+    std::vector<int> sig;                      // items with equal signatures share kernel instantiations
+};
+
+struct MultiPlan {
+    std::vector<MultiItemPlan> items;
+    size_t seq_enc_off = 0, seq_enc_bytes = 0, seq_cb_off = 0, seq_cb_bytes = 0, total = 0;
+    int rows = 0;
+};
+
+static thread_local int t_multi_launches = 0;      // kernel launches queued by the calling thread's last multi call (its grouped part)
+
+static int wavek_shape_key(const WaveKPlan& w) { return (w.MT == 1 ? 1000 : 0) + w.NT * 100 + w.waves * 10 + w.depth; }
+
+// Can the scan of (cb, n detections, col_stride) run as one object's share of scan_stream_multi_kernel?
+static bool multi_scan_groupable(const aae_codebook* cb, int n, int col_stride, const aae_codebook** eff_out, int* idx_scale) {
+    const aae_codebook* eff = cb;
+    *idx_scale = 1;
+    if (col_stride > 1) {
+        if (!(cb->upright && cb->upright_stride == col_stride)) return false;      // (the masked full scan: per-object path)
+        eff = cb->upright;
+        *idx_scale = col_stride;
+    }
+    *eff_out = eff;
+    if (n < 1 || n > 4 || eff->dtype != AAE_DTYPE_F32 || eff->scan_ticket == 0 || eff->scan_walk) return false;
+    return plan_scan(eff, n, 1).stream;
+}
+
+static bool multi_encoder_groupable(const aae_encoder* enc, int n, std::vector<WaveKPlan>& plans, std::vector<int>& sig) {
+    const size_t nl = enc->layers.size();
+    if (n < 1 || n > 4 || nl < 2 || runs_split(enc, n) || enc->detect_chain || enc->wavek_ablate || enc->wavek_timeline) return false;
+    const Layer& L0 = enc->layers[0];
+    if (L0.kind != KIND_FIRST_MFMA || n * ceil_div(L0.Ho * L0.Wo, 128) > enc->first_group_split_max_tiles) return false;
+    const Layer& D = enc->dense;
+    if (D.kind != KIND_IGEMM || !enc->dense_gemv || n > gemv_max_batch(enc) || D.K() % aae::kGemvChunk != 0 || !gemv_uses_ticket(enc, D)) return false;
+    plans.assign(nl, WaveKPlan());
+    sig.clear();
+    sig.push_back(n);
+    const int32_t* d = reinterpret_cast<const int32_t*>(&enc->desc);
+    for (size_t i = 0; i < sizeof(aae_encoder_desc) / sizeof(int32_t); ++i) sig.push_back(d[i]);      // (bn_eps as its bit pattern)
+    for (size_t li = 1; li < nl; ++li) {
+        const Layer& L = enc->layers[li];
+        if (L.kind != KIND_IGEMM) return false;
+        const WaveKPlan w = plan_wavek(enc, L, (long long)n * L.Ho * L.Wo, false);
+        if (!w.use || w.waves != 4 || w.depth != 2) return false;
+        const int key = wavek_shape_key(w);
+        const bool spread = key == 1142 ? (enc->wavek_spread & 2) != 0 : (key == 242 ? (enc->wavek_spread & 1) != 0 : false);
+        if (!((key == 1142 && spread) || key == 142 || (key == 242 && spread))) return false;         // (the instantiated grouped forms = the defaults)
+        plans[li] = w;
+        sig.push_back(key);
+    }
+    return true;
+}
+
+// Layout of one call: [shared slice of the per-object path: encoder part, codebook part][grouped item 0: encoder, codebook][item 1] ...
+static int plan_multi(const aae_multi_item* items, int n_items, bool scan_only, MultiPlan& mp) {
+    if (!items || n_items < 1) return fail(AAE_ERR_INVALID, "multi-object query: no items");
+    mp.items.assign((size_t)n_items, MultiItemPlan());
+    int row = 0;
+    for (int i = 0; i < n_items; ++i) {
+        const aae_multi_item& it = items[i];
+        MultiItemPlan& p = mp.items[(size_t)i];
+        if (!it.cb || (!scan_only && !it.enc)) return fail(AAE_ERR_INVALID, "multi-object query: item %d has a null handle", i);
+        if (it.n < 1) return fail(AAE_ERR_INVALID, "multi-object query: item %d has %d detections (want >= 1)", i, it.n);
+        if (it.col_stride < 1) return fail(AAE_ERR_INVALID, "multi-object query: item %d col_stride %d < 1", i, it.col_stride);
+        if (!scan_only && it.cb->J != it.enc->desc.latent_size)
+            return fail(AAE_ERR_INVALID, "multi-object query: item %d pairs a %d-d encoder with a %d-d codebook", i, it.enc->desc.latent_size, it.cb->J);
+        if (scan_only && it.cb->J != items[0].cb->J)
+            return fail(AAE_ERR_INVALID, "multi-object query: item %d has latent size %d, item 0 has %d (one [rows, J] latent array serves all)", i, it.cb->J, items[0].cb->J);
+        if (!scan_only && it.enc->desc.latent_size != items[0].enc->desc.latent_size)
+            return fail(AAE_ERR_INVALID, "multi-object query: item %d has latent size %d, item 0 has %d (one [rows, J] latent array serves all)", i,
+                        it.enc->desc.latent_size, items[0].enc->desc.latent_size);
+        p.n = it.n;
+        p.row0 = row;
+        row += it.n;
+        p.grouped = multi_scan_groupable(it.cb, it.n, it.col_stride, &p.eff, &p.idx_scale) &&
+                    (scan_only || multi_encoder_groupable(it.enc, it.n, p.plans, p.sig));
+        if (scan_only) p.sig.assign(1, it.n);
+        if (p.grouped) {
+            p.sp = plan_scan(p.eff, it.n, 1);
+            p.cb_bytes = align_up(p.sp.total, 256);
+            if (!scan_only) {
+                p.ws = plan_workspace(it.enc, it.n);
+                p.enc_bytes = align_up(p.ws.total, 256);
+            }
+        } else {
+            if (!scan_only) mp.seq_enc_bytes = std::max(mp.seq_enc_bytes, align_up(plan_workspace(it.enc, it.n).total, 256));
+            mp.seq_cb_bytes = std::max(mp.seq_cb_bytes, align_up(plan_scan(it.cb, it.n, 1).total, 256));
+        }
+    }
+    mp.rows = row;
+    size_t off = 0;
+    mp.seq_enc_off = off; off += mp.seq_enc_bytes;
+    mp.seq_cb_off = off; off += mp.seq_cb_bytes;
+    for (MultiItemPlan& p : mp.items)
+        if (p.grouped) {
+            p.enc_off = off; off += p.enc_bytes;
+            p.cb_off = off; off += p.cb_bytes;
+        }
+    mp.total = off;
+    return AAE_OK;
+}
+
+template <int KS, int C>
+static void launch_first_multi_t(const aae::ConvFirstMultiArgs& m, bool u8, bool vec4, dim3 grid, int smem, hipStream_t stream) {
+    if (u8 && vec4) {
+        (void)hipFuncSetAttribute((const void*)aae::conv_first_multi_kernel<KS, C, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        AAE_LAUNCH((aae::conv_first_multi_kernel<KS, C, true, true>), grid, dim3(256), smem, stream, m);
+    } else if (u8) {
+        (void)hipFuncSetAttribute((const void*)aae::conv_first_multi_kernel<KS, C, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        AAE_LAUNCH((aae::conv_first_multi_kernel<KS, C, true, false>), grid, dim3(256), smem, stream, m);
+    } else {
+        (void)hipFuncSetAttribute((const void*)aae::conv_first_multi_kernel<KS, C, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        AAE_LAUNCH((aae::conv_first_multi_kernel<KS, C, false, false>), grid, dim3(256), smem, stream, m);
+    }
+}
+
+template <int MT, int NT, bool SPREAD>
+static void launch_wavek_multi_t(const aae::ConvWaveKMultiArgs& m, int tag, int nblk, hipStream_t stream) {
+    constexpr int smem = aae::conv_wavek_smem<MT, NT, 4>();
+    // TAG only makes the symbol unique per encoder layer (separate rows in rocprofv3 --stats)
+    if (tag == 1) {
+        (void)hipFuncSetAttribute((const void*)aae::conv_wavek_multi_kernel<MT, NT, 4, 2, 1, SPREAD>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        AAE_LAUNCH((aae::conv_wavek_multi_kernel<MT, NT, 4, 2, 1, SPREAD>), dim3(nblk), dim3(256), smem, stream, m);
+    } else if (tag == 2) {
+        (void)hipFuncSetAttribute((const void*)aae::conv_wavek_multi_kernel<MT, NT, 4, 2, 2, SPREAD>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        AAE_LAUNCH((aae::conv_wavek_multi_kernel<MT, NT, 4, 2, 2, SPREAD>), dim3(nblk), dim3(256), smem, stream, m);
+    } else if (tag == 3) {
+        (void)hipFuncSetAttribute((const void*)aae::conv_wavek_multi_kernel<MT, NT, 4, 2, 3, SPREAD>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        AAE_LAUNCH((aae::conv_wavek_multi_kernel<MT, NT, 4, 2, 3, SPREAD>), dim3(nblk), dim3(256), smem, stream, m);
+    } else {
+        (void)hipFuncSetAttribute((const void*)aae::conv_wavek_multi_kernel<MT, NT, 4, 2, 0, SPREAD>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        AAE_LAUNCH((aae::conv_wavek_multi_kernel<MT, NT, 4, 2, 0, SPREAD>), dim3(nblk), dim3(256), smem, stream, m);
+    }
+}
+
+// the scan of up to kMultiMax grouped items in one launch (z: the items' raw latent codes, rows in item order)
+static int launch_scan_multi(const MultiPlan& mp, const std::vector<int>& members, const float* z, int J, int64_t* idx_out, float* score_out,
+                             unsigned char* base, unsigned nonce, hipStream_t stream) {
+    aae::ScanMultiArgs m;
+    memset(&m, 0, sizeof(m));
+    const int n = mp.items[(size_t)members[0]].n;
+    int at = 0;
+    m.range.n = (int)members.size();
+    for (size_t k = 0; k < members.size(); ++k) {
+        const MultiItemPlan& p = mp.items[(size_t)members[k]];
+        const aae_codebook* eff = p.eff;
+        unsigned char* cbase = base + p.cb_off;
+        aae::ScanArgs& a = m.item[k];
+        a.E = eff->E; a.e_bytes = (unsigned)((size_t)eff->N * eff->J * sizeof(float));
+        a.q = nullptr; a.qp = nullptr; a.cs = nullptr;
+        a.z = z + (size_t)p.row0 * J;
+        a.pval = reinterpret_cast<float*>(cbase + p.sp.pval_off);
+        a.pidx = reinterpret_cast<int*>(cbase + p.sp.pidx_off);
+        a.N = eff->N; a.J = eff->J; a.Jpad = p.sp.Jpad; a.B = p.n; a.Bpad = p.sp.Bpad; a.Bstride = p.sp.Bstride; a.col_stride = 1;
+        a.tickets = reinterpret_cast<unsigned long long*>(cbase + p.sp.ticket_off); a.nonce = nonce;
+        a.idx_out = reinterpret_cast<long long*>(idx_out + p.row0); a.score_out = score_out + p.row0; a.idx_scale = p.idx_scale;
+        m.range.first[k] = at;
+        at += p.sp.nblk;
+    }
+    m.range.first[members.size()] = at;
+    const int smem = n * 128 * (int)sizeof(float) + aae::kScanTicketSmem;
+    if (n == 1) AAE_LAUNCH((aae::scan_stream_multi_kernel<1>), dim3(at), dim3(256), smem, stream, m);
+    else if (n == 2) AAE_LAUNCH((aae::scan_stream_multi_kernel<2>), dim3(at), dim3(256), smem, stream, m);
+    else if (n == 3) AAE_LAUNCH((aae::scan_stream_multi_kernel<3>), dim3(at), dim3(256), smem, stream, m);
+    else AAE_LAUNCH((aae::scan_stream_multi_kernel<4>), dim3(at), dim3(256), smem, stream, m);
+    AAE_HIP_TRY(hipGetLastError());
+    ++t_multi_launches;
+    return AAE_OK;
+}
+
+// conv1 ... dense of up to kMultiMax grouped items (equal signatures): one launch per layer
+static int launch_encoder_multi(const aae_multi_item* items, const MultiPlan& mp, const std::vector<int>& members, const void* x, int x_dtype,
+                                float* z_out, unsigned char* base, unsigned nonce, hipStream_t stream) {
+    const aae_encoder* enc0 = items[members[0]].enc;
+    const size_t nl = enc0->layers.size();
+    const int n = mp.items[(size_t)members[0]].n, J = enc0->desc.latent_size;
+    const bool u8 = x_dtype == AAE_DTYPE_U8;
+    const size_t crop_bytes = (size_t)enc0->desc.in_h * enc0->desc.in_w * enc0->desc.in_c * (u8 ? 1 : 4);
+    auto enc_base = [&](size_t k) { return base + mp.items[(size_t)members[k]].enc_off; };
+    auto tickets_of = [&](size_t k) { return reinterpret_cast<unsigned long long*>(enc_base(k) + mp.items[(size_t)members[k]].ws.ticket_off); };
+
+    // ---- conv1 (+ one ticket-preparation block per object)
+    {
+        aae::ConvFirstMultiArgs m;
+        memset(&m, 0, sizeof(m));
+        m.range.n = (int)members.size();
+        m.nonce = nonce;
+        int at = 0, vec4 = -1;
+        for (size_t k = 0; k < members.size(); ++k) {
+            const aae_multi_item& it = items[members[k]];
+            const MultiItemPlan& p = mp.items[(size_t)members[k]];
+            const Layer& L = it.enc->layers[0];
+            const void* xk = static_cast<const unsigned char*>(x) + (size_t)p.row0 * crop_bytes;
+            const int runs = first_core_args(it.enc, L, xk, u8, n, reinterpret_cast<float*>(enc_base(k) + p.ws.act_off[0]), false, m.item[k]);
+            if (vec4 < 0) vec4 = m.item[k].vec4;
+            if (m.item[k].vec4 != vec4) return fail(AAE_ERR_RUNTIME, "multi-object query: objects disagree on the dword staging of conv1 (option first_vec4)");
+            m.range.first[k] = at;
+            at += runs;
+            aae::MultiTicketPrep& tp = m.prep[k];
+            tp.n = 0;
+            if (it.enc->ticket_prep) {
+                auto add = [&](unsigned long long* words, int count) {
+                    if (tp.n < aae::kMultiPrepRanges) { tp.words[tp.n] = words; tp.count[tp.n] = count; ++tp.n; }
+                };
+                for (size_t li = 1; li < nl; ++li)
+                    if (p.plans[li].gsplits > 1 || p.plans[li].tail_tiles > 0)
+                        add(tickets_of(k) + li * kLayerTicketWords, p.plans[li].tail_tiles > 0 ? p.plans[li].tail_tiles : p.plans[li].num_mt * p.plans[li].num_nt);
+                add(tickets_of(k) + kConvTicketBytes / 8, (it.enc->dense.CoutPad / 128) * aae::kTicketSlotWords);
+                add(reinterpret_cast<unsigned long long*>(base + p.cb_off + p.sp.ticket_off), aae::kTicketSlotWords);
+            }
+        }
+        m.range.first[members.size()] = at;
+        const Layer& L0 = enc0->layers[0];
+        const dim3 grid(at + (unsigned)members.size(), ceil_div(L0.Cout, 128), 4);
+        if (L0.Cin == 3) launch_first_multi_t<5, 3>(m, u8, vec4 != 0, grid, L0.first_smem, stream);
+        else launch_first_multi_t<5, 1>(m, u8, vec4 != 0, grid, L0.first_smem, stream);
+        AAE_HIP_TRY(hipGetLastError());
+        ++t_multi_launches;
+    }
+    // ---- conv2 ...: the wave-split-K kernel, every object with its own plan
+    for (size_t li = 1; li < nl; ++li) {
+        aae::ConvWaveKMultiArgs m;
+        memset(&m, 0, sizeof(m));
+        m.range.n = (int)members.size();
+        int at = 0;
+        for (size_t k = 0; k < members.size(); ++k) {
+            const aae_multi_item& it = items[members[k]];
+            const MultiItemPlan& p = mp.items[(size_t)members[k]];
+            const Layer& L = it.enc->layers[li];
+            const WaveKPlan& w = p.plans[li];
+            m.item[k] = wavek_args(it.enc, L, w, reinterpret_cast<const float*>(enc_base(k) + p.ws.act_off[li - 1]), n * L.Ho * L.Wo,
+                                   reinterpret_cast<float*>(enc_base(k) + p.ws.act_off[li]), reinterpret_cast<float*>(enc_base(k) + p.ws.partial_off),
+                                   tickets_of(k) + li * kLayerTicketWords, nonce, (int)li);
+            m.item[k].timeline = nullptr;
+            m.nblk[k] = w.blocks();
+            m.range.first[k] = at;
+            at += (w.blocks() + 7) / 8 * 8;              // (every object's first block on XCD 0: xcd_remap counts from it)
+        }
+        m.range.first[members.size()] = at;
+        const WaveKPlan& w0 = mp.items[(size_t)members[0]].plans[li];
+        const int tag = li <= 3 ? (int)li : 0;
+        switch (wavek_shape_key(w0)) {
+            case 1142: launch_wavek_multi_t<1, 1, true>(m, tag, at, stream); break;
+            case 142: launch_wavek_multi_t<2, 1, false>(m, tag, at, stream); break;
+            case 242: launch_wavek_multi_t<2, 2, true>(m, tag, at, stream); break;
+            default: return fail(AAE_ERR_RUNTIME, "multi-object query: no grouped wave-split-K instantiation for shape key %d", wavek_shape_key(w0));
+        }
+        AAE_HIP_TRY(hipGetLastError());
+        ++t_multi_launches;
+    }
+    // ---- dense layer: the ticketed GEMV
+    {
+        aae::DenseGemvMultiArgs m;
+        memset(&m, 0, sizeof(m));
+        m.range.n = (int)members.size();
+        int at = 0;
+        for (size_t k = 0; k < members.size(); ++k) {
+            const aae_multi_item& it = items[members[k]];
+            const MultiItemPlan& p = mp.items[(size_t)members[k]];
+            const Layer& D = it.enc->dense;
+            aae::DenseGemvArgs a = gemv_args(D, reinterpret_cast<const float*>(enc_base(k) + p.ws.act_off[nl - 1]), n, reinterpret_cast<float*>(enc_base(k) + p.ws.partial_off));
+            a.bias = D.bias; a.bn_scale = D.bn_scale; a.bn_shift = D.bn_shift; a.out = z_out + (size_t)p.row0 * J;
+            a.tickets = tickets_of(k) + kConvTicketBytes / 8; a.nonce = nonce; a.relu = D.relu;
+            m.item[k] = a;
+            m.range.first[k] = at;
+            at += ceil_div(a.K, aae::kGemvChunk);
+        }
+        m.range.first[members.size()] = at;
+        const Layer& D0 = enc0->dense;
+        const dim3 grid(at, D0.CoutPad / 128);
+        int smem = 2 * n * aae::kGemvChunk * (int)sizeof(float) + 16;
+        if (smem < aae::kGemvTicketSmem) smem = aae::kGemvTicketSmem;
+        if (n == 1) AAE_LAUNCH((aae::dense_gemv_multi_kernel<1>), grid, dim3(256), smem, stream, m);
+        else if (n == 2) AAE_LAUNCH((aae::dense_gemv_multi_kernel<2>), grid, dim3(256), smem, stream, m);
+        else if (n == 3) AAE_LAUNCH((aae::dense_gemv_multi_kernel<3>), grid, dim3(256), smem, stream, m);
+        else AAE_LAUNCH((aae::dense_gemv_multi_kernel<4>), grid, dim3(256), smem, stream, m);
+        AAE_HIP_TRY(hipGetLastError());
+        ++t_multi_launches;
+    }
+    return AAE_OK;
+}
+
+// groups of the grouped items: equal signatures, at most kMultiMax members each, in item order
+static std::vector<std::vector<int>> multi_groups(const MultiPlan& mp) {
+    std::vector<std::vector<int>> groups;
+    for (size_t i = 0; i < mp.items.size(); ++i) {
+        if (!mp.items[i].grouped) continue;
+        bool placed = false;
+        for (auto& g : groups)
+            if ((int)g.size() < aae::kMultiMax && mp.items[(size_t)g[0]].sig == mp.items[i].sig) { g.push_back((int)i); placed = true; break; }
+        if (!placed) groups.push_back(std::vector<int>(1, (int)i));
+    }
+    return groups;
+}
+
+static int multi_impl(const aae_multi_item* items, int n_items, const void* x, int x_dtype, const float* z_in, float* z_out, int64_t* idx_out,
+                      float* score_out, void* workspace, size_t ws_bytes, void* stream_v) {
+    const bool scan_only = z_in != nullptr;
+    t_multi_launches = 0;
+    MultiPlan mp;
+    if (int rc = plan_multi(items, n_items, scan_only, mp)) return rc;
+    if (!idx_out || !score_out || (!scan_only && (!x || !z_out))) return fail(AAE_ERR_INVALID, "multi-object query: null argument");
+    if (!scan_only && x_dtype != AAE_DTYPE_U8 && x_dtype != AAE_DTYPE_F32)
+        return fail(AAE_ERR_INVALID, "multi-object query: x_dtype %d (want AAE_DTYPE_U8 or AAE_DTYPE_F32)", x_dtype);
+    if (ws_bytes < mp.total) return fail(AAE_ERR_WORKSPACE, "workspace %zu B < required %zu B (aae_multi_workspace_bytes)", ws_bytes, mp.total);
+    if (!workspace || ((uintptr_t)workspace & 255)) return fail(AAE_ERR_WORKSPACE, "workspace must be non-null and 256-B aligned");
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    unsigned char* base = static_cast<unsigned char*>(workspace);
+    const int J = items[0].cb->J;
+    const float* z = scan_only ? z_in : z_out;
+    // ---- the items the grouped kernels do not cover: the per-object path, one after the other in the shared slice
+    for (int i = 0; i < n_items; ++i) {
+        const MultiItemPlan& p = mp.items[(size_t)i];
+        if (p.grouped) continue;
+        const aae_multi_item& it = items[i];
+        int rc;
+        if (scan_only)
+            rc = aae_codebook_nn(it.cb, z + (size_t)p.row0 * J, it.n, 1, it.col_stride, idx_out + p.row0, score_out + p.row0, base + mp.seq_cb_off, mp.seq_cb_bytes, stream_v);
+        else {
+            const size_t crop_bytes = (size_t)it.enc->desc.in_h * it.enc->desc.in_w * it.enc->desc.in_c * (x_dtype == AAE_DTYPE_U8 ? 1 : 4);
+            if (crop_bytes != (size_t)items[0].enc->desc.in_h * items[0].enc->desc.in_w * items[0].enc->desc.in_c * (x_dtype == AAE_DTYPE_U8 ? 1 : 4))
+                return fail(AAE_ERR_INVALID, "multi-object query: item %d takes crops of another shape than item 0 (one [rows, H, W, C] crop array serves all)", i);
+            rc = aae_encode_nn(it.enc, it.cb, static_cast<const unsigned char*>(x) + (size_t)p.row0 * crop_bytes, x_dtype, it.n, it.col_stride,
+                               z_out + (size_t)p.row0 * J, idx_out + p.row0, score_out + p.row0, base + mp.seq_enc_off, mp.seq_enc_bytes,
+                               base + mp.seq_cb_off, mp.seq_cb_bytes, stream_v);
+        }
+        if (rc) return rc;
+    }
+    // ---- grouped items: one launch per layer and group
+    const std::vector<std::vector<int>> groups = multi_groups(mp);
+    if (!groups.empty()) t_x3h_last_slot = -1;
+    for (const std::vector<int>& g : groups) {
+        const unsigned nonce = next_nonce();           // one per group and call: every ticketed launch has its own words
+        if (!scan_only) {
+            for (int i : g) {
+                const aae_encoder_desc &a = items[i].enc->desc, &b = items[g[0]].enc->desc;
+                if (a.in_h != b.in_h || a.in_w != b.in_w || a.in_c != b.in_c) return fail(AAE_ERR_RUNTIME, "multi-object query: group members differ in crop shape");
+            }
+            if (int rc = launch_encoder_multi(items, mp, g, x, x_dtype, z_out, base, nonce, stream)) return rc;
+        }
+        if (int rc = launch_scan_multi(mp, g, z, J, idx_out, score_out, base, nonce, stream)) return rc;
+    }
+    return AAE_OK;
+}
+
+}  // namespace aae_host
+
+extern "C" {
+
+size_t aae_multi_workspace_bytes(const aae_multi_item* items, int n_items, int scan_only) {
+    aae_host::MultiPlan mp;
+    if (aae_host::plan_multi(items, n_items, scan_only != 0, mp) != AAE_OK) return 0;
+    return mp.total;
+}
+
+int aae_multi_rows(const aae_multi_item* items, int n_items) {
+    if (!items || n_items < 1) return 0;
+    long long rows = 0;
+    for (int i = 0; i < n_items; ++i) rows += items[i].n > 0 ? items[i].n : 0;
+    return rows > 0x7fffffff ? 0 : (int)rows;
+}
+
+int aae_encode_nn_multi(const aae_multi_item* items, int n_items, const void* x, int x_dtype, float* z_out, int64_t* idx_out, float* score_out,
+                        void* workspace, size_t ws_bytes, void* stream) {
+    return aae_host::multi_impl(items, n_items, x, x_dtype, nullptr, z_out, idx_out, score_out, workspace, ws_bytes, stream);
+}
+
+int aae_codebook_nn_multi(const aae_multi_item* items, int n_items, const float* z, int64_t* idx_out, float* score_out, void* workspace,
+                          size_t ws_bytes, void* stream) {
+    if (!z) return aae_host::fail(AAE_ERR_INVALID, "aae_codebook_nn_multi: null latent array");
+    return aae_host::multi_impl(items, n_items, nullptr, AAE_DTYPE_F32, z, nullptr, idx_out, score_out, workspace, ws_bytes, stream);
+}
+
+int aae_detect_nn_multi(const aae_multi_item* items, int n_items, const void* img, int H, int W, int C, const int32_t* boxes, void* crops,
+                        float* z_out, int64_t* idx_out, float* score_out, void* workspace, size_t ws_bytes, void* stream) {
+    using namespace aae_host;
+    if (!items || n_items < 1 || !items[0].enc || !crops) return fail(AAE_ERR_INVALID, "aae_detect_nn_multi: null argument");
+    const aae_encoder_desc& d = items[0].enc->desc;
+    if (C != d.in_c) return fail(AAE_ERR_INVALID, "aae_detect_nn_multi: image has %d channels, the encoders take %d", C, d.in_c);
+    for (int i = 1; i < n_items; ++i)
+        if (!items[i].enc || items[i].enc->desc.in_h != d.in_h || items[i].enc->desc.in_w != d.in_w || items[i].enc->desc.in_c != d.in_c)
+            return fail(AAE_ERR_INVALID, "aae_detect_nn_multi: item %d takes crops of another shape than item 0 (one crop array serves all)", i);
+    const int rows = aae_multi_rows(items, n_items);
+    if (rows < 1) return fail(AAE_ERR_INVALID, "aae_detect_nn_multi: no detections");
+    for (int a = 0; a < rows; a += 65535) {              // (the crop kernel's grid.y)
+        const int m = std::min(65535, rows - a);
+        if (int rc = aae_crop_resize_u8(img, H, W, C, boxes + (size_t)a * 5, m, d.in_h, d.in_w,
+                                        static_cast<unsigned char*>(crops) + (size_t)a * d.in_h * d.in_w * d.in_c, stream)) return rc;
+    }
+    return aae_encode_nn_multi(items, n_items, crops, AAE_DTYPE_U8, z_out, idx_out, score_out, workspace, ws_bytes, stream);
+}
+
+int aae_multi_last_launches(void) { return aae_host::t_multi_launches; }
+
+}  // extern "C"

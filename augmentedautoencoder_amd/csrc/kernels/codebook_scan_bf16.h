@@ -233,8 +233,8 @@ __global__ __launch_bounds__(256) void scan_stream_bf16_kernel(const ScanArgs p)
         sc[b * 256 + wave * 64 + lane] = cand ? dot : kNegInf;
     }
     __syncthreads();
-    scan_block_argmax_store<NQ, 256>(p, sc, blockIdx.x * 256);   // wave b: (max, first row) of query b over the block's 256 rows
-    if (p.tickets) scan_ticket_finish<NQ>(p, sc + NQ * 256);
+    scan_block_argmax_store<NQ, 256>(p, sc, blockIdx.x * 256, blockIdx.x, gridDim.x);   // wave b: (max, first row) of query b over the block's 256 rows
+    if (p.tickets) scan_ticket_finish<NQ>(p, sc + NQ * 256, blockIdx.x, gridDim.x);
 }
 
 }  // namespace aae

@@ -104,7 +104,7 @@ __device__ __forceinline__ void block_best(float& bv, int& bi, float* red) {
 // tools/ubench/scan_stream_ablate.hip).  Separate reduce launch (no tickets): the [block][query] score and row arrays
 // argmax_reduce_kernel reads.
 template <int NQ>
-__device__ __forceinline__ void scan_store_block_partials(const ScanArgs& p, const float* red_v, const int* red_i) {
+__device__ __forceinline__ void scan_store_block_partials(const ScanArgs& p, const float* red_v, const int* red_i, const unsigned blk, const unsigned nblk) {
     if (threadIdx.x != 0) return;
     float v[NQ];
     int ix[NQ];
@@ -117,7 +117,7 @@ __device__ __forceinline__ void scan_store_block_partials(const ScanArgs& p, con
             if (better(red_v[w * NQ + b], red_i[w * NQ + b], v[b], ix[b])) { v[b] = red_v[w * NQ + b]; ix[b] = red_i[w * NQ + b]; }
     }
     if (p.tickets) {
-        const buffer_rsrc pbuf = make_buffer(p.pval, gridDim.x * (unsigned)p.Bstride * 4u);
+        const buffer_rsrc pbuf = make_buffer(p.pval, nblk * (unsigned)p.Bstride * 4u);
 #pragma unroll
         for (int h = 0; h < (NQ + 1) / 2; ++h) {
             u32x4 piece;
@@ -125,14 +125,14 @@ __device__ __forceinline__ void scan_store_block_partials(const ScanArgs& p, con
             piece[1] = (uint32_t)ix[2 * h];
             piece[2] = 2 * h + 1 < NQ ? __builtin_bit_cast(uint32_t, v[(2 * h + 1) % NQ]) : 0u;
             piece[3] = 2 * h + 1 < NQ ? (uint32_t)ix[(2 * h + 1) % NQ] : 0u;
-            coherent_store4(pbuf, (blockIdx.x * (unsigned)p.Bstride + 4u * h) * 4u, __builtin_bit_cast(f32x4, piece));
+            coherent_store4(pbuf, (blk * (unsigned)p.Bstride + 4u * h) * 4u, __builtin_bit_cast(f32x4, piece));
         }
     } else {
 #pragma unroll
         for (int b = 0; b < NQ; ++b)
             if (b < p.B) {
-                p.pval[(long long)blockIdx.x * p.Bstride + b] = v[b];
-                p.pidx[(long long)blockIdx.x * p.Bstride + b] = ix[b];
+                p.pval[(long long)blk * p.Bstride + b] = v[b];
+                p.pidx[(long long)blk * p.Bstride + b] = ix[b];
             }
     }
 }
@@ -145,12 +145,12 @@ __device__ __forceinline__ void scan_store_block_partials(const ScanArgs& p, con
 // eight block barriers.
 constexpr int kScanTicketSmem = 64 + 8 * 4 * 4;
 template <int NQ>
-__device__ __forceinline__ void scan_ticket_finish(const ScanArgs& p, float* red) {
+__device__ __forceinline__ void scan_ticket_finish(const ScanArgs& p, float* red, const unsigned blk, const unsigned nblk_u) {
     int* flag = reinterpret_cast<int*>(red) + 10;
-    if (!block_ticket_arrive(p.tickets, p.nonce, gridDim.x, blockIdx.x, flag)) return;
+    if (!block_ticket_arrive(p.tickets, p.nonce, nblk_u, blk, flag)) return;
     float* fin_v = red + 16;                                     // [4][NQ]
     int* fin_i = reinterpret_cast<int*>(fin_v + 4 * NQ);         // [4][NQ]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nblk = (int)gridDim.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nblk = (int)nblk_u;
     const buffer_rsrc pbuf = make_buffer(p.pval, (unsigned)nblk * p.Bstride * 4u);
     float bv[NQ];
     int bi[NQ];
@@ -262,7 +262,7 @@ __device__ __forceinline__ float scan_scores32(const f32x4 (&e)[16], const f32x4
 // tools/ubench/scan_stream_ablate.hip) -- and its lane 0 stores the block partial: 8 device-coherent bytes (score, row) into
 // the query's slot of the packed partial row (in-launch finish) or the [block][query] arrays (separate reduce launch).
 template <int NQ, int ROWS>
-__device__ __forceinline__ void scan_block_argmax_store(const ScanArgs& p, const float* sc, int row_base) {
+__device__ __forceinline__ void scan_block_argmax_store(const ScanArgs& p, const float* sc, int row_base, const unsigned blk, const unsigned nblk) {
     const int lane = threadIdx.x & 63, wave = wave_uniform(threadIdx.x >> 6);
     if (wave >= NQ || wave >= p.B) return;                       // wave-uniform
     float v[ROWS / 64];
@@ -273,23 +273,23 @@ __device__ __forceinline__ void scan_block_argmax_store(const ScanArgs& p, const
     if (lane != 0) return;
     const int ix = m > kNegInf ? row_base + first : 0x7fffffff;
     if (p.tickets)
-        coherent_store2(make_buffer(p.pval, gridDim.x * (unsigned)p.Bstride * 4u), (blockIdx.x * (unsigned)p.Bstride + 2u * wave) * 4u,
+        coherent_store2(make_buffer(p.pval, nblk * (unsigned)p.Bstride * 4u), (blk * (unsigned)p.Bstride + 2u * wave) * 4u,
                         __builtin_bit_cast(uint32_t, m), (uint32_t)ix);
     else {
-        p.pval[(long long)blockIdx.x * p.Bstride + wave] = m;
-        p.pidx[(long long)blockIdx.x * p.Bstride + wave] = ix;
+        p.pval[(long long)blk * p.Bstride + wave] = m;
+        p.pidx[(long long)blk * p.Bstride + wave] = ix;
     }
 }
 
+// block `blk` of the `nblk` blocks that scan this codebook (sm: NQ * 128 floats of scores + kScanTicketSmem bytes)
 template <int NQ, bool UPRIGHT, bool WITH_CS>
-__global__ __launch_bounds__(256) void scan_stream_kernel(const ScanArgs p) {
-    AAE_DYN_SMEM(smem_raw);
+__device__ __forceinline__ void scan_stream_block(const ScanArgs& p, const int blk, const int nblk, unsigned char* smem_raw) {
     float* sc = reinterpret_cast<float*>(smem_raw);              // [NQ][128] scores of the block's rows
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = (lane & 31) * 4;
     const bool col_ok = col < p.J;
-    const int row_first = blockIdx.x * 128 + wave * 32;
+    const int row_first = blk * 128 + wave * 32;
 
     f32x4 zv[NQ];
 #pragma unroll
@@ -301,7 +301,7 @@ __global__ __launch_bounds__(256) void scan_stream_kernel(const ScanArgs p) {
     f32x4 e[16];
     scan_issue32(p, ebuf, row_first, p.N, e);
 
-    if (p.tickets && blockIdx.x == 0) ticket_prepare_slot(p.tickets, p.nonce, gridDim.x);   // the block's loads are in flight; arrivals come microseconds later
+    if (p.tickets && blk == 0) ticket_prepare_slot(p.tickets, p.nonce, (unsigned)nblk);   // the block's loads are in flight; arrivals come microseconds later
 
     f32x4 qv[NQ];
     scan_normalise_queries<NQ>(zv, qv);
@@ -318,8 +318,28 @@ __global__ __launch_bounds__(256) void scan_stream_kernel(const ScanArgs p) {
         if (!(lane & 1)) sc[b * 128 + wave * 32 + (lane >> 1)] = cand ? d : kNegInf;
     }
     __syncthreads();
-    scan_block_argmax_store<NQ, 128>(p, sc, blockIdx.x * 128);
-    if (p.tickets) scan_ticket_finish<NQ>(p, sc + NQ * 128);
+    scan_block_argmax_store<NQ, 128>(p, sc, blk * 128, (unsigned)blk, (unsigned)nblk);
+    if (p.tickets) scan_ticket_finish<NQ>(p, sc + NQ * 128, (unsigned)blk, (unsigned)nblk);
+}
+
+template <int NQ, bool UPRIGHT, bool WITH_CS>
+__global__ __launch_bounds__(256) void scan_stream_kernel(const ScanArgs p) {
+    AAE_DYN_SMEM(smem_raw);
+    scan_stream_block<NQ, UPRIGHT, WITH_CS>(p, (int)blockIdx.x, (int)gridDim.x, smem_raw);
+}
+
+// ---- SEVERAL codebooks in one launch (multi_launch.h): blocks [first[o], first[o + 1]) stream codebook o against object o's
+// (<= 4) latent codes and answer through object o's ticket -- C codebooks of 47 MB behind ONE launch ramp.  Top-1, stride 1 (the
+// upright search runs on its compacted copy), answers inside the launch.
+struct ScanMultiArgs {
+    MultiRange range;
+    ScanArgs item[kMultiMax];
+};
+template <int NQ>
+__global__ __launch_bounds__(256) void scan_stream_multi_kernel(const ScanMultiArgs m) {
+    AAE_DYN_SMEM(smem_raw);
+    const int o = multi_find(m.range, (int)blockIdx.x);
+    scan_stream_block<NQ, false, false>(m.item[o], (int)blockIdx.x - m.range.first[o], m.range.first[o + 1] - m.range.first[o], smem_raw);
 }
 
 // ------------------------------------------------------------ scan_stream_walk
@@ -395,8 +415,8 @@ __global__ __launch_bounds__(256) void scan_stream_walk_kernel(const ScanArgs p)
         for (int b = 0; b < NQ; ++b) { red_v[wave * NQ + b] = best_v[b]; red_i[wave * NQ + b] = best_i[b]; }
     }
     __syncthreads();
-    scan_store_block_partials<NQ>(p, red_v, red_i);
-    if (p.tickets) scan_ticket_finish<NQ>(p, red_v + 8 * NQ);
+    scan_store_block_partials<NQ>(p, red_v, red_i, blockIdx.x, gridDim.x);
+    if (p.tickets) scan_ticket_finish<NQ>(p, red_v + 8 * NQ, blockIdx.x, gridDim.x);
 }
 
 // ------------------------------------------------------------------- scan_gemv

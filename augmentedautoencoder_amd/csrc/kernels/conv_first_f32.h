@@ -37,7 +37,7 @@
 
 namespace aae {
 
-struct ConvFirstArgs {
+struct ConvFirstCore {
     const void* x;          // [B,H,W,C] uint8 or float32
     const float* lut;       // [256] (uint8 input only)
     const float* w;         // HWIO [KS][KS][C][Cout] == [K][Cout]
@@ -56,6 +56,8 @@ struct ConvFirstArgs {
     int relu;
     float out_scale;        // OUT_PLANES: 2^act_shift of the f32x3h activation format
     int* sat_flag;          // OUT_PLANES: sticky "a value left the fp16 pair range" flag of the encoder (or nullptr)
+};
+struct ConvFirstArgs : ConvFirstCore {
     TicketPrep prep;        // ticket words of the later launches of this forward call (n == 0: none), see conv_wavek_f32.h
 };
 
@@ -70,8 +72,9 @@ constexpr unsigned kFirstNoRow = 0xFFFu;                // "column outside the i
 // GROUP_SPLIT (per-detection batches): the four 32-pixel groups of a tile go to four blocks (blockIdx.z = group), each staging
 // the tile's patch and running ONE accumulator chain of 38 MFMA steps instead of four -- at B = 1 a tile kernel launch is 32
 // blocks x 152 MFMA steps on a chip of 256 CUs; split, it is 128 blocks x 38.  Same steps in the same order: bit-identical.
-template <int KS, int C, bool IN_U8, bool OUT_PLANES, bool VEC4 = false, bool GROUP_SPLIT = false>
-__global__ __launch_bounds__(256) void conv_first_f32_kernel(const ConvFirstArgs p) {
+// One block's share of the layer: block (bx, by, bz) = (run of tiles, 128-channel tile, GROUP_SPLIT: 32-pixel group).
+template <int KS, int C, bool IN_U8, bool OUT_PLANES, bool VEC4, bool GROUP_SPLIT>
+__device__ __forceinline__ void conv_first_block(const ConvFirstCore& p, const int bx, const int by, const int bz) {
     static_assert(!VEC4 || IN_U8, "dword staging is the uint8 path");
     static_assert(!GROUP_SPLIT || !OUT_PLANES, "the group-split form exists for the fp32 per-detection path");
     constexpr int KROW = KS * C;
@@ -84,16 +87,10 @@ __global__ __launch_bounds__(256) void conv_first_f32_kernel(const ConvFirstArgs
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
-    const int n = blockIdx.y * 128 + wave * 32 + i;
+    const int n = by * 128 + wave * 32 + i;
     const bool n_ok = n < p.Cout;
-    const bool wave_n_ok = (int)blockIdx.y * 128 + wave * 32 + 32 <= p.Cout;      // wave-uniform
+    const bool wave_n_ok = by * 128 + wave * 32 + 32 <= p.Cout;      // wave-uniform
 
-    // ticket preparation for the later launches of this forward: an EXTRA block (the host adds one to the grid) does
-    // nothing else, so no working block is delayed (at B = 1 the 32 working blocks leave most CUs free anyway)
-    if (p.prep.n > 0 && blockIdx.x == gridDim.x - 1) {
-        if (blockIdx.y == 0 && blockIdx.z == 0) ticket_prep_install(p.prep);
-        return;
-    }
     if (IN_U8) lut_s[tid] = p.lut[tid];
 
     // this wave's weights: breg[s] = W[2s+h][n]
@@ -111,7 +108,7 @@ __global__ __launch_bounds__(256) void conv_first_f32_kernel(const ConvFirstArgs
 
     const int HoWo = p.Ho * p.Wo;
     const int WC = p.W * C;
-    const int t_begin = blockIdx.x * p.tiles_per_block;
+    const int t_begin = bx * p.tiles_per_block;
     const int t_end = min(t_begin + p.tiles_per_block, p.total_tiles);
     if (t_begin >= t_end) return;
 
@@ -263,7 +260,7 @@ __global__ __launch_bounds__(256) void conv_first_f32_kernel(const ConvFirstArgs
             // what the SIMD's other wave already hides, so the default keeps four chains.
             constexpr int kChains = GROUP_SPLIT ? 1 : AAE_FIRST_CHAINS;
             constexpr int kBatches = GROUP_SPLIT ? 1 : 4 / kChains;             // batches of kChains groups this block runs
-            const int g0 = GROUP_SPLIT ? (int)blockIdx.z : 0;                   // its first (only) group
+            const int g0 = GROUP_SPLIT ? bz : 0;                                // its first (only) group
             constexpr int kRing = 8;
             constexpr int kVals = 16 * kChains;
             static_assert(NK2 >= kRing && 4 % kChains == 0, "ring deeper than the chain");
@@ -335,6 +332,38 @@ __global__ __launch_bounds__(256) void conv_first_f32_kernel(const ConvFirstArgs
     using T0 = std::false_type;
     if (p.relu) { if (p.bn_scale) run(T1{}, T1{}); else run(T1{}, T0{}); }
     else        { if (p.bn_scale) run(T0{}, T1{}); else run(T0{}, T0{}); }
+}
+
+template <int KS, int C, bool IN_U8, bool OUT_PLANES, bool VEC4 = false, bool GROUP_SPLIT = false>
+__global__ __launch_bounds__(256) void conv_first_f32_kernel(const ConvFirstArgs p) {
+    // ticket preparation for the later launches of this forward: an EXTRA block (the host adds one to the grid) does
+    // nothing else, so no working block is delayed (at B = 1 the 32 working blocks leave most CUs free anyway)
+    if (p.prep.n > 0 && blockIdx.x == gridDim.x - 1) {
+        if (blockIdx.y == 0 && blockIdx.z == 0) ticket_prep_install(p.prep);
+        return;
+    }
+    conv_first_block<KS, C, IN_U8, OUT_PLANES, VEC4, GROUP_SPLIT>(p, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z);
+}
+
+// ---- the same layer for SEVERAL objects in one launch (multi_launch.h): blocks [first[o], first[o + 1]) of grid.x run object o's
+// crops with object o's weights; behind them one ticket-preparation block per object.  Per-detection form only (uint8 or float
+// crops, fp32 output, one block per 32-pixel group).
+struct ConvFirstMultiArgs {
+    MultiRange range;                      // working blocks per object
+    ConvFirstCore item[kMultiMax];
+    MultiTicketPrep prep[kMultiMax];       // (n == 0: nothing to prepare for that object)
+    unsigned nonce;                        // one per call: every ticketed launch of the call has its own words
+};
+template <int KS, int C, bool IN_U8, bool VEC4>
+__global__ __launch_bounds__(256) void conv_first_multi_kernel(const ConvFirstMultiArgs m) {
+    const int total = m.range.first[m.range.n];
+    if ((int)blockIdx.x >= total) {                                   // the preparation blocks: one per object
+        const int o = (int)blockIdx.x - total;
+        if (blockIdx.y == 0 && blockIdx.z == 0 && o < m.range.n) multi_ticket_prep_install(m.prep[o], m.nonce);
+        return;
+    }
+    const int o = multi_find(m.range, (int)blockIdx.x);
+    conv_first_block<KS, C, IN_U8, false, VEC4, true>(m.item[o], (int)blockIdx.x - m.range.first[o], (int)blockIdx.y, (int)blockIdx.z);
 }
 
 }  // namespace aae

@@ -479,4 +479,24 @@ __global__ __launch_bounds__(64 * WAVES, (MT * NT == 4 && WAVES == 4 && DEPTH ==
     conv_wavek_block<MT, NT, WAVES, DEPTH, false, SPREAD>(p, (int)blockIdx.x, (int)gridDim.x, red, flag, none, false);
 }
 
+// ---- the same layer of SEVERAL objects in one launch (multi_launch.h): blocks [first[o], first[o] + nblk[o]) run object o's layer --
+// its activations, its weights, its partial buffer, its ticket words -- exactly as its own launch would (logical block index and
+// block count of that object), so a frame with eight classes fills the chip eight times over behind one launch ramp.
+struct ConvWaveKMultiArgs {
+    MultiRange range;                      // (padded to multiples of 8 blocks per object: xcd_remap counts from the object's first block)
+    int nblk[kMultiMax];                   // real block count of each object's layer
+    ConvWaveKArgs item[kMultiMax];
+};
+template <int MT, int NT, int WAVES, int DEPTH, int TAG = 0, bool SPREAD = false>
+__global__ __launch_bounds__(64 * WAVES, (MT * NT == 4 && WAVES == 4 && DEPTH == 2 ? 2 : 1)) void conv_wavek_multi_kernel(const ConvWaveKMultiArgs m) {
+    AAE_DYN_SMEM(smem_raw);
+    float* red = reinterpret_cast<float*>(smem_raw);
+    int* flag = reinterpret_cast<int*>(red + WAVES * MT * NT * 16 * 64);
+    const int o = multi_find(m.range, (int)blockIdx.x);
+    const int L = (int)blockIdx.x - m.range.first[o];
+    if (L >= m.nblk[o]) return;                                  // (padding block)
+    WaveKPrefetch none;
+    conv_wavek_block<MT, NT, WAVES, DEPTH, false, SPREAD>(m.item[o], L, m.nblk[o], red, flag, none, false);
+}
+
 }  // namespace aae

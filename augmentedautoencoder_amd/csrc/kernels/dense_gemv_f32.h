@@ -239,4 +239,17 @@ __global__ __launch_bounds__(256) void dense_gemv_f32_kernel(const DenseGemvArgs
     dense_gemv_block<MQ, TICKET, false>(p, (int)blockIdx.x, (int)blockIdx.y, (int)gridDim.x, smem_raw, none, false);
 }
 
+// ---- the dense layer of SEVERAL objects in one launch (multi_launch.h): grid.x = the objects' chunk ranges one behind the other
+struct DenseGemvMultiArgs {
+    MultiRange range;
+    DenseGemvArgs item[kMultiMax];
+};
+template <int MQ>
+__global__ __launch_bounds__(256) void dense_gemv_multi_kernel(const DenseGemvMultiArgs m) {
+    AAE_DYN_SMEM(smem_raw);
+    const int o = multi_find(m.range, (int)blockIdx.x);
+    f32x4 none[16];
+    dense_gemv_block<MQ, true, false>(m.item[o], (int)blockIdx.x - m.range.first[o], (int)blockIdx.y, m.range.first[o + 1] - m.range.first[o], smem_raw, none, false);
+}
+
 }  // namespace aae

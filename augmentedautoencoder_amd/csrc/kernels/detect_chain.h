@@ -178,9 +178,9 @@ __global__ __launch_bounds__(256, 1) void detect_chain_kernel(const DetectChainA
         for (int b = 0; b < MQ; ++b) { red_v[wave * MQ + b] = best_v[b]; red_i[wave * MQ + b] = best_i[b]; }
     }
     __syncthreads();
-    scan_store_block_partials<MQ>(s, red_v, red_i);
+    scan_store_block_partials<MQ>(s, red_v, red_i, blockIdx.x, gridDim.x);
     stamp();                                                     // this block's rows scanned
-    scan_ticket_finish<MQ>(s, red_v + 32);
+    scan_ticket_finish<MQ>(s, red_v + 32, blockIdx.x, gridDim.x);
     stamp();
 }
 

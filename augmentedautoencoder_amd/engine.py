@@ -540,6 +540,110 @@ class CodebookEngine(object):
         return q
 
 
+class MultiObjectQuery(object):
+    """A frame's detections of SEVERAL objects in one C call (aae_encode_nn_multi): the reference keeps one AAE per object
+    class in one process and runs one session.run per detected box, whatever its class
+    (m3_interface/ae_pose_estimator.py:61-78,143-170; 30 classes for T-LESS, cfg_m3vision/m3_config_tless.cfg:10-39).
+    items: [(EncoderEngine, CodebookEngine, n detections[, col_stride])] in the order the crops are concatenated.  Items
+    with n <= 4 at the default options are GROUPED -- one launch per layer across all of them (six launches per distinct n
+    instead of six per object); the rest take the per-object path inside the same call.  Bit-identical to one
+    EncoderEngine.encode_nn call per item.  The layout is fixed at construction (a detector's class mix changes per
+    frame: AePoseEstimator builds the item array per frame instead -- detect_nn_multi below); outputs are static device
+    tensors, valid until the next call."""
+
+    def __init__(self, items, device=None):
+        torch = _torch()
+        self.lib = _lib.load()
+        norm = [(it[0], it[1], int(it[2]), int(it[3]) if len(it) > 3 else 1) for it in items]
+        if not norm:
+            raise ValueError('MultiObjectQuery needs at least one item')
+        self.device = norm[0][1].device if device is None else torch.device(device)
+        for enc, cb, n, stride in norm:
+            if cb.device != self.device or (enc is not None and enc.device != self.device):
+                raise ValueError('MultiObjectQuery: every engine must live on %s' % (self.device,))
+            cb.ensure_upright(stride, 1)
+        self._keep = norm                                   # the engines own the handles: keep them alive
+        self.items = multi_item_array(norm)
+        self.n_items = len(norm)
+        self.rows = int(self.lib.aae_multi_rows(self.items, self.n_items))
+        encs = [e for e, _, _, _ in norm if e is not None]
+        self.cfg = encs[0].cfg if encs else None
+        self.J = norm[0][1].J
+        self.ws = _Workspace(self.device)
+        self.z = torch.empty((self.rows, self.J), dtype=torch.float32, device=self.device)
+        self.idx = torch.empty((self.rows,), dtype=torch.int64, device=self.device)
+        self.score = torch.empty((self.rows,), dtype=torch.float32, device=self.device)
+        self.launches = None                                # kernel launches of the grouped part of the last call
+
+    def __call__(self, x):
+        """x: the crops of all items, [rows,H,W,C] uint8 or float32 on the device, in item order -> (z, idx, score)"""
+        torch = _torch()
+        if self.cfg is None:
+            raise ValueError('MultiObjectQuery without encoders answers nn(z) only')
+        if (not torch.is_tensor(x) or x.device != self.device or not x.is_contiguous() or tuple(x.shape) != (self.rows,) + tuple(self.cfg.shape)
+                or x.dtype not in (torch.uint8, torch.float32)):
+            raise ValueError('MultiObjectQuery: need a contiguous uint8 / float32 device tensor of shape %s' % (((self.rows,) + tuple(self.cfg.shape)),))
+        dt = _lib.AAE_DTYPE_U8 if x.dtype == torch.uint8 else _lib.AAE_DTYPE_F32
+        nbytes = self.lib.aae_multi_workspace_bytes(self.items, self.n_items, 0)
+        _, ws_ptr = self.ws.get(nbytes)
+        with _on_device(self.device):
+            rc = self.lib.aae_encode_nn_multi(self.items, self.n_items, ctypes.c_void_p(x.data_ptr()), dt, ctypes.c_void_p(self.z.data_ptr()),
+                                              ctypes.c_void_p(self.idx.data_ptr()), ctypes.c_void_p(self.score.data_ptr()),
+                                              ctypes.c_void_p(ws_ptr), nbytes, _stream_ptr(torch))
+        _lib.check(self.lib, rc, 'aae_encode_nn_multi')
+        self.launches = int(self.lib.aae_multi_last_launches())
+        return self.z, self.idx, self.score
+
+    def nn(self, z):
+        """the codebook stage alone (aae_codebook_nn_multi): z [rows,J] raw latent codes in item order -> (idx, score);
+        the grouped items' codebooks are streamed by ONE launch per distinct n"""
+        torch = _torch()
+        if not torch.is_tensor(z) or z.device != self.device or z.dtype != torch.float32 or not z.is_contiguous() or tuple(z.shape) != (self.rows, self.J):
+            raise ValueError('MultiObjectQuery.nn: need a contiguous float32 device tensor [%d,%d]' % (self.rows, self.J))
+        nbytes = self.lib.aae_multi_workspace_bytes(self.items, self.n_items, 1)
+        _, ws_ptr = self.ws.get(nbytes)
+        with _on_device(self.device):
+            rc = self.lib.aae_codebook_nn_multi(self.items, self.n_items, ctypes.c_void_p(z.data_ptr()), ctypes.c_void_p(self.idx.data_ptr()),
+                                                ctypes.c_void_p(self.score.data_ptr()), ctypes.c_void_p(ws_ptr), nbytes, _stream_ptr(torch))
+        _lib.check(self.lib, rc, 'aae_codebook_nn_multi')
+        self.launches = int(self.lib.aae_multi_last_launches())
+        return self.idx, self.score
+
+
+def multi_item_array(items):
+    """[(EncoderEngine or None, CodebookEngine, n, col_stride)] -> the aae_multi_item array of the C ABI"""
+    arr = (_lib.MultiItem * len(items))()
+    for k, (enc, cb, n, stride) in enumerate(items):
+        arr[k].enc = enc.handle if enc is not None else None
+        arr[k].cb = cb.handle
+        arr[k].n = int(n)
+        arr[k].col_stride = int(stride)
+    return arr
+
+
+def detect_nn_multi(items, image, rows, crops, z, idx, score, ws):
+    """ALL detections of a frame -- every class, in the order of `items` [(EncoderEngine, CodebookEngine, n, col_stride)] -- in
+    ONE C call (aae_detect_nn_multi): crop + bilinear resize of the boxes `rows` (int32 [total,5]) out of `image`, then
+    one launch per layer across the classes with at most four detections each (per-object path for the rest).  Storage as
+    for EncoderEngine.detect_nn; ws: a _Workspace on the engines' device.  Returns the launches of the grouped part."""
+    torch = _torch()
+    lib = _lib.load()
+    arr = multi_item_array(items)
+    k = len(items)
+    dev = items[0][0].device
+    for enc, cb, n, stride in items:
+        cb.ensure_upright(stride, 1)
+    nbytes = lib.aae_multi_workspace_bytes(arr, k, 0)
+    _, ws_ptr = ws.get(nbytes)
+    with _on_device(dev):
+        rc = lib.aae_detect_nn_multi(arr, k, ctypes.c_void_p(image.data_ptr()), int(image.shape[0]), int(image.shape[1]), int(image.shape[2]),
+                                     ctypes.c_void_p(rows.data_ptr()), ctypes.c_void_p(crops.data_ptr()), ctypes.c_void_p(z.data_ptr()),
+                                     ctypes.c_void_p(idx.data_ptr()), ctypes.c_void_p(score.data_ptr()), ctypes.c_void_p(ws_ptr), nbytes,
+                                     _stream_ptr(torch))
+    _lib.check(lib, rc, 'aae_detect_nn_multi')
+    return int(lib.aae_multi_last_launches())
+
+
 def _pair_operand(t, dtype, device, what):
     torch = _torch()
     if not torch.is_tensor(t) or t.dtype != dtype or t.device != device:

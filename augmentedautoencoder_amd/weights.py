@@ -91,6 +91,12 @@ class EncoderConfig(object):
             f += 2 * Ho * Wo * k * k * ci * co
         return f + 2 * self.flatten_size * self.latent_space_size
 
+    def param_bytes(self):
+        """fp32 bytes of the encoder's kernels + biases (59.4 MB for the default net: SURVEY.md section 8a)"""
+        k = self.kernel_size
+        n = sum(k * k * ci * co + co for (_, _, ci, _, _, co) in self.layer_shapes())
+        return 4 * (n + self.flatten_size * self.latent_space_size + self.latent_space_size)
+
     def to_desc(self):
         d = _lib.EncoderDesc()
         d.in_h, d.in_w, d.in_c = self.shape

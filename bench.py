@@ -48,9 +48,11 @@ PEAK_X3H_TFLOPS = 2500.0 / 3   # f32x3h: dense fp16 MFMA peak / 3 MFMAs per fp32
 PEAK_HBM_GBPS = 8000.0         # HBM3E spec
 
 
-def cpu_baseline(weights, E, crops, min_seconds=12.0, max_iters=60):
+def cpu_baseline(weights, E, crops, min_seconds=10.0, max_iters=60):
     """The oracle's fp32 torch-CPU restatement of the same step on a bounded sample
-    (checker code timed as the CPU reference point; never on the product path)."""
+    (checker code timed as the CPU reference point; never on the product path).  Three legs, as BASELINE.md section 2
+    lays them out: B = 64 end to end (the value), its encode-only / NN-only split, and B = 1 -- the reference's real
+    operating point, one session.run per detection (m3_interface/ae_pose_estimator.py:143-170)."""
     import numpy as np
     import torch
     from oracle import reference_cpu as ref
@@ -60,16 +62,32 @@ def cpu_baseline(weights, E, crops, min_seconds=12.0, max_iters=60):
     nthreads = min(32, os.cpu_count() or 1)
     torch.set_num_threads(nthreads)
     sample = crops[:64]
-    ref.encoder_forward_torch(ref.input_to_float(sample[:8]), weights, [2, 2, 2, 2], False, 'float32')   # warm-up
-    done, t0 = 0, time.perf_counter()
-    while True:
-        z = ref.encoder_forward_torch(ref.input_to_float(sample), weights, [2, 2, 2, 2], False, 'float32')
+
+    def encode(x):
+        return ref.encoder_forward_torch(ref.input_to_float(x), weights, [2, 2, 2, 2], False, 'float32')
+
+    def nn(z):
         cs = ref.cos_similarity(z, E, np.float32)
-        ref.nearest_indices_reference(cs, 1)
-        done += 1
-        el = time.perf_counter() - t0
-        if el >= min_seconds or done >= max_iters:
-            break
+        return ref.nearest_indices_reference(cs, 1)
+
+    def run(fn, seconds, cap):
+        done, t0 = 0, time.perf_counter()
+        while True:
+            fn()
+            done += 1
+            el = time.perf_counter() - t0
+            if el >= seconds or done >= cap:
+                return done, el
+    encode(sample[:8])                                             # warm-up
+    done, el = run(lambda: nn(encode(sample)), min_seconds, max_iters)
+    z64 = encode(sample)
+    d_e, t_e = run(lambda: encode(sample), 1.5, 20)
+    d_n, t_n = run(lambda: nn(z64), 1.0, 50)
+    one = sample[:1]
+    encode(one)
+    d_1, t_1 = run(lambda: nn(encode(one)), 2.0, 400)
+    d_1e, t_1e = run(lambda: encode(one), 1.0, 400)
+    d_1n, t_1n = run(lambda: nn(z64[:1]), 0.7, 400)
     model = 'unknown'
     try:
         with open('/proc/cpuinfo') as f:
@@ -79,6 +97,11 @@ def cpu_baseline(weights, E, crops, min_seconds=12.0, max_iters=60):
     return {'value': round(done * len(sample) / el, 2), 'unit': 'crops/s', 'cores': nthreads, 'kind': 'port',
             'sample': '%d x %d crops, fp32 torch-CPU (oneDNN) encoder + numpy fp32 codebook matmul/argmax, %.1f s'
                       % (done, len(sample), el),
+            'B64': {'encode+nn_crops_per_s': round(done * 64 / el, 2), 'encode_only_crops_per_s': round(d_e * 64 / t_e, 2),
+                    'nn_only_crops_per_s': round(d_n * 64 / t_n, 1)},
+            'B1': {'encode+nn_crops_per_s': round(d_1 / t_1, 2), 'encode+nn_ms': round(t_1 / d_1 * 1e3, 2),
+                   'encode_only_ms': round(t_1e / d_1e * 1e3, 2), 'nn_only_ms': round(t_1n / d_1n * 1e3, 2),
+                   'note': "the reference's operating point: one session.run + np.argmax per detection"},
             'host': {'cpu_model': model, 'logical_cpus': os.cpu_count(),
                      'note': 'threads = best point of a sweep (8..256) on this host; more threads are slower'}}
 
@@ -148,7 +171,8 @@ def main():
     ap.add_argument('--enc-opt', action='append', default=[], metavar='NAME=INT',
                     help='set an encoder option before measuring (kernel-variant A/B under a profiler); recorded in config')
     ap.add_argument('--no-extras', action='store_true', help='skip the secondary measurements (latency, scan, config3, config5, pcie, decoder)')
-    ap.add_argument('--no-config4', action='store_true', help='(process-group runs) skip the mixed-batch config4 measurement')
+    ap.add_argument('--no-config4', action='store_true', help='skip the mixed-batch config4 measurement (eight objects, 256 crops)')
+    ap.add_argument('--config4', action='store_true', help='measure config4 even under --no-extras')
     ap.add_argument('--dry-run-dist', action='store_true',
                     help='take the N-rank launch path on CPU (gloo): process group + one all_gather, no GPU work (launch-path test)')
     args = ap.parse_args()
@@ -261,12 +285,14 @@ def main():
         dom_flops = per[dom['kernel']][1]
         achieved = dom_flops / (dom['ms'] * 1e-3) / 1e12
         peak = PEAK_F32_TFLOPS if precision == 'f32' else PEAK_X3H_TFLOPS
-        traffic, traffic_src = None, None
+        traffic, traffic_src, busy = None, None, {}
         try:      # HBM-side bytes per launch from the committed rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE)
             with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
                 tj = json.load(f)
             traffic = tj.get(precision, {}).get(dom['kernel'].split(':')[0])
             traffic_src = tj.get(precision + '_source')
+            if precision == 'f32':
+                busy = dict(tj.get('mfma', {}).get(dom['kernel'].split(':')[0], {}), source=tj.get('mfma_source'))
         except Exception:
             traffic = None
         return {
@@ -276,7 +302,9 @@ def main():
                          'unit': 'TFLOP/s', 'frac': round(achieved / peak, 4), 'traffic': traffic,
                          'traffic_source': ('profiles/traffic.json <- ' + (traffic_src or 'rocprofv3 PMC passes of an earlier run of this command: 2*FETCH_SIZE + WRITE_SIZE') +
                                             '; a committed measurement, not taken in this run (PMC collection needs the profiler)') if traffic is not None else None,
-                         'flops_per_launch': dom_flops, 'avg_ms': dom['ms']},
+                         'flops_per_launch': dom_flops, 'avg_ms': dom['ms'],
+                         'mfma_busy_frac': busy.get('mfma_busy_frac'), 'delivered_GHz_under_pmc': busy.get('delivered_GHz'),
+                         'mfma_busy_source': busy.get('source')},
             'encoder_tflops': round(cfg.flops_per_crop() * B / (sum(k['ms'] for k in kernels) * 1e-3) / 1e12, 2),
             'kernels': kernels,
             'rank_ms_per_step': rank_ms,
@@ -303,19 +331,37 @@ def main():
         return e0.elapsed_time(e1) / reps * 1e3
 
     extras = {}
-    if use_dist and not args.no_config4 and args.precision == 'f32':
-        # ---- BASELINE config 4 as SURVEY 8d defines it: ONE mixed batch of 256 crops, class labels integers(0, N_obj), N_obj = N
-        # objects sharded one per GPU; every rank runs encode + scan on its bucket (the host routes by class id, as the
-        # reference's per-box loop does, m3_interface/ae_pose_estimator.py:143-170) and one RCCL all_gather of the padded
-        # (index, score) pairs re-assembles the batch.  Strong scaling of a fixed 256-crop batch: per-GPU batches shrink to
-        # 256 / N, so this is a latency-regime number, reported beside the weak-scaling headline.
+    N_OBJ = 8                                          # eight objects (seeds 2024 + i / 7 + i)
+    objs = {rank: (enc, cb)}
+
+    def obj(i):
+        """object i: its own encoder weights and its own 92232-row codebook (object `rank` is the headline's)"""
+        if i not in objs:
+            objs[i] = (EncoderEngine(cfg, synth.make_weights(seed=2024 + i), device=dev, max_batch=B),
+                       CodebookEngine(synth.make_codebook(N_ROWS, 128, seed=7 + i), device=dev))
+        return objs[i]
+
+    if not args.no_config4 and (not args.no_extras or args.config4) and args.precision == 'f32':
+        # ---- BASELINE config 4 as SURVEY 8d defines it: ONE mixed batch of 256 crops with class labels integers(0, 8): EIGHT objects at
+        # every N, object o on rank o mod N (8 / N objects per GPU); every rank runs encode + scan on its buckets (the host routes by
+        # class id, as the reference's per-box loop does, m3_interface/ae_pose_estimator.py:143-170) and -- N > 1 -- one RCCL all_gather
+        # of the padded (index, score) pairs re-assembles the batch.  Strong scaling of a fixed 256-crop batch over 1 / 2 / 4 / 8 GPUs:
+        # the N = 1 line is the single-GPU multi-object number the curve starts from.
         import numpy as np
-        from augmentedautoencoder_amd.dist import ShardedPoseEngine
-        labels = np.random.default_rng(0).integers(0, world, BATCH)
+        from augmentedautoencoder_amd.dist import ShardedPoseEngine, owner_of
+        labels = np.random.default_rng(0).integers(0, N_OBJ, BATCH)
         all_crops = torch.from_numpy(synth.make_crops(BATCH, seed=4321)).to(dev)     # the same mixed batch on every rank
-        mine = torch.from_numpy(np.flatnonzero(labels == rank)).to(dev)
-        my_bucket = {rank: all_crops[mine].contiguous()}                             # host-side routing, outside the timed region
-        spe = ShardedPoseEngine(lambda obj, c: enc.encode_nn(cb, c, 1)[1:], device=dev, pack_pairs=pack_pairs, unpack_pairs=unpack_pairs)
+        mine = [o for o in range(N_OBJ) if owner_of(o, world) == rank]
+        my_bucket = {o: all_crops[torch.from_numpy(np.flatnonzero(labels == o)).to(dev)].contiguous() for o in mine
+                     if (labels == o).any()}                                         # host-side routing, outside the timed region
+        for o in mine:
+            obj(o)
+
+        def local_infer(o, c):
+            e, c_b = objs[o]
+            return e.encode_nn(c_b, c, 1)[1:]
+        spe = ShardedPoseEngine(local_infer, world_size=None if use_dist else 1, rank=None if use_dist else 0, device=dev,
+                                pack_pairs=pack_pairs, unpack_pairs=unpack_pairs)
         for _ in range(max(args.warmup, 3)):
             spe.infer(my_bucket, labels)
         fence()
@@ -323,17 +369,21 @@ def main():
         for _ in range(args.steps):
             idx4, _ = spe.infer(my_bucket, labels)
         torch.cuda.synchronize()
-        dist.barrier()
-        torch.cuda.synchronize()
-        t4 = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
-        dist.all_reduce(t4, op=dist.ReduceOp.MAX)
-        t4 = float(t4.item())
-        extras['config4'] = {'workload': 'one mixed batch of %d crops, %d objects sharded 1 per GPU, routed by class id, RCCL all_gather of '
-                                         '(idx, score) pairs padded to %d rows per rank' % (BATCH, world, BATCH),
+        t4 = time.perf_counter() - t0
+        if use_dist:
+            dist.barrier()
+            torch.cuda.synchronize()
+            t4 = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+            dist.all_reduce(t4, op=dist.ReduceOp.MAX)
+            t4 = float(t4.item())
+        extras['config4'] = {'workload': 'one mixed batch of %d crops over %d objects (own weights + own 92232-row codebook each), object o on rank o mod %d '
+                                         '(%d per GPU), routed by class id%s' % (BATCH, N_OBJ, world, len(mine),
+                                                                               ', RCCL all_gather of (idx, score) pairs padded to %d rows per rank' % BATCH if use_dist else ', single GPU: no collective'),
                              'value': round(BATCH * args.steps / t4, 1), 'unit': 'crops/s', 'ms_per_batch': round(t4 / args.steps * 1e3, 4),
-                             'bucket_sizes': np.bincount(labels, minlength=world).tolist(), 'scaling': 'strong (global batch fixed)',
+                             'objects': N_OBJ, 'objects_per_gpu': len(mine),
+                             'bucket_sizes': np.bincount(labels, minlength=N_OBJ).tolist(), 'scaling': 'strong (global batch and object count fixed)',
                              'answers_complete': bool((idx4 >= 0).all().item()),
-                             'launches_per_step_besides_encode_nn': 'pack_pairs, all_gather, unpack_pairs (buffers owned by the cached plan)'}
+                             'launches_per_step_besides_encode_nn': 'pack_pairs per object, %sunpack_pairs (buffers owned by the cached plan)' % ('all_gather, ' if use_dist else '')}
     if not use_dist and not args.no_extras and args.precision == 'f32':
         from augmentedautoencoder_amd.engine import CapturedNearestNeighbour, DecoderEngine, StreamingNearestNeighbour
         from augmentedautoencoder_amd.weights import DecoderConfig
@@ -355,7 +405,58 @@ def main():
                        'inside its own launch; floor of this chain = 27 us of fp32 MFMA work (4.28 GFLOP at 157 TF) + 107 MB of weights/codebook.  '
                        'The same query as conv1 + ONE persistent launch (option detect_chain, grid barriers between the phases) is built, '
                        'bit-identical and measured slower: profiles/r11_small/chain_vs_six_launches_latency.jsonl')
+        # cold: the same query rotating over 4 objects (4 x 107 MB of weights + codebook > the 256 MB Infinity Cache), so that every
+        # call finds its weights and codebook in HBM -- a frame's detections belong to different classes (ae_pose_estimator.py:61-78)
+        rot = [obj(i) for i in range(4)]
+        for b in (1, 4):
+            xb = x[:b].contiguous()
+            k = [0]
+
+            def cold_query():
+                e, c_b = rot[k[0] % len(rot)]
+                e.encode_nn(c_b, xb, 1)
+                k[0] += 1
+            lat['B%d_cold_us' % b] = round(time_us(cold_query, 200, warm=8), 2)
         extras['latency'] = lat
+        # ---- a frame with detections of EIGHT classes (the reference keeps one AAE per class in one process and a frame's boxes spread
+        # over them: m3_config_tless.cfg:10-39, ae_pose_estimator.py:61-78,143-170): 8 objects x d detections, visited in turn, so
+        # 8 x 107 MB = 856 MB of weights + codebooks cannot sit in the Infinity Cache.  sequential = one aae_encode_nn per object;
+        # grouped = ONE launch per layer across the objects (aae_encode_nn_multi), bit-identical answers.
+        all8 = [obj(i) for i in range(N_OBJ)]
+        xs = [torch.from_numpy(synth.make_crops(4, seed=500 + i)).to(dev) for i in range(N_OBJ)]
+        from augmentedautoencoder_amd import engine as _engine
+        MultiQuery = getattr(_engine, 'MultiObjectQuery', None)
+        lm = {'objects': N_OBJ, 'weights_plus_codebooks_MB': round(N_OBJ * (cfg.param_bytes() + cb_bytes) / 1e6, 1)}
+        for d in (1, 4):
+            def frame_seq():
+                for (e, c_b), xi in zip(all8, xs):
+                    e.encode_nn(c_b, xi[:d], 1)
+            seq = time_us(frame_seq, 40, warm=4)
+            row = {'sequential_us': round(seq, 1), 'sequential_us_per_detection': round(seq / (N_OBJ * d), 2)}
+            if MultiQuery is not None:
+                mq = MultiQuery([(e, c_b, d) for e, c_b in all8], device=dev)
+                xcat = torch.cat([xi[:d] for xi in xs]).contiguous()
+                grp = time_us(lambda: mq(xcat), 40, warm=4)
+                row.update({'grouped_us': round(grp, 1), 'grouped_us_per_detection': round(grp / (N_OBJ * d), 2),
+                            'grouped_over_sequential': round(grp / seq, 3), 'launches_grouped': mq.launches, 'launches_sequential': 6 * N_OBJ,
+                            'mfma_floor_us': round(N_OBJ * d * cfg.flops_per_crop() / (PEAK_F32_TFLOPS * 1e6), 1),
+                            'hbm_floor_us': round(N_OBJ * (cfg.param_bytes() + cb_bytes) / (PEAK_HBM_GBPS * 1e3), 1)})
+            lm['8x%d' % d] = row
+        if MultiQuery is not None:
+            # the codebook stage alone over the eight codebooks (378 MB > the 256 MB Infinity Cache: every call streams from HBM):
+            # ONE launch (aae_codebook_nn_multi) against eight aae_codebook_nn calls
+            z8 = torch.randn(N_OBJ, 128, device=dev)
+            mqs = MultiQuery([(None, c_b, 1) for _, c_b in all8], device=dev)
+            one = time_us(lambda: mqs.nn(z8), 100, warm=10)
+
+            def scans_seq():
+                for k8, (_, c_b) in enumerate(all8):
+                    c_b.nn(z8[k8:k8 + 1], 1, 1)
+            seq8 = time_us(scans_seq, 100, warm=10)
+            lm['scan_8_codebooks'] = {'grouped_us': round(one, 2), 'sequential_us': round(seq8, 2), 'bytes': N_OBJ * cb_bytes,
+                                      'grouped_GBps': round(N_OBJ * cb_bytes / one / 1e3, 1), 'grouped_frac_of_hbm_peak': round(N_OBJ * cb_bytes / one / 1e3 / PEAK_HBM_GBPS, 3),
+                                      'sequential_frac_of_hbm_peak': round(N_OBJ * cb_bytes / seq8 / 1e3 / PEAK_HBM_GBPS, 3), 'launches_grouped': mqs.launches}
+        extras['latency_multi'] = lm
         # ---- the codebook query alone
         z = enc.encode(x)
         z1 = z[:1].contiguous()

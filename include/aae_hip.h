@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define AAE_ABI_VERSION 2
+#define AAE_ABI_VERSION 3
 
 #define AAE_OK 0
 #define AAE_ERR_INVALID (-1)      /* bad argument                                  */
@@ -291,6 +291,40 @@ int aae_crop_resize_u8(const void* img, int H, int W, int C, const int32_t* boxe
 int aae_detect_nn(aae_encoder* enc, aae_codebook* cb, const void* img, int H, int W, int C, const int32_t* boxes, int n,
                   int col_stride, void* crops, float* z_out, int64_t* idx_out, float* score_out,
                   void* enc_workspace, size_t enc_ws_bytes, void* cb_workspace, size_t cb_ws_bytes, void* stream);
+
+/* ---- A frame's detections of SEVERAL objects in one call: one launch per LAYER across the objects ---------------------------
+ * The reference keeps one AAE (encoder weights + codebook) per object class in one process -- 30 for T-LESS
+ * (auto_pose/cfg_m3vision/m3_config_tless.cfg:10-39, m3_interface/ae_pose_estimator.py:61-78) -- and runs one session.run per
+ * detected box (:143-170), whatever class it belongs to.  An item = (that class's encoder, its codebook, the n boxes of the
+ * class in this frame, col_stride as in aae_codebook_nn).  Inputs and outputs are concatenated in item order: x / crops
+ * [rows,H,W,C], z_out [rows,latent], idx_out [rows] int64, score_out [rows], rows = sum of n (aae_multi_rows).
+ * Items with n <= 4 whose per-object call would run the per-detection chain (fp32, default options, fp32 codebook, stride 1
+ * or a prepared upright copy) are GROUPED: conv1, every later conv layer, the dense GEMV and the codebook scan each run as ONE
+ * launch over all grouped items of equal n -- every block the per-object launch's block on the per-object launch's arguments,
+ * tickets per (object, tile) -- so a frame with C classes costs 6 launches per distinct n instead of 6 C.  All other items are
+ * answered by aae_encode_nn inside the same call.  Answers are bit-identical to per-object aae_encode_nn calls either way.
+ * All encoders must share the crop shape and the latent size.  The workspace (aae_multi_workspace_bytes; scan_only = 1 for
+ * aae_codebook_nn_multi) holds a slice per grouped item: nothing in it outlives the call. */
+typedef struct aae_multi_item {
+    aae_encoder* enc;        /* may be NULL for aae_codebook_nn_multi */
+    aae_codebook* cb;
+    int32_t n;               /* detections of this object (>= 1) */
+    int32_t col_stride;      /* 1, or num_cyclo for the upright search */
+} aae_multi_item;
+
+size_t aae_multi_workspace_bytes(const aae_multi_item* items, int n_items, int scan_only);
+int aae_multi_rows(const aae_multi_item* items, int n_items);
+int aae_encode_nn_multi(const aae_multi_item* items, int n_items, const void* x, int x_dtype, float* z_out, int64_t* idx_out,
+                        float* score_out, void* workspace, size_t ws_bytes, void* stream);
+/* the codebook stage alone: z [rows,J] raw latent codes in item order; grouped items: ONE scan launch over their codebooks */
+int aae_codebook_nn_multi(const aae_multi_item* items, int n_items, const float* z, int64_t* idx_out, float* score_out,
+                          void* workspace, size_t ws_bytes, void* stream);
+/* aae_crop_resize_u8 of all boxes (device or pinned int32 [rows,5], item order) into `crops` (device scratch [rows,H,W,C] uint8)
+ * + aae_encode_nn_multi: all launches of a frame in ONE call (what AePoseEstimator.process does box by box). */
+int aae_detect_nn_multi(const aae_multi_item* items, int n_items, const void* img, int H, int W, int C, const int32_t* boxes,
+                        void* crops, float* z_out, int64_t* idx_out, float* score_out, void* workspace, size_t ws_bytes, void* stream);
+/* kernel launches the grouped part of the calling thread's last multi call queued (diagnostics / bench) */
+int aae_multi_last_launches(void);
 
 /* ---- Decoder ("next" row N4): auto_pose/ae/decoder.py:36-84 (Decoder.x), inference only ---------
  * Decoder(reconstruction_target, latent_code, num_filters, kernel_size, strides, ...) as

@@ -235,3 +235,82 @@ class EmuDecoder(object):
         if self.h:
             self.L.aae_decoder_destroy(self.h)
             self.h = None
+
+
+# ---- grouped multi-object query (aae_encode_nn_multi / aae_codebook_nn_multi / aae_detect_nn_multi) ----------------------------
+def _multi_items(items):
+    arr = (_lib.MultiItem * len(items))()
+    for k, (enc, cb, n, stride) in enumerate(items):
+        arr[k].enc = enc.h if enc is not None else None
+        arr[k].cb = cb.h
+        arr[k].n = int(n)
+        arr[k].col_stride = int(stride)
+    return arr
+
+
+class MultiWorkspace(object):
+    """One grow-only scratch buffer reused from call to call (what an estimator does): whatever the previous frame left in
+    it -- activations, partials, ticket words of OTHER objects at other offsets -- is what the next frame finds."""
+
+    def __init__(self):
+        self.buf = _aligned(256)
+
+    def get(self, n):
+        if len(self.buf) < n:
+            self.buf = _aligned(n)
+        return self.buf
+
+
+def encode_nn_multi(items, x, ws=None):
+    """items: [(EmuEncoder, EmuCodebook, n, col_stride)]; x: the crops of all items, concatenated in item order.
+    Returns (z [rows,J], idx [rows], score [rows], launches of the grouped part)."""
+    L = lib()
+    arr = _multi_items(items)
+    x = np.ascontiguousarray(x)
+    dt = _lib.AAE_DTYPE_U8 if x.dtype == np.uint8 else _lib.AAE_DTYPE_F32
+    rows = L.aae_multi_rows(arr, len(items))
+    assert rows == x.shape[0], (rows, x.shape)
+    nbytes = L.aae_multi_workspace_bytes(arr, len(items), 0)
+    buf = (ws or MultiWorkspace()).get(nbytes)
+    J = items[0][0].cfg.latent_space_size
+    z = np.full((rows, J), np.nan, dtype=np.float32)
+    idx = np.full((rows,), -7, dtype=np.int64)
+    score = np.full((rows,), np.nan, dtype=np.float32)
+    rc = L.aae_encode_nn_multi(arr, len(items), x.ctypes.data, dt, z.ctypes.data, idx.ctypes.data, score.ctypes.data, buf.ctypes.data, nbytes, None)
+    _lib.check(L, rc, 'aae_encode_nn_multi')
+    return z, idx, score, L.aae_multi_last_launches()
+
+
+def codebook_nn_multi(items, z, ws=None):
+    L = lib()
+    arr = _multi_items(items)
+    z = np.ascontiguousarray(z, dtype=np.float32)
+    rows = L.aae_multi_rows(arr, len(items))
+    assert rows == z.shape[0]
+    nbytes = L.aae_multi_workspace_bytes(arr, len(items), 1)
+    buf = (ws or MultiWorkspace()).get(nbytes)
+    idx = np.full((rows,), -7, dtype=np.int64)
+    score = np.full((rows,), np.nan, dtype=np.float32)
+    rc = L.aae_codebook_nn_multi(arr, len(items), z.ctypes.data, idx.ctypes.data, score.ctypes.data, buf.ctypes.data, nbytes, None)
+    _lib.check(L, rc, 'aae_codebook_nn_multi')
+    return idx, score, L.aae_multi_last_launches()
+
+
+def detect_nn_multi(items, img, boxes, ws=None):
+    L = lib()
+    arr = _multi_items(items)
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    boxes = np.ascontiguousarray(np.asarray(boxes, dtype=np.int32).reshape(-1, 5))
+    rows = L.aae_multi_rows(arr, len(items))
+    assert rows == boxes.shape[0]
+    cfg = items[0][0].cfg
+    crops = np.full((rows,) + tuple(cfg.shape), 123, dtype=np.uint8)
+    nbytes = L.aae_multi_workspace_bytes(arr, len(items), 0)
+    buf = (ws or MultiWorkspace()).get(nbytes)
+    z = np.full((rows, cfg.latent_space_size), np.nan, dtype=np.float32)
+    idx = np.full((rows,), -7, dtype=np.int64)
+    score = np.full((rows,), np.nan, dtype=np.float32)
+    rc = L.aae_detect_nn_multi(arr, len(items), img.ctypes.data, img.shape[0], img.shape[1], img.shape[2], boxes.ctypes.data, crops.ctypes.data,
+                               z.ctypes.data, idx.ctypes.data, score.ctypes.data, buf.ctypes.data, nbytes, None)
+    _lib.check(L, rc, 'aae_detect_nn_multi')
+    return crops, z, idx, score

@@ -50,10 +50,11 @@ def test_more_ranks_than_gpus_is_one_json_line_with_an_error_and_no_traceback():
 @pytest.mark.gpu
 def test_rccl_code_path_of_the_bench_on_one_gpu():
     """the N > 1 code path (RCCL process group, pair packing, all_gather, config4) as a subprocess at world size 1"""
-    rc, out, err = _run(['--gpus', '1', '--force-dist', '--steps', '2', '--warmup', '1', '--no-extras', '--no-split-precision',
+    rc, out, err = _run(['--gpus', '1', '--force-dist', '--steps', '2', '--warmup', '1', '--no-extras', '--config4', '--no-split-precision',
                          '--no-cpu-baseline', '--profile-steps', '1'])
     assert rc == 0, err[-3000:]
     line = out[-1]
     assert line['rccl_world_size'] == 1 and line['n_gpus'] == 1
     assert line['config4']['answers_complete'] is True
+    assert line['config4']['objects'] == 8 and line['config4']['objects_per_gpu'] == 8        # eight objects at every N (SURVEY 8d)
     assert line['value'] > 1000

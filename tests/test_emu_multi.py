@@ -1,0 +1,217 @@
+"""The grouped multi-object query (aae_encode_nn_multi & co., csrc/aae_multi_impl.h, kernels/multi_launch.h) on the CPU fiber
+emulator: one launch per layer across objects must give, bit for bit, what one aae_encode_nn call per object gives -- in
+every block order (every split reduction is finished by 'the last block to arrive'), with a workspace that carries
+whatever another frame's objects left in it, and for items the grouped kernels do not cover (answered by the per-object
+path inside the same call)."""
+import numpy as np
+import pytest
+
+import emu_backend as eb
+from augmentedautoencoder_amd import _lib
+from augmentedautoencoder_amd.weights import EncoderConfig
+from oracle import reference_cpu as ref
+from oracle import synth
+
+
+def _object(cfg, seed, N, opts=None, dtype='f32'):
+    w = synth.make_weights(seed=seed, shape=cfg.shape, num_filter=cfg.num_filter, strides=cfg.strides, latent=cfg.latent_space_size,
+                           batch_norm=cfg.batch_norm, kernel_size=cfg.kernel_size)
+    enc = eb.EmuEncoder(w, cfg)
+    for k, v in (opts or {}).items():
+        enc.set_option(k, v)
+    cb = eb.EmuCodebook(synth.make_codebook(N, cfg.latent_space_size, seed=seed + 100, planted_duplicates=5), dtype=dtype)
+    return enc, cb, w
+
+
+def _per_object(items, x):
+    zs, idxs, scores, at = [], [], [], 0
+    for enc, cb, n, stride in items:
+        z, i, s = eb.encode_nn(enc, cb, x[at:at + n], stride)
+        zs.append(z), idxs.append(i[:, 0]), scores.append(s[:, 0])
+        at += n
+    return np.concatenate(zs), np.concatenate(idxs), np.concatenate(scores)
+
+
+def _close(objs):
+    for enc, cb, _ in objs:
+        enc.close()
+        cb.close()
+
+
+# (detections per object, filters of the four conv layers, planner thresholds) that make plan_wavek choose each wave-tile shape the
+# grouped kernels are instantiated for on a 16 x 16 input (tests/test_emu_kernels.py: the persistent launch's cases)
+_SHAPE_CASES = {
+    '000': (1, [32, 64, 64, 64], {}),
+    '100': (2, [32, 256, 64, 64], {'wavek_tiny_max_tiles': 2, 'wavek_narrow_max_tiles': 128}),
+    '010': (3, [32, 64, 256, 64], {'wavek_tiny_max_tiles': 2, 'wavek_narrow_max_tiles': 128}),
+    '210': (4, [32, 384, 256, 64], {'wavek_tiny_max_tiles': 2, 'wavek_narrow_max_tiles': 4}),
+}
+
+
+@pytest.mark.parametrize('order', [0, 1, 2])
+@pytest.mark.parametrize('shapes', ['000', '100', '010', '210'])
+def test_one_launch_per_layer_across_objects_equals_the_per_object_calls(shapes, order):
+    n, filters, opts = _SHAPE_CASES[shapes]
+    cfg = EncoderConfig((16, 16, 3), filters, [2, 2, 2, 1], 5, 128, True)
+    eb.set_block_order(order)
+    try:
+        objs = [_object(cfg, 300 + 7 * o, 36 * (9 + 2 * o) + 3 * o, opts) for o in range(3)]       # three objects, codebooks of different sizes
+        items = [(e, c, n, 1) for e, c, _ in objs]
+        x = synth.make_crops(3 * n, seed=55, shape=cfg.shape)
+        z0, i0, s0 = _per_object(items, x)
+        z1, i1, s1, launches = eb.encode_nn_multi(items, x)
+        assert launches == 6                                             # conv1, three wave-split-K layers, dense GEMV, scan -- for all three objects
+        assert np.array_equal(z1, z0) and np.array_equal(i1, i0) and np.array_equal(s1, s0)
+        for k, (e, c, w) in enumerate(objs):                             # ... and the answers are right, not just equal
+            z64 = ref.encoder_forward_np(ref.input_to_float(x[k * n:(k + 1) * n]), w, cfg.strides, cfg.batch_norm)
+            assert np.abs(z1[k * n:(k + 1) * n] - z64).max() / np.abs(z64).max() < 5e-6
+            cs = c.similarity(z1[k * n:(k + 1) * n])
+            assert np.array_equal(i1[k * n:(k + 1) * n], np.argmax(cs, axis=1))
+        _close(objs)
+    finally:
+        eb.set_block_order(0)
+
+
+@pytest.mark.parametrize('order', [0, 2])
+def test_mixed_frame_groups_by_detection_count_and_falls_back_per_item(order):
+    """detections {1, 2, 1, 6, 4, 1, 3, 2} over five objects: the n = 1 items form one group, n = 2 another, n = 3 and n = 4 one
+    each; n = 6, the bf16 codebook and the un-prepared upright query go through the per-object path inside the same call; the
+    upright query on a prepared copy is grouped.  An object may appear twice (two slices of the workspace)."""
+    cfg = EncoderConfig((16, 16, 3), [32, 64], [2, 2], 5, 128)
+    eb.set_block_order(order)
+    try:
+        objs = [_object(cfg, 500 + 11 * o, 36 * (8 + o) + o) for o in range(4)]
+        objs.append(_object(cfg, 590, 36 * 9, dtype='bf16'))
+        objs[1][1].prepare_upright(36)
+        e = [o[0] for o in objs]
+        c = [o[1] for o in objs]
+        items = [(e[0], c[0], 1, 1), (e[1], c[1], 2, 36), (e[2], c[2], 1, 1), (e[3], c[3], 6, 1), (e[0], c[0], 4, 1),
+                 (e[4], c[4], 1, 1), (e[2], c[2], 3, 1), (e[3], c[3], 2, 1), (e[2], c[2], 1, 36), (e[1], c[1], 1, 1)]
+        rows = sum(it[2] for it in items)
+        x = synth.make_crops(rows, seed=77, shape=cfg.shape)
+        z0, i0, s0 = _per_object(items, x)
+        ws = eb.MultiWorkspace()
+        z1, i1, s1, launches = eb.encode_nn_multi(items, x, ws)
+        # groups: n = 1 (items 0, 2, 9), n = 2 stride 36 / stride 1 (items 1, 7: one group, the stride is per item), n = 4, n = 3
+        assert launches == 4 * 4, launches
+        assert np.array_equal(z1, z0) and np.array_equal(i1, i0) and np.array_equal(s1, s0)
+        assert (i1[1:3] % 36 == 0).all()                                 # the upright answers are multiples of the stride
+        # the same workspace again, now with the items in another order: every slice lands on other objects' leftovers
+        perm = [4, 0, 8, 1, 9, 3, 2, 7, 5, 6]
+        starts = np.cumsum([0] + [it[2] for it in items])
+        items2 = [items[p] for p in perm]
+        x2 = np.concatenate([x[starts[p]:starts[p + 1]] for p in perm])
+        z2, i2, s2, _ = eb.encode_nn_multi(items2, x2, ws)
+        assert np.array_equal(z2, np.concatenate([z0[starts[p]:starts[p + 1]] for p in perm]))
+        assert np.array_equal(i2, np.concatenate([i0[starts[p]:starts[p + 1]] for p in perm]))
+        assert np.array_equal(s2, np.concatenate([s0[starts[p]:starts[p + 1]] for p in perm]))
+        _close(objs)
+    finally:
+        eb.set_block_order(0)
+
+
+def test_alternating_class_mixes_in_one_workspace_never_meet_a_stale_ticket():
+    """frames alternate between two class mixes in ONE workspace: a slice's ticket words are then wherever the previous frame
+    kept activations, partial sums or other objects' tickets -- nonce-tagged words and the preparation by conv1's extra blocks
+    must make that invisible (also with the preparation switched off: the install path)."""
+    cfg = EncoderConfig((16, 16, 3), [32, 64], [2, 2], 5, 128, True)
+    objs = [_object(cfg, 700 + 13 * o, 36 * 7 + 5 * o) for o in range(4)]
+    e = [o[0] for o in objs]
+    c = [o[1] for o in objs]
+    mix_a = [(e[0], c[0], 1, 1), (e[1], c[1], 1, 1), (e[2], c[2], 2, 1), (e[3], c[3], 1, 1)]
+    mix_b = [(e[3], c[3], 2, 1), (e[0], c[0], 4, 1), (e[2], c[2], 1, 1)]
+    xa = synth.make_crops(5, seed=91, shape=cfg.shape)
+    xb = synth.make_crops(7, seed=92, shape=cfg.shape)
+    want_a, want_b = _per_object(mix_a, xa), _per_object(mix_b, xb)
+    ws = eb.MultiWorkspace()
+    for order in (0, 2, 1):
+        eb.set_block_order(order)
+        try:
+            for prep in (1, 0):
+                for enc in e:
+                    enc.set_option('ticket_prep', prep)
+                for frame in range(4):
+                    items, x, want = (mix_a, xa, want_a) if frame % 2 == 0 else (mix_b, xb, want_b)
+                    z, i, s, _ = eb.encode_nn_multi(items, x, ws)
+                    assert np.array_equal(z, want[0]) and np.array_equal(i, want[1]) and np.array_equal(s, want[2]), (order, prep, frame)
+        finally:
+            eb.set_block_order(0)
+    _close(objs)
+
+
+@pytest.mark.parametrize('order', [0, 2])
+def test_several_codebooks_in_one_scan_launch(order):
+    """aae_codebook_nn_multi: the codebook stage alone -- the grouped items' codebooks streamed by ONE launch, each through its
+    own ticket; equal to one aae_codebook_nn per item."""
+    eb.set_block_order(order)
+    try:
+        J = 128
+        cbs = [eb.EmuCodebook(synth.make_codebook(36 * (6 + 3 * k) + k, J, seed=40 + k, planted_duplicates=4)) for k in range(5)]
+        cbs[3].prepare_upright(36)
+        ns = [1, 3, 1, 3, 7]
+        strides = [1, 1, 1, 36, 1]
+        items = [(None, cb, n, st) for cb, n, st in zip(cbs, ns, strides)]
+        z = np.random.default_rng(5).standard_normal((sum(ns), J)).astype(np.float32)
+        want_i, want_s, at = [], [], 0
+        for cb, n, st in zip(cbs, ns, strides):
+            i, s = cb.nn(z[at:at + n], 1, st)
+            want_i.append(i[:, 0]), want_s.append(s[:, 0])
+            at += n
+        idx, score, launches = eb.codebook_nn_multi(items, z)
+        assert launches == 2                                             # n = 1 (two codebooks) and n = 3 (two codebooks, one of them the upright copy); n = 7: per-object path
+        assert np.array_equal(idx, np.concatenate(want_i)) and np.array_equal(score, np.concatenate(want_s))
+        for cb in cbs:
+            cb.close()
+    finally:
+        eb.set_block_order(0)
+
+
+def test_more_objects_than_one_launch_holds():
+    """kMultiMax = 16 objects per launch: 19 items of one shape take two launches per layer"""
+    cfg = EncoderConfig((16, 16, 3), [32, 64], [2, 2], 5, 128)
+    objs = [_object(cfg, 900 + o, 36 * 5 + o) for o in range(3)]
+    items = [(objs[k % 3][0], objs[k % 3][1], 1, 1) for k in range(19)]
+    x = synth.make_crops(19, seed=3, shape=cfg.shape)
+    z0, i0, s0 = _per_object(items, x)
+    z1, i1, s1, launches = eb.encode_nn_multi(items, x)
+    assert launches == 2 * 4
+    assert np.array_equal(z1, z0) and np.array_equal(i1, i0) and np.array_equal(s1, s0)
+    _close(objs)
+
+
+def test_frame_in_one_call_crops_included():
+    """aae_detect_nn_multi = aae_crop_resize_u8 over all boxes + aae_encode_nn_multi"""
+    cfg = EncoderConfig((16, 16, 3), [32, 64], [2, 2], 5, 128)
+    objs = [_object(cfg, 950 + o, 36 * 6 + o) for o in range(2)]
+    img = np.random.default_rng(8).integers(0, 256, (60, 80, 3), dtype=np.uint8)
+    boxes = np.array([[5, 4, 30, 20, 36], [40, 10, 25, 40, 48], [-6, 30, 40, 28, 44]], dtype=np.int32)
+    items = [(objs[0][0], objs[0][1], 2, 1), (objs[1][0], objs[1][1], 1, 1)]
+    crops, z, idx, score = eb.detect_nn_multi(items, img, boxes)
+    assert np.array_equal(crops, eb.crop_resize(img, boxes, (16, 16)))
+    z0, i0, s0 = _per_object(items, crops)
+    assert np.array_equal(z, z0) and np.array_equal(idx, i0) and np.array_equal(score, s0)
+    _close(objs)
+
+
+def test_argument_errors_are_reported_not_crashed():
+    cfg = EncoderConfig((16, 16, 3), [32, 64], [2, 2], 5, 128)
+    cfg64 = EncoderConfig((16, 16, 3), [32, 64], [2, 2], 5, 64)
+    a, b = _object(cfg, 11, 200), _object(cfg64, 12, 200)
+    x = synth.make_crops(2, seed=1, shape=cfg.shape)
+    with pytest.raises(ValueError, match='latent size'):
+        eb.encode_nn_multi([(a[0], a[1], 1, 1), (b[0], b[1], 1, 1)], x)
+    with pytest.raises(ValueError, match='pairs a'):
+        eb.encode_nn_multi([(a[0], b[1], 2, 1)], x)
+    L = eb.lib()
+    arr = eb._multi_items([(a[0], a[1], 2, 1)])
+    assert L.aae_multi_workspace_bytes(arr, 0, 0) == 0
+    n = L.aae_multi_workspace_bytes(arr, 1, 0)
+    buf = eb._aligned(n)
+    z = np.zeros((2, 128), np.float32)
+    idx = np.zeros(2, np.int64)
+    sc = np.zeros(2, np.float32)
+    assert L.aae_encode_nn_multi(arr, 1, x.ctypes.data, _lib.AAE_DTYPE_U8, z.ctypes.data, idx.ctypes.data, sc.ctypes.data, buf.ctypes.data, n - 256, None) == -4
+    assert L.aae_encode_nn_multi(arr, 1, x.ctypes.data, 7, z.ctypes.data, idx.ctypes.data, sc.ctypes.data, buf.ctypes.data, n, None) == -1
+    arr[0].n = 0
+    assert L.aae_encode_nn_multi(arr, 1, x.ctypes.data, _lib.AAE_DTYPE_U8, z.ctypes.data, idx.ctypes.data, sc.ctypes.data, buf.ctypes.data, n, None) == -1
+    _close([a, b])

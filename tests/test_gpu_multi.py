@@ -1,0 +1,160 @@
+"""The grouped multi-object query on the MI355X: one launch per layer across objects (aae_encode_nn_multi,
+aae_codebook_nn_multi, aae_detect_nn_multi) against (a) the per-object calls -- bit for bit -- and (b) the fp64 oracle OF EACH
+OBJECT (cosine within 1e-5, tie-aware index).  The reference's layout: one AAE per class in one process, a frame's boxes
+spread over the classes (m3_interface/ae_pose_estimator.py:61-78,143-170; cfg_m3vision/m3_config_tless.cfg:10-39)."""
+import numpy as np
+import pytest
+
+from oracle import reference_cpu as ref
+from oracle import synth
+import parity_report as report
+from test_gpu_parity import COS_TOL, STRIDES, _check_indices
+
+pytestmark = pytest.mark.gpu
+
+N_OBJ = 8
+
+
+@pytest.fixture(scope='module')
+def eight_objects():
+    import torch
+    from augmentedautoencoder_amd.engine import CodebookEngine, EncoderEngine
+    from augmentedautoencoder_amd.weights import EncoderConfig
+    weights = [synth.make_weights(seed=2024 + o) for o in range(N_OBJ)]
+    books = [synth.make_codebook(92232, 128, seed=7 + o, planted_duplicates=8) for o in range(N_OBJ)]
+    objs = [(EncoderEngine(EncoderConfig(), weights[o], max_batch=64), CodebookEngine(books[o])) for o in range(N_OBJ)]
+    yield weights, books, objs, torch.device('cuda', 0)
+    for e, c in objs:
+        e.close()
+        c.close()
+
+
+def _per_object(objs, counts, x):
+    import torch
+    zs, idxs, scores, at = [], [], [], 0
+    for (e, c), n in zip(objs, counts):
+        z, i, s = e.encode_nn(c, x[at:at + n], 1)
+        zs.append(z.clone()), idxs.append(i[:, 0].clone()), scores.append(s[:, 0].clone())
+        at += n
+    return torch.cat(zs), torch.cat(idxs), torch.cat(scores)
+
+
+def test_eight_objects_one_launch_per_layer_against_per_object_calls_and_the_fp64_oracle(eight_objects):
+    """8 objects x {1, 1, 2, 4, 1, 3, 1, 2} detections: four groups (n = 1, 2, 3, 4) of six launches each instead of 48 launches"""
+    import torch
+    from augmentedautoencoder_amd.engine import MultiObjectQuery
+    weights, books, objs, dev = eight_objects
+    counts = [1, 1, 2, 4, 1, 3, 1, 2]
+    rows = sum(counts)
+    crops_host = synth.make_crops(rows, seed=8765)
+    x = torch.from_numpy(crops_host).to(dev)
+    z0, i0, s0 = _per_object(objs, counts, x)
+    mq = MultiObjectQuery([(e, c, n) for (e, c), n in zip(objs, counts)])
+    z1, i1, s1 = mq(x)
+    torch.cuda.synchronize()
+    assert mq.launches == 4 * 6
+    assert torch.equal(z1, z0) and torch.equal(i1, i0) and torch.equal(s1, s0)           # bit-identical to the per-object calls
+    at, flips = 0, 0
+    for o, n in enumerate(counts):
+        z64 = ref.encoder_forward_torch(ref.input_to_float(crops_host[at:at + n]), weights[o], STRIDES, False, 'float64')
+        cs64 = ref.cos_similarity(z64, books[o])
+        got_z = z1[at:at + n].cpu().numpy()
+        assert np.abs(got_z - z64).max() / np.abs(z64).max() < 2e-5, o
+        assert np.abs(s1[at:at + n].cpu().numpy() - cs64.max(axis=1)).max() <= COS_TOL, o
+        flips += _check_indices(i1[at:at + n].cpu().numpy(), cs64, where='grouped multi-object query, object %d (%d detections)' % (o, n))
+        at += n
+    # one detection per object: ONE group, six launches for the whole frame
+    mq1 = MultiObjectQuery([(e, c, 1) for e, c in objs])
+    x1 = torch.from_numpy(synth.make_crops(N_OBJ, seed=99)).to(dev)
+    z2, i2, s2 = mq1(x1)
+    assert mq1.launches == 6
+    w0, wi, wsc = _per_object(objs, [1] * N_OBJ, x1)
+    assert torch.equal(z2, w0) and torch.equal(i2, wi) and torch.equal(s2, wsc)
+    # float input takes the same path
+    xf = torch.from_numpy(ref.input_to_float(crops_host).astype(np.float32)).to(dev)
+    zf, idf, sf = MultiObjectQuery([(e, c, n) for (e, c), n in zip(objs, counts)])(xf)
+    assert torch.equal(zf, z0) and torch.equal(idf, i0) and torch.equal(sf, s0)
+
+
+def test_fifty_frames_alternating_two_class_mixes_in_one_workspace(eight_objects):
+    """the same workspace serves frames whose class mixes differ: every object's slice (activations, partial sums, ticket
+    words) lands where ANOTHER object's data of the previous frame lies.  Stale ticket words or partials would show as a
+    differing answer; 50 frames, compared with the per-object answers bit for bit."""
+    import torch
+    from augmentedautoencoder_amd.engine import MultiObjectQuery
+    _, _, objs, dev = eight_objects
+    mix_a = [(0, 1), (1, 1), (2, 2), (3, 1), (5, 4), (6, 1)]
+    mix_b = [(7, 2), (4, 1), (2, 1), (0, 3), (1, 1), (3, 1), (6, 2), (5, 1)]
+    qa = MultiObjectQuery([(objs[o][0], objs[o][1], n) for o, n in mix_a])
+    qb = MultiObjectQuery([(objs[o][0], objs[o][1], n) for o, n in mix_b])
+    qb.ws = qa.ws                                              # ONE scratch buffer for both layouts
+    xa = torch.from_numpy(synth.make_crops(qa.rows, seed=31)).to(dev)
+    xb = torch.from_numpy(synth.make_crops(qb.rows, seed=32)).to(dev)
+    want_a = _per_object([objs[o] for o, _ in mix_a], [n for _, n in mix_a], xa)
+    want_b = _per_object([objs[o] for o, _ in mix_b], [n for _, n in mix_b], xb)
+    qb(xb)                                                     # (sizes the shared buffer for the larger layout first)
+    bad = 0
+    for frame in range(50):
+        q, x, want = (qa, xa, want_a) if frame % 2 == 0 else (qb, xb, want_b)
+        z, i, s = q(x)
+        bad += int(not (torch.equal(z, want[0]) and torch.equal(i, want[1]) and torch.equal(s, want[2])))
+    torch.cuda.synchronize()
+    report.record('multi', report.current_test(), frames=50, frames_differing_from_the_per_object_calls=bad)
+    assert bad == 0
+
+
+def test_codebook_stage_alone_streams_eight_codebooks_in_one_launch(eight_objects):
+    import torch
+    from augmentedautoencoder_amd.engine import MultiObjectQuery
+    _, books, objs, dev = eight_objects
+    counts = [1, 4, 1, 1, 4, 1, 1, 1]
+    rows = sum(counts)
+    rng = np.random.default_rng(12)
+    z = torch.from_numpy(rng.standard_normal((rows, 128)).astype(np.float32)).to(dev)
+    mq = MultiObjectQuery([(None, c, n) for (_, c), n in zip(objs, counts)])
+    idx, score = mq.nn(z)
+    assert mq.launches == 2                                    # n = 1: six codebooks in one launch; n = 4: two
+    at = 0
+    for (_, c), n, E in zip(objs, counts, books):
+        wi, ws = c.nn(z[at:at + n], 1, 1)
+        assert torch.equal(idx[at:at + n], wi[:, 0]) and torch.equal(score[at:at + n], ws[:, 0])
+        cs64 = ref.cos_similarity(z[at:at + n].cpu().numpy().astype(np.float64), E)
+        _check_indices(idx[at:at + n].cpu().numpy(), cs64, where='grouped scan, %d queries' % n)
+        at += n
+
+
+def test_frame_in_one_call_with_upright_and_large_classes(eight_objects):
+    """aae_detect_nn_multi through engine.detect_nn_multi: crops + every class in one C call; a class with 9 detections and a
+    class in split precision take the per-object path inside the call, an upright class is grouped on its compacted copy"""
+    import torch
+    from augmentedautoencoder_amd.engine import _Workspace, crop_resize, detect_nn_multi
+    _, _, objs, dev = eight_objects
+    rng = np.random.default_rng(3)
+    img = torch.from_numpy(rng.integers(0, 256, (480, 640, 3), dtype=np.uint8)).to(dev)
+    counts = [2, 9, 1, 3]
+    strides = [1, 1, 36, 1]
+    total = sum(counts)
+    boxes = np.stack([rng.integers(0, 400, total), rng.integers(0, 300, total), rng.integers(40, 200, total), rng.integers(40, 160, total)], axis=1)
+    rows_np = np.concatenate([boxes, (np.maximum(boxes[:, 2], boxes[:, 3]) * 1.2).astype(np.int64)[:, None]], axis=1).astype(np.int32)
+    rows = torch.from_numpy(rows_np).to(dev)
+    items = [(objs[o][0], objs[o][1], n, st) for o, (n, st) in enumerate(zip(counts, strides))]
+    crops = torch.empty((total, 128, 128, 3), dtype=torch.uint8, device=dev)
+    z = torch.empty((total, 128), dtype=torch.float32, device=dev)
+    idx = torch.empty((total,), dtype=torch.int64).pin_memory()          # answers straight into pinned host memory
+    score = torch.empty((total,), dtype=torch.float32, device=dev)
+    ws = _Workspace(dev)
+    objs[3][0].set_option('precision', 2)                                # (B = 3 stays exact fp32 under 'where it is faster'; the item stays grouped)
+    try:
+        launches = detect_nn_multi(items, img, rows, crops, z, idx, score, ws)
+        torch.cuda.synchronize()
+    finally:
+        objs[3][0].set_option('precision', 0)
+    assert launches == 3 * 6                                             # n = 2, n = 1 (upright), n = 3; the 9-detection class: per-object path
+    assert torch.equal(crops, crop_resize(img, rows_np, (128, 128)))
+    at = 0
+    for (e, c, n, st) in items:
+        wz, wi, wsc = e.encode_nn(c, crops[at:at + n], st)
+        assert torch.equal(z[at:at + n], wz) and torch.equal(idx[at:at + n], wi[:, 0].cpu()) and torch.equal(score[at:at + n], wsc[:, 0])
+        if st > 1:
+            assert (idx[at:at + n] % st == 0).all()
+        at += n

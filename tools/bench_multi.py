@@ -1,0 +1,98 @@
+#!/usr/bin/env python
+"""A frame with detections of several object classes (one AAE per class: m3_interface/ae_pose_estimator.py:61-78):
+per-object calls against the grouped query (one launch per layer across the objects).  One JSON object per line.
+
+    python tools/bench_multi.py                 # objects x detections sweep, sequential vs grouped, cold by construction
+    python tools/bench_multi.py --profile 1     # a loop of 8 x 1 frames, grouped then sequential: for rocprofv3 --kernel-trace --stats
+"""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+
+from augmentedautoencoder_amd import synth
+from augmentedautoencoder_amd.engine import CodebookEngine, EncoderEngine, MultiObjectQuery
+from augmentedautoencoder_amd.weights import EncoderConfig
+
+PEAK_F32_TFLOPS, PEAK_HBM_GBPS = 157.3, 8000.0
+
+
+def time_us(fn, reps, warm=4):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps * 1e3
+
+
+def main():
+    profile = int(sys.argv[sys.argv.index('--profile') + 1]) if '--profile' in sys.argv else 0
+    n_max = 8 if profile else 16
+    cfg = EncoderConfig()
+    dev = torch.device('cuda', 0)
+    objs = [(EncoderEngine(cfg, synth.make_weights(seed=2024 + i), device=dev, max_batch=64),
+             CodebookEngine(synth.make_codebook(92232, 128, seed=7 + i), device=dev)) for i in range(n_max)]
+    xs = [torch.from_numpy(synth.make_crops(4, seed=500 + i)).to(dev) for i in range(n_max)]
+    cb_bytes = 92232 * 128 * 4
+
+    def frames(n_obj, d):
+        sel = objs[:n_obj]
+
+        def seq():
+            for (e, c), xi in zip(sel, xs):
+                e.encode_nn(c, xi[:d], 1)
+        mq = MultiObjectQuery([(e, c, d) for e, c in sel], device=dev)
+        xcat = torch.cat([xi[:d] for xi in xs[:n_obj]]).contiguous()
+        return seq, (lambda: mq(xcat)), mq
+
+    if profile:
+        seq, grp, mq = frames(8, profile)
+        for _ in range(40):
+            grp()
+        torch.cuda.synchronize()
+        for _ in range(40):
+            seq()
+        torch.cuda.synchronize()
+        return
+    for n_obj in (1, 2, 4, 8, 16):
+        for d in (1, 2, 4):
+            seq, grp, mq = frames(n_obj, d)
+            t_seq = time_us(seq, 40)
+            t_grp = time_us(grp, 40)
+            # bit-identity of the two paths on this box, on the timed inputs
+            want = [objs[k][0].encode_nn(objs[k][1], xs[k][:d], 1) for k in range(n_obj)]
+            z, idx, score = grp()
+            same = all(torch.equal(z[k * d:(k + 1) * d], w[0]) and torch.equal(idx[k * d:(k + 1) * d], w[1][:, 0]) and torch.equal(score[k * d:(k + 1) * d], w[2][:, 0])
+                       for k, w in enumerate(want))
+            print(json.dumps({'what': 'frame', 'objects': n_obj, 'detections_per_object': d, 'sequential_us': round(t_seq, 1), 'grouped_us': round(t_grp, 1),
+                              'grouped_over_sequential': round(t_grp / t_seq, 3), 'us_per_detection_grouped': round(t_grp / (n_obj * d), 2),
+                              'launches_grouped': mq.launches, 'launches_sequential': 6 * n_obj, 'bit_identical': bool(same),
+                              'mfma_floor_us': round(n_obj * d * cfg.flops_per_crop() / (PEAK_F32_TFLOPS * 1e6), 1),
+                              'hbm_floor_us': round(n_obj * (cfg.param_bytes() + cb_bytes) / (PEAK_HBM_GBPS * 1e3), 1),
+                              'resident_MB': round(n_obj * (cfg.param_bytes() + cb_bytes) / 1e6, 1)}), flush=True)
+    # the codebook stage alone
+    for n_obj in (1, 2, 4, 8, 16):
+        for d in (1, 4):
+            z = torch.randn(n_obj * d, 128, device=dev)
+            mq = MultiObjectQuery([(None, c, d) for _, c in objs[:n_obj]], device=dev)
+            t_grp = time_us(lambda: mq.nn(z), 100, warm=10)
+
+            def seq():
+                for k, (_, c) in enumerate(objs[:n_obj]):
+                    c.nn(z[k * d:(k + 1) * d], 1, 1)
+            t_seq = time_us(seq, 100, warm=10)
+            print(json.dumps({'what': 'scan', 'codebooks': n_obj, 'queries_per_codebook': d, 'grouped_us': round(t_grp, 2), 'sequential_us': round(t_seq, 2),
+                              'MB': round(n_obj * cb_bytes / 1e6, 1), 'grouped_frac_of_hbm_peak': round(n_obj * cb_bytes / t_grp / 1e3 / PEAK_HBM_GBPS, 3),
+                              'sequential_frac_of_hbm_peak': round(n_obj * cb_bytes / t_seq / 1e3 / PEAK_HBM_GBPS, 3)}), flush=True)
+
+
+if __name__ == '__main__':
+    main()

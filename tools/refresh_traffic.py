@@ -26,6 +26,15 @@ for name, layer in (('conv2', 1), ('conv3', 2), ('conv4', 3)):
         best = max(rows, key=lambda v: v.get('dispatches_seen', 0))
         t['f32'][name] = int(round(best['hbm_side_bytes'], -5))
         changed[name] = t['f32'][name]
+    # matrix-pipe occupancy of the same kernels: SQ_VALU_MFMA_BUSY_CYCLES counts busy cycles per SIMD (1024 SIMDs), GRBM_GUI_ACTIVE the
+    # active cycles summed over the 8 XCDs -> busy fraction = busy / (GUI_ACTIVE / 8 * 1024); delivered clock = GUI_ACTIVE / 8 / duration
+    busy = [v for k, v in main.items() if k.startswith('conv_igemm_f32_kernel<false, true, false, %d, true' % layer)
+            and 'SQ_VALU_MFMA_BUSY_CYCLES' in v and v.get('GRBM_GUI_ACTIVE', 0) > 0]
+    if busy:
+        b = max(busy, key=lambda v: v.get('dispatches_seen', 0))
+        t.setdefault('mfma', {})[name] = {'mfma_busy_frac': round(b['SQ_VALU_MFMA_BUSY_CYCLES'] / (b['GRBM_GUI_ACTIVE'] / 8.0 * 1024.0), 4),
+                                          'delivered_GHz': round(b['GRBM_GUI_ACTIVE'] / 8.0 / b['avg_ns_under_pmc'], 3)}
+t['mfma_source'] = 'profiles/%s/pmc_summary.json: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs); delivered_GHz = GRBM_GUI_ACTIVE / 8 / kernel duration under the PMC pass' % tag
 t['f32_source'] = 'profiles/%s/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the default bench command in round %s: 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 per launch)' % (tag, tag)
 if len(args) > 1:
     mix = json.load(open(args[1]))
