@@ -103,7 +103,7 @@ def declare(lib):
     lib.aae_encoder_x3h_poll.restype = c_int
     lib.aae_encoder_x3h_poll.argtypes = [c_void_p, POINTER(c_int), c_int, POINTER(c_int), c_void_p]
     lib.aae_encoder_x3h_release_slot.restype = c_int
-    lib.aae_encoder_x3h_release_slot.argtypes = [c_void_p, c_int]
+    lib.aae_encoder_x3h_release_slot.argtypes = [c_void_p, c_int, c_void_p]
     lib.aae_encoder_debug_timeline.restype = c_int
     lib.aae_encoder_debug_timeline.argtypes = [c_void_p, POINTER(c_int64)]
     lib.aae_encoder_activation_info.restype = c_int

@@ -144,7 +144,8 @@ struct aae_encoder {
     int wavek_max_tiles = 512;             // used while the layer has at most this many 64 x 64 output tiles (two rounds of one block per CU; 256 until the tile shape was balanced: B = 5 ... 12 gain 7-9 %)
     int wavek_tiny_max_tiles = 64;         // <= this many 64 x 64 tiles: 32 x 32 wave tiles (four times the tiles: K is split across fewer blocks or none);
                                            // measured: wins up to 64 tiles (B=1: 94 -> 87 us), loses from 128 on (twice the operand loads per MFMA)
-    int wavek_target_blocks = 256;         // blocks a split layer is cut into (tiles x K splits): one per CU
+    int wavek_target_blocks = 0;           // blocks of one "round" of the chip = blocks a split layer is cut into (tiles x K splits): 0 = one per compute unit of the
+                                           // device (wavek_round_blocks(): 256 on MI355X, the value the cost model was fitted with); > 0 pins it (tests, A/B)
     int wavek_waves = 4;                   // waves per block (4 | 8), each with its own K range
     int wavek_eff64x32_pct = 74;           // cost model: efficiency of the 64 x 32 wave tile, per cent (0.72 in round 3's fit; with the tail cut it
                                            // wins more often than that predicted: 74 takes conv4 at B = 24 from 198 to 175 us and changes nothing
@@ -184,6 +185,9 @@ struct aae_encoder {
     int detect_chain = 0;
     int detect_chain_blocks = 256;         // its grid: one block per CU, never more than the device has (every block must be resident)
     int cu_count = 0;                      // compute units of the device the handle lives on
+    int multi_force_shape = 0, multi_force_g = 0;   // A/B of plan_wavek_group: wave tile (nibble per conv layer) / K split (byte per conv layer) forced
+    int multi_group_plan = 1;              // aae_encode_nn_multi: a group of objects runs ONE launch plan chosen for the group's total tile count
+                                           // (aae_multi_impl.h, plan_wavek_group); 0 = every object its own plan: bit-identical to aae_encode_nn
     int chain_timeline = 0;                // profiling aid: the persistent launch stamps its phase edges into the wavek_timeline buffer
 };
 
@@ -388,10 +392,16 @@ static bool runs_split(const aae_encoder* enc, int B) {
     return ((M + 63) / 64) * (L.CoutPad / 64) >= enc->x3h_min_tiles;
 }
 
+// blocks the chip runs at once, one per compute unit: the planner's round size
+static int wavek_round_blocks(const aae_encoder* enc) {
+    if (enc->wavek_target_blocks > 0) return enc->wavek_target_blocks;
+    return enc->cu_count > 0 ? std::min(enc->cu_count, 2 * kLayerTicketWords) : 256;
+}
+
 // K splits of a wave-split-K layer of `tiles` output tiles: one block per CU, never a second round of blocks; every wave keeps
 // at least two slabs; one ticket word per tile
 static int wavek_gsplits(const aae_encoder* enc, int tiles, int slabs, int waves, int boost = 1) {
-    int g = enc->wavek_target_blocks * boost / tiles;
+    int g = wavek_round_blocks(enc) * boost / tiles;
     const int gmax = slabs / (2 * waves);
     if (g > gmax) g = gmax;
     if (g > (int)aae::kTicketSingleLevelMax) g = (int)aae::kTicketSingleLevelMax;
@@ -419,7 +429,7 @@ static double wavek_cost_us(const aae_encoder* enc, int tiles, int g, int slabs,
     static const double fixed[3] = {0.0, 0.0, 5.0};
     const double* eff = (enc->wavek_spread & 1) ? eff_spread : eff_burst;          // (64 x 64 tiles with the spread schedule: +9 % measured, round 4)
     const int shape = mt == 1 ? 0 : (nt == 1 ? 1 : 2);
-    const int cus = enc->wavek_target_blocks > 0 ? enc->wavek_target_blocks : 256;
+    const int cus = wavek_round_blocks(enc);
     return (double)ceil_div(tiles * g, cus) * (ceil_div(slabs, 4 * g) + 4) * (mt * nt) * kSlabUs / eff[shape] + fixed[shape] + (g > 1 ? 3.0 : 0.0);
 }
 
@@ -433,7 +443,7 @@ static int wavek_tail_split(const aae_encoder* enc, int tiles, int slabs, int wa
     static const double fixed[3] = {0.0, 0.0, 5.0};
     const double* eff = (enc->wavek_spread & 1) ? eff_spread : eff_burst;
     const int shape = mt == 1 ? 0 : (nt == 1 ? 1 : 2);
-    const int cus = enc->wavek_target_blocks > 0 ? enc->wavek_target_blocks : 256;
+    const int cus = wavek_round_blocks(enc);
     const int tail = tiles % cus, full_rounds = tiles / cus;
     *tail_tiles = 0;
     *cost = wavek_cost_us(enc, tiles, 1, slabs, mt, nt);
@@ -456,7 +466,7 @@ static double igemm_cost_us(const aae_encoder* enc, const Layer& L, long long M)
     const bool wide = s == 1 && enc->igemm_dma && enc->igemm_breg && enc->igemm_breg_wide && (L.index == 1 || L.index == 2) && L.CoutPad % 256 == 0 &&
                       mt * (L.CoutPad / 256) >= enc->igemm_breg_wide_min_blocks;          // (launch_igemm's 128 x 256 tiles)
     const int blocks = wide ? mt * (L.CoutPad / 256) : mt * nt * s;
-    const int cus = enc->wavek_target_blocks > 0 ? enc->wavek_target_blocks : 256;
+    const int cus = wavek_round_blocks(enc);
     if (wide) return (double)ceil_div(blocks, 2 * cus) * 2.0 * (slabs + 2) * (8 * kSlabUs) / 0.90 + 5.0;
     return (double)ceil_div(blocks, cus) * (ceil_div(slabs, s) + 2) * (4 * kSlabUs) / 0.86 + (s > 1 ? 10.0 : 0.0) + 5.0;
 }
@@ -536,7 +546,7 @@ static WaveKPlan plan_wavek_core(const aae_encoder* enc, const Layer& L, long lo
     // runs at B = 2 ... 4 (profiles/r09_small): 64 x 64 1.0, 64 x 32 0.97, 32 x 32 0.88.  (Layers that split K are left alone: there
     // the hand-off cost decides, and the thresholds above were set by measuring it.)
     if (enc->wavek_balance && w.waves == 4 && w.MT * w.NT > 1) {
-        const int cus = enc->wavek_target_blocks > 0 ? enc->wavek_target_blocks : 1;
+        const int cus = wavek_round_blocks(enc);
         auto tiles_of = [&](int mt, int nt) { return ((M + 32 * mt - 1) / (32 * mt)) * (long long)(L.CoutPad / (32 * nt)); };
         auto cost_of = [&](int mt, int nt, double eff) { return (double)((tiles_of(mt, nt) + cus - 1) / cus) * (mt * nt) / eff; };
         if (tiles_of(w.MT, w.NT) >= cus / 2) {                    // (fewer tiles than that: the layer splits K)
@@ -1730,6 +1740,9 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
     else if (!strcmp(name, "wavek_balance")) enc->wavek_balance = value ? 1 : 0;
     else if (!strcmp(name, "planner_cost_model")) enc->planner_cost_model = value ? 1 : 0;
     else if (!strcmp(name, "ticket_prep")) enc->ticket_prep = value ? 1 : 0;
+    else if (!strcmp(name, "multi_group_plan")) enc->multi_group_plan = value ? 1 : 0;
+    else if (!strcmp(name, "multi_force_shape")) enc->multi_force_shape = value;
+    else if (!strcmp(name, "multi_force_g")) enc->multi_force_g = value;
     else if (!strcmp(name, "detect_chain")) {
         if (value) {
             // the persistent launch's grid barrier needs EVERY block resident: refuse the option unless the runtime confirms that one
@@ -1768,7 +1781,7 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
     }
     else if (!strcmp(name, "wavek_max_tiles")) enc->wavek_max_tiles = value < 0 ? 0 : (value > aae_host::kWaveKTileCap ? aae_host::kWaveKTileCap : value);
     else if (!strcmp(name, "wavek_narrow_max_tiles")) enc->wavek_narrow_max_tiles = value < 0 ? 0 : value;
-    else if (!strcmp(name, "wavek_target_blocks")) enc->wavek_target_blocks = value < 1 ? 1 : (value > 2 * aae_host::kLayerTicketWords ? 2 * aae_host::kLayerTicketWords : value);
+    else if (!strcmp(name, "wavek_target_blocks")) enc->wavek_target_blocks = value < 0 ? 0 : (value > 2 * aae_host::kLayerTicketWords ? 2 * aae_host::kLayerTicketWords : value);
     else if (!strcmp(name, "wavek_tiny_max_tiles")) enc->wavek_tiny_max_tiles = value < 0 ? 0 : value;
     else if (!strcmp(name, "wavek_waves")) {
         if (value != 4 && value != 8) return fail(AAE_ERR_INVALID, "wavek_waves %d: 4 or 8", value);
@@ -1887,14 +1900,16 @@ int aae_encoder_x3h_poll(aae_encoder* enc, const int* slots, int n, int* flags_o
     return AAE_OK;
 }
 
-int aae_encoder_x3h_release_slot(aae_encoder* enc, int slot) {
+int aae_encoder_x3h_release_slot(aae_encoder* enc, int slot, void* stream_v) {
     using namespace aae_host;
     if (!enc) return fail(AAE_ERR_INVALID, "aae_encoder_x3h_release_slot: null handle");
     if (slot < kX3hRing || slot >= kX3hRing + kX3hCaptured) return fail(AAE_ERR_INVALID, "aae_encoder_x3h_release_slot: slot %d is not a captured forward's", slot);
     std::lock_guard<std::mutex> lk(enc->x3h_mu);
     if (slot >= kX3hRing + enc->x3h_captured || std::find(enc->x3h_free.begin(), enc->x3h_free.end(), slot) != enc->x3h_free.end())
         return fail(AAE_ERR_INVALID, "aae_encoder_x3h_release_slot: slot %d is not in use", slot);
-    AAE_HIP_TRY(hipMemset(enc->x3h_sat + slot, 0, sizeof(int)));          // (the next owner starts from a lowered flag)
+    // (the next owner starts from a lowered flag; asynchronous on the caller's stream: a synchronous null-stream memset is
+    //  invalid while any stream of the process is being captured)
+    AAE_HIP_TRY(hipMemsetAsync(enc->x3h_sat + slot, 0, sizeof(int), static_cast<hipStream_t>(stream_v)));
     enc->x3h_free.push_back(slot);
     return AAE_OK;
 }

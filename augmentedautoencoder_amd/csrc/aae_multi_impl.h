@@ -30,6 +30,7 @@ struct MultiItemPlan {
 
 struct MultiPlan {
     std::vector<MultiItemPlan> items;
+    std::vector<std::vector<int>> groups;      // grouped items that share launches: equal signatures, at most kMultiMax members, item order
     size_t seq_enc_off = 0, seq_enc_bytes = 0, seq_cb_off = 0, seq_cb_bytes = 0, total = 0;
     int rows = 0;
 };
@@ -62,6 +63,9 @@ static bool multi_encoder_groupable(const aae_encoder* enc, int n, std::vector<W
     plans.assign(nl, WaveKPlan());
     sig.clear();
     sig.push_back(n);
+    sig.push_back(enc->multi_group_plan);      // ... and the options the group's plan is made from
+    sig.push_back(enc->wavek_spread); sig.push_back(enc->wavek_g_boost); sig.push_back(wavek_round_blocks(enc)); sig.push_back(enc->wavek_eff64x32_pct);
+    sig.push_back(enc->compact_workspace); sig.push_back(enc->first_vec4); sig.push_back(enc->multi_force_shape); sig.push_back(enc->multi_force_g);
     const int32_t* d = reinterpret_cast<const int32_t*>(&enc->desc);
     for (size_t i = 0; i < sizeof(aae_encoder_desc) / sizeof(int32_t); ++i) sig.push_back(d[i]);      // (bn_eps as its bit pattern)
     for (size_t li = 1; li < nl; ++li) {
@@ -76,6 +80,73 @@ static bool multi_encoder_groupable(const aae_encoder* enc, int n, std::vector<W
         sig.push_back(key);
     }
     return true;
+}
+
+// The launch plan of one conv layer for a GROUP of `members` objects (option "multi_group_plan", default on).  The per-object plan
+// cuts ONE object's layer into a chip-full of blocks -- at one detection that means the smallest wave tile (32 x 32: twice the
+// operand bytes per MFMA of the 64 x 64 tile) and K splits that leave every wave a dozen slabs behind a four-slab pipeline fill.
+// A group brings `members` times the tiles, so the wave tile and the K split are chosen for the group's TOTAL tile count, and
+// every member runs that plan.  The rule is the outcome of a sweep of every (wave tile, K split) per layer on MI355X at 2 ... 16
+// objects x 1 ... 4 detections (tools/multi_plan_ab.py -> profiles/r13/multi_plan_ab.jsonl; the planner-by-cost's estimate,
+// fitted to single-object mid batches, mis-ranks these launches by up to 8 %):
+//   * 64 x 64 wave tiles, K cut so that the group fills TWO blocks per compute unit (the kernel's launch bound; 0.70 of the
+//     matrix peak measured, the best any wave-split-K form reaches) ...
+//   * ... unless that needs K cut four or more ways (few, long-K tiles: conv4 of the reference network, 400 slabs): then
+//     64 x 32 tiles at ONE block per compute unit -- half the K cuts for the same bytes per tile, a quarter of the partial
+//     sums to hand over (8 objects x 1 detection: conv4 99.8 -> 68 us);
+//   * the 32 x 32 tile never wins once two objects share a launch.
+// Same fma chains per output element up to where K is cut: results differ from the per-object call's by fp32 summation
+// order only (like a batch of another size does); "multi_group_plan" = 0 keeps every object on its own plan, bit-identical
+// to aae_encode_nn.
+static WaveKPlan plan_wavek_group(const aae_encoder* enc, const Layer& L, long long M, int members) {
+    const int slabs = (int)(L.K() / 32), waves = 4, cus = wavek_round_blocks(enc);
+    const int layer = L.index > 0 ? L.index - 1 : 0;
+    const int force = (enc->multi_force_shape >> (4 * layer)) & 15;          // (A/B: one nibble per conv layer, 1 = 32 x 32, 2 = 64 x 32, 3 = 64 x 64)
+    const int force_g = (enc->multi_force_g >> (8 * layer)) & 255;           // (A/B: one byte per conv layer)
+    auto make = [&](int mt, int nt, int blocks_per_cu) {
+        WaveKPlan w;
+        const long long tiles_o = ((M + 32 * mt - 1) / (32 * mt)) * (long long)(L.CoutPad / (32 * nt));
+        const long long total = tiles_o * members;
+        if (tiles_o > kWaveKTileCap || total > (1 << 20)) return w;
+        int g = force_g ? force_g : (int)((long long)cus * blocks_per_cu / total);
+        const int gmax = std::min(slabs / (2 * waves), (int)aae::kTicketSingleLevelMax);
+        if (g > gmax) g = gmax;
+        if (g < 1 || tiles_o > kLayerTicketWords) g = 1;
+        w.use = true;
+        w.MT = mt; w.NT = nt; w.waves = waves; w.depth = 2;
+        w.num_mt = (int)((M + 32 * mt - 1) / (32 * mt));
+        w.num_nt = L.CoutPad / (32 * nt);
+        w.gsplits = g;
+        w.tail_tiles = 0; w.tail_g = 1;
+        w.partial_bytes = g > 1 ? (size_t)w.blocks() * (mt * nt * 16) * 64 * sizeof(float) : 0;
+        return w;
+    };
+    const bool have64 = (enc->wavek_spread & 1) != 0, have32 = (enc->wavek_spread & 2) != 0;      // (the instantiated grouped forms)
+    if (force == 1 && have32) return make(1, 1, 2);
+    if (force == 2) return make(2, 1, 1);
+    if (force == 3 && have64) return make(2, 2, 2);
+    WaveKPlan a = have64 ? make(2, 2, 2) : WaveKPlan();
+    if (a.use && a.gsplits < 4) return a;
+    WaveKPlan b = make(2, 1, 1);
+    return b.use ? b : a;
+}
+
+// workspace slice of a grouped item: ticket words, one activation buffer per conv layer, the largest partial buffer of its plans
+static Workspace plan_workspace_grouped(const aae_encoder* enc, int n, const std::vector<WaveKPlan>& plans) {
+    Workspace ws;
+    size_t off = kTicketBytes;
+    size_t partial = gemv_partial_bytes(enc->dense, n);
+    for (size_t li = 0; li < enc->layers.size(); ++li) {
+        const Layer& L = enc->layers[li];
+        ws.act_off.push_back(off);
+        off += align_up((size_t)n * L.Ho * L.Wo * L.Cout * sizeof(float), 256);
+        if (li < plans.size() && plans[li].use) partial = std::max(partial, plans[li].partial_bytes);
+    }
+    ws.partial_off = off;
+    ws.partial_bytes = partial;
+    off += align_up(partial, 256);
+    ws.total = off;
+    return ws;
 }
 
 // Layout of one call: [shared slice of the per-object path: encoder part, codebook part][grouped item 0: encoder, codebook][item 1] ...
@@ -105,15 +176,37 @@ static int plan_multi(const aae_multi_item* items, int n_items, bool scan_only, 
         if (p.grouped) {
             p.sp = plan_scan(p.eff, it.n, 1);
             p.cb_bytes = align_up(p.sp.total, 256);
-            if (!scan_only) {
-                p.ws = plan_workspace(it.enc, it.n);
-                p.enc_bytes = align_up(p.ws.total, 256);
-            }
         } else {
             if (!scan_only) mp.seq_enc_bytes = std::max(mp.seq_enc_bytes, align_up(plan_workspace(it.enc, it.n).total, 256));
             mp.seq_cb_bytes = std::max(mp.seq_cb_bytes, align_up(plan_scan(it.cb, it.n, 1).total, 256));
         }
     }
+    // groups: equal signatures, at most kMultiMax members each, in item order
+    mp.groups.clear();
+    for (size_t i = 0; i < mp.items.size(); ++i) {
+        if (!mp.items[i].grouped) continue;
+        bool placed = false;
+        for (auto& g : mp.groups)
+            if ((int)g.size() < aae::kMultiMax && mp.items[(size_t)g[0]].sig == mp.items[i].sig) { g.push_back((int)i); placed = true; break; }
+        if (!placed) mp.groups.push_back(std::vector<int>(1, (int)i));
+    }
+    if (!scan_only)
+        for (const std::vector<int>& g : mp.groups) {
+            const aae_encoder* enc0 = items[g[0]].enc;
+            if (g.size() >= 2 && enc0->multi_group_plan) {               // the group's own plan (every member the same network shape and n)
+                std::vector<WaveKPlan> gp(enc0->layers.size());
+                for (size_t li = 1; li < enc0->layers.size(); ++li) {
+                    const Layer& L = enc0->layers[li];
+                    gp[li] = plan_wavek_group(enc0, L, (long long)mp.items[(size_t)g[0]].n * L.Ho * L.Wo, (int)g.size());
+                }
+                for (int i : g) mp.items[(size_t)i].plans = gp;
+            }
+            for (int i : g) {
+                MultiItemPlan& p = mp.items[(size_t)i];
+                p.ws = plan_workspace_grouped(items[i].enc, p.n, p.plans);
+                p.enc_bytes = align_up(p.ws.total, 256);
+            }
+        }
     mp.rows = row;
     size_t off = 0;
     mp.seq_enc_off = off; off += mp.seq_enc_bytes;
@@ -307,19 +400,6 @@ static int launch_encoder_multi(const aae_multi_item* items, const MultiPlan& mp
     return AAE_OK;
 }
 
-// groups of the grouped items: equal signatures, at most kMultiMax members each, in item order
-static std::vector<std::vector<int>> multi_groups(const MultiPlan& mp) {
-    std::vector<std::vector<int>> groups;
-    for (size_t i = 0; i < mp.items.size(); ++i) {
-        if (!mp.items[i].grouped) continue;
-        bool placed = false;
-        for (auto& g : groups)
-            if ((int)g.size() < aae::kMultiMax && mp.items[(size_t)g[0]].sig == mp.items[i].sig) { g.push_back((int)i); placed = true; break; }
-        if (!placed) groups.push_back(std::vector<int>(1, (int)i));
-    }
-    return groups;
-}
-
 static int multi_impl(const aae_multi_item* items, int n_items, const void* x, int x_dtype, const float* z_in, float* z_out, int64_t* idx_out,
                       float* score_out, void* workspace, size_t ws_bytes, void* stream_v) {
     const bool scan_only = z_in != nullptr;
@@ -354,9 +434,8 @@ static int multi_impl(const aae_multi_item* items, int n_items, const void* x, i
         if (rc) return rc;
     }
     // ---- grouped items: one launch per layer and group
-    const std::vector<std::vector<int>> groups = multi_groups(mp);
-    if (!groups.empty()) t_x3h_last_slot = -1;
-    for (const std::vector<int>& g : groups) {
+    if (!mp.groups.empty()) t_x3h_last_slot = -1;
+    for (const std::vector<int>& g : mp.groups) {
         const unsigned nonce = next_nonce();           // one per group and call: every ticketed launch has its own words
         if (!scan_only) {
             for (int i : g) {

@@ -58,15 +58,29 @@ class _on_device(object):
 class _Workspace(object):
     """One grow-only device scratch buffer per engine.  The pointer handed out is 256-B aligned and has at least the
     requested bytes behind it; a fresh buffer starts zeroed (the ticket words of the in-launch reductions are then in
-    their clean state from the first call on -- the kernels tolerate garbage, this only saves the install path)."""
+    their clean state from the first call on -- the kernels tolerate garbage, this only saves the install path).
+    A buffer SHARED by several engines (share_workspaces) serves calls of ONE stream only: it remembers the stream of its
+    first use and raises when asked from another one (two streams would scratch in the same memory at the same time)."""
 
     def __init__(self, device):
         self.device = device
         self.buf = None
+        self.shared = False
+        self.stream = None
 
     def get(self, nbytes):
         torch = _torch()
         nbytes = int(nbytes)
+        if self.shared:
+            cur = _stream_ptr(torch).value or 0
+            if self.stream is None:
+                self.stream = cur
+            elif cur != self.stream and self._idle(torch, self.stream):
+                self.stream = cur              # (the earlier stream has drained: the buffer moves to the new one)
+            elif cur != self.stream:
+                raise RuntimeError('this scratch buffer is shared by several engines (engine.share_workspaces / AePoseEstimator) and serves one '
+                                   'stream; stream %#x still has work queued, the call comes from %#x.  Build the estimator with share_workspaces=False, or call '
+                                   'unshare_workspaces(), to use its engines from several streams' % (self.stream, cur))
         if self.buf is None or self._usable() < nbytes:
             self.buf = None
             self.buf = torch.zeros(nbytes + 256, dtype=torch.uint8, device=self.device)
@@ -77,6 +91,13 @@ class _Workspace(object):
     def _usable(self):
         return self.buf.numel() - (-self.buf.data_ptr()) % 256
 
+    def _idle(self, torch, stream_ptr):
+        try:
+            st = torch.cuda.ExternalStream(stream_ptr, device=self.device) if stream_ptr else torch.cuda.default_stream(self.device)
+            return bool(st.query())
+        except Exception:
+            return False
+
 
 def share_workspaces(engines):
     """Engines that only ever run one after the other on one stream -- the N objects of one pose estimator
@@ -84,18 +105,34 @@ def share_workspaces(engines):
     memory: N x 973 MB of encoder workspace at batch 256 become one (7.8 GB -> 1 GB for eight objects).  `engines`: objects with
     a `.ws` scratch buffer and a `.device`, all of one kind (encoders, or codebooks: one call uses an encoder's and a codebook's
     workspace at the same time, so the two kinds never share).  Nothing in a workspace outlives a call (the ticket words at its
-    front are nonce-tagged per launch), so sharing changes no result; engines used CONCURRENTLY on several streams must keep
-    their own."""
-    pools = {}
+    front are nonce-tagged per launch), so sharing changes no result.  Explicit and reversible: every engine remembers its own
+    buffer (`_own_ws`), the shared buffer refuses calls from a second stream, and unshare_workspaces() undoes it.  Returns the
+    engines whose buffer was rebound."""
+    pools, rebound = {}, []
     for e in engines:
         ws = getattr(e, 'ws', None)
         if e is None or ws is None or not hasattr(e, 'device'):
             continue
         key = (type(e), str(e.device))
         if key in pools:
-            e.ws = pools[key]
+            if e.ws is not pools[key]:
+                if not hasattr(e, '_own_ws'):
+                    e._own_ws = e.ws
+                e.ws = pools[key]
+                pools[key].shared = True
+                rebound.append(e)
         else:
             pools[key] = ws
+    return rebound
+
+
+def unshare_workspaces(engines):
+    """undo share_workspaces for these engines: each gets the buffer it owned before"""
+    for e in engines:
+        own = getattr(e, '_own_ws', None)
+        if own is not None:
+            e.ws = own
+            del e._own_ws
 
 
 class EncoderEngine(object):
@@ -919,7 +956,8 @@ class CapturedNearestNeighbour(object):
         self._x3h_slot = -1
         if slot >= 0 and getattr(self.enc, 'handle', None):
             _torch().cuda.synchronize(self.enc.device)          # (no replay may still be writing the flag)
-            _lib.check(self.enc.lib, self.enc.lib.aae_encoder_x3h_release_slot(self.enc.handle, int(slot)), 'aae_encoder_x3h_release_slot')
+            with _on_device(self.enc.device):
+                _lib.check(self.enc.lib, self.enc.lib.aae_encoder_x3h_release_slot(self.enc.handle, int(slot), _stream_ptr(_torch())), 'aae_encoder_x3h_release_slot')
 
     def __del__(self):
         try:

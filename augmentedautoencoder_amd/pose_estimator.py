@@ -56,6 +56,7 @@ class _FrameStage(object):
         self.direct_rows = 8                # frames with up to this many boxes are read by the crop kernel in place (no H2D copy)
         self.img_host = self.img_dev = None
         self.crops = self.z = self.score = self.idx_host = None
+        self.multi_ws = None                # scratch of the one-call-per-frame path (aae_detect_nn_multi)
 
     @staticmethod
     def _grow(torch, old, n, dtype, device=None, pin=False):
@@ -97,7 +98,7 @@ class _FrameStage(object):
 
 class AePoseEstimator(object):
 
-    def __init__(self, test_config_path=None, codebooks=None, train_args=None, upright=False, topk=1, camPose=False):
+    def __init__(self, test_config_path=None, codebooks=None, train_args=None, upright=False, topk=1, camPose=False, share_workspaces=True):
         """Either ``test_config_path`` (the m3 cfg with an [auto_pose] section, as in the
         reference) or explicit ``codebooks`` / ``train_args`` dicts keyed by class name."""
         self._process_requirements = ['color_img', 'camK', 'bboxes']
@@ -140,17 +141,23 @@ class AePoseEstimator(object):
                 self._register(k, codebooks[k], train_args[k])
         if topk > 1:
             raise NotImplementedError('topk > 1 not implemented (as in the reference, ae_pose_estimator.py:36-39)')
-        # the objects of one estimator run one after the other on one stream: they scratch in the same device memory
-        # (one encoder workspace -- 973 MB at batch 256 -- instead of one per object)
-        try:
-            from .engine import share_workspaces
-            share_workspaces([getattr(getattr(c, '_encoder', None), 'engine', None) for c in self.all_codebooks.values()])
-            share_workspaces([getattr(c, 'engine', None) for c in self.all_codebooks.values()])
-        except ImportError:
-            pass
+        # The objects of one estimator run one after the other on ONE stream: by default they scratch in the same device memory (one
+        # encoder workspace -- 973 MB at batch 256 -- instead of one per object).  That rebinds the .ws of engines the caller may
+        # own: share_workspaces=False leaves them alone; close() / unshare_workspaces() puts the engines' own buffers back.  While
+        # shared, an engine used from another stream raises instead of scribbling over a running call's scratch (engine._Workspace).
+        self._shared_engines = []
+        if share_workspaces:
+            try:
+                from .engine import share_workspaces as _share
+                encs = [getattr(getattr(c, '_encoder', None), 'engine', None) for c in self.all_codebooks.values()]
+                cbs = [getattr(c, 'engine', None) for c in self.all_codebooks.values()]
+                self._shared_engines = _share(encs) + _share(cbs)
+            except ImportError:
+                pass
         self._camPose, self._upright, self._topk = bool(camPose), bool(upright), int(topk)
         self.upload_union_only = True      # process(): upload the union rectangle of the boxes instead of the frame
         self.poll_results = True           # process(): watch the pinned index buffer instead of waiting on an event per chunk (exact fp32 only)
+        self.multi_call = True             # process(): a frame with several classes is ONE C call (aae_detect_nn_multi: one launch per layer across the classes with <= 4 detections)
         self.geometry_chunk = 16           # process(): classes with more than 2 x this many detections go to the GPU in chunks (_chunk_sizes), the last of this size
         if self._camPose:
             self._process_requirements.append('camPose')
@@ -163,7 +170,7 @@ class AePoseEstimator(object):
         exposed: it is geometry_chunk detections, or the whole last class when that has at most twice as many.  Chunks never
         span classes (one encoder per object).  64 of one class -> 48 + 16; 256 -> 192 + 48 + 16; 43 + 21 of two classes ->
         one chunk each."""
-        c = self.geometry_chunk
+        c = max(1, int(self.geometry_chunk))          # (<= 0 would never shrink `left`)
         plan = [[] for _ in counts]
         behind = 0
         for ci in range(len(counts) - 1, -1, -1):
@@ -173,6 +180,7 @@ class AePoseEstimator(object):
                     take = left if left <= 2 * c else c
                 else:
                     take = left if left <= 3 * behind + c else 3 * behind     # (no sliver in front: a remainder of at most one chunk joins its neighbour)
+                take = max(int(take), 1)
                 sizes.append(take)
                 left -= take
                 behind += take
@@ -192,10 +200,17 @@ class AePoseEstimator(object):
     def close(self):
         """Free the device state of every object (N encoders + N codebooks live in one process,
         ae_pose_estimator.py:61-78); the estimator must not be used afterwards."""
+        self.unshare_workspaces()
         for cb in self.all_codebooks.values():
             if hasattr(cb, 'close'):
                 cb.close(close_encoder=True)
         self.all_codebooks, self.all_train_args = {}, {}
+
+    def unshare_workspaces(self):
+        """give every engine its own scratch buffer back (engines that outlive the estimator, or move to other streams)"""
+        from .engine import unshare_workspaces as _unshare
+        _unshare(self._shared_engines)
+        self._shared_engines = []
 
     def __enter__(self):
         return self
@@ -314,6 +329,48 @@ class AePoseEstimator(object):
                 poses[j] = (clas, Rs[k], ts[k])
         return poses
 
+    @staticmethod
+    def _pinned_stores_arrive(torch, device):
+        """Does a kernel's store to pinned host memory become visible to the host WITHOUT a stream synchronisation?  (It does for
+        coherent pinned memory, the default; with HIP_HOST_COHERENT=0 or another allocator it may not.)  Probed once per device: a
+        two-element unpack_pairs launch writes into a pinned buffer and the host watches for at most 50 ms."""
+        import time
+        from .engine import unpack_pairs
+        try:
+            dst = torch.full((2,), -1, dtype=torch.int64).pin_memory()
+            sc = torch.empty((2,), dtype=torch.float32, device=device)
+            src = torch.tensor([[5, 0], [6, 0]], dtype=torch.int64, device=device)
+            torch.cuda.current_stream().synchronize()
+            unpack_pairs(src, None, 2, 2, dst, sc)
+            view = dst.numpy()
+            t0 = time.perf_counter()
+            while time.perf_counter() - t0 < 0.05:
+                if view.min() >= 0:
+                    return bool(view[0] == 5 and view[1] == 6)
+            torch.cuda.current_stream().synchronize()
+            return False
+        except Exception:
+            return False
+
+    @staticmethod
+    def _await_indices(torch, chunk, queued):
+        """Wait until every index of `chunk` (a view of the pinned result buffer, -1 = not there yet) has been stored by the scan's
+        last block.  The spin is bounded by WALL TIME -- 2 ms + 0.2 ms per detection queued up to this chunk, several times what the
+        GPU needs -- and then hands over to a blocking stream synchronisation, after which the indices are there or the runtime has
+        reported why not.  (Only the indices are awaited: the latents and scores of the chunk in the estimator's device scratch are
+        complete once the stream has drained, not necessarily when process() returns.)"""
+        import time
+        deadline = None
+        while chunk.min() < 0:                                     # (one 8-byte store per index; every index of the chunk must have landed)
+            now = time.perf_counter()
+            if deadline is None:
+                deadline = now + 2e-3 + 2e-4 * queued
+            elif now > deadline:
+                torch.cuda.current_stream().synchronize()
+                if chunk.min() < 0:
+                    raise RuntimeError('aae_detect_nn: the indices of a chunk never arrived')
+                return
+
     def _process_staged(self, accepted, classes, frame, off_x, off_y, camK, device):
         """The same on the GPU with everything queued before the first wait: frame (union rectangle) and box rows travel in ONE
         pinned staging buffer and one copy, every class (in chunks when it has many detections) is ONE C call -- aae_detect_nn:
@@ -361,36 +418,56 @@ class AePoseEstimator(object):
             # stores them into pinned host memory, the host watches the sentinel it put there disappear.  An event behind the
             # chunk costs a signal + wake-up on top (~8 us per frame with one detection).  Split precision keeps the events: a
             # chunk that left the fp16 range is recomputed on the stream first (settle()).
-            poll = self.poll_results and all(self.all_codebooks[c]._encoder.engine.options.get('precision', 0) == 0 for c in classes)
+            if self.poll_results and device not in self.__dict__.setdefault('_poll_probed', {}):
+                self._poll_probed[device] = self._pinned_stores_arrive(torch, device)         # once per device
+            poll = (self.poll_results and self._poll_probed.get(device, False)
+                    and all(self.all_codebooks[c]._encoder.engine.options.get('precision', 0) == 0 for c in classes))
             if poll:
                 idx_host[:total] = -1
-            for clas, members, a, n in groups:
-                codebook = self.all_codebooks[clas]
-                stride = int(codebook._dataset._kw['num_cyclo']) if self._upright else 1
-                # ONE C call per chunk: crop + resize, encoder, top-1 query; the indices land in pinned host memory directly
-                codebook._encoder.engine.detect_nn(codebook.engine, image_dev, rows_dev[a:a + n], n, stride, crops_all[a:a + n], z_all[a:a + n],
-                                                   stage.idx_host[a:a + n], stage.score[a:a + n])
-                if poll:
-                    events.append(None)
-                else:
+            exact = all(self.all_codebooks[c]._encoder.engine.options.get('precision', 0) == 0 for c in classes)
+            if self.multi_call and exact and len(groups) >= 2:
+                # ONE C call per FRAME (aae_detect_nn_multi): the crops of every class in one launch, then the classes with at most four
+                # detections -- a frame's boxes spread over the classes, ae_pose_estimator.py:143-170 -- share one launch per layer
+                # (six launches per distinct detection count instead of six per class); larger classes take the per-object path inside
+                # the same call.  The rows are already in item order (class by class, chunk by chunk).
+                from .engine import _Workspace, detect_nn_multi
+                if stage.multi_ws is None:
+                    stage.multi_ws = _Workspace(device)
+                items = []
+                for clas, members, a, n in groups:
+                    codebook = self.all_codebooks[clas]
+                    items.append((codebook._encoder.engine, codebook.engine, n, int(codebook._dataset._kw['num_cyclo']) if self._upright else 1))
+                detect_nn_multi(items, image_dev, rows_dev[:total], crops_all, z_all, stage.idx_host[:total], stage.score[:total], stage.multi_ws)
+                ev = None
+                if not poll:
                     ev = torch.cuda.Event()
                     ev.record()
-                    events.append(ev)
+                events = [ev] * len(groups)
+                # the per-object items (more than four detections) are queued first and finish first: their geometry goes first
+                order = sorted(range(len(groups)), key=lambda k: (groups[k][3] <= 4, k))
+            else:
+                order = list(range(len(groups)))
+                for clas, members, a, n in groups:
+                    codebook = self.all_codebooks[clas]
+                    stride = int(codebook._dataset._kw['num_cyclo']) if self._upright else 1
+                    # ONE C call per chunk: crop + resize, encoder, top-1 query; the indices land in pinned host memory directly
+                    codebook._encoder.engine.detect_nn(codebook.engine, image_dev, rows_dev[a:a + n], n, stride, crops_all[a:a + n], z_all[a:a + n],
+                                                       stage.idx_host[a:a + n], stage.score[a:a + n])
+                    if poll:
+                        events.append(None)
+                    else:
+                        ev = torch.cuda.Event()
+                        ev.record()
+                        events.append(ev)
             poses = {}
             # while the GPU works: the part of the float64 geometry that does not depend on the matched rows
             prepared = [self.all_codebooks[clas].poses_prepare([bb for _, bb in members], camK, self.all_train_args[clas])
                         for clas, members, _, _ in groups]
-            for (clas, members, a, n), ev, prep in zip(groups, events, prepared):
+            for k in order:
+                (clas, members, a, n), ev, prep = groups[k], events[k], prepared[k]
                 codebook = self.all_codebooks[clas]
                 if ev is None:
-                    chunk = idx_host[a:a + n]
-                    spins = 0
-                    while chunk.min() < 0:                         # (one 8-byte store per index; every index of the chunk must have landed)
-                        spins += 1
-                        if spins > 2000000:                        # ~seconds: the GPU work behind this chunk failed -- let the runtime report it
-                            torch.cuda.current_stream().synchronize()
-                            if chunk.min() < 0:
-                                raise RuntimeError('aae_detect_nn: the indices of a chunk never arrived')
+                    self._await_indices(torch, idx_host[a:a + n], a + n)
                 else:
                     ev.synchronize()
                     codebook._encoder.engine.settle()              # (split precision, out of range: recomputed in fp32, indices rewritten in place)

@@ -101,7 +101,9 @@ def cpu_baseline(weights, E, crops, min_seconds=10.0, max_iters=60):
                     'nn_only_crops_per_s': round(d_n * 64 / t_n, 1)},
             'B1': {'encode+nn_crops_per_s': round(d_1 / t_1, 2), 'encode+nn_ms': round(t_1 / d_1 * 1e3, 2),
                    'encode_only_ms': round(t_1e / d_1e * 1e3, 2), 'nn_only_ms': round(t_1n / d_1n * 1e3, 2),
-                   'note': "the reference's operating point: one session.run + np.argmax per detection"},
+                   'note': "the reference's operating point: one session.run + np.argmax per detection.  encode+nn alternates between torch's OpenMP pool and "
+                           "NumPy's BLAS pool every call and pays for it (it costs more than the sum of its parts); a single-runtime reference (TensorFlow) "
+                           "would sit near encode_only_ms + nn_only_ms"},
             'host': {'cpu_model': model, 'logical_cpus': os.cpu_count(),
                      'note': 'threads = best point of a sweep (8..256) on this host; more threads are slower'}}
 
@@ -123,15 +125,26 @@ def self_launch(args, argv):
                               'warmup': args.warmup, 'error': '--gpus %d but %d GPU(s) visible to this process' % (args.gpus, visible),
                               'visible_gpus': visible}))
             return 2
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
-        sk.bind(('127.0.0.1', 0))
-        port = sk.getsockname()[1]
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
-           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')          # dmabuf IPC only on this host driver (RCCL needs it)
     env.setdefault('OMP_NUM_THREADS', '8')
-    return subprocess.call(cmd, env=env)
+    # a free port is found by bind + close; between the close and torch.distributed.run's own bind another process (parallel CI)
+    # may take it: a launch that dies of "address already in use" is repeated on another port
+    rc = 1
+    for attempt in range(4):
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+            sk.bind(('127.0.0.1', 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus),
+               '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + list(argv)
+        p = subprocess.run(cmd, env=env, stderr=subprocess.PIPE)
+        err = p.stderr.decode('utf-8', 'replace')
+        rc = p.returncode
+        if rc != 0 and attempt < 3 and ('address already in use' in err.lower() or 'eaddrinuse' in err.lower()):
+            continue
+        sys.stderr.write(err)
+        break
+    return rc
 
 
 def dry_run_dist(args):

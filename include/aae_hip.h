@@ -193,7 +193,7 @@ int aae_encoder_x3h_last_slot(void);
 int aae_encoder_x3h_poll(aae_encoder* enc, const int* slots, int n, int* flags_out, void* stream);
 /* A forward recorded into a HIP graph owns its slot (one of 64) until the owner of the graph gives it back: call this when
  * the graph is destroyed (the Python mirror: CapturedNearestNeighbour.close()).  Slots of eager forwards need no release. */
-int aae_encoder_x3h_release_slot(aae_encoder* enc, int slot);
+int aae_encoder_x3h_release_slot(aae_encoder* enc, int slot, void* stream);   /* the flag is reset asynchronously on `stream` */
 
 /* 1 when a forward of batch B on this handle runs in f32x3h (precision 1, or precision 2 and a large enough batch):
  * the layer outputs in the workspace are then fp16 (hi, lo) pairs instead of fp32 (aae_encoder_activation_info). */

@@ -58,6 +58,9 @@ class EmuEncoder(object):
         self.h = h
         self.ws = None
         self.options = {}
+        # the planner's round size is one block per compute unit of the DEVICE; the emulated device has three (hip_emu.h), the launch
+        # plans under test are the MI355X's: pin its 256
+        self.set_option('wavek_target_blocks', 256)
 
     def set_option(self, name, value):
         _lib.check(self.L, self.L.aae_encoder_set_option(self.h, name.encode(), int(value)), 'set_option')

@@ -29,6 +29,12 @@ def eight_objects():
         c.close()
 
 
+def _group_plan(objs, on):
+    """option multi_group_plan of every object: 1 (default) = one launch plan per group, 0 = every object its own plan"""
+    for e, _ in objs:
+        e.set_option('multi_group_plan', int(on))
+
+
 def _per_object(objs, counts, x):
     import torch
     zs, idxs, scores, at = [], [], [], 0
@@ -49,31 +55,49 @@ def test_eight_objects_one_launch_per_layer_against_per_object_calls_and_the_fp6
     crops_host = synth.make_crops(rows, seed=8765)
     x = torch.from_numpy(crops_host).to(dev)
     z0, i0, s0 = _per_object(objs, counts, x)
-    mq = MultiObjectQuery([(e, c, n) for (e, c), n in zip(objs, counts)])
-    z1, i1, s1 = mq(x)
-    torch.cuda.synchronize()
-    assert mq.launches == 4 * 6
-    assert torch.equal(z1, z0) and torch.equal(i1, i0) and torch.equal(s1, s0)           # bit-identical to the per-object calls
-    at, flips = 0, 0
-    for o, n in enumerate(counts):
-        z64 = ref.encoder_forward_torch(ref.input_to_float(crops_host[at:at + n]), weights[o], STRIDES, False, 'float64')
-        cs64 = ref.cos_similarity(z64, books[o])
-        got_z = z1[at:at + n].cpu().numpy()
-        assert np.abs(got_z - z64).max() / np.abs(z64).max() < 2e-5, o
-        assert np.abs(s1[at:at + n].cpu().numpy() - cs64.max(axis=1)).max() <= COS_TOL, o
-        flips += _check_indices(i1[at:at + n].cpu().numpy(), cs64, where='grouped multi-object query, object %d (%d detections)' % (o, n))
-        at += n
-    # one detection per object: ONE group, six launches for the whole frame
-    mq1 = MultiObjectQuery([(e, c, 1) for e, c in objs])
-    x1 = torch.from_numpy(synth.make_crops(N_OBJ, seed=99)).to(dev)
-    z2, i2, s2 = mq1(x1)
-    assert mq1.launches == 6
+    x1_host = synth.make_crops(N_OBJ, seed=99)
+    x1 = torch.from_numpy(x1_host).to(dev)
     w0, wi, wsc = _per_object(objs, [1] * N_OBJ, x1)
-    assert torch.equal(z2, w0) and torch.equal(i2, wi) and torch.equal(s2, wsc)
-    # float input takes the same path
-    xf = torch.from_numpy(ref.input_to_float(crops_host).astype(np.float32)).to(dev)
-    zf, idf, sf = MultiObjectQuery([(e, c, n) for (e, c), n in zip(objs, counts)])(xf)
-    assert torch.equal(zf, z0) and torch.equal(idf, i0) and torch.equal(sf, s0)
+
+    def against_oracle(z, idx, score, cnts, host, tag):
+        at = 0
+        for o, n in enumerate(cnts):
+            z64 = ref.encoder_forward_torch(ref.input_to_float(host[at:at + n]), weights[o], STRIDES, False, 'float64')
+            cs64 = ref.cos_similarity(z64, books[o])
+            assert np.abs(z[at:at + n].cpu().numpy() - z64).max() / np.abs(z64).max() < 2e-5, (tag, o)
+            assert np.abs(score[at:at + n].cpu().numpy() - cs64.max(axis=1)).max() <= COS_TOL, (tag, o)
+            _check_indices(idx[at:at + n].cpu().numpy(), cs64, where='grouped multi-object query (%s), object %d (%d detections)' % (tag, o, n))
+            at += n
+    try:
+        # ---- every object on its own launch plan: bit-identical to the per-object calls
+        _group_plan(objs, 0)
+        mq = MultiObjectQuery([(e, c, n) for (e, c), n in zip(objs, counts)])
+        z1, i1, s1 = mq(x)
+        torch.cuda.synchronize()
+        assert mq.launches == 4 * 6
+        assert torch.equal(z1, z0) and torch.equal(i1, i0) and torch.equal(s1, s0)
+        against_oracle(z1, i1, s1, counts, crops_host, 'per-object plans')
+        mq1 = MultiObjectQuery([(e, c, 1) for e, c in objs])            # one detection per object: ONE group, six launches for the whole frame
+        z2, i2, s2 = mq1(x1)
+        assert mq1.launches == 6
+        assert torch.equal(z2, w0) and torch.equal(i2, wi) and torch.equal(s2, wsc)
+        xf = torch.from_numpy(ref.input_to_float(crops_host).astype(np.float32)).to(dev)       # float input takes the same path
+        zf, idf, sf = MultiObjectQuery([(e, c, n) for (e, c), n in zip(objs, counts)])(xf)
+        assert torch.equal(zf, z0) and torch.equal(idf, i0) and torch.equal(sf, s0)
+    finally:
+        _group_plan(objs, 1)
+    # ---- the default: one launch plan per group (larger wave tiles, K split for the group's tile count): summation order differs
+    mq = MultiObjectQuery([(e, c, n) for (e, c), n in zip(objs, counts)])
+    z3, i3, s3 = mq(x)
+    assert mq.launches == 4 * 6
+    assert float((z3 - z0).abs().max() / z0.abs().max()) < 1e-5
+    against_oracle(z3, i3, s3, counts, crops_host, 'group plans')
+    mq1 = MultiObjectQuery([(e, c, 1) for e, c in objs])
+    z4, i4, s4 = mq1(x1)
+    assert mq1.launches == 6
+    against_oracle(z4, i4, s4, [1] * N_OBJ, x1_host, 'group plan, 8 x 1')
+    z5, i5, s5 = [t.clone() for t in mq1(x1)]
+    assert torch.equal(z5, z4) and torch.equal(i5, i4) and torch.equal(s5, s4)               # deterministic
 
 
 def test_fifty_frames_alternating_two_class_mixes_in_one_workspace(eight_objects):
@@ -93,14 +117,22 @@ def test_fifty_frames_alternating_two_class_mixes_in_one_workspace(eight_objects
     want_a = _per_object([objs[o] for o, _ in mix_a], [n for _, n in mix_a], xa)
     want_b = _per_object([objs[o] for o, _ in mix_b], [n for _, n in mix_b], xb)
     qb(xb)                                                     # (sizes the shared buffer for the larger layout first)
-    bad = 0
-    for frame in range(50):
-        q, x, want = (qa, xa, want_a) if frame % 2 == 0 else (qb, xb, want_b)
-        z, i, s = q(x)
-        bad += int(not (torch.equal(z, want[0]) and torch.equal(i, want[1]) and torch.equal(s, want[2])))
+    bad = {0: 0, 1: 0}
+    try:
+        for plan in (0, 1):
+            _group_plan(objs, plan)
+            if plan == 1:                                      # group plans: the reference answers are the layout's own first frame (summation order differs from the per-object calls)
+                want_a = [t.clone() for t in qa(xa)]
+                want_b = [t.clone() for t in qb(xb)]
+            for frame in range(50):
+                q, x, want = (qa, xa, want_a) if frame % 2 == 0 else (qb, xb, want_b)
+                z, i, s = q(x)
+                bad[plan] += int(not (torch.equal(z, want[0]) and torch.equal(i, want[1]) and torch.equal(s, want[2])))
+    finally:
+        _group_plan(objs, 1)
     torch.cuda.synchronize()
-    report.record('multi', report.current_test(), frames=50, frames_differing_from_the_per_object_calls=bad)
-    assert bad == 0
+    report.record('multi', report.current_test(), frames=100, frames_differing_with_per_object_plans=bad[0], frames_differing_with_group_plans=bad[1])
+    assert bad == {0: 0, 1: 0}
 
 
 def test_codebook_stage_alone_streams_eight_codebooks_in_one_launch(eight_objects):

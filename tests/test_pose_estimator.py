@@ -270,6 +270,20 @@ def test_process_on_gpu_full_size_two_objects():
     est.upload_union_only = True
     for a, b, c in zip(got, chunked, whole):
         assert a.name == b.name == c.name and np.array_equal(a.trafo, b.trafo) and np.array_equal(a.trafo, c.trafo)
+    # one C call per frame (aae_detect_nn_multi, the default) against one aae_detect_nn call per class: the same poses
+    assert est.multi_call
+    est.multi_call = False
+    per_class = est.process(dets, img, camK, mm=True)
+    est.multi_call = True
+    assert all(a.name == b.name and np.array_equal(a.trafo, b.trafo) for a, b in zip(got, per_class))
+    # ... and with the completion events instead of watching the pinned index buffer
+    est.poll_results = False
+    with_events = est.process(dets, img, camK, mm=True)
+    est.poll_results = True
+    assert all(np.array_equal(a.trafo, b.trafo) for a, b in zip(got, with_events))
+    est.geometry_chunk = 0                               # (used to hang the chunk planner: ADVICE r4)
+    assert all(np.array_equal(a.trafo, b.trafo) for a, b in zip(got, est.process(dets, img, camK, mm=True)))
+    est.geometry_chunk = 16
     # frames with few boxes are not copied to the device at all: the crop kernel reads the pinned staging buffer in place
     for stage in getattr(est, '_stages', {}).values():
         stage.direct_rows = 64
@@ -437,5 +451,30 @@ def test_detection_chunks_cover_every_count_and_end_in_a_small_chunk():
         for s in flat[::-1]:
             assert s <= (32 if behind < 16 else 3 * behind + 16), (counts, plan)
             behind += s
+    for bad in (0, -3):                                   # a non-positive chunk size means "one detection at the end", never an endless loop
+        sh.geometry_chunk = bad
+        assert [sum(p) for p in sh._chunk_plan([5, 0, 17])] == [5, 0, 17]
+    sh.geometry_chunk = 16
     assert AePoseEstimator._chunk_sizes(sh, 64) == [48, 16] and AePoseEstimator._chunk_sizes(sh, 256) == [192, 48, 16]
     assert sh._chunk_plan([43, 21]) == [[43], [21]] and sh._chunk_plan([21, 43]) == [[21], [27, 16]] and sh._chunk_plan([300, 2]) == [[230, 54, 16], [2]]
+
+
+def test_workspace_sharing_is_explicit_and_reversible():
+    """engine.share_workspaces rebinds the scratch buffer of every engine but the first of a kind to ONE buffer, remembers
+    each engine's own, and unshare_workspaces puts them back (the estimator must not silently keep the
+    caller's engines tied together)"""
+    from augmentedautoencoder_amd import engine as E
+
+    class WS(object):
+        shared = False
+
+    class Eng(object):
+        def __init__(self):
+            self.ws, self.device = WS(), 'cuda:0'
+    a, b, c = Eng(), Eng(), Eng()
+    own = [a.ws, b.ws, c.ws]
+    rebound = E.share_workspaces([a, None, b, c])
+    assert rebound == [b, c] and a.ws is b.ws is c.ws is own[0] and own[0].shared
+    assert E.share_workspaces([a, b]) == []                # idempotent
+    E.unshare_workspaces(rebound)
+    assert [a.ws, b.ws, c.ws] == own and not hasattr(b, '_own_ws')

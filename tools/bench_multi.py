@@ -55,26 +55,40 @@ def main():
 
     if profile:
         seq, grp, mq = frames(8, profile)
+        if '--per-object-plans' in sys.argv:
+            for e, _ in objs:
+                e.set_option('multi_group_plan', 0)
         for _ in range(40):
             grp()
         torch.cuda.synchronize()
-        for _ in range(40):
-            seq()
-        torch.cuda.synchronize()
+        if '--sequential' in sys.argv:
+            for _ in range(40):
+                seq()
+            torch.cuda.synchronize()
         return
     for n_obj in (1, 2, 4, 8, 16):
         for d in (1, 2, 4):
             seq, grp, mq = frames(n_obj, d)
             t_seq = time_us(seq, 40)
             t_grp = time_us(grp, 40)
-            # bit-identity of the two paths on this box, on the timed inputs
+            # ... with every object on its own launch plan (option multi_group_plan = 0): bit-identical to the per-object calls, checked on the timed inputs
+            for e, _ in objs:
+                e.set_option('multi_group_plan', 0)
+            seq0, grp0, mq0 = frames(n_obj, d)
+            t_grp0 = time_us(grp0, 40)
             want = [objs[k][0].encode_nn(objs[k][1], xs[k][:d], 1) for k in range(n_obj)]
-            z, idx, score = grp()
+            z, idx, score = grp0()
             same = all(torch.equal(z[k * d:(k + 1) * d], w[0]) and torch.equal(idx[k * d:(k + 1) * d], w[1][:, 0]) and torch.equal(score[k * d:(k + 1) * d], w[2][:, 0])
                        for k, w in enumerate(want))
+            for e, _ in objs:
+                e.set_option('multi_group_plan', 1)
+            zg, idxg, _ = grp()
+            same_idx = bool(torch.equal(idxg, idx))
             print(json.dumps({'what': 'frame', 'objects': n_obj, 'detections_per_object': d, 'sequential_us': round(t_seq, 1), 'grouped_us': round(t_grp, 1),
+                              'grouped_per_object_plans_us': round(t_grp0, 1),
                               'grouped_over_sequential': round(t_grp / t_seq, 3), 'us_per_detection_grouped': round(t_grp / (n_obj * d), 2),
-                              'launches_grouped': mq.launches, 'launches_sequential': 6 * n_obj, 'bit_identical': bool(same),
+                              'launches_grouped': mq.launches, 'launches_sequential': 6 * n_obj, 'per_object_plans_bit_identical': bool(same),
+                              'group_plan_same_indices': same_idx, 'group_plan_z_max_rel_diff': float((zg - z).abs().max() / z.abs().max()),
                               'mfma_floor_us': round(n_obj * d * cfg.flops_per_crop() / (PEAK_F32_TFLOPS * 1e6), 1),
                               'hbm_floor_us': round(n_obj * (cfg.param_bytes() + cb_bytes) / (PEAK_HBM_GBPS * 1e3), 1),
                               'resident_MB': round(n_obj * (cfg.param_bytes() + cb_bytes) / 1e6, 1)}), flush=True)
