@@ -20,10 +20,17 @@ AAE_SCAN_AUTO_PACKED, AAE_SCAN_AUTO_RH2, AAE_SCAN_AUTO_FIN = 7, 8, 9
 AAE_ABI_VERSION = 3
 
 LIB_NAME = 'libaae_hip.so'
+# the same sources with -DAAE_EXPERIMENTS: every kernel variant that measured slower than the defaults + the profiling / ablation
+# aids (tools/, the A/B tests).  Chosen for the whole process by AAE_EXPERIMENTS=1 in the environment; never the default.
+EXPERIMENTS_LIB_NAME = 'libaae_hip_experiments.so'
+
+
+def experiments_requested():
+    return os.environ.get('AAE_EXPERIMENTS', '0') not in ('', '0')
 
 # every symbol include/aae_hip.h declares (tests check the .so exports all of them)
 EXPORTED_SYMBOLS = (
-    'aae_abi_version', 'aae_last_error',
+    'aae_abi_version', 'aae_has_experiments', 'aae_last_error',
     'aae_encoder_create', 'aae_encoder_destroy', 'aae_encoder_set_option', 'aae_encoder_workspace_bytes', 'aae_encoder_forward',
     'aae_encoder_forward_timed', 'aae_encoder_kernel_label', 'aae_encoder_kernel_flops',
     'aae_encoder_activation_info', 'aae_encoder_debug_timeline', 'aae_encoder_x3h_saturated', 'aae_encoder_x3h_last_slot', 'aae_encoder_x3h_poll',
@@ -74,6 +81,8 @@ def declare(lib):
     """Attach argtypes/restypes for every entry point of include/aae_hip.h."""
     lib.aae_abi_version.restype = c_int
     lib.aae_abi_version.argtypes = []
+    lib.aae_has_experiments.restype = c_int
+    lib.aae_has_experiments.argtypes = []
     lib.aae_last_error.restype = c_char_p
     lib.aae_last_error.argtypes = []
 
@@ -176,7 +185,7 @@ def declare(lib):
 
 
 def library_path():
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), LIB_NAME)
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), EXPERIMENTS_LIB_NAME if experiments_requested() else LIB_NAME)
 
 
 _LIB = None
@@ -193,8 +202,8 @@ def load():
     path = library_path()
     if not os.path.exists(path):
         raise RuntimeError(
-            '%s not built: run `python -c "import __graft_entry__ as g; g.build()"` at the repo root '
-            '(hipcc --offload-arch=gfx950).  There is no CPU fallback.' % path)
+            '%s not built: run `python -c "import __graft_entry__ as g; g.build(%s)"` at the repo root '
+            '(hipcc --offload-arch=gfx950).  There is no CPU fallback.' % (path, 'experiments=True' if experiments_requested() else ''))
     lib = declare(ctypes.CDLL(path))
     if lib.aae_abi_version() != AAE_ABI_VERSION:
         raise RuntimeError('libaae_hip.so ABI version %d != expected %d' % (lib.aae_abi_version(), AAE_ABI_VERSION))

@@ -136,13 +136,21 @@ __device__ __forceinline__ void conv_wavek_block(const ConvWaveKArgs& p, const i
 
     const int tid = threadIdx.x, lane = tid & 63, wave = wave_uniform(tid >> 6);
     const int i = lane & 31, h = lane >> 5;
+#ifdef AAE_EXPERIMENTS
     auto stamp = [&](int k) {                                   // (CHAIN: the 100 MHz wall clock of the launch's other stamps)
         if (p.timeline && tid == 0) p.timeline[(long long)Lphys * 8 + k] = CHAIN ? wall_ticks() : clock_ticks();
     };
+#else
+    auto stamp = [](int) {};                                    // (phase stamps: the experiments build's profiling aid)
+#endif
     stamp(0);
 
     const int pH = p.H, pW = p.W, pCin = p.Cin, pKS = p.KS;
+#ifdef AAE_EXPERIMENTS
     const int ablate = CHAIN ? 0 : p.ablate;                    // (timing experiments exist for the stand-alone launches only)
+#else
+    constexpr int ablate = 0;                                   // (the product build has no option that makes results wrong)
+#endif
     const int tiles = p.num_mt * p.num_nt;
     // logical block -> (tile, K part g of gs).  Head tiles [0, head): gsplits parts each, part-major; tail tiles: tail_gsplits parts.
     // Head and tail are remapped to the XCDs separately (each XCD gets a contiguous chunk of BOTH), and the tail blocks -- the

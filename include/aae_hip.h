@@ -42,24 +42,11 @@ extern "C" {
 
 #define AAE_MAX_LAYERS 8
 
-#define AAE_SCAN_AUTO 0           /* B <= 4: streaming kernel; B > 4, top-1, stride 1: query-resident MFMA kernel;
-                                    * else the tile-resident MFMA kernels                                           */
-#define AAE_SCAN_GEMV 1           /* vector-ALU, shuffle reductions, B <= 4 (first version, kept for A/B) */
-#define AAE_SCAN_MFMA 2           /* tile-resident matrix-core kernels, any B       */
-#define AAE_SCAN_STREAM 3         /* fused normalise + HBM stream + DPP reductions, B <= 4 (AUTO picks it); top-1 finishes
-                                     inside the same launch (the last block to arrive merges the block partials) */
-#define AAE_SCAN_STREAM_2L 4      /* the same stream kernel followed by a separate arg-max reduce launch (A/B, race screen) */
-#define AAE_SCAN_AUTO_NO_PRUNE 5  /* AUTO, but the top-k lists inside the query-resident scan take every candidate (no bound shared
-                                     between the blocks): A/B of the pruning, same answers */
-#define AAE_SCAN_STREAM_WALK 6    /* STREAM with a block per compute unit walking the codebook, two 32-row batches in flight per wave,
-                                     instead of one batch per wave and the whole codebook requested at once: A/B, same answers */
+#define AAE_SCAN_AUTO 0           /* B <= 4: streaming kernel that answers inside its launch; B > 4, top-1 / top-2..8, stride 1:
+                                    * query-resident MFMA kernel; else the tile-resident MFMA kernels                        */
 #define AAE_SCAN_AUTO_PACKED 7    /* AUTO, but the top-1 query-resident scan (B > 4) reads queries normalised and packed by a
-                                     launch in front instead of normalising the raw codes in its own prologue: A/B, same answers */
-#define AAE_SCAN_AUTO_RH2 8       /* AUTO, but the top-1 query-resident scan of at most 32 queries splits the rows of a tile over two waves
-                                     per query group (rounds 2-3) instead of four: A/B, same answers */
-#define AAE_SCAN_AUTO_FIN 9       /* AUTO, and the top-1 query-resident scan of at most 32 queries answers inside its own launch (the last
-                                     row block to arrive merges the block partials: the stream scan's ticket finish) instead of an arg-max
-                                     reduce launch behind it: opt-in, same answers */
+                                     launch in front instead of normalising the raw codes in its own prologue: A/B, same answers
+                                     (the other A/B modes: include/aae_hip_tuning.h) */
 
 typedef struct aae_encoder aae_encoder;
 typedef struct aae_codebook aae_codebook;
@@ -80,6 +67,9 @@ typedef struct aae_encoder_desc {
 } aae_encoder_desc;
 
 int aae_abi_version(void);
+/* 1 in the experiments build (-DAAE_EXPERIMENTS: every kernel variant that measured slower than the defaults, the profiling and
+ * ablation aids -- tools/ and the A/B tests), 0 in the product library (include/aae_hip_tuning.h lists what lives where) */
+int aae_has_experiments(void);
 const char* aae_last_error(void);
 
 /* ---- Encoder: auto_pose/ae/encoder.py:37-68 (encoder_out + z) -----------------
@@ -92,65 +82,27 @@ int aae_encoder_create(const aae_encoder_desc* desc, const void* const* host_wei
                        aae_encoder** out);
 void aae_encoder_destroy(aae_encoder* enc);
 
-/* Options (set before sizing the workspace):
+/* Options (set before sizing the workspace).  The ones a caller may want:
  *   "precision" (0): 0 = exact fp32 matrix-core arithmetic (bitwise an fp32 fma chain);
- *                    1 = "f32x3h": fp32 in/out, every product of conv2..dense evaluated as three
- *                        fp16 MFMAs on (hi, lo) operand pairs with fp32 accumulation (>= 22-bit
- *                        operands).  Explicit opt-in; same parity tolerances; activations then
- *                        live in the workspace as fp16 (hi, lo) pairs of x * 2^x3h_act_shift, interleaved per 32-channel chunk.
- *                    2 = f32x3h where it is faster: batches whose first implicit-GEMM layer has at least
- *                        "x3h_min_tiles" (256) 64x64 output tiles (B >= 4 of the default net) run as 1, smaller ones
- *                        as 0 -- per-detection batches are faster AND exact on the fp32 wave-split-K path.
- *   "x3h_act_shift" (4): power-of-two activation pre-scale of the f32x3h format (|x| < 4094
- *                        keeps full accuracy; larger values saturate gracefully up to 2x).
- *   "splitk_min_base_blocks" (384): split the K loop of a layer only if its un-split grid
- *                                   has fewer blocks than this (small batches);
- *   "splitk_target_blocks"   (512): ... and then aim for about this many blocks;
- *   "igemm_stagger" (0): experimental start delay (kcycles) for every 2nd block generation;
- *   "igemm_dma" (1) / "x3h_dma" (1): operand slabs of the implicit GEMM travel global -> LDS by
- *                        LDS-DMA (buffer_load ... lds); 0 selects the register-staged variant
- *                        (bit-identical results, kept for A/B measurements);
- *   "igemm_breg" (1): un-split fp32 conv layers take their weight fragments straight from global memory
- *                        into registers (A operand alone goes through LDS-DMA; 32 KB of LDS, three blocks
- *                        per CU); "igemm_breg_min_blocks" (768): smaller grids keep the 64 KB footprint;
- *   "igemm_breg_wide" (1): ... with 128x256 block tiles for layers whose padded Cout is a multiple of 256 and
- *                        whose grid stays >= 512 blocks;
- *   "dense_gemv" (1): batches of <= "dense_gemv_max_batch" (8; 4 in rounds 2-3) run the dense layer as a weight-streaming GEMV
- *                        instead of a padded matrix-core tile (same value up to fp32 summation order);
- *   "x3h_wide_min_blocks" (0): > 0 lets f32x3h conv layers use 256x128 tiles when that still yields this
- *                        many blocks (measured neutral);
- *   "x3h_wide256" (1), "x3h_wide256_min_blocks" (256): f32x3h conv layers with Cout % 256 == 0 whose grid
- *                        still has that many blocks run 256x256 tiles / 8 waves of 64x128 (bit-identical to
- *                        the 128x128 kernel, 10-14 % faster at B = 256);
- *   "first_target_blocks" (512), "first_max_tiles_per_block" (16): conv1 grid shaping;
- *   "first_vec4" (1): stage uint8 rows of conv1 as aligned dwords when W*C % 4 == 0;
- *   "reduce_small" (1): split-K sums of <= 8 splits over >= 16k outputs by the barrier-free float4 kernel;
- *   small batches (the reference's one crop per detection):
- *   "wavek" (1): layers with at most "wavek_max_tiles" (512) output tiles of 64x64 run the wave-split-K implicit GEMM
- *                        (operands straight into MFMA fragments, K split over the waves of a block and over blocks, the
- *                        cross-block sum finished inside the launch by the last block to arrive); "wavek_dense" (1): the
- *                        dense layer too (every B > 4); wave tile 32x32 up to "wavek_tiny_max_tiles" (64) tiles, 64x32 up to
- *                        "wavek_narrow_max_tiles" (128), 64x64 above; "wavek_waves" (4 | 8), "wavek_depth" (2 | 3 slabs in
- *                        flight), "wavek_target_blocks" (256), "wavek_balance" (1: a smaller wave tile when the larger one would leave CUs idle
- *                        in its last round of blocks) -- defaults set from per-layer rocprofv3 sweeps;
- *   "planner_cost_model" (1): B >= 5: each conv layer runs the implicit-GEMM family and wave-tile shape with the smallest ESTIMATED time
- *                        (block-count rounds x slabs x MFMA time / fitted efficiency, plan_wavek) instead of the tile-count thresholds above
- *                        ("wavek_max_tiles" etc. then steer B = 1, 2, 4 and the dense layer only; B = 3: "planner_cost_batch3" (1));
- *                        B = 24 / 40 / 96 gain 14 / 17 / 6 %;
- *   "wavek_tail_split" (1): where whole tiles leave the last round of blocks partly empty, the tiles of that round are cut in K inside
- *                        the launch (kernel label ..._g1t<tiles>x<parts>; B = 9 438 -> 369 us, B = 12 504 -> 439); "wavek_g_boost" (2): layers
- *                        the estimate splits in K are split for this many blocks per CU; "wavek_eff64x32_pct" (74): a constant of the estimate;
- *                        "wavek_force_tail_tiles" / "wavek_force_tail_g": tests -- cut the last n tiles of every un-split layer g ways;
- *   "detect_chain" (0), "detect_chain_blocks" (256): B <= 4 of a four-layer encoder as conv1 + ONE persistent launch (conv2 ... dense,
- *                        in aae_encode_nn also the scan; grid barriers between the phases) -- bit-identical to the stand-alone launches and,
- *                        measured on MI355X, slower than them (92 vs 82 us at B = 1): opt-in, kept for the record and for other parts;
- *   "gemv_ticket" (1): dense GEMV (B <= 4) adds its chunk rows in the same launch; "ticket_prep" (1): the first kernel of a
- *                        forward installs the ticket nonces of the later launches; "first_group_split_max_tiles" (128): conv1
- *                        runs one block per 32-pixel group for batches of at most that many 128-pixel tiles;
- *   "compact_workspace" (0): two alternating activation buffers instead of one per layer (layer outputs not inspectable);
- *   "wavek_ablate", "wavek_timeline": profiling aids (tools/ablate_wavek.py); results are wrong while wavek_ablate != 0.
- * All variants selected by these knobs are bit-identical to each other or differ by fp32 summation order only (split-K forms, the
- * GEMV, a cut tail tile); every one is held to the fp64 oracle by tests/test_gpu_parity.py and tools/gpu_fuzz.py. */
+ *                    1 = "f32x3h": fp32 in/out, every product of conv2..dense evaluated as three fp16 MFMAs on (hi, lo) operand
+ *                        pairs with fp32 accumulation (>= 22-bit operands).  Explicit opt-in; same parity tolerances; activations
+ *                        then live in the workspace as fp16 (hi, lo) pairs of x * 2^x3h_act_shift, interleaved per 32-channel chunk.
+ *                    2 = f32x3h where it is faster: batches whose first implicit-GEMM layer has at least 256 64x64 output tiles
+ *                        (B >= 4 of the default net) run as 1, smaller ones as 0 -- per-detection batches are faster AND exact on
+ *                        the fp32 wave-split-K path.
+ *   "x3h_act_shift" (4): power-of-two activation pre-scale of the f32x3h format (|x| < 4094 keeps full accuracy; larger values
+ *                        saturate gracefully up to 2x and raise the range flag, aae_encoder_x3h_poll).
+ *   "compact_workspace" (0): two alternating activation buffers instead of one per layer (805 instead of 973 MB at B = 256; layer
+ *                        outputs are then not inspectable through aae_encoder_activation_info).
+ *   "dense_gemv" (1): batches of <= 8 run the dense layer as a weight-streaming GEMV instead of a padded matrix-core tile
+ *                        (same value up to fp32 summation order).
+ *   "multi_group_plan" (1): aae_encode_nn_multi -- a group of objects runs ONE launch plan chosen for the group's total tile count
+ *                        (answers differ from per-object aae_encode_nn calls by fp32 summation order only); 0 = every object its
+ *                        own plan: bit-identical to aae_encode_nn.
+ * Everything else the call accepts -- the planner's constants, kernel-variant switches for A/B measurements -- is listed in
+ * include/aae_hip_tuning.h.  In this (product) build every accepted value gives results that are bit-identical to the defaults
+ * or differ by fp32 summation order only; variants that measured slower and the profiling aids live in the experiments build
+ * (aae_has_experiments()) and are refused here with AAE_ERR_UNSUPPORTED. */
 int aae_encoder_set_option(aae_encoder* enc, const char* name, int value);
 
 size_t aae_encoder_workspace_bytes(const aae_encoder* enc, int B);
@@ -199,11 +151,6 @@ int aae_encoder_x3h_release_slot(aae_encoder* enc, int slot, void* stream);   /*
  * the layer outputs in the workspace are then fp16 (hi, lo) pairs instead of fp32 (aae_encoder_activation_info). */
 int aae_encoder_split_precision_for_batch(const aae_encoder* enc, int B);
 
-/* Profiling aid (tools/ablate_wavek.py): with option "wavek_timeline" = 1 wave 0 of every block of the small-batch
- * igemm stamps the shader clock at 8 phase boundaries; this copies the [3 layers][512 blocks][8] stamps of the most
- * recent forward to host memory (synchronises the device).  Not part of the reference-facing surface. */
-int aae_encoder_debug_timeline(aae_encoder* enc, long long* host_out);
-
 int aae_encoder_activation_info(const aae_encoder* enc, int B, int layer, size_t* offset_bytes,
                                 size_t* count);
 
@@ -215,7 +162,7 @@ int aae_encoder_activation_info(const aae_encoder* enc, int B, int layer, size_t
 int aae_codebook_create(const void* E, int N, int J, int dtype, int src_is_device, aae_codebook** out);
 int aae_codebook_update(aae_codebook* cb, const void* E, int src_is_device, void* stream);  /* embedding_assign_op */
 void aae_codebook_destroy(aae_codebook* cb);
-int aae_codebook_set_scan_mode(aae_codebook* cb, int mode);     /* AAE_SCAN_* (tuning / tests) */
+int aae_codebook_set_scan_mode(aae_codebook* cb, int mode);     /* AAE_SCAN_AUTO (default) | AAE_SCAN_AUTO_PACKED | the A/B modes of aae_hip_tuning.h */
 /* Upright search (codebook.py:65-66: arg-max over columns 0, k, 2k, ... of the similarity, k = num_cyclo): builds /
  * refreshes a compacted device copy of every col_stride-th row, so that aae_codebook_nn(col_stride = k) scans N/k
  * rows instead of masking a full scan (same scores, same tie rule).  Allocates; call it once outside timed /

@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_header_and_binding_table_list_the_same_symbols():
-    text = open(os.path.join(ROOT, 'include', 'aae_hip.h')).read()
+    text = open(os.path.join(ROOT, 'include', 'aae_hip.h')).read() + open(os.path.join(ROOT, 'include', 'aae_hip_tuning.h')).read()
     text = re.sub(r'/\*.*?\*/', '', text, flags=re.S)
     declared = set(re.findall(r'\b(aae_[a-z0-9_]+)\s*\(', text))
     assert declared == set(_lib.EXPORTED_SYMBOLS)

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """Where does a wave-split-K layer spend its time at B = 1?  Per-kernel HIP-event times with parts of the kernel
 switched off (encoder option wavek_ablate: 1 no A loads, 2 no B loads, 4 no MFMAs, 8 no cross-block hand-off)."""
+import _experiments  # noqa: F401  (the kernel variants compared here live in the experiments build: libaae_hip_experiments.so)
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

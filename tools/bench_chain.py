@@ -2,6 +2,7 @@
 """Per-detection latency of the fused query (aae_encode_nn), B = 1 ... 4: conv1 + ONE persistent launch (detect_chain.h)
 against the six stand-alone launches, eager and as one HIP-graph replay; optional encoder options name=value,...
 One JSON object per line.  Usage: python tools/bench_chain.py [reps] [opt=value,...]"""
+import _experiments  # noqa: F401  (the kernel variants compared here live in the experiments build: libaae_hip_experiments.so)
 import json
 import os
 import sys

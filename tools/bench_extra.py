@@ -56,7 +56,10 @@ def main():
             for mode, name in ((_lib.AAE_SCAN_STREAM, 'stream'), (_lib.AAE_SCAN_GEMV, 'gemv'), (_lib.AAE_SCAN_MFMA, 'mfma'), (_lib.AAE_SCAN_AUTO, 'auto')):
                 if mode in (_lib.AAE_SCAN_STREAM, _lib.AAE_SCAN_GEMV) and B > 4:
                     continue
-                cb.set_scan_mode(mode)
+                try:
+                    cb.set_scan_mode(mode)
+                except ValueError:                      # (the round-1 shuffle scan: experiments build, AAE_EXPERIMENTS=1)
+                    continue
                 ms = timeit(lambda: cb.nn(z, 1, 1), 100)
                 print(json.dumps({'what': 'scan', 'B': B, 'mode': name, 'ms': round(ms, 4),
                                   'algorithmic_GBps': round(nbytes / ms / 1e6, 1), 'frac_of_8TBps': round(nbytes / ms / 1e6 / 8000, 3)}))

@@ -5,6 +5,7 @@ replay.  One JSON object per line on stdout.
 
     python tools/bench_small.py [latency] [variants] [thresholds] [prof]
 """
+import _experiments  # noqa: F401  (the kernel variants compared here live in the experiments build: libaae_hip_experiments.so)
 import json
 import os
 import sys

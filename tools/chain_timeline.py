@@ -2,6 +2,7 @@
 """Where the time goes inside the persistent per-detection launch (detect_chain.h): option chain_timeline makes thread 0 of
 every block stamp the 100 MHz wall clock at each phase edge; this prints, per edge, when the first / median / last block
 passed it (microseconds after the first block started) over a few queries.  Usage: python tools/chain_timeline.py [B] [opt=value,...]"""
+import _experiments  # noqa: F401  (the kernel variants compared here live in the experiments build: libaae_hip_experiments.so)
 import ctypes
 import json
 import os

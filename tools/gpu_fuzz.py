@@ -62,8 +62,11 @@ def main():
         opts['wavek_g_boost'] = int(rng.choice([1, 2, 3]))
         opts['dense_gemv_max_batch'] = int(rng.choice([4, 8]))
         opts['planner_cost_batch3'] = int(rng.integers(0, 2))
-        for k, v in opts.items():
-            enc.set_option(k, v)
+        for k, v in list(opts.items()):
+            try:
+                enc.set_option(k, v)
+            except ValueError:                             # a kernel variant of the experiments build (AAE_EXPERIMENTS=1): the product library keeps its default
+                opts[k] = 'default'
         precision = int(rng.integers(0, 2)) if cfg.shape[2] in (1, 3) and all(f % 32 == 0 for f in filters) else 0
         try:
             enc.set_option('precision', precision)
@@ -89,7 +92,10 @@ def main():
             cb = CodebookEngine(E, dtype=dtype)
             # AAE_SCAN_AUTO, or one of its A/B forms: the walking stream scan (B <= 4), packed-query planes instead of the in-scan
             # normalisation, two instead of four waves per query group (B <= 32)
-            cb.set_scan_mode(int(rng.choice([0, 0, 6, 7, 8])))
+            try:
+                cb.set_scan_mode(int(rng.choice([0, 0, 6, 7, 8])))
+            except ValueError:                             # (the walking stream scan: experiments build)
+                cb.set_scan_mode(0)
             cs = cb.similarity(z).cpu().numpy()
             from augmentedautoencoder_amd.weights import bf16_bits_to_f32, to_bf16_bits
             Eo = bf16_bits_to_f32(to_bf16_bits(E)) if dtype == 'bf16' else E

@@ -2,6 +2,7 @@
 """Eager latency of the fused per-detection query (aae_encode_nn) at B = 1 ... 4 (+ 8, 16) under named sets of encoder options,
 alternating the variants (A B A B) so that box drift cancels.  Usage: python tools/latency_variants.py "base= tiny8=wavek_tiny_waves=8"
 One JSON line per (B, variant)."""
+import _experiments  # noqa: F401  (the kernel variants compared here live in the experiments build: libaae_hip_experiments.so)
 import json
 import os
 import sys

@@ -1,6 +1,7 @@
 #!/usr/bin/env python
 """encode + nn at a small batch size, for `rocprofv3 --kernel-trace --stats` (per-kernel GPU durations without
 the event-timing launch gaps).  Usage: python tools/prof_small.py [B] [reps] [new|old|noprep] [opt=value,...]"""
+import _experiments  # noqa: F401  (the kernel variants compared here live in the experiments build: libaae_hip_experiments.so)
 import os
 import sys
 

@@ -2,6 +2,7 @@
 """Soak run for the kernels whose correctness depends on DMA / load landing order (LDS-DMA igemm, weights-to-registers
 variant with counted vmcnt + bare barrier, f32x3h DMA): thousands of launches, with and without a second stream saturating
 HBM, every result compared bit for bit with the register-staged kernels.  Not part of the test suite (takes ~1 GPU-minute)."""
+import _experiments  # noqa: F401  (the kernel variants compared here live in the experiments build: libaae_hip_experiments.so)
 import json
 import os
 import sys
