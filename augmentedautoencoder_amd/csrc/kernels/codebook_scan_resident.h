@@ -378,6 +378,12 @@ __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(con
     // tile t (vmcnt counts in issue order: the four of tile t + 1 stay in flight), the barrier covers the other waves'.
     dma(tile0, Et);
     if (kStages == 3) dma(tile0 + 1, Et + kTileFloats);
+    if constexpr (K == 0) {
+        // in-launch finish: block 0 gives the ticket words this launch's nonce now, with its first tiles in flight -- the arrivals come
+        // microseconds later and then all take the one-atomic path (round 4 measured the finish WITHOUT this: every arrival of a
+        // stand-alone query met a foreign word and queued behind the install, 20.7 against 16.1 us)
+        if (p.tickets != nullptr && blockIdx.x == 0) ticket_prepare_slot(p.tickets, p.nonce, gridDim.x);
+    }
     if constexpr (NORM) {
         if (active) scan_resident_normalise<BF16>(zraw, bq);
     }

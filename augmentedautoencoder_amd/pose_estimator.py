@@ -76,7 +76,24 @@ class _FrameStage(object):
         self.img_host = self._grow(torch, self.img_host, total, torch.uint8, pin=True)
         self.img_dev = self._grow(torch, self.img_dev, total, torch.uint8, self.device)
         host = self.img_host.numpy()
-        np.copyto(host[:n].reshape(h, w, c), frame)
+        dst = host[:n].reshape(h, w, c)
+        # The crop kernel reads nothing but the pixels INSIDE the boxes (crop_resize_u8.h: a tap outside its box is black).  When the
+        # boxes cover less than half of the rectangle -- a handful of detections spread over a 1080p frame -- only their rectangles
+        # are copied into the staging image, at their own positions (8 boxes: 0.9 MB instead of 3.7-6 MB of host memcpy in front of the
+        # first launch); what lies between them is stale and never read.
+        sparse = False
+        if 2 <= len(rows) <= 64 and h * w >= 65536:        # (one box: the rectangle IS the box; tiny frames: the bookkeeping costs more than the copy)
+            x0 = np.clip(rows[:, 0], 0, w)
+            y0 = np.clip(rows[:, 1], 0, h)
+            x1 = np.clip(rows[:, 0] + rows[:, 2], 0, w)
+            y1 = np.clip(rows[:, 1] + rows[:, 3], 0, h)
+            sparse = 2 * int(((x1 - x0) * (y1 - y0)).sum()) < h * w
+        if sparse:
+            for a, b, cc, d in zip(y0.tolist(), y1.tolist(), x0.tolist(), x1.tolist()):
+                if b > a and d > cc:
+                    dst[a:b, cc:d] = frame[a:b, cc:d]
+        else:
+            np.copyto(dst, frame)
         host[off:total].view(np.int32)[:] = rows.reshape(-1)
         if len(rows) <= self.direct_rows:
             # a few boxes: the crop kernel reads its pixels and the rows straight out of the pinned buffer (device-accessible) --
@@ -247,7 +264,8 @@ class AePoseEstimator(object):
             xywh = np.array(boxes_xywh, dtype=np.float64).reshape(-1, 4).astype(np.int32)      # float64 -> int32 truncates like the per-box cast
             rows[:, :4] = xywh
             # size: int(np.maximum(h, w) * pad) -- int32 maximum times a Python float = float64 product, truncated
-            rows[:, 4] = (np.maximum(xywh[:, 3], xywh[:, 2]) * float(pad_factor)).astype(np.int64)
+            pad = pad_factor if isinstance(pad_factor, np.ndarray) else float(pad_factor)       # (a factor per row: the estimator's frame-wide call)
+            rows[:, 4] = (np.maximum(xywh[:, 3], xywh[:, 2]) * pad).astype(np.int64)
         return rows
 
     def extract_square_patches(self, scene_img, boxes_xywh, pad_factor, resize=(128, 128)):
@@ -334,14 +352,21 @@ class AePoseEstimator(object):
         """Does a kernel's store to pinned host memory become visible to the host WITHOUT a stream synchronisation?  (It does for
         coherent pinned memory, the default; with HIP_HOST_COHERENT=0 or another allocator it may not.)  Probed once per device: a
         two-element unpack_pairs launch writes into a pinned buffer and the host watches for at most 50 ms."""
+        import ctypes
         import time
-        from .engine import unpack_pairs
+        from . import _lib
+        from .engine import _on_device, _stream_ptr
         try:
+            lib = _lib.load()
             dst = torch.full((2,), -1, dtype=torch.int64).pin_memory()
             sc = torch.empty((2,), dtype=torch.float32, device=device)
             src = torch.tensor([[5, 0], [6, 0]], dtype=torch.int64, device=device)
             torch.cuda.current_stream().synchronize()
-            unpack_pairs(src, None, 2, 2, dst, sc)
+            with _on_device(device):                     # (the C entry point directly: the Python wrapper insists on device outputs)
+                rc = lib.aae_unpack_pairs(ctypes.c_void_p(src.data_ptr()), None, 2, 2, ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(sc.data_ptr()),
+                                          _stream_ptr(torch))
+            if rc != 0:
+                return False
             view = dst.numpy()
             t0 = time.perf_counter()
             while time.perf_counter() - t0 < 0.05:
@@ -360,8 +385,12 @@ class AePoseEstimator(object):
         reported why not.  (Only the indices are awaited: the latents and scores of the chunk in the estimator's device scratch are
         complete once the stream has drained, not necessarily when process() returns.)"""
         import time
-        deadline = None
-        while chunk.min() < 0:                                     # (one 8-byte store per index; every index of the chunk must have landed)
+        deadline, spins = None, 0
+        last = chunk[-1:]                                          # (the scan's last block stores a chunk's indices in order: watch the last one, then check all)
+        while last[0] < 0 or chunk.min() < 0:                      # (one 8-byte store per index; every index of the chunk must have landed)
+            spins += 1
+            if spins & 63:
+                continue
             now = time.perf_counter()
             if deadline is None:
                 deadline = now + 2e-3 + 2e-4 * queued
@@ -397,13 +426,14 @@ class AePoseEstimator(object):
             # box rows of all classes, class by class; classes with many detections are cut into chunks so that the host's
             # float64 geometry of chunk k runs while the GPU works on chunk k + 1 (the geometry of the LAST chunk is all that
             # stays exposed: 16 detections instead of a whole class)
-            rows_all = np.empty((total, 5), dtype=np.int32)
             groups, at = [], 0
             by_class = [[(j, bb) for j, c, bb in accepted if c == clas] for clas in classes]
             plan = self._chunk_plan([len(m) for m in by_class])
+            # the [x, y, w, h, size] rows of every class in one go (box_rows with a pad factor per row: the same float64 product, truncated)
+            rows_all = self.box_rows([[bb[0] - off_x, bb[1] - off_y, bb[2], bb[3]] for members in by_class for _, bb in members],
+                                     np.array([float(self.pad_factors[clas]) for clas, members in zip(classes, by_class) for _ in members], dtype=np.float64))
             for clas, members, sizes in zip(classes, by_class, plan):
                 n = len(members)
-                rows_all[at:at + n] = self.box_rows([[bb[0] - off_x, bb[1] - off_y, bb[2], bb[3]] for _, bb in members], self.pad_factors[clas])
                 a = 0
                 for step in sizes:
                     groups.append((clas, members[a:a + step], at + a, step))

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Host-side profile of AePoseEstimator.process (N1) on a 1080p frame: cProfile over repeated calls with D detections.
-Usage: python tools/prof_estimator.py [D] [reps]"""
+Usage: python tools/prof_estimator.py [D] [reps] [classes]   (classes > 2: detection i belongs to class i % classes, each class its own AAE)"""
 import cProfile
 import configparser
 import io
@@ -21,13 +21,14 @@ from augmentedautoencoder_amd.encoder import Encoder
 from augmentedautoencoder_amd.pose_estimator import AePoseEstimator, BoundingBox
 
 
-def build():
+def build(n_classes=2):
     targs = configparser.ConfigParser()
     targs.read_string("[Dataset]\nH: 128\nW: 128\nC: 3\nRADIUS: 700\nPAD_FACTOR: 1.2\nK: [1075.65, 0, 720/2, 0, 1073.90, 540/2, 0, 0, 1]\n"
                       "[Embedding]\nEMBED_BB: True\nMIN_N_VIEWS: 2562\nNUM_CYCLO: 36\n")
     S.reset_default_graph()
     books = {}
-    for k, name in enumerate(['obj_a', 'obj_b']):
+    names = ['obj_a', 'obj_b'] if n_classes <= 2 else ['obj_%02d' % k for k in range(n_classes)]
+    for k, name in enumerate(names):
         ds = Dataset('', h=128, w=128, c=3, min_n_views=2562, radius=700, num_cyclo=36)
         with S.variable_scope(name):
             e = Encoder(S.Placeholder((128, 128, 3)), 128, [128, 256, 512, 512], 5, [2, 2, 2, 2], False)
@@ -37,25 +38,26 @@ def build():
         r = np.random.default_rng(70 + k)
         c.assign_obj_bbs(np.stack([r.integers(250, 350, 92232), r.integers(180, 260, 92232), r.integers(80, 200, 92232), r.integers(80, 200, 92232)], 1))
         books[name] = c
-    return AePoseEstimator(codebooks=books, train_args={'obj_a': targs, 'obj_b': targs})
+    return AePoseEstimator(codebooks=books, train_args={n: targs for n in names}), names
 
 
-def detections(rng, D):
+def detections(rng, D, names=None):
     dets = []
     for i in range(D):
         x, y, w, h = rng.uniform(0, 1500), rng.uniform(0, 800), rng.uniform(60, 400), rng.uniform(60, 270)
-        dets.append(BoundingBox(xmin=x / 1920, xmax=(x + w) / 1920, ymin=y / 1080, ymax=(y + h) / 1080, classes={'obj_a' if i % 3 else 'obj_b': 1.0}))
+        dets.append(BoundingBox(xmin=x / 1920, xmax=(x + w) / 1920, ymin=y / 1080, ymax=(y + h) / 1080, classes={(names[i % len(names)] if names and len(names) > 2 else ('obj_a' if i % 3 else 'obj_b')): 1.0}))
     return dets
 
 
 if __name__ == '__main__':
     D = int(sys.argv[1]) if len(sys.argv) > 1 else 1
     reps = int(sys.argv[2]) if len(sys.argv) > 2 else 300
-    est = build()
+    n_classes = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+    est, names = build(n_classes)
     rng = np.random.default_rng(0)
     img = rng.integers(0, 256, (1080, 1920, 3), dtype=np.uint8)
     camK = np.array([[1075.65, 0, 960.0], [0, 1073.9, 540.0], [0, 0, 1]])
-    dets = detections(rng, D)
+    dets = detections(rng, D, names)
     for _ in range(5):
         est.process(dets, img, camK)
     torch.cuda.synchronize()
