@@ -304,8 +304,7 @@ def main():
                 tj = json.load(f)
             traffic = tj.get(precision, {}).get(dom['kernel'].split(':')[0])
             traffic_src = tj.get(precision + '_source')
-            if precision == 'f32':
-                busy = dict(tj.get('mfma', {}).get(dom['kernel'].split(':')[0], {}), source=tj.get('mfma_source'))
+            busy = dict(tj.get('mfma' if precision == 'f32' else 'mfma_x3h', {}).get(dom['kernel'].split(':')[0], {}), source=tj.get('mfma_source'))
         except Exception:
             traffic = None
         return {
@@ -317,7 +316,9 @@ def main():
                                             '; a committed measurement, not taken in this run (PMC collection needs the profiler)') if traffic is not None else None,
                          'flops_per_launch': dom_flops, 'avg_ms': dom['ms'],
                          'mfma_busy_frac': busy.get('mfma_busy_frac'), 'delivered_GHz_under_pmc': busy.get('delivered_GHz'),
-                         'mfma_busy_source': busy.get('source')},
+                         'mfma_busy_source': busy.get('source'),
+                         # (the split-precision mode is clock-limited: its fraction of the peak AT THE DELIVERED CLOCK, nominal 2.4 GHz)
+                         'frac_of_peak_at_delivered_clock': round(achieved / (peak * busy['delivered_GHz'] / 2.4), 4) if busy.get('delivered_GHz') else None},
             'encoder_tflops': round(cfg.flops_per_crop() * B / (sum(k['ms'] for k in kernels) * 1e-3) / 1e12, 2),
             'kernels': kernels,
             'rank_ms_per_step': rank_ms,

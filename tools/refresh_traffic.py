@@ -34,6 +34,13 @@ for name, layer in (('conv2', 1), ('conv3', 2), ('conv4', 3)):
         b = max(busy, key=lambda v: v.get('dispatches_seen', 0))
         t.setdefault('mfma', {})[name] = {'mfma_busy_frac': round(b['SQ_VALU_MFMA_BUSY_CYCLES'] / (b['GRBM_GUI_ACTIVE'] / 8.0 * 1024.0), 4),
                                           'delivered_GHz': round(b['GRBM_GUI_ACTIVE'] / 8.0 / b['avg_ns_under_pmc'], 3)}
+# the opt-in split-precision mode is power / clock limited: what clock did the chip deliver under its dominant kernel?
+for name, kern in (('conv2', 'conv_igemm_x3h_wide_kernel<1, 1>'), ('conv3', 'conv_igemm_x3h_wide_kernel<1, 2>'), ('conv4', 'conv_igemm_x3h_dma_kernel<1, 3, 2>')):
+    rows = [v for k, v in main.items() if k.startswith(kern) and 'SQ_VALU_MFMA_BUSY_CYCLES' in v and v.get('GRBM_GUI_ACTIVE', 0) > 0]
+    if rows:
+        b = max(rows, key=lambda v: v.get('dispatches_seen', 0))
+        t.setdefault('mfma_x3h', {})[name] = {'mfma_busy_frac': round(b['SQ_VALU_MFMA_BUSY_CYCLES'] / (b['GRBM_GUI_ACTIVE'] / 8.0 * 1024.0), 4),
+                                              'delivered_GHz': round(b['GRBM_GUI_ACTIVE'] / 8.0 / b['avg_ns_under_pmc'], 3)}
 t['mfma_source'] = 'profiles/%s/pmc_summary.json: SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs); delivered_GHz = GRBM_GUI_ACTIVE / 8 / kernel duration under the PMC pass' % tag
 t['f32_source'] = 'profiles/%s/pmc_summary.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the default bench command in round %s: 2*FETCH_SIZE*1024 + WRITE_SIZE*1024 per launch)' % (tag, tag)
 if len(args) > 1:
