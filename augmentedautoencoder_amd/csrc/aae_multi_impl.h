@@ -62,7 +62,8 @@ static bool multi_encoder_groupable(const aae_encoder* enc, int n, std::vector<W
     if (D.kind != KIND_IGEMM || !enc->dense_gemv || n > gemv_max_batch(enc) || D.K() % aae::kGemvChunk != 0 || !gemv_uses_ticket(enc, D)) return false;
     plans.assign(nl, WaveKPlan());
     sig.clear();
-    sig.push_back(n);
+    sig.push_back(enc->multi_group_plan ? 0 : n);   // per-object plans: one group per detection count (MQ / NQ of the GEMV and the scan are part of the
+                                                   // per-object call's summation order); group plans: objects with 1 ... 4 detections share their launches
     sig.push_back(enc->multi_group_plan);      // ... and the options the group's plan is made from
     sig.push_back(enc->wavek_spread); sig.push_back(enc->wavek_g_boost); sig.push_back(wavek_round_blocks(enc)); sig.push_back(enc->wavek_eff64x32_pct);
     sig.push_back(enc->compact_workspace); sig.push_back(enc->first_vec4); sig.push_back(enc->multi_force_shape); sig.push_back(enc->multi_force_g);
@@ -77,7 +78,7 @@ static bool multi_encoder_groupable(const aae_encoder* enc, int n, std::vector<W
         const bool spread = key == 1142 ? (enc->wavek_spread & 2) != 0 : (key == 242 ? (enc->wavek_spread & 1) != 0 : false);
         if (!((key == 1142 && spread) || key == 142 || (key == 242 && spread))) return false;         // (the instantiated grouped forms = the defaults)
         plans[li] = w;
-        sig.push_back(key);
+        sig.push_back(enc->multi_group_plan ? 0 : key);
     }
     return true;
 }
@@ -98,37 +99,45 @@ static bool multi_encoder_groupable(const aae_encoder* enc, int n, std::vector<W
 // Same fma chains per output element up to where K is cut: results differ from the per-object call's by fp32 summation
 // order only (like a batch of another size does); "multi_group_plan" = 0 keeps every object on its own plan, bit-identical
 // to aae_encode_nn.
-static WaveKPlan plan_wavek_group(const aae_encoder* enc, const Layer& L, long long M, int members) {
+// rows[k] = GEMM rows (detections x Ho x Wo) of member k's layer; the members share (wave tile, K cut), each has its own tile count
+static std::vector<WaveKPlan> plan_wavek_group(const aae_encoder* enc, const Layer& L, const std::vector<long long>& rows) {
     const int slabs = (int)(L.K() / 32), waves = 4, cus = wavek_round_blocks(enc);
     const int layer = L.index > 0 ? L.index - 1 : 0;
     const int force = (enc->multi_force_shape >> (4 * layer)) & 15;          // (A/B: one nibble per conv layer, 1 = 32 x 32, 2 = 64 x 32, 3 = 64 x 64)
     const int force_g = (enc->multi_force_g >> (8 * layer)) & 255;           // (A/B: one byte per conv layer)
     auto make = [&](int mt, int nt, int blocks_per_cu) {
-        WaveKPlan w;
-        const long long tiles_o = ((M + 32 * mt - 1) / (32 * mt)) * (long long)(L.CoutPad / (32 * nt));
-        const long long total = tiles_o * members;
-        if (tiles_o > kWaveKTileCap || total > (1 << 20)) return w;
+        std::vector<WaveKPlan> out(rows.size());
+        long long total = 0, most = 0;
+        for (long long M : rows) {
+            const long long tiles_o = ((M + 32 * mt - 1) / (32 * mt)) * (long long)(L.CoutPad / (32 * nt));
+            total += tiles_o;
+            most = std::max(most, tiles_o);
+        }
+        if (most > kWaveKTileCap || total > (1 << 20)) return std::vector<WaveKPlan>();
         int g = force_g ? force_g : (int)((long long)cus * blocks_per_cu / total);
         const int gmax = std::min(slabs / (2 * waves), (int)aae::kTicketSingleLevelMax);
         if (g > gmax) g = gmax;
-        if (g < 1 || tiles_o > kLayerTicketWords) g = 1;
-        w.use = true;
-        w.MT = mt; w.NT = nt; w.waves = waves; w.depth = 2;
-        w.num_mt = (int)((M + 32 * mt - 1) / (32 * mt));
-        w.num_nt = L.CoutPad / (32 * nt);
-        w.gsplits = g;
-        w.tail_tiles = 0; w.tail_g = 1;
-        w.partial_bytes = g > 1 ? (size_t)w.blocks() * (mt * nt * 16) * 64 * sizeof(float) : 0;
-        return w;
+        if (g < 1 || most > kLayerTicketWords) g = 1;
+        for (size_t k = 0; k < rows.size(); ++k) {
+            WaveKPlan& w = out[k];
+            w.use = true;
+            w.MT = mt; w.NT = nt; w.waves = waves; w.depth = 2;
+            w.num_mt = (int)((rows[k] + 32 * mt - 1) / (32 * mt));
+            w.num_nt = L.CoutPad / (32 * nt);
+            w.gsplits = g;
+            w.tail_tiles = 0; w.tail_g = 1;
+            w.partial_bytes = g > 1 ? (size_t)w.blocks() * (mt * nt * 16) * 64 * sizeof(float) : 0;
+        }
+        return out;
     };
     const bool have64 = (enc->wavek_spread & 1) != 0, have32 = (enc->wavek_spread & 2) != 0;      // (the instantiated grouped forms)
     if (force == 1 && have32) return make(1, 1, 2);
     if (force == 2) return make(2, 1, 1);
     if (force == 3 && have64) return make(2, 2, 2);
-    WaveKPlan a = have64 ? make(2, 2, 2) : WaveKPlan();
-    if (a.use && a.gsplits < 4) return a;
-    WaveKPlan b = make(2, 1, 1);
-    return b.use ? b : a;
+    std::vector<WaveKPlan> a = have64 ? make(2, 2, 2) : std::vector<WaveKPlan>();
+    if (!a.empty() && a[0].gsplits < 4) return a;
+    std::vector<WaveKPlan> b = make(2, 1, 1);
+    return b.empty() ? a : b;
 }
 
 // workspace slice of a grouped item: ticket words, one activation buffer per conv layer, the largest partial buffer of its plans
@@ -193,13 +202,15 @@ static int plan_multi(const aae_multi_item* items, int n_items, bool scan_only, 
     if (!scan_only)
         for (const std::vector<int>& g : mp.groups) {
             const aae_encoder* enc0 = items[g[0]].enc;
-            if (g.size() >= 2 && enc0->multi_group_plan) {               // the group's own plan (every member the same network shape and n)
-                std::vector<WaveKPlan> gp(enc0->layers.size());
+            if (g.size() >= 2 && enc0->multi_group_plan) {               // the group's own plan (every member the same network shape)
                 for (size_t li = 1; li < enc0->layers.size(); ++li) {
                     const Layer& L = enc0->layers[li];
-                    gp[li] = plan_wavek_group(enc0, L, (long long)mp.items[(size_t)g[0]].n * L.Ho * L.Wo, (int)g.size());
+                    std::vector<long long> rows;
+                    for (int i : g) rows.push_back((long long)mp.items[(size_t)i].n * L.Ho * L.Wo);
+                    const std::vector<WaveKPlan> gp = plan_wavek_group(enc0, L, rows);
+                    if (gp.size() == g.size())
+                        for (size_t k = 0; k < g.size(); ++k) mp.items[(size_t)g[k]].plans[li] = gp[k];
                 }
-                for (int i : g) mp.items[(size_t)i].plans = gp;
             }
             for (int i : g) {
                 MultiItemPlan& p = mp.items[(size_t)i];
@@ -258,7 +269,8 @@ static int launch_scan_multi(const MultiPlan& mp, const std::vector<int>& member
                              unsigned char* base, unsigned nonce, hipStream_t stream) {
     aae::ScanMultiArgs m;
     memset(&m, 0, sizeof(m));
-    const int n = mp.items[(size_t)members[0]].n;
+    int n = 1;                                  // NQ of the launch: the largest detection count among its objects (an object with fewer leaves rows idle;
+    for (int i : members) n = std::max(n, mp.items[(size_t)i].n);      //  per-row scores and the arg-max do not depend on it)
     int at = 0;
     m.range.n = (int)members.size();
     for (size_t k = 0; k < members.size(); ++k) {
@@ -293,7 +305,9 @@ static int launch_encoder_multi(const aae_multi_item* items, const MultiPlan& mp
                                 float* z_out, unsigned char* base, unsigned nonce, hipStream_t stream) {
     const aae_encoder* enc0 = items[members[0]].enc;
     const size_t nl = enc0->layers.size();
-    const int n = mp.items[(size_t)members[0]].n, J = enc0->desc.latent_size;
+    const int J = enc0->desc.latent_size;
+    int nmax = 1;                               // MQ of the GEMV launch: the largest detection count among the group's objects
+    for (int i : members) nmax = std::max(nmax, mp.items[(size_t)i].n);
     const bool u8 = x_dtype == AAE_DTYPE_U8;
     const size_t crop_bytes = (size_t)enc0->desc.in_h * enc0->desc.in_w * enc0->desc.in_c * (u8 ? 1 : 4);
     auto enc_base = [&](size_t k) { return base + mp.items[(size_t)members[k]].enc_off; };
@@ -311,7 +325,7 @@ static int launch_encoder_multi(const aae_multi_item* items, const MultiPlan& mp
             const MultiItemPlan& p = mp.items[(size_t)members[k]];
             const Layer& L = it.enc->layers[0];
             const void* xk = static_cast<const unsigned char*>(x) + (size_t)p.row0 * crop_bytes;
-            const int runs = first_core_args(it.enc, L, xk, u8, n, reinterpret_cast<float*>(enc_base(k) + p.ws.act_off[0]), false, m.item[k]);
+            const int runs = first_core_args(it.enc, L, xk, u8, p.n, reinterpret_cast<float*>(enc_base(k) + p.ws.act_off[0]), false, m.item[k]);
             if (vec4 < 0) vec4 = m.item[k].vec4;
             if (m.item[k].vec4 != vec4) return fail(AAE_ERR_RUNTIME, "multi-object query: objects disagree on the dword staging of conv1 (option first_vec4)");
             m.range.first[k] = at;
@@ -348,10 +362,12 @@ static int launch_encoder_multi(const aae_multi_item* items, const MultiPlan& mp
             const MultiItemPlan& p = mp.items[(size_t)members[k]];
             const Layer& L = it.enc->layers[li];
             const WaveKPlan& w = p.plans[li];
-            m.item[k] = wavek_args(it.enc, L, w, reinterpret_cast<const float*>(enc_base(k) + p.ws.act_off[li - 1]), n * L.Ho * L.Wo,
+            m.item[k] = wavek_args(it.enc, L, w, reinterpret_cast<const float*>(enc_base(k) + p.ws.act_off[li - 1]), p.n * L.Ho * L.Wo,
                                    reinterpret_cast<float*>(enc_base(k) + p.ws.act_off[li]), reinterpret_cast<float*>(enc_base(k) + p.ws.partial_off),
                                    tickets_of(k) + li * kLayerTicketWords, nonce, (int)li);
             m.item[k].timeline = nullptr;
+            if (wavek_shape_key(w) != wavek_shape_key(mp.items[(size_t)members[0]].plans[li]))       // (one kernel instantiation serves the launch)
+                return fail(AAE_ERR_RUNTIME, "multi-object query: the members of a group disagree on the wave tile of conv%zu", li + 1);
             m.nblk[k] = w.blocks();
             m.range.first[k] = at;
             at += (w.blocks() + 7) / 8 * 8;              // (every object's first block on XCD 0: xcd_remap counts from it)
@@ -378,7 +394,7 @@ static int launch_encoder_multi(const aae_multi_item* items, const MultiPlan& mp
             const aae_multi_item& it = items[members[k]];
             const MultiItemPlan& p = mp.items[(size_t)members[k]];
             const Layer& D = it.enc->dense;
-            aae::DenseGemvArgs a = gemv_args(D, reinterpret_cast<const float*>(enc_base(k) + p.ws.act_off[nl - 1]), n, reinterpret_cast<float*>(enc_base(k) + p.ws.partial_off));
+            aae::DenseGemvArgs a = gemv_args(D, reinterpret_cast<const float*>(enc_base(k) + p.ws.act_off[nl - 1]), p.n, reinterpret_cast<float*>(enc_base(k) + p.ws.partial_off));
             a.bias = D.bias; a.bn_scale = D.bn_scale; a.bn_shift = D.bn_shift; a.out = z_out + (size_t)p.row0 * J;
             a.tickets = tickets_of(k) + kConvTicketBytes / 8; a.nonce = nonce; a.relu = D.relu;
             m.item[k] = a;
@@ -388,11 +404,11 @@ static int launch_encoder_multi(const aae_multi_item* items, const MultiPlan& mp
         m.range.first[members.size()] = at;
         const Layer& D0 = enc0->dense;
         const dim3 grid(at, D0.CoutPad / 128);
-        int smem = 2 * n * aae::kGemvChunk * (int)sizeof(float) + 16;
+        int smem = 2 * nmax * aae::kGemvChunk * (int)sizeof(float) + 16;
         if (smem < aae::kGemvTicketSmem) smem = aae::kGemvTicketSmem;
-        if (n == 1) AAE_LAUNCH((aae::dense_gemv_multi_kernel<1>), grid, dim3(256), smem, stream, m);
-        else if (n == 2) AAE_LAUNCH((aae::dense_gemv_multi_kernel<2>), grid, dim3(256), smem, stream, m);
-        else if (n == 3) AAE_LAUNCH((aae::dense_gemv_multi_kernel<3>), grid, dim3(256), smem, stream, m);
+        if (nmax == 1) AAE_LAUNCH((aae::dense_gemv_multi_kernel<1>), grid, dim3(256), smem, stream, m);
+        else if (nmax == 2) AAE_LAUNCH((aae::dense_gemv_multi_kernel<2>), grid, dim3(256), smem, stream, m);
+        else if (nmax == 3) AAE_LAUNCH((aae::dense_gemv_multi_kernel<3>), grid, dim3(256), smem, stream, m);
         else AAE_LAUNCH((aae::dense_gemv_multi_kernel<4>), grid, dim3(256), smem, stream, m);
         AAE_HIP_TRY(hipGetLastError());
         ++t_multi_launches;

@@ -104,6 +104,20 @@ def test_group_plan_same_bits_in_every_block_order_and_right_against_the_oracle(
         assert np.abs(z1[k * n:(k + 1) * n] - z64).max() / np.abs(z64).max() < 5e-6
         cs = c.similarity(z1[k * n:(k + 1) * n])
         assert np.array_equal(i1[k * n:(k + 1) * n], np.argmax(cs, axis=1))
+    # objects with DIFFERENT detection counts share the group's launches too (the GEMV / scan instantiated for the largest count)
+    if n > 1:
+        mixed = [(e, c, max(1, n - k), 1) for k, (e, c, _) in enumerate(objs)]
+        rows = sum(it[2] for it in mixed)
+        xm = synth.make_crops(rows, seed=57, shape=cfg.shape)
+        zm, im, sm, launches = eb.encode_nn_multi(mixed, xm, ws)
+        assert launches == 6
+        zp, ip, sp = _per_object(mixed, xm)
+        assert np.abs(zm - zp).max() / np.abs(zp).max() < 2e-6
+        at = 0
+        for (e, c, k, _) in mixed:
+            cs = c.similarity(zm[at:at + k])
+            assert np.array_equal(im[at:at + k], np.argmax(cs, axis=1)) and np.array_equal(sm[at:at + k], cs.max(axis=1))
+            at += k
     # a single-member group keeps the per-object plan: bit-identical to aae_encode_nn
     z2, i2, s2, _ = eb.encode_nn_multi(items[:1], x[:n], ws)
     assert np.array_equal(z2, z0[:n]) and np.array_equal(i2, i0[:n]) and np.array_equal(s2, s0[:n])

@@ -89,7 +89,7 @@ def test_eight_objects_one_launch_per_layer_against_per_object_calls_and_the_fp6
     # ---- the default: one launch plan per group (larger wave tiles, K split for the group's tile count): summation order differs
     mq = MultiObjectQuery([(e, c, n) for (e, c), n in zip(objs, counts)])
     z3, i3, s3 = mq(x)
-    assert mq.launches == 4 * 6
+    assert mq.launches == 6                                    # objects with 1 ... 4 detections share ONE group: six launches for the frame's 15 detections
     assert float((z3 - z0).abs().max() / z0.abs().max()) < 1e-5
     against_oracle(z3, i3, s3, counts, crops_host, 'group plans')
     mq1 = MultiObjectQuery([(e, c, 1) for e, c in objs])
@@ -179,14 +179,21 @@ def test_frame_in_one_call_with_upright_and_large_classes(eight_objects):
     try:
         launches = detect_nn_multi(items, img, rows, crops, z, idx, score, ws)
         torch.cuda.synchronize()
+        assert launches == 6                                             # n = 2, n = 1 (upright), n = 3 in ONE group; the 9-detection class: per-object path
+        assert torch.equal(crops, crop_resize(img, rows_np, (128, 128)))
+        z_grp, idx_grp = z.clone(), idx.clone()
+        _group_plan(objs, 0)                                             # every object its own plan: one group per detection count, bit-identical answers
+        launches = detect_nn_multi(items, img, rows, crops, z, idx, score, ws)
+        torch.cuda.synchronize()
+        assert launches == 3 * 6
     finally:
         objs[3][0].set_option('precision', 0)
-    assert launches == 3 * 6                                             # n = 2, n = 1 (upright), n = 3; the 9-detection class: per-object path
-    assert torch.equal(crops, crop_resize(img, rows_np, (128, 128)))
+        _group_plan(objs, 1)
     at = 0
     for (e, c, n, st) in items:
         wz, wi, wsc = e.encode_nn(c, crops[at:at + n], st)
         assert torch.equal(z[at:at + n], wz) and torch.equal(idx[at:at + n], wi[:, 0].cpu()) and torch.equal(score[at:at + n], wsc[:, 0])
+        assert torch.equal(idx_grp[at:at + n], wi[:, 0].cpu()) and float((z_grp[at:at + n] - wz).abs().max() / wz.abs().max()) < 1e-5
         if st > 1:
             assert (idx[at:at + n] % st == 0).all()
         at += n

@@ -92,6 +92,28 @@ def main():
                               'mfma_floor_us': round(n_obj * d * cfg.flops_per_crop() / (PEAK_F32_TFLOPS * 1e6), 1),
                               'hbm_floor_us': round(n_obj * (cfg.param_bytes() + cb_bytes) / (PEAK_HBM_GBPS * 1e3), 1),
                               'resident_MB': round(n_obj * (cfg.param_bytes() + cb_bytes) / 1e6, 1)}), flush=True)
+    # a frame whose classes have DIFFERENT detection counts (the usual case): per-object plans need one group per count
+    for counts in ([1, 1, 2, 4, 1, 3, 1, 2], [2, 1, 1, 3], [4, 4, 1, 1, 1, 1, 2, 2, 1, 1, 3, 1]):
+        sel = objs[:len(counts)]
+        xcat = torch.cat([xs[k][:n] for k, n in enumerate(counts)]).contiguous()
+
+        def seq():
+            for (e, c), xi, n in zip(sel, xs, counts):
+                e.encode_nn(c, xi[:n], 1)
+        mq = MultiObjectQuery([(e, c, n) for (e, c), n in zip(sel, counts)], device=dev)
+        t_seq, t_grp = time_us(seq, 40), time_us(lambda: mq(xcat), 40)
+        launches = mq.launches
+        for e, _ in objs:
+            e.set_option('multi_group_plan', 0)
+        mq0 = MultiObjectQuery([(e, c, n) for (e, c), n in zip(sel, counts)], device=dev)
+        t_grp0 = time_us(lambda: mq0(xcat), 40)
+        launches0 = mq0.launches
+        for e, _ in objs:
+            e.set_option('multi_group_plan', 1)
+        print(json.dumps({'what': 'mixed_frame', 'detections_per_object': counts, 'detections': sum(counts), 'sequential_us': round(t_seq, 1), 'grouped_us': round(t_grp, 1),
+                          'grouped_per_object_plans_us': round(t_grp0, 1), 'grouped_over_sequential': round(t_grp / t_seq, 3), 'launches_grouped': launches,
+                          'launches_grouped_per_object_plans': launches0, 'launches_sequential': 6 * len(counts),
+                          'mfma_floor_us': round(sum(counts) * cfg.flops_per_crop() / (PEAK_F32_TFLOPS * 1e6), 1)}), flush=True)
     # the codebook stage alone
     for n_obj in (1, 2, 4, 8, 16):
         for d in (1, 4):
