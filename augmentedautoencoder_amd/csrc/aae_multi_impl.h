@@ -66,7 +66,7 @@ static bool multi_encoder_groupable(const aae_encoder* enc, int n, std::vector<W
                                                    // per-object call's summation order); group plans: objects with 1 ... 4 detections share their launches
     sig.push_back(enc->multi_group_plan);      // ... and the options the group's plan is made from
     sig.push_back(enc->wavek_spread); sig.push_back(enc->wavek_g_boost); sig.push_back(wavek_round_blocks(enc)); sig.push_back(enc->wavek_eff64x32_pct);
-    sig.push_back(enc->compact_workspace); sig.push_back(enc->first_vec4); sig.push_back(enc->multi_force_shape); sig.push_back(enc->multi_force_g);
+    sig.push_back(enc->compact_workspace); sig.push_back(enc->first_vec4); sig.push_back(enc->multi_force_shape); sig.push_back(enc->multi_force_g); sig.push_back(enc->multi_xcd_affine);
     const int32_t* d = reinterpret_cast<const int32_t*>(&enc->desc);
     for (size_t i = 0; i < sizeof(aae_encoder_desc) / sizeof(int32_t); ++i) sig.push_back(d[i]);      // (bn_eps as its bit pattern)
     for (size_t li = 1; li < nl; ++li) {
@@ -373,6 +373,13 @@ static int launch_encoder_multi(const aae_multi_item* items, const MultiPlan& mp
             at += (w.blocks() + 7) / 8 * 8;              // (every object's first block on XCD 0: xcd_remap counts from it)
         }
         m.range.first[members.size()] = at;
+        m.xcd_affine = 0;
+        if (enc0->multi_xcd_affine && members.size() % 8 == 0) {          // equal-sized objects, a multiple of 8 of them: one XCD per object
+            const int nb = m.range.first[1] - m.range.first[0];
+            bool equal = true;
+            for (size_t k = 0; k < members.size(); ++k) equal = equal && m.range.first[k + 1] - m.range.first[k] == nb;
+            if (equal) m.xcd_affine = nb;
+        }
         const WaveKPlan& w0 = mp.items[(size_t)members[0]].plans[li];
         const int tag = li <= 3 ? (int)li : 0;
         switch (wavek_shape_key(w0)) {

@@ -493,6 +493,10 @@ __global__ __launch_bounds__(64 * WAVES, (MT * NT == 4 && WAVES == 4 && DEPTH ==
 struct ConvWaveKMultiArgs {
     MultiRange range;                      // (padded to multiples of 8 blocks per object: xcd_remap counts from the object's first block)
     int nblk[kMultiMax];                   // real block count of each object's layer
+    // > 0: every object has this many (padded) blocks and the number of objects is a multiple of 8 -- then ALL blocks of an object run on
+    // ONE XCD (physical block p runs on XCD p % 8: object = p % 8 + 8 * ((p / 8) / xcd_affine), block (p / 8) % xcd_affine of it), so that an
+    // object's weights and activations live in one 4 MB L2 instead of being streamed through all eight
+    int xcd_affine;
     ConvWaveKArgs item[kMultiMax];
 };
 template <int MT, int NT, int WAVES, int DEPTH, int TAG = 0, bool SPREAD = false>
@@ -500,8 +504,15 @@ __global__ __launch_bounds__(64 * WAVES, (MT * NT == 4 && WAVES == 4 && DEPTH ==
     AAE_DYN_SMEM(smem_raw);
     float* red = reinterpret_cast<float*>(smem_raw);
     int* flag = reinterpret_cast<int*>(red + WAVES * MT * NT * 16 * 64);
-    const int o = multi_find(m.range, (int)blockIdx.x);
-    const int L = (int)blockIdx.x - m.range.first[o];
+    int o, L;
+    if (m.xcd_affine > 0) {
+        const int p = (int)blockIdx.x, idx = p >> 3;
+        o = (p & 7) + 8 * (idx / m.xcd_affine);
+        L = idx % m.xcd_affine;
+    } else {
+        o = multi_find(m.range, (int)blockIdx.x);
+        L = (int)blockIdx.x - m.range.first[o];
+    }
     if (L >= m.nblk[o]) return;                                  // (padding block)
     WaveKPrefetch none;
     conv_wavek_block<MT, NT, WAVES, DEPTH, false, SPREAD>(m.item[o], L, m.nblk[o], red, flag, none, false);

@@ -218,6 +218,29 @@ def test_several_codebooks_in_one_scan_launch(order):
         eb.set_block_order(0)
 
 
+def test_eight_equal_objects_one_xcd_per_object_mapping_is_only_a_permutation_of_blocks():
+    """8 (16, ...) equal-sized objects: the conv launches put all blocks of an object on one XCD (ConvWaveKMultiArgs::xcd_affine) -- another
+    assignment of physical blocks to (object, tile), the same work: bit-identical answers with the mapping on and off"""
+    cfg = EncoderConfig((16, 16, 3), [32, 64], [2, 2], 5, 128)
+    objs = [_object(cfg, 1200 + o, 36 * 5 + o) for o in range(8)]
+    items = [(e, c, 1, 1) for e, c, _ in objs]
+    x = synth.make_crops(8, seed=4, shape=cfg.shape)
+    got = {}
+    for affine in (1, 0):
+        for e, _, _ in objs:
+            e.set_option('multi_xcd_affine', affine)
+        eb.set_block_order(2 if affine else 0)
+        try:
+            got[affine] = eb.encode_nn_multi(items, x)
+        finally:
+            eb.set_block_order(0)
+    assert got[1][3] == got[0][3] == 4
+    assert all(np.array_equal(a, b) for a, b in zip(got[1][:3], got[0][:3]))
+    zp, ip, sp = _per_object(items, x)
+    assert np.abs(got[1][0] - zp).max() / np.abs(zp).max() < 2e-6 and np.array_equal(got[1][1], ip)
+    _close(objs)
+
+
 def test_more_objects_than_one_launch_holds():
     """kMultiMax = 16 objects per launch: 19 items of one shape take two launches per layer"""
     cfg = EncoderConfig((16, 16, 3), [32, 64], [2, 2], 5, 128)
