@@ -440,7 +440,10 @@ def main():
         xs = [torch.from_numpy(synth.make_crops(4, seed=500 + i)).to(dev) for i in range(N_OBJ)]
         from augmentedautoencoder_amd import engine as _engine
         MultiQuery = getattr(_engine, 'MultiObjectQuery', None)
-        lm = {'objects': N_OBJ, 'weights_plus_codebooks_MB': round(N_OBJ * (cfg.param_bytes() + cb_bytes) / 1e6, 1)}
+        lm = {'objects': N_OBJ, 'weights_plus_codebooks_MB': round(N_OBJ * (cfg.param_bytes() + cb_bytes) / 1e6, 1),
+              'note': 'sequential = one six-launch aae_encode_nn chain per object; grouped = aae_encode_nn_multi: one launch per layer across the objects (problem table in the '
+                      'kernel arguments, tickets per (object, tile), one scan launch over all codebooks), the launch plan chosen for the group (option multi_group_plan; 0 = '
+                      'per-object plans, bit-identical to the sequential calls).  Cold by construction: 853 MB of weights + codebooks against a 256 MB Infinity Cache'}
         for d in (1, 4):
             def frame_seq():
                 for (e, c_b), xi in zip(all8, xs):
@@ -457,6 +460,19 @@ def main():
                             'hbm_floor_us': round(N_OBJ * (cfg.param_bytes() + cb_bytes) / (PEAK_HBM_GBPS * 1e3), 1)})
             lm['8x%d' % d] = row
         if MultiQuery is not None:
+            # the usual frame: classes with DIFFERENT detection counts -- still six launches (the group's GEMV / scan are instantiated for the largest count)
+            counts = [1, 1, 2, 4, 1, 3, 1, 2]
+
+            def mixed_seq():
+                for (e, c_b), xi, n in zip(all8, xs, counts):
+                    e.encode_nn(c_b, xi[:n], 1)
+            mqm = MultiQuery([(e, c_b, n) for (e, c_b), n in zip(all8, counts)], device=dev)
+            xmix = torch.cat([xi[:n] for xi, n in zip(xs, counts)]).contiguous()
+            seq_m = time_us(mixed_seq, 40, warm=4)
+            grp_m = time_us(lambda: mqm(xmix), 40, warm=4)
+            lm['8x{1,1,2,4,1,3,1,2}'] = {'detections': sum(counts), 'sequential_us': round(seq_m, 1), 'grouped_us': round(grp_m, 1), 'grouped_over_sequential': round(grp_m / seq_m, 3),
+                                         'launches_grouped': mqm.launches, 'launches_sequential': 6 * N_OBJ,
+                                         'mfma_floor_us': round(sum(counts) * cfg.flops_per_crop() / (PEAK_F32_TFLOPS * 1e6), 1)}
             # the codebook stage alone over the eight codebooks (378 MB > the 256 MB Infinity Cache: every call streams from HBM):
             # ONE launch (aae_codebook_nn_multi) against eight aae_codebook_nn calls
             z8 = torch.randn(N_OBJ, 128, device=dev)
