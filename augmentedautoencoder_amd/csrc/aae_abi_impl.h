@@ -206,6 +206,7 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
     else if (!strcmp(name, "ticket_prep")) enc->ticket_prep = value ? 1 : 0;
     else if (!strcmp(name, "multi_group_plan")) enc->multi_group_plan = value ? 1 : 0;
     else if (!strcmp(name, "multi_xcd_affine")) enc->multi_xcd_affine = value ? 1 : 0;
+    else if (!strcmp(name, "multi_force_depth")) enc->multi_force_depth = value;
     else if (!strcmp(name, "multi_force_shape")) enc->multi_force_shape = value;
     else if (!strcmp(name, "multi_force_g")) enc->multi_force_g = value;
 #ifdef AAE_EXPERIMENTS

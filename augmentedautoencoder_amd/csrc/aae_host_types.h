@@ -154,6 +154,7 @@ struct aae_encoder {
     int detect_chain_blocks = 256;         // its grid: one block per CU, never more than the device has (every block must be resident)
     int cu_count = 0;                      // compute units of the device the handle lives on
     int multi_xcd_affine = 1;              // grouped query, 8 | 16 equal-sized objects: all blocks of an object on one XCD (conv_wavek_f32.h, ConvWaveKMultiArgs)
+    int multi_force_depth = 0;             // A/B: slabs in flight of the group plan's 64 x 32 layers (nibble per conv layer)
     int multi_force_shape = 0, multi_force_g = 0;   // A/B of plan_wavek_group: wave tile (nibble per conv layer) / K split (byte per conv layer) forced
     int multi_group_plan = 1;              // aae_encode_nn_multi: a group of objects runs ONE launch plan chosen for the group's total tile count
                                            // (aae_multi_impl.h, plan_wavek_group); 0 = every object its own plan: bit-identical to aae_encode_nn

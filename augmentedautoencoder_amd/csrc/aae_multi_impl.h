@@ -66,7 +66,7 @@ static bool multi_encoder_groupable(const aae_encoder* enc, int n, std::vector<W
                                                    // per-object call's summation order); group plans: objects with 1 ... 4 detections share their launches
     sig.push_back(enc->multi_group_plan);      // ... and the options the group's plan is made from
     sig.push_back(enc->wavek_spread); sig.push_back(enc->wavek_g_boost); sig.push_back(wavek_round_blocks(enc)); sig.push_back(enc->wavek_eff64x32_pct);
-    sig.push_back(enc->compact_workspace); sig.push_back(enc->first_vec4); sig.push_back(enc->multi_force_shape); sig.push_back(enc->multi_force_g); sig.push_back(enc->multi_xcd_affine);
+    sig.push_back(enc->compact_workspace); sig.push_back(enc->first_vec4); sig.push_back(enc->multi_force_shape); sig.push_back(enc->multi_force_g); sig.push_back(enc->multi_xcd_affine); sig.push_back(enc->multi_force_depth);
     const int32_t* d = reinterpret_cast<const int32_t*>(&enc->desc);
     for (size_t i = 0; i < sizeof(aae_encoder_desc) / sizeof(int32_t); ++i) sig.push_back(d[i]);      // (bn_eps as its bit pattern)
     for (size_t li = 1; li < nl; ++li) {
@@ -105,6 +105,7 @@ static std::vector<WaveKPlan> plan_wavek_group(const aae_encoder* enc, const Lay
     const int layer = L.index > 0 ? L.index - 1 : 0;
     const int force = (enc->multi_force_shape >> (4 * layer)) & 15;          // (A/B: one nibble per conv layer, 1 = 32 x 32, 2 = 64 x 32, 3 = 64 x 64)
     const int force_g = (enc->multi_force_g >> (8 * layer)) & 255;           // (A/B: one byte per conv layer)
+    const int force_depth = (enc->multi_force_depth >> (4 * layer)) & 15;    // (A/B: one nibble per conv layer: 2 | 3 slabs in flight, 64 x 32 tiles only)
     auto make = [&](int mt, int nt, int blocks_per_cu) {
         std::vector<WaveKPlan> out(rows.size());
         long long total = 0, most = 0;
@@ -121,7 +122,13 @@ static std::vector<WaveKPlan> plan_wavek_group(const aae_encoder* enc, const Lay
         for (size_t k = 0; k < rows.size(); ++k) {
             WaveKPlan& w = out[k];
             w.use = true;
-            w.MT = mt; w.NT = nt; w.waves = waves; w.depth = 2;
+            w.MT = mt; w.NT = nt; w.waves = waves;
+#ifdef AAE_EXPERIMENTS
+            w.depth = (mt == 2 && nt == 1 && force_depth == 3) ? 3 : 2;
+#else
+            w.depth = 2;
+            (void)force_depth;
+#endif
             w.num_mt = (int)((rows[k] + 32 * mt - 1) / (32 * mt));
             w.num_nt = L.CoutPad / (32 * nt);
             w.gsplits = g;
@@ -245,22 +252,22 @@ static void launch_first_multi_t(const aae::ConvFirstMultiArgs& m, bool u8, bool
     }
 }
 
-template <int MT, int NT, bool SPREAD>
+template <int MT, int NT, bool SPREAD, int DEPTH = 2>
 static void launch_wavek_multi_t(const aae::ConvWaveKMultiArgs& m, int tag, int nblk, hipStream_t stream) {
     constexpr int smem = aae::conv_wavek_smem<MT, NT, 4>();
     // TAG only makes the symbol unique per encoder layer (separate rows in rocprofv3 --stats)
     if (tag == 1) {
-        (void)hipFuncSetAttribute((const void*)aae::conv_wavek_multi_kernel<MT, NT, 4, 2, 1, SPREAD>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        AAE_LAUNCH((aae::conv_wavek_multi_kernel<MT, NT, 4, 2, 1, SPREAD>), dim3(nblk), dim3(256), smem, stream, m);
+        (void)hipFuncSetAttribute((const void*)aae::conv_wavek_multi_kernel<MT, NT, 4, DEPTH, 1, SPREAD>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        AAE_LAUNCH((aae::conv_wavek_multi_kernel<MT, NT, 4, DEPTH, 1, SPREAD>), dim3(nblk), dim3(256), smem, stream, m);
     } else if (tag == 2) {
-        (void)hipFuncSetAttribute((const void*)aae::conv_wavek_multi_kernel<MT, NT, 4, 2, 2, SPREAD>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        AAE_LAUNCH((aae::conv_wavek_multi_kernel<MT, NT, 4, 2, 2, SPREAD>), dim3(nblk), dim3(256), smem, stream, m);
+        (void)hipFuncSetAttribute((const void*)aae::conv_wavek_multi_kernel<MT, NT, 4, DEPTH, 2, SPREAD>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        AAE_LAUNCH((aae::conv_wavek_multi_kernel<MT, NT, 4, DEPTH, 2, SPREAD>), dim3(nblk), dim3(256), smem, stream, m);
     } else if (tag == 3) {
-        (void)hipFuncSetAttribute((const void*)aae::conv_wavek_multi_kernel<MT, NT, 4, 2, 3, SPREAD>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        AAE_LAUNCH((aae::conv_wavek_multi_kernel<MT, NT, 4, 2, 3, SPREAD>), dim3(nblk), dim3(256), smem, stream, m);
+        (void)hipFuncSetAttribute((const void*)aae::conv_wavek_multi_kernel<MT, NT, 4, DEPTH, 3, SPREAD>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        AAE_LAUNCH((aae::conv_wavek_multi_kernel<MT, NT, 4, DEPTH, 3, SPREAD>), dim3(nblk), dim3(256), smem, stream, m);
     } else {
-        (void)hipFuncSetAttribute((const void*)aae::conv_wavek_multi_kernel<MT, NT, 4, 2, 0, SPREAD>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        AAE_LAUNCH((aae::conv_wavek_multi_kernel<MT, NT, 4, 2, 0, SPREAD>), dim3(nblk), dim3(256), smem, stream, m);
+        (void)hipFuncSetAttribute((const void*)aae::conv_wavek_multi_kernel<MT, NT, 4, DEPTH, 0, SPREAD>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
+        AAE_LAUNCH((aae::conv_wavek_multi_kernel<MT, NT, 4, DEPTH, 0, SPREAD>), dim3(nblk), dim3(256), smem, stream, m);
     }
 }
 
@@ -385,6 +392,11 @@ static int launch_encoder_multi(const aae_multi_item* items, const MultiPlan& mp
         switch (wavek_shape_key(w0)) {
             case 1142: launch_wavek_multi_t<1, 1, true>(m, tag, at, stream); break;
             case 142: launch_wavek_multi_t<2, 1, false>(m, tag, at, stream); break;
+#ifdef AAE_EXPERIMENTS
+            // three slabs in flight for the 64 x 32 layers (option multi_force_depth): conv4 of a few-detection frame streams 26 MB of cold weights
+            // per object against 5 us of MFMA work -- more bytes in flight changed NOTHING (8 x 1: 397 vs 397 us, profiles/r13_multi/depth_ab.jsonl)
+            case 143: launch_wavek_multi_t<2, 1, false, 3>(m, tag, at, stream); break;
+#endif
             case 242: launch_wavek_multi_t<2, 2, true>(m, tag, at, stream); break;
             default: return fail(AAE_ERR_RUNTIME, "multi-object query: no grouped wave-split-K instantiation for shape key %d", wavek_shape_key(w0));
         }
