@@ -391,7 +391,13 @@ static int launch_encoder_multi(const aae_multi_item* items, const MultiPlan& mp
         const int tag = li <= 3 ? (int)li : 0;
         switch (wavek_shape_key(w0)) {
             case 1142: launch_wavek_multi_t<1, 1, true>(m, tag, at, stream); break;
-            case 142: launch_wavek_multi_t<2, 1, false>(m, tag, at, stream); break;
+            case 142:
+#ifdef AAE_EXPERIMENTS
+                // (A/B: the spread load schedule for 64 x 32 tiles -- loads between the MFMAs of its two accumulators: 8 x 1 434 against 400 us,
+                //  16 x 1 807 against 743: slower, as on single objects in round 4; profiles/r13_multi/depth_and_schedule_ab.jsonl)
+                if (enc0->multi_force_depth & 0x10000) { launch_wavek_multi_t<2, 1, true>(m, tag, at, stream); break; }
+#endif
+                launch_wavek_multi_t<2, 1, false>(m, tag, at, stream); break;
 #ifdef AAE_EXPERIMENTS
             // three slabs in flight for the 64 x 32 layers (option multi_force_depth): conv4 of a few-detection frame streams 26 MB of cold weights
             // per object against 5 us of MFMA work -- more bytes in flight changed NOTHING (8 x 1: 397 vs 397 us, profiles/r13_multi/depth_ab.jsonl)

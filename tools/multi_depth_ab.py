@@ -20,12 +20,12 @@ dev = torch.device('cuda', 0)
 objs = [(EncoderEngine(cfg, synth.make_weights(seed=2024 + i), device=dev, max_batch=64),
          CodebookEngine(synth.make_codebook(92232, 128, seed=7 + i), device=dev)) for i in range(16)]
 xs = [torch.from_numpy(synth.make_crops(4, seed=500 + i)).to(dev) for i in range(16)]
-for n_obj, d in ((8, 1), (8, 1), (4, 1), (16, 1), (8, 2), (2, 1)):
+for n_obj, d in ((8, 1), (4, 1), (16, 1), (8, 2)):
     xcat = torch.cat([xi[:d] for xi in xs[:n_obj]]).contiguous()
-    out = {'objects': n_obj, 'detections_per_object': d, 'depth2_us': [], 'depth3_conv4_us': [], 'depth3_conv3_conv4_us': []}
+    out = {'objects': n_obj, 'detections_per_object': d, 'depth2_us': [], 'depth3_conv4_us': [], 'depth3_conv3_conv4_us': [], 'spread_64x32_us': []}
     ref = None
     for rnd in range(4):
-        for key, v in (('depth2_us', 0), ('depth3_conv4_us', 3 << 8), ('depth3_conv3_conv4_us', (3 << 8) | (3 << 4))):
+        for key, v in (('depth2_us', 0), ('depth3_conv4_us', 3 << 8), ('depth3_conv3_conv4_us', (3 << 8) | (3 << 4)), ('spread_64x32_us', 0x10000)):
             for e, _ in objs:
                 e.set_option('multi_force_depth', v)
             mq = MultiObjectQuery([(e, c, d) for e, c in objs[:n_obj]], device=dev)
