@@ -157,6 +157,36 @@ void aae_encoder_destroy(aae_encoder* enc) {
     delete enc;
 }
 
+// Option "winograd": transform and upload the Winograd-domain weights of every eligible layer (once; 49/25 of the layer's weight bytes).
+static int prepare_winograd(aae_encoder* enc) {
+    using namespace aae_host;
+    bool any = false;
+    for (Layer& L : enc->layers) {
+        const int geom = winograd_geometry(L);
+        if (geom < 0) continue;
+        any = true;
+        if (L.wino[0]) continue;
+        std::vector<float> w((size_t)L.K() * L.Cout);
+        AAE_HIP_TRY(hipMemcpy(w.data(), L.w_hwio, w.size() * sizeof(float), hipMemcpyDeviceToHost));
+        for (int eh = 0; eh < 2; ++eh)
+            for (int ew = 0; ew < 2; ++ew) {
+                const std::vector<float> U = pack_weights_winograd(w.data(), L.KS, L.Cin, L.Cout, eh, ew, !eh && ew);
+                if (int rc = upload(enc, U.data(), U.size(), &L.wino[2 * eh + ew])) return rc;
+            }
+        L.wino_geom = geom;
+    }
+    if (!any) return fail(AAE_ERR_UNSUPPORTED, "winograd: no layer is eligible (5 x 5 stride-2 'SAME' layers behind the first one with 32 | Cin, 64 | Cout and 16 | Ho, Wo or an 8 x 8 output)");
+    (void)hipFuncSetAttribute((const void*)aae::conv_wino_phase_kernel<3, 3, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::wino_smem_bytes<0>());
+    (void)hipFuncSetAttribute((const void*)aae::conv_wino_phase_kernel<3, 2, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::wino_smem_bytes<0>());
+    (void)hipFuncSetAttribute((const void*)aae::conv_wino_phase_kernel<3, 2, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::wino_smem_bytes<0>());
+    (void)hipFuncSetAttribute((const void*)aae::conv_wino_phase_kernel<2, 2, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::wino_smem_bytes<0>());
+    (void)hipFuncSetAttribute((const void*)aae::conv_wino_phase_kernel<3, 3, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::wino_smem_bytes<1>());
+    (void)hipFuncSetAttribute((const void*)aae::conv_wino_phase_kernel<3, 2, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::wino_smem_bytes<1>());
+    (void)hipFuncSetAttribute((const void*)aae::conv_wino_phase_kernel<3, 2, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::wino_smem_bytes<1>());
+    (void)hipFuncSetAttribute((const void*)aae::conv_wino_phase_kernel<2, 2, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::wino_smem_bytes<1>());
+    return AAE_OK;
+}
+
 int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
     using namespace aae_host;
     if (!enc || !name) return fail(AAE_ERR_INVALID, "aae_encoder_set_option: null argument");
@@ -273,6 +303,12 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
     else if (!strcmp(name, "x3h_act_shift")) {
         if (value < -8 || value > 12) return fail(AAE_ERR_INVALID, "x3h_act_shift %d outside [-8, 12]", value);
         enc->x3h_act_shift = value;
+    } else if (!strcmp(name, "winograd")) {
+        if (value != 0)
+            if (int rc = prepare_winograd(enc)) return rc;
+        enc->winograd = value ? 1 : 0;
+    } else if (!strcmp(name, "winograd_min_batch")) {
+        enc->winograd_min_batch = value < 1 ? 1 : value;
     } else if (!strcmp(name, "precision")) {
         if (value < 0 || value > 2) return fail(AAE_ERR_INVALID, "precision %d: 0 = fp32, 1 = f32x3h, 2 = f32x3h where it is faster", value);
         if (value != 0) {

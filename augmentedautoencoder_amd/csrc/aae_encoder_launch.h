@@ -531,6 +531,46 @@ static int launch_detect_chain(aae_encoder* enc, int B, const std::vector<WaveKP
 
 #endif  // AAE_EXPERIMENTS
 
+// A conv layer as four polyphase Winograd launches (conv_winograd_f32.h): the phases add up in the output buffer, the last one applies
+// bias / ReLU / BN.  The 3 x 3-tap phase goes first (it stores), the 2 x 2-tap one last.
+template <int GEOM>
+static void launch_wino_phase(const aae::ConvWinoArgs& a, int eh, int ew, unsigned grid, hipStream_t stream) {
+    constexpr int smem = aae::wino_smem_bytes<GEOM>();
+    if (eh && ew) AAE_LAUNCH((aae::conv_wino_phase_kernel<3, 3, false, GEOM>), dim3(grid), dim3(512), smem, stream, a);
+    else if (eh) AAE_LAUNCH((aae::conv_wino_phase_kernel<3, 2, false, GEOM>), dim3(grid), dim3(512), smem, stream, a);
+    else if (ew) AAE_LAUNCH((aae::conv_wino_phase_kernel<3, 2, true, GEOM>), dim3(grid), dim3(512), smem, stream, a);
+    else AAE_LAUNCH((aae::conv_wino_phase_kernel<2, 2, false, GEOM>), dim3(grid), dim3(512), smem, stream, a);
+}
+
+static int launch_winograd(aae_encoder* enc, const Layer& L, const float* x, int B, float* out, hipStream_t stream, Timer& tm, const char* name) {
+    (void)enc;
+    aae::ConvWinoArgs a;
+    a.x = x; a.bias = L.bias; a.bn_scale = L.bn_scale; a.bn_shift = L.bn_shift; a.out = out;
+    a.B = B; a.H = L.H; a.W = L.W; a.Cin = L.Cin; a.Cout = L.Cout; a.Ho = L.Ho; a.Wo = L.Wo; a.relu = L.relu;
+    a.blocks_x = L.wino_geom == 0 ? L.Wo / 16 : 1;
+    a.blocks_y = L.wino_geom == 0 ? L.Ho / 16 : 1;
+    const unsigned grid = (unsigned)(L.Cout / 64) * (L.wino_geom == 0 ? (unsigned)(a.blocks_x * a.blocks_y * B) : (unsigned)ceil_div(B, 4));
+    static const int order[4][2] = {{1, 1}, {1, 0}, {0, 1}, {0, 0}};
+    for (int i = 0; i < 4; ++i) {
+        const int eh = order[i][0], ew = order[i][1];
+        a.eh = eh; a.ew = ew; a.U = L.wino[2 * eh + ew];
+        a.mode = i == 0 ? 0 : (i == 3 ? 2 : 1);
+        if (L.wino_geom == 0) launch_wino_phase<0>(a, eh, ew, grid, stream);
+        else launch_wino_phase<1>(a, eh, ew, grid, stream);
+        const int taps = (eh ? 3 : 2) * (ew ? 3 : 2);
+        char label[112];
+        snprintf(label, sizeof(label), "%s:conv_wino_f32 phase %d%d (%d taps as %d products) M=%d N=%d C=%d", name, eh, ew, taps,
+                 ((eh ? 3 : 2) + 1) * ((ew ? 3 : 2) + 1), B * L.Ho * L.Wo, L.Cout, L.Cin);
+        note_kernel({label, 2.0 * (double)B * L.Ho * L.Wo * taps * (double)L.Cin * (double)L.Cout});
+        AAE_HIP_TRY(hipGetLastError());
+    }
+    return tm.mark();
+}
+
+static bool runs_winograd(const aae_encoder* enc, const Layer& L, int B) {
+    return enc->winograd && L.wino_geom >= 0 && L.wino[0] && B >= enc->winograd_min_batch;
+}
+
 static int forward_impl(aae_encoder* enc, const void* x, int x_dtype, int B, float* z_out, void* workspace,
                         size_t ws_bytes, void* stream_v, Timer& tm, const ExtraTicketPrep* extra = nullptr, bool* extra_prepared = nullptr,
                         bool* scan_done = nullptr) {
@@ -600,7 +640,7 @@ static int forward_impl(aae_encoder* enc, const void* x, int x_dtype, int B, flo
     for (size_t li = 0; li < nl; ++li) {
         const Layer& L = enc->layers[li];
         const bool first_mfma = li == 0 && L.kind == KIND_FIRST_MFMA;
-        if (!first_mfma && L.kind == KIND_IGEMM && !(li == 0 && cur_u8)) plans[li] = plan_wavek(enc, L, (long long)B * L.Ho * L.Wo, false);
+        if (!first_mfma && L.kind == KIND_IGEMM && !(li == 0 && cur_u8) && !runs_winograd(enc, L, B)) plans[li] = plan_wavek(enc, L, (long long)B * L.Ho * L.Wo, false);
     }
 #ifdef AAE_EXPERIMENTS
     const bool dense_gemv = D.kind == KIND_IGEMM && B <= gemv_max_batch(enc) && enc->dense_gemv && D.K() % aae::kGemvChunk == 0;
@@ -670,7 +710,8 @@ static int forward_impl(aae_encoder* enc, const void* x, int x_dtype, int B, flo
         int rc;
         if (li == 0 && L.kind == KIND_FIRST_MFMA) rc = launch_first(enc, L, cur, cur_u8, B, out, false, stream, tm, can_prepare ? &prep : nullptr);
         else if (L.kind == KIND_IGEMM && !cur_u8) {
-            if (plans[li].use)
+            if (runs_winograd(enc, L, B)) rc = launch_winograd(enc, L, static_cast<const float*>(cur), B, out, stream, tm, name);
+            else if (plans[li].use)
                 rc = launch_wavek(enc, L, plans[li], static_cast<const float*>(cur), B * L.Ho * L.Wo, out, partial, layer_tickets(li), nonces[li],
                                   stream, tm, name, (int)li);
             else rc = launch_igemm(enc, L, static_cast<const float*>(cur), B * L.Ho * L.Wo, out, partial, stream, tm, name, (int)li);

@@ -54,6 +54,46 @@ static std::vector<float> pack_weights(const float* w, int taps, int Cin, int Co
     return out;
 }
 
+// Winograd-domain weights of ONE polyphase component (conv_winograd_f32.h) of a 5 x 5 stride-2 layer: the taps kh = 2 k + (eh ? 0 : 1)
+// (3 taps on the odd rows, 2 on the even ones; the same along the columns) are transformed with G g G^T in float64, rounded once, and
+// laid out as the kernel's B fragments: [32-column block][8-channel group][point a PB + b][K half][32 columns][4 channels], a = point
+// index along the split dimension A (rows, or columns when swap), b along the other one.
+static std::vector<float> pack_weights_winograd(const float* w_hwio, int KS, int Cin, int Cout, int eh, int ew, bool swap) {
+    static const double G3[4][3] = {{1, 0, 0}, {0.5, 0.5, 0.5}, {0.5, -0.5, 0.5}, {0, 0, 1}};
+    static const double G2[3][2] = {{1, 0}, {1, 1}, {0, 1}};
+    const int th = eh ? 3 : 2, tw = ew ? 3 : 2;                      // taps along rows / columns
+    const int tA = swap ? tw : th, tB = swap ? th : tw, PA = tA + 1, PB = tB + 1, NP = PA * PB;
+    auto gA = [&](int a, int k) { return tA == 3 ? G3[a][k] : G2[a][k]; };
+    auto gB = [&](int b, int k) { return tB == 3 ? G3[b][k] : G2[b][k]; };
+    std::vector<float> out((size_t)NP * Cin * Cout);
+    for (int c = 0; c < Cin; ++c)
+        for (int n = 0; n < Cout; ++n)
+            for (int a = 0; a < PA; ++a)
+                for (int b = 0; b < PB; ++b) {
+                    double acc = 0.0;
+                    for (int ka = 0; ka < tA; ++ka)
+                        for (int kb = 0; kb < tB; ++kb) {
+                            const int kr = swap ? kb : ka, kc = swap ? ka : kb;          // tap index along rows / columns
+                            const int kh = 2 * kr + (eh ? 0 : 1), kw = 2 * kc + (ew ? 0 : 1);
+                            acc += gA(a, ka) * gB(b, kb) * (double)w_hwio[((size_t)(kh * KS + kw) * Cin + c) * Cout + n];
+                        }
+                    const int p = a * PB + b, n32 = n >> 5, nn = n & 31, kg = c >> 3, hh = (c >> 2) & 1, q = c & 3;
+                    out[((((size_t)n32 * (Cin / 8) + kg) * NP + p) * 64 + hh * 32 + nn) * 4 + q] = (float)acc;
+                }
+    return out;
+}
+
+// ... which layers can take it: 5 x 5, stride 2, 'SAME' with one row / column of padding in front (even input size), 32 | Cin, 64 | Cout,
+// and an output of whole 16 x 16-pixel regions (geometry 0) or exactly 8 x 8 (geometry 1: four images per block)
+static int winograd_geometry(const Layer& L) {
+    if (L.index < 1 || L.kind != KIND_IGEMM) return -1;
+    if (L.KS != 5 || L.S != 2 || L.pt != 1 || L.pl != 1 || (L.H & 1) || (L.W & 1) || L.H != 2 * L.Ho || L.W != 2 * L.Wo) return -1;
+    if (L.Cin % 32 != 0 || L.Cout % 64 != 0) return -1;
+    if (L.Ho % 16 == 0 && L.Wo % 16 == 0) return 0;
+    if (L.Ho == 8 && L.Wo == 8) return 1;
+    return -1;
+}
+
 // f32x3h weights: w*2^shift split into (hi, lo) halves, packed per K-slab as
 // [8 slots][CoutPad][8 halves] with slot = plane*4 + kgroup8 (kernel K order, see pack_weights).
 static std::vector<unsigned short> pack_weights_x3h(const float* w, int taps, int Cin, int Cout, int CoutPad, int* shift_out) {

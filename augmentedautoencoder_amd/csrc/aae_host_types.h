@@ -48,6 +48,8 @@ struct Layer {
     float* wp = nullptr;        // device [K/4][CoutPad][4]      (igemm)
     unsigned* wp16 = nullptr;   // device [slabs][8][CoutPad][4 dwords]: (hi, lo) halves of w*2^w_shift (f32x3h)
     int w_shift = 0;
+    float* wino[4] = {nullptr, nullptr, nullptr, nullptr};   // Winograd-domain weights of the four polyphase components (conv_winograd_f32.h), index 2 eh + ew;
+    int wino_geom = -1;         // ... and the block geometry the layer runs with (-1: not eligible / not prepared)
     float* bias = nullptr;
     float* bn_scale = nullptr;  // folded inference BN: x*scale + shift
     float* bn_shift = nullptr;
@@ -89,6 +91,9 @@ struct aae_encoder {
     int splitk_target_blocks = 512;        // ... and then aim for about this many blocks
     int reduce_small = 1;                  // <= 8 splits over >= 16k outputs: barrier-free float4 reduce kernel
     int precision = 0;                     // 0: exact fp32 MFMA; 1: f32x3h split-precision igemm (explicit opt-in)
+    int winograd = 0;                      // 1: conv layers behind the first one as polyphase Winograd F(2 x 2) on the fp32 matrix cores (2.04 x fewer multiplies,
+                                           // results differ from the direct kernels by fp32 rounding: conv_winograd_f32.h) for batches >= winograd_min_batch
+    int winograd_min_batch = 64;
     int first_target_blocks = 512;         // conv1 grid size aimed at (x N tiles); 2 blocks fit a CU
     int first_group_split_max_tiles = 128; // conv1: batches of at most this many 128-pixel tiles (B <= 4 of the default net) run one block per 32-pixel group
     int first_vec4 = 1;                    // conv1: stage uint8 rows as aligned dwords when W*C % 4 == 0

@@ -1,0 +1,72 @@
+"""Polyphase Winograd convolution (csrc/kernels/conv_winograd_f32.h, encoder option "winograd") on the CPU fiber emulator against
+the fp64 oracle: the four phase shapes (3 x 3, 3 x 2, 2 x 3 with the split along the columns, 2 x 2 with the uneven point split),
+both block geometries (16 x 16-pixel regions of one image / four 8 x 8 images), window halo = 'SAME' padding, several 32-channel
+stages, several blocks per image, ragged image groups, the accumulating output modes and the BN epilogue."""
+import numpy as np
+import pytest
+
+import emu_backend as eb
+from augmentedautoencoder_amd.weights import EncoderConfig
+from oracle import reference_cpu as ref
+from oracle import synth
+
+
+def _run(cfg, B, seed, options=None):
+    w = synth.make_weights(seed=seed, shape=cfg.shape, num_filter=cfg.num_filter, strides=cfg.strides,
+                           latent=cfg.latent_space_size, batch_norm=cfg.batch_norm, kernel_size=cfg.kernel_size)
+    x = synth.make_crops(B, seed=seed + 1, shape=cfg.shape)
+    enc = eb.EmuEncoder(w, cfg)
+    enc.set_option('winograd_min_batch', 1)
+    enc.set_option('winograd', 1)
+    for k, v in (options or {}).items():
+        enc.set_option(k, v)
+    z = enc.forward(x)
+    z64, acts = ref.encoder_forward_np(ref.input_to_float(x), w, cfg.strides, cfg.batch_norm, return_activations=True)
+    errs = []
+    for i, a in enumerate(acts):
+        err = np.abs(enc.activation(i) - a).max() / max(np.abs(a).max(), 1e-9)
+        errs.append(err)
+        assert err < 5e-6, 'layer %d rel err %.2e (%s)' % (i, err, enc.labels())
+    assert np.abs(z - z64).max() / np.abs(z64).max() < 5e-6
+    labels = enc.labels()
+    enc.close()
+    return labels, errs
+
+
+def test_one_region_per_image_one_stage():
+    # conv2: 32 x 32 x 32 -> 16 x 16 x 64: geometry 0, one block per image and phase, one 32-channel stage
+    labels, _ = _run(EncoderConfig((64, 64, 3), [32, 64], [2, 2], 5, 128), 2, 11)
+    wino = [l for l in labels if 'conv_wino_f32' in l]
+    assert len(wino) == 4 and all(l.startswith('conv2') for l in wino)
+    assert [l.split('phase ')[1][:2] for l in wino] == ['11', '10', '01', '00']
+
+
+def test_several_regions_per_image_two_stages_two_column_blocks():
+    # conv2: 64 x 64 x 64 -> 32 x 32 x 128: 2 x 2 regions per image, two stages, two 64-column blocks
+    labels, _ = _run(EncoderConfig((128, 128, 3), [64, 128], [2, 2], 5, 64), 1, 23)
+    assert sum('conv_wino_f32' in l for l in labels) == 4
+
+
+@pytest.mark.parametrize('B', [1, 5])
+def test_four_images_per_block_ragged_groups(B):
+    # conv2: 16 x 16 x 32 -> 8 x 8 x 64: geometry 1; B = 5: the second block holds one image and three empty slots
+    labels, _ = _run(EncoderConfig((32, 32, 3), [32, 64], [2, 2], 5, 128), B, 31 + B)
+    assert sum('conv_wino_f32' in l for l in labels) == 4
+
+
+def test_both_geometries_in_one_network_with_batch_norm():
+    labels, _ = _run(EncoderConfig((64, 64, 3), [32, 64, 64], [2, 2, 2], 5, 128, True), 3, 47)
+    assert sum('conv_wino_f32' in l for l in labels) == 8
+    assert labels[0].startswith('conv1') and 'wino' not in labels[0]
+
+
+def test_min_batch_and_ineligible_layers_keep_the_direct_kernels():
+    cfg = EncoderConfig((64, 64, 3), [32, 64], [2, 2], 5, 128)
+    labels, _ = _run(cfg, 2, 5, options={'winograd_min_batch', 3} and {'winograd_min_batch': 3})
+    assert not any('wino' in l for l in labels)
+    # a 24 x 24 output is neither whole 16 x 16 regions nor 8 x 8: refused at option time, nothing changes
+    w = synth.make_weights(seed=3, shape=(96, 96, 3), num_filter=[32, 64], strides=[2, 2], latent=128)
+    enc = eb.EmuEncoder(w, EncoderConfig((96, 96, 3), [32, 64], [2, 2], 5, 128))
+    with pytest.raises(Exception):
+        enc.set_option('winograd', 1)
+    enc.close()

@@ -28,7 +28,7 @@ def main():
         with open(path) as f:
             for row in csv.DictReader(f):
                 k = short(row['Kernel_Name'])
-                if not any(t in k for t in ('conv_', 'scan_', 'splitk', 'argmax', 'l2norm', 'upconv', 'topk', 'dense_gemv', 'detect_')):
+                if not any(t in k for t in ('conv_', 'scan_', 'splitk', 'argmax', 'l2norm', 'upconv', 'topk', 'dense_gemv', 'detect_', 'wino_')):
                     continue
                 k = '%s grid=%s' % (k, row['Grid_Size'])          # the conv layers share one kernel; the grid tells them apart
                 acc[k][row['Counter_Name']].append(float(row['Counter_Value']))

@@ -22,6 +22,7 @@
 #include "device_intrinsics.h"
 #include "kernels/tile_f32.h"
 #include "kernels/conv_igemm_f32.h"
+#include "winograd_fused.h"
 
 #define CHECK(x) do { hipError_t e__ = (x); if (e__ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e__)); return 1; } } while (0)
 
@@ -196,33 +197,94 @@ int main() {
                t_out, total, wino / (t_gemm * 1e-3) / 1e12, nominal / (total * 1e-3) / 1e12, nominal / (total * 1e-3) / 1e12 / 142.0,
                ((double)hs.size() * 4 + 2.0 * 16 * kT * kC * 4 + 2.0 * 16 * kT * kN * 4 + (double)kB * kO * kO * kN * 4) / 1e6, nominal / 142e12 * 1e3);
     }
-    // ---- accuracy on two images: float64 direct evaluation vs the Winograd result and vs a direct fp32 fma chain
-    std::vector<float> hout((size_t)2 * kO * kO * kN);
-    CHECK(hipMemcpy(hout.data(), dout, hout.size() * 4, hipMemcpyDeviceToHost));
-    double worst_w = 0, worst_d = 0, scale = 0;
-    for (int b = 0; b < 2; ++b)
-        for (int oy = 0; oy < kO; ++oy)
-            for (int ox = 0; ox < kO; ++ox)
-                for (int n = 0; n < kN; n += 7) {                 // every 7th column: 74 of 512
-                    double acc = hbias[n];
-                    float acc32 = 0.f;
-                    for (int a = 0; a < 3; ++a)
-                        for (int c = 0; c < 3; ++c) {
-                            const float* sp = &hs[(((size_t)b * kS + oy + a) * kS + ox + c) * kC];
-                            const float* gp = &hg[(size_t)(a * 3 + c) * kC * kN + n];
-                            for (int k = 0; k < kC; ++k) {
-                                acc += (double)sp[k] * (double)gp[(size_t)k * kN];
-                                acc32 = fmaf(sp[k], gp[(size_t)k * kN], acc32);
+    // ---- the fused kernel (winograd_fused.h): one launch, transforms on MFMA fragments in registers
+    std::vector<float> hUp((size_t)16 * kC * kN);
+    for (int p = 0; p < 16; ++p)
+        for (int k = 0; k < kC; ++k)
+            for (int n = 0; n < kN; ++n) hUp[wf::packed_u_index(p, k, n, kC)] = U[p][(size_t)k * kN + n];
+    float* dUp;
+    CHECK(hipMalloc(&dUp, hUp.size() * 4));
+    CHECK(hipMemcpy(dUp, hUp.data(), hUp.size() * 4, hipMemcpyHostToDevice));
+    const wf::Args fa{ds, dUp, dbias, dout, kC, kN};
+    CHECK(hipFuncSetAttribute((const void*)wf::wino_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, wf::kSmemBytes));
+    CHECK(hipFuncSetAttribute((const void*)wf::wino_fused4x2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, wf::kSmemBytes4));
+    CHECK(hipFuncSetAttribute((const void*)wf::wino_fused8_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, wf::kSmemBytes));
+    CHECK(hipFuncSetAttribute((const void*)wf::wino_fused8_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, wf::kSmemBytes));
+    CHECK(hipFuncSetAttribute((const void*)wf::wino_fused8_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, wf::kSmemBytes));
+    CHECK(hipFuncSetAttribute((const void*)wf::wino_fused8_kernel<16 + 32 + 64>, hipFuncAttributeMaxDynamicSharedMemorySize, wf::kSmemBytes));
+    CHECK(hipFuncSetAttribute((const void*)wf::wino_fused8_kernel<16 + 32 + 64 + 128>, hipFuncAttributeMaxDynamicSharedMemorySize, wf::kSmemBytes));
+    CHECK(hipFuncSetAttribute((const void*)wf::wino_fused8_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, wf::kSmemBytes));
+    CHECK(hipFuncSetAttribute((const void*)wf::wino_fused8_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, wf::kSmemBytes));
+    CHECK(hipFuncSetAttribute((const void*)wf::wino_fused8_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, wf::kSmemBytes));
+    auto launch_fused = [&](int variant) {
+        if (variant == 0) hipLaunchKernelGGL(wf::wino_fused_kernel, dim3(kB * (kN / 64)), dim3(256), wf::kSmemBytes, 0, fa);
+        else if (variant == 1) hipLaunchKernelGGL(wf::wino_fused8_kernel<0>, dim3(kB * (kN / 64)), dim3(512), wf::kSmemBytes, 0, fa);
+        else if (variant == 2) hipLaunchKernelGGL(wf::wino_fused4x2_kernel, dim3(kB * 2 * (kN / 64)), dim3(256), wf::kSmemBytes4, 0, fa);
+        else if (variant == 3) hipLaunchKernelGGL(wf::wino_fused8_kernel<1>, dim3(kB * (kN / 64)), dim3(512), wf::kSmemBytes, 0, fa);
+        else if (variant == 4) hipLaunchKernelGGL(wf::wino_fused8_kernel<2>, dim3(kB * (kN / 64)), dim3(512), wf::kSmemBytes, 0, fa);
+        else if (variant == 5) hipLaunchKernelGGL(wf::wino_fused8_kernel<16>, dim3(kB * (kN / 64)), dim3(512), wf::kSmemBytes, 0, fa);
+        else if (variant == 6) hipLaunchKernelGGL(wf::wino_fused8_kernel<32>, dim3(kB * (kN / 64)), dim3(512), wf::kSmemBytes, 0, fa);
+        else if (variant == 7) hipLaunchKernelGGL(wf::wino_fused8_kernel<64>, dim3(kB * (kN / 64)), dim3(512), wf::kSmemBytes, 0, fa);
+        else if (variant == 8) hipLaunchKernelGGL(wf::wino_fused8_kernel<16 + 32 + 64>, dim3(kB * (kN / 64)), dim3(512), wf::kSmemBytes, 0, fa);
+        else hipLaunchKernelGGL(wf::wino_fused8_kernel<16 + 32 + 64 + 128>, dim3(kB * (kN / 64)), dim3(512), wf::kSmemBytes, 0, fa);
+    };
+    const int fused_variants = getenv("WF_ABLATE") ? 10 : 3;
+    auto check_accuracy = [&](const char* what) -> int {
+        std::vector<float> hout((size_t)2 * kO * kO * kN);
+        CHECK(hipMemcpy(hout.data(), dout, hout.size() * 4, hipMemcpyDeviceToHost));
+        double worst_w = 0, worst_d = 0, scale = 0;
+        for (int b = 0; b < 2; ++b)
+            for (int oy = 0; oy < kO; ++oy)
+                for (int ox = 0; ox < kO; ++ox)
+                    for (int n = 0; n < kN; n += 7) {                 // every 7th column: 74 of 512
+                        double acc = hbias[n];
+                        float acc32 = 0.f;
+                        for (int a = 0; a < 3; ++a)
+                            for (int c = 0; c < 3; ++c) {
+                                const float* sp = &hs[(((size_t)b * kS + oy + a) * kS + ox + c) * kC];
+                                const float* gp = &hg[(size_t)(a * 3 + c) * kC * kN + n];
+                                for (int k = 0; k < kC; ++k) {
+                                    acc += (double)sp[k] * (double)gp[(size_t)k * kN];
+                                    acc32 = fmaf(sp[k], gp[(size_t)k * kN], acc32);
+                                }
                             }
-                        }
-                    const double want = acc > 0 ? acc : 0, got = hout[(((size_t)b * kO + oy) * kO + ox) * kN + n];
-                    const double d32 = (double)fmaxf(acc32 + hbias[n], 0.f);
-                    worst_w = fmax(worst_w, fabs(got - want));
-                    worst_d = fmax(worst_d, fabs(d32 - want));
-                    scale = fmax(scale, fabs(want));
-                }
-    printf("{\"what\": \"accuracy\", \"outputs_checked\": %d, \"max_abs_output\": %.4f, \"winograd_max_abs_err\": %.3e, \"winograd_max_rel_to_scale\": %.3e, "
-           "\"direct_fp32_fma_chain_max_abs_err\": %.3e, \"direct_max_rel_to_scale\": %.3e}\n",
-           2 * kO * kO * ((kN + 6) / 7), scale, worst_w, worst_w / scale, worst_d, worst_d / scale);
+                        const double want = acc > 0 ? acc : 0, got = hout[(((size_t)b * kO + oy) * kO + ox) * kN + n];
+                        const double d32 = (double)fmaxf(acc32 + hbias[n], 0.f);
+                        worst_w = fmax(worst_w, fabs(got - want));
+                        worst_d = fmax(worst_d, fabs(d32 - want));
+                        scale = fmax(scale, fabs(want));
+                    }
+        printf("{\"what\": \"accuracy\", \"of\": \"%s\", \"outputs_checked\": %d, \"max_abs_output\": %.4f, \"winograd_max_abs_err\": %.3e, \"winograd_max_rel_to_scale\": %.3e, "
+               "\"direct_fp32_fma_chain_max_abs_err\": %.3e, \"direct_max_rel_to_scale\": %.3e}\n",
+               what, 2 * kO * kO * ((kN + 6) / 7), scale, worst_w, worst_w / scale, worst_d, worst_d / scale);
+        return 0;
+    };
+    if (check_accuracy("unfused pipeline")) return 1;
+    for (int variant = 0; variant < fused_variants; ++variant) {
+        CHECK(hipMemset(dout, 0xFF, (size_t)kB * kO * kO * kN * 4));
+        for (int w = 0; w < 3; ++w) launch_fused(variant);
+        CHECK(hipDeviceSynchronize());
+        const int reps = 20;
+        CHECK(hipEventRecord(e[0], 0));
+        for (int r = 0; r < reps; ++r) launch_fused(variant);
+        CHECK(hipEventRecord(e[1], 0));
+        CHECK(hipEventSynchronize(e[1]));
+        float ms = 0;
+        CHECK(hipEventElapsedTime(&ms, e[0], e[1]));
+        ms /= reps;
+        const char* name = variant == 0 ? "wino_fused_kernel (4 waves: 16 point accumulators per wave)"
+                           : variant == 1 ? "wino_fused8_kernel (8 waves: the points of a tile split over two waves, two waves per SIMD)"
+                           : variant == 2 ? "wino_fused4x2_kernel (4 waves = 32 tiles x 64 channels, two blocks per CU)"
+                           : variant == 3 ? "ABLATION (results wrong): 8 waves, weight fragments of every group from one address"
+                           : variant == 4 ? "ABLATION (results wrong): 8 waves, patch of every group from one LDS plane"
+                           : variant == 5 ? "ABLATION (results wrong): 8 waves, no patch read / transform after the first group"
+                           : variant == 6 ? "ABLATION (results wrong): 8 waves, no weight loads after the first group"
+                           : variant == 7 ? "ABLATION (results wrong): 8 waves, no stage fill"
+                           : variant == 8 ? "ABLATION (results wrong): 8 waves, MFMAs + barriers only" : "ABLATION (results wrong): 8 waves, MFMAs only";
+        printf("{\"what\": \"winograd_f2x2_3x3_phase_of_conv3_FUSED\", \"kernel\": \"%s\", "
+               "\"B\": %d, \"total_ms\": %.4f, \"mfma_tflops\": %.1f, \"mfma_frac_of_157\": %.3f, \"tf_equivalent_of_the_direct_phase\": %.1f, \"vs_direct_kernel_at_142_tf\": %.3f}\n",
+               name, kB, ms, wino / (ms * 1e-3) / 1e12, wino / (ms * 1e-3) / 1e12 / 157.3, nominal / (ms * 1e-3) / 1e12, nominal / (ms * 1e-3) / 1e12 / 142.0);
+        if (check_accuracy(name)) return 1;
+    }
     return 0;
 }
