@@ -78,6 +78,16 @@ int aae_encoder_create(const aae_encoder_desc* d, const void* const* hw, int n_w
             if (int rc = upload(enc, packed.data(), packed.size(), &L.wp)) return bail(rc);
             const std::vector<unsigned short> p16 = pack_weights_x3h(k, L.KS * L.KS, L.Cin, L.Cout, L.CoutPad, &L.w_shift);
             if (int rc = upload(enc, reinterpret_cast<const float*>(p16.data()), p16.size() / 2, reinterpret_cast<float**>(&L.wp16))) return bail(rc);
+            // the Winograd-domain weights of the four polyphase components (conv_winograd_f32.h; 49/25 of the layer's weight bytes)
+            const int geom = winograd_geometry(L);
+            if (geom >= 0) {
+                for (int eh = 0; eh < 2; ++eh)
+                    for (int ew = 0; ew < 2; ++ew) {
+                        const std::vector<float> U = pack_weights_winograd(k, L.KS, L.Cin, L.Cout, eh, ew, !eh && ew);
+                        if (int rc = upload(enc, U.data(), U.size(), &L.wino[2 * eh + ew])) return bail(rc);
+                    }
+                L.wino_geom = geom;
+            }
         }
         enc->layers.push_back(L);
         H = L.Ho; W = L.Wo; C = L.Cout;
@@ -106,6 +116,14 @@ int aae_encoder_create(const aae_encoder_desc* d, const void* const* hw, int n_w
     (void)hipFuncSetAttribute((const void*)aae::conv_igemm_f32_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
     (void)hipFuncSetAttribute((const void*)aae::conv_igemm_f32_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
 #endif
+    (void)hipFuncSetAttribute((const void*)aae::conv_wino_phase_kernel<3, 3, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::wino_smem_bytes<0>());
+    (void)hipFuncSetAttribute((const void*)aae::conv_wino_phase_kernel<3, 2, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::wino_smem_bytes<0>());
+    (void)hipFuncSetAttribute((const void*)aae::conv_wino_phase_kernel<3, 2, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::wino_smem_bytes<0>());
+    (void)hipFuncSetAttribute((const void*)aae::conv_wino_phase_kernel<2, 2, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::wino_smem_bytes<0>());
+    (void)hipFuncSetAttribute((const void*)aae::conv_wino_phase_kernel<3, 3, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::wino_smem_bytes<1>());
+    (void)hipFuncSetAttribute((const void*)aae::conv_wino_phase_kernel<3, 2, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::wino_smem_bytes<1>());
+    (void)hipFuncSetAttribute((const void*)aae::conv_wino_phase_kernel<3, 2, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::wino_smem_bytes<1>());
+    (void)hipFuncSetAttribute((const void*)aae::conv_wino_phase_kernel<2, 2, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::wino_smem_bytes<1>());
     (void)hipFuncSetAttribute((const void*)aae::conv_igemm_f32_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
     (void)hipFuncSetAttribute((const void*)aae::conv_igemm_f32_kernel<false, true, false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
     (void)hipFuncSetAttribute((const void*)aae::conv_igemm_f32_kernel<false, true, false, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
@@ -155,36 +173,6 @@ void aae_encoder_destroy(aae_encoder* enc) {
     if (!enc) return;
     for (void* p : enc->allocations) (void)hipFree(p);
     delete enc;
-}
-
-// Option "winograd": transform and upload the Winograd-domain weights of every eligible layer (once; 49/25 of the layer's weight bytes).
-static int prepare_winograd(aae_encoder* enc) {
-    using namespace aae_host;
-    bool any = false;
-    for (Layer& L : enc->layers) {
-        const int geom = winograd_geometry(L);
-        if (geom < 0) continue;
-        any = true;
-        if (L.wino[0]) continue;
-        std::vector<float> w((size_t)L.K() * L.Cout);
-        AAE_HIP_TRY(hipMemcpy(w.data(), L.w_hwio, w.size() * sizeof(float), hipMemcpyDeviceToHost));
-        for (int eh = 0; eh < 2; ++eh)
-            for (int ew = 0; ew < 2; ++ew) {
-                const std::vector<float> U = pack_weights_winograd(w.data(), L.KS, L.Cin, L.Cout, eh, ew, !eh && ew);
-                if (int rc = upload(enc, U.data(), U.size(), &L.wino[2 * eh + ew])) return rc;
-            }
-        L.wino_geom = geom;
-    }
-    if (!any) return fail(AAE_ERR_UNSUPPORTED, "winograd: no layer is eligible (5 x 5 stride-2 'SAME' layers behind the first one with 32 | Cin, 64 | Cout and 16 | Ho, Wo or an 8 x 8 output)");
-    (void)hipFuncSetAttribute((const void*)aae::conv_wino_phase_kernel<3, 3, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::wino_smem_bytes<0>());
-    (void)hipFuncSetAttribute((const void*)aae::conv_wino_phase_kernel<3, 2, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::wino_smem_bytes<0>());
-    (void)hipFuncSetAttribute((const void*)aae::conv_wino_phase_kernel<3, 2, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::wino_smem_bytes<0>());
-    (void)hipFuncSetAttribute((const void*)aae::conv_wino_phase_kernel<2, 2, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::wino_smem_bytes<0>());
-    (void)hipFuncSetAttribute((const void*)aae::conv_wino_phase_kernel<3, 3, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::wino_smem_bytes<1>());
-    (void)hipFuncSetAttribute((const void*)aae::conv_wino_phase_kernel<3, 2, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::wino_smem_bytes<1>());
-    (void)hipFuncSetAttribute((const void*)aae::conv_wino_phase_kernel<3, 2, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::wino_smem_bytes<1>());
-    (void)hipFuncSetAttribute((const void*)aae::conv_wino_phase_kernel<2, 2, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::wino_smem_bytes<1>());
-    return AAE_OK;
 }
 
 int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
@@ -304,8 +292,11 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
         if (value < -8 || value > 12) return fail(AAE_ERR_INVALID, "x3h_act_shift %d outside [-8, 12]", value);
         enc->x3h_act_shift = value;
     } else if (!strcmp(name, "winograd")) {
-        if (value != 0)
-            if (int rc = prepare_winograd(enc)) return rc;
+        if (value != 0) {
+            bool any = false;
+            for (const Layer& L : enc->layers) any = any || L.wino_geom >= 0;
+            if (!any) return fail(AAE_ERR_UNSUPPORTED, "winograd: no layer is eligible (5 x 5 stride-2 'SAME' layers behind the first one with 32 | Cin, 64 | Cout and 16 | Ho, Wo or an 8 x 8 output)");
+        }
         enc->winograd = value ? 1 : 0;
     } else if (!strcmp(name, "winograd_min_batch")) {
         enc->winograd_min_batch = value < 1 ? 1 : value;

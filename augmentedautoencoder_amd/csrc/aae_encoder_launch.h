@@ -557,14 +557,17 @@ static int launch_winograd(aae_encoder* enc, const Layer& L, const float* x, int
         a.mode = i == 0 ? 0 : (i == 3 ? 2 : 1);
         if (L.wino_geom == 0) launch_wino_phase<0>(a, eh, ew, grid, stream);
         else launch_wino_phase<1>(a, eh, ew, grid, stream);
-        const int taps = (eh ? 3 : 2) * (ew ? 3 : 2);
-        char label[112];
-        snprintf(label, sizeof(label), "%s:conv_wino_f32 phase %d%d (%d taps as %d products) M=%d N=%d C=%d", name, eh, ew, taps,
-                 ((eh ? 3 : 2) + 1) * ((ew ? 3 : 2) + 1), B * L.Ho * L.Wo, L.Cout, L.Cin);
-        note_kernel({label, 2.0 * (double)B * L.Ho * L.Wo * taps * (double)L.Cin * (double)L.Cout});
+        // (the record carries the flops the kernel EXECUTES -- products x channels -- so that its TFLOP/s figure is a statement about the
+        //  kernel; the direct form of the phase would multiply taps x 4 per tile where this multiplies `points`)
+        const int taps = (eh ? 3 : 2) * (ew ? 3 : 2), points = ((eh ? 3 : 2) + 1) * ((ew ? 3 : 2) + 1);
+        char label[128];
+        snprintf(label, sizeof(label), "%s:conv_wino_f32 phase %d%d (%d taps as %d products per 2x2 outputs) M=%d N=%d C=%d", name, eh, ew, taps, points,
+                 B * L.Ho * L.Wo, L.Cout, L.Cin);
+        note_kernel({label, 2.0 * (double)B * (L.Ho / 2) * (L.Wo / 2) * points * (double)L.Cin * (double)L.Cout});
         AAE_HIP_TRY(hipGetLastError());
+        if (int rc = tm.mark()) return rc;
     }
-    return tm.mark();
+    return AAE_OK;
 }
 
 static bool runs_winograd(const aae_encoder* enc, const Layer& L, int B) {

@@ -67,19 +67,29 @@ static std::vector<float> pack_weights_winograd(const float* w_hwio, int KS, int
     auto gB = [&](int b, int k) { return tB == 3 ? G3[b][k] : G2[b][k]; };
     std::vector<float> out((size_t)NP * Cin * Cout);
     for (int c = 0; c < Cin; ++c)
-        for (int n = 0; n < Cout; ++n)
+        for (int n = 0; n < Cout; ++n) {
+            double g[3][3], t[4][3];                                  // taps [along A][along B], G_A g
+            for (int ka = 0; ka < tA; ++ka)
+                for (int kb = 0; kb < tB; ++kb) {
+                    const int kr = swap ? kb : ka, kc = swap ? ka : kb;              // tap index along rows / columns
+                    const int kh = 2 * kr + (eh ? 0 : 1), kw = 2 * kc + (ew ? 0 : 1);
+                    g[ka][kb] = (double)w_hwio[((size_t)(kh * KS + kw) * Cin + c) * Cout + n];
+                }
+            for (int a = 0; a < PA; ++a)
+                for (int kb = 0; kb < tB; ++kb) {
+                    double acc = 0.0;
+                    for (int ka = 0; ka < tA; ++ka) acc += gA(a, ka) * g[ka][kb];
+                    t[a][kb] = acc;
+                }
+            const int n32 = n >> 5, nn = n & 31, kg = c >> 3, hh = (c >> 2) & 1, q = c & 3;
+            float* dst = &out[((((size_t)n32 * (Cin / 8) + kg) * NP) * 64 + hh * 32 + nn) * 4 + q];
             for (int a = 0; a < PA; ++a)
                 for (int b = 0; b < PB; ++b) {
                     double acc = 0.0;
-                    for (int ka = 0; ka < tA; ++ka)
-                        for (int kb = 0; kb < tB; ++kb) {
-                            const int kr = swap ? kb : ka, kc = swap ? ka : kb;          // tap index along rows / columns
-                            const int kh = 2 * kr + (eh ? 0 : 1), kw = 2 * kc + (ew ? 0 : 1);
-                            acc += gA(a, ka) * gB(b, kb) * (double)w_hwio[((size_t)(kh * KS + kw) * Cin + c) * Cout + n];
-                        }
-                    const int p = a * PB + b, n32 = n >> 5, nn = n & 31, kg = c >> 3, hh = (c >> 2) & 1, q = c & 3;
-                    out[((((size_t)n32 * (Cin / 8) + kg) * NP + p) * 64 + hh * 32 + nn) * 4 + q] = (float)acc;
+                    for (int kb = 0; kb < tB; ++kb) acc += t[a][kb] * gB(b, kb);
+                    dst[(size_t)(a * PB + b) * 64 * 4] = (float)acc;
                 }
+        }
     return out;
 }
 

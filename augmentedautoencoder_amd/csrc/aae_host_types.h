@@ -91,7 +91,7 @@ struct aae_encoder {
     int splitk_target_blocks = 512;        // ... and then aim for about this many blocks
     int reduce_small = 1;                  // <= 8 splits over >= 16k outputs: barrier-free float4 reduce kernel
     int precision = 0;                     // 0: exact fp32 MFMA; 1: f32x3h split-precision igemm (explicit opt-in)
-    int winograd = 0;                      // 1: conv layers behind the first one as polyphase Winograd F(2 x 2) on the fp32 matrix cores (2.04 x fewer multiplies,
+    int winograd = 1;                      // 1: conv layers behind the first one as polyphase Winograd F(2 x 2) on the fp32 matrix cores (2.04 x fewer multiplies,
                                            // results differ from the direct kernels by fp32 rounding: conv_winograd_f32.h) for batches >= winograd_min_batch
     int winograd_min_batch = 64;
     int first_target_blocks = 512;         // conv1 grid size aimed at (x N tiles); 2 blocks fit a CU

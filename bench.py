@@ -34,6 +34,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -253,10 +254,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(precision):
+    def measure(precision, winograd=1):
         """W warm-up steps, then exactly K timed steps between barrier+synchronize fences, max over
         ranks; then per-kernel durations from HIP events on the launch stream."""
         enc.set_option('precision', 1 if precision == 'f32x3h' else 0)
+        enc.set_option('winograd', winograd)
         for kv in args.enc_opt:
             enc.set_option(kv.split('=')[0], int(kv.split('=')[1]))
         for _ in range(args.warmup):
@@ -297,14 +299,19 @@ def main():
         dom = max(kernels, key=lambda k: k['ms'])
         dom_flops = per[dom['kernel']][1]
         achieved = dom_flops / (dom['ms'] * 1e-3) / 1e12
+        # a polyphase-Winograd launch (csrc/kernels/conv_winograd_f32.h): its record counts the multiply-adds it EXECUTES (`points` products per
+        # 2 x 2 outputs and channel pair), so that achieved / peak stays a statement about the kernel; the direct form of the same phase
+        # multiplies 4 x taps per tile -- its flops / the same time is the "TF-equivalent" figure
+        wino = re.search(r'conv_wino_f32 phase (\d)(\d) \((\d+) taps as (\d+) products', dom['kernel'])
+        traffic_key = dom['kernel'].split(':')[0] + ('/wino%s%s' % (wino.group(1), wino.group(2)) if wino else '')
         peak = PEAK_F32_TFLOPS if precision == 'f32' else PEAK_X3H_TFLOPS
         traffic, traffic_src, busy = None, None, {}
         try:      # HBM-side bytes per launch from the committed rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE)
             with open(os.path.join(ROOT, 'profiles', 'traffic.json')) as f:
                 tj = json.load(f)
-            traffic = tj.get(precision, {}).get(dom['kernel'].split(':')[0])
+            traffic = tj.get(precision, {}).get(traffic_key)
             traffic_src = tj.get(precision + '_source')
-            busy = dict(tj.get('mfma' if precision == 'f32' else 'mfma_x3h', {}).get(dom['kernel'].split(':')[0], {}), source=tj.get('mfma_source'))
+            busy = dict(tj.get('mfma' if precision == 'f32' else 'mfma_x3h', {}).get(traffic_key, {}), source=tj.get('mfma_source'))
         except Exception:
             traffic = None
         return {
@@ -315,6 +322,10 @@ def main():
                          'traffic_source': ('profiles/traffic.json <- ' + (traffic_src or 'rocprofv3 PMC passes of an earlier run of this command: 2*FETCH_SIZE + WRITE_SIZE') +
                                             '; a committed measurement, not taken in this run (PMC collection needs the profiler)') if traffic is not None else None,
                          'flops_per_launch': dom_flops, 'avg_ms': dom['ms'],
+                         'arithmetic': ('polyphase Winograd F(2x2): flops_per_launch = the multiply-adds the launch executes (%s products per 2x2 outputs where the '
+                                        'direct form of this phase multiplies %d)' % (wino.group(4), 4 * int(wino.group(3)))) if wino else 'direct',
+                         'direct_form_flops_per_launch': dom_flops * 4 * int(wino.group(3)) / int(wino.group(4)) if wino else None,
+                         'tf_equivalent_of_the_direct_form': round(achieved * 4 * int(wino.group(3)) / int(wino.group(4)), 2) if wino else None,
                          'mfma_busy_frac': busy.get('mfma_busy_frac'), 'delivered_GHz_under_pmc': busy.get('delivered_GHz'),
                          'mfma_busy_source': busy.get('source'),
                          # (the split-precision mode is clock-limited: its fraction of the peak AT THE DELIVERED CLOCK, nominal 2.4 GHz)
@@ -326,10 +337,13 @@ def main():
         }
 
     main_res = measure(args.precision)
+    # the same step on the direct fp32 kernels (option winograd = 0: what rounds 1-4 reported as the headline)
+    direct_res = measure('f32', winograd=0) if args.precision == 'f32' and not args.no_split_precision else None
     split_res = None
     if args.precision == 'f32' and not args.no_split_precision:
         split_res = measure('f32x3h')
         enc.set_option('precision', 0)
+    enc.set_option('winograd', 1)
 
     def time_us(fn, reps, warm=5):
         """average microseconds per call of fn over `reps` back-to-back calls (HIP events on the launch stream)"""
@@ -624,6 +638,7 @@ def main():
                        'parallelism': 'objects sharded 1 per GPU; all_gather of (idx, score) only' if use_dist else 'single GPU'},
             'roofline': main_res['roofline'],
             'encoder_tflops': main_res['encoder_tflops'],
+            'encoder_tflops_note': 'algorithmic (direct-form) flops of the encoder / kernel time: with the polyphase-Winograd conv layers a TF-EQUIVALENT that may exceed the matrix peak',
             'kernels': main_res['kernels'],
         }
         if use_dist:
@@ -637,6 +652,10 @@ def main():
         if args.enc_opt:
             out['config']['encoder_options'] = args.enc_opt
         out.update(extras)
+        if direct_res is not None:
+            out['direct_fp32'] = {'mode': 'encoder option winograd = 0: every conv layer as a direct implicit GEMM (25 multiplies per tap set instead of 12.25)',
+                                  'value': direct_res['value'], 'unit': 'crops/s', 'ms_per_step': direct_res['ms_per_step'], 'roofline': direct_res['roofline'],
+                                  'encoder_tflops': direct_res['encoder_tflops'], 'kernels': direct_res['kernels']}
         if split_res is not None:
             out['split_precision'] = {'mode': x3h_label, 'value': split_res['value'], 'unit': 'crops/s',
                                       'ms_per_step': split_res['ms_per_step'], 'roofline': split_res['roofline'],

@@ -151,12 +151,13 @@ def bench_inputs_and_oracle():
     return weights, crops, E, z64, acts, ref.cos_similarity(z64, E)
 
 
-@pytest.mark.parametrize('precision', [0, 1])
-def test_headline_kernels_on_the_bench_inputs_match_fp64_oracle(bench_inputs_and_oracle, precision):
+@pytest.mark.parametrize('precision,winograd', [(0, 1), (0, 0), (1, 1)])
+def test_headline_kernels_on_the_bench_inputs_match_fp64_oracle(bench_inputs_and_oracle, precision, winograd):
     """The exact launches bench.py times (its seeds: weights 2024, crops 1234, codebook 7; B = 256, one chunk):
     kernel labels as in the bench line, then ALL four layer activations, all 256 latents, the similarity of all
     256 crops and all 256 indices against the fp64 oracle (encoder.py:37-68, codebook.py:27,50,64-68) -- in
-    exact fp32 (precision 0, the headline) and in the opt-in f32x3h mode (precision 1)."""
+    fp32 with the polyphase-Winograd conv layers (the default and the headline), on the direct fp32 kernels (option
+    winograd = 0: the bench's `direct_fp32` leg) and in the opt-in f32x3h mode (precision 1)."""
     from augmentedautoencoder_amd.engine import CodebookEngine, EncoderEngine
     from augmentedautoencoder_amd.weights import EncoderConfig
     weights, crops, E, z64, acts, cs64 = bench_inputs_and_oracle
@@ -164,9 +165,13 @@ def test_headline_kernels_on_the_bench_inputs_match_fp64_oracle(bench_inputs_and
     enc = EncoderEngine(EncoderConfig(), weights, max_batch=B)
     cb = CodebookEngine(E)
     enc.set_option('precision', precision)
+    enc.set_option('winograd', winograd)
     z, recs = enc.encode_timed(crops)
     labels = [l for l, _, _ in recs]
-    if precision == 0:
+    if precision == 0 and winograd:
+        want = ['conv1:conv_first_f32'] + ['conv%d:conv_wino_f32 phase %s' % (l, ph) for l in (2, 3, 4) for ph in ('11', '10', '01', '00')] + \
+               ['dense:conv_wavek_f32_32x32_w4_d2_g8 ']
+    elif precision == 0:
         want = ['conv1:conv_first_f32', 'conv2:conv_igemm_f32_dma_breg_n256', 'conv3:conv_igemm_f32_dma_breg_n256',
                 'conv4:conv_igemm_f32_dma_breg ', 'dense:conv_wavek_f32_32x32_w4_d2_g8 ']     # (dense: one launch, ticketed K reduction)
     else:
@@ -490,7 +495,7 @@ def test_fp32_igemm_lds_dma_variant_is_bit_identical():
     from augmentedautoencoder_amd.weights import EncoderConfig
     weights = synth.make_weights(seed=2024)
     enc = EncoderEngine(EncoderConfig(), weights)
-    for name in ('wavek', 'wavek_dense', 'gemv_ticket'):    # this test is about the 128 x 128 igemm family at every batch size
+    for name in ('wavek', 'wavek_dense', 'gemv_ticket', 'winograd'):    # this test is about the 128 x 128 igemm family at every batch size
         enc.set_option(name, 0)
     for B in (1, 5, 256):
         crops = synth.make_crops(B, seed=500 + B)

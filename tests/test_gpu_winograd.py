@@ -1,0 +1,115 @@
+"""Polyphase Winograd conv layers (csrc/kernels/conv_winograd_f32.h, encoder option "winograd", default for batches >= 64) on the
+MI355X: every layer and the latent against the fp64 oracle and against the direct fp32 kernels, whole and ragged image groups,
+BN epilogue, determinism under HBM load, garbage in the workspace, and the nearest-neighbour answer of the full query."""
+import numpy as np
+import pytest
+
+from oracle import reference_cpu as ref
+from oracle import synth
+
+pytestmark = pytest.mark.gpu
+
+STRIDES = [2, 2, 2, 2]
+
+
+def _rel(a, b):
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-12))
+
+
+@pytest.mark.parametrize('B', [64, 67, 130, 256])
+def test_layers_and_latent_against_the_fp64_oracle_and_the_direct_kernels(B):
+    from augmentedautoencoder_amd.engine import EncoderEngine
+    from augmentedautoencoder_amd.weights import EncoderConfig
+    weights = synth.make_weights(seed=77)
+    crops = synth.make_crops(B, seed=300 + B)
+    enc = EncoderEngine(EncoderConfig(), weights, max_batch=B)
+    z, recs = enc.encode_timed(crops)
+    labels = [l for l, _, _ in recs]
+    assert sum('conv_wino_f32' in l for l in labels) == 12, labels          # conv2 .. conv4, four phases each
+    acts_w = [enc.activation(i).cpu().numpy() for i in range(4)]
+    z_w = z.cpu().numpy()
+    enc.set_option('winograd', 0)
+    z_d = enc.encode(crops).cpu().numpy()
+    assert not any('wino' in l for l, _, _ in enc.encode_timed(crops)[1])
+    n = min(B, 24)                                                           # (the fp64 oracle of 24 crops takes seconds)
+    z64, acts = ref.encoder_forward_torch(ref.input_to_float(crops[-n:]), weights, STRIDES, False, 'float64', return_activations=True)
+    for i, a in enumerate(acts):
+        assert _rel(acts_w[i][-n:], a) < 2e-5, 'layer %d: %.2e' % (i, _rel(acts_w[i][-n:], a))
+    assert _rel(z_w[-n:], z64) < 5e-6, 'latent vs fp64: %.2e' % _rel(z_w[-n:], z64)
+    assert _rel(z_w, z_d) < 1e-5, 'latent vs the direct kernels: %.2e' % _rel(z_w, z_d)
+    cos = (z_w * z_d).sum(1) / np.linalg.norm(z_w, axis=1) / np.linalg.norm(z_d, axis=1)
+    assert cos.min() > 1 - 1e-6
+    enc.close()
+
+
+def test_min_batch_switches_back_to_the_per_detection_kernels():
+    from augmentedautoencoder_amd.engine import EncoderEngine
+    from augmentedautoencoder_amd.weights import EncoderConfig
+    enc = EncoderEngine(EncoderConfig(), synth.make_weights(seed=5), max_batch=64)
+    for B, want in ((4, False), (63, False), (64, True)):
+        labels = [l for l, _, _ in enc.encode_timed(synth.make_crops(B, seed=B))[1]]
+        assert any('wino' in l for l in labels) == want, (B, labels)
+    enc.set_option('winograd_min_batch', 16)
+    assert any('wino' in l for l, _, _ in enc.encode_timed(synth.make_crops(16, seed=1))[1])
+    enc.close()
+
+
+def test_three_layer_net_with_batch_norm_and_both_block_geometries():
+    from augmentedautoencoder_amd.engine import EncoderEngine
+    from augmentedautoencoder_amd.weights import EncoderConfig
+    cfg = EncoderConfig((64, 64, 3), [64, 128, 256], [2, 2, 2], 5, 64, True)
+    weights = synth.make_weights(seed=9, shape=cfg.shape, num_filter=cfg.num_filter, strides=cfg.strides, latent=64, batch_norm=True)
+    B = 70
+    crops = synth.make_crops(B, seed=10, shape=cfg.shape)
+    enc = EncoderEngine(cfg, weights, max_batch=B)
+    z, recs = enc.encode_timed(crops)
+    assert sum('conv_wino_f32' in l for l, _, _ in recs) == 8                 # conv2: 16 x 16 outputs (regions), conv3: 8 x 8 (four images per block)
+    z64, acts = ref.encoder_forward_torch(ref.input_to_float(crops), weights, cfg.strides, True, 'float64', return_activations=True)
+    for i, a in enumerate(acts):
+        assert _rel(enc.activation(i).cpu().numpy(), a) < 2e-5, 'layer %d' % i
+    assert _rel(z.cpu().numpy(), z64) < 5e-6
+    enc.close()
+
+
+def test_deterministic_under_memory_load_and_with_garbage_in_the_workspace():
+    import torch
+    from augmentedautoencoder_amd.engine import EncoderEngine
+    from augmentedautoencoder_amd.weights import EncoderConfig
+    B = 256
+    enc = EncoderEngine(EncoderConfig(), synth.make_weights(seed=2024), max_batch=B)
+    crops = torch.from_numpy(synth.make_crops(B, seed=4)).cuda()
+    z0 = enc.encode(crops).clone()
+    side = torch.cuda.Stream()
+    big_a = torch.empty(512 << 20, dtype=torch.uint8, device='cuda')
+    big_b = torch.zeros(512 << 20, dtype=torch.uint8, device='cuda')
+    gen = torch.Generator(device='cuda').manual_seed(3)
+    for rep in range(12):
+        if rep % 3 == 0:      # the phases ADD into the layer's output buffer: whatever the buffer held must not matter (the first phase stores)
+            buf, _ = enc.ws.get(0)
+            buf.copy_(torch.randint(0, 256, buf.shape, dtype=torch.uint8, device='cuda', generator=gen))
+        with torch.cuda.stream(side):
+            for _ in range(20):
+                big_a.copy_(big_b)
+        assert torch.equal(enc.encode(crops), z0), 'repeat %d' % rep
+    torch.cuda.synchronize()
+    enc.close()
+
+
+def test_full_query_answers_match_the_fp64_oracle():
+    from augmentedautoencoder_amd.engine import CodebookEngine, EncoderEngine
+    from augmentedautoencoder_amd.weights import EncoderConfig
+    weights = synth.make_weights(seed=2024)
+    E = synth.make_codebook(92232, 128, seed=7)
+    B = 96
+    crops = synth.make_crops(B, seed=55)
+    enc, cb = EncoderEngine(EncoderConfig(), weights, max_batch=B), CodebookEngine(E)
+    _, idx, score = enc.encode_nn(cb, crops)
+    z64 = ref.encoder_forward_torch(ref.input_to_float(crops), weights, STRIDES, False, 'float64')
+    cs64 = ref.cos_similarity(z64, E)
+    idx, score = idx.cpu().numpy().reshape(-1), score.cpu().numpy().reshape(-1)
+    assert np.abs(score - cs64.max(axis=1)).max() <= 1e-5
+    top2 = np.sort(cs64, axis=1)[:, -2:]
+    for i in range(B):      # index equal to the oracle's except on the oracle's own near-ties (rows 36 k and 36 k + 35 are the same rotation)
+        assert idx[i] == cs64[i].argmax() or top2[i, 1] - top2[i, 0] < 2e-5 or cs64[i, idx[i]] >= top2[i, 1] - 2e-5, i
+    enc.close()
+    cb.close()
