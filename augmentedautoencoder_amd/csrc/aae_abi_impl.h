@@ -116,6 +116,9 @@ int aae_encoder_create(const aae_encoder_desc* d, const void* const* hw, int n_w
     (void)hipFuncSetAttribute((const void*)aae::conv_igemm_f32_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
     (void)hipFuncSetAttribute((const void*)aae::conv_igemm_f32_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
 #endif
+    (void)hipFuncSetAttribute((const void*)aae::conv_wino_layer_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::wino_layer_smem_bytes<0>());
+    (void)hipFuncSetAttribute((const void*)aae::conv_wino_layer_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::wino_layer_smem_bytes<1>());
+#ifdef AAE_EXPERIMENTS
     (void)hipFuncSetAttribute((const void*)aae::conv_wino_phase_kernel<3, 3, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::wino_smem_bytes<0>());
     (void)hipFuncSetAttribute((const void*)aae::conv_wino_phase_kernel<3, 2, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::wino_smem_bytes<0>());
     (void)hipFuncSetAttribute((const void*)aae::conv_wino_phase_kernel<3, 2, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::wino_smem_bytes<0>());
@@ -124,6 +127,7 @@ int aae_encoder_create(const aae_encoder_desc* d, const void* const* hw, int n_w
     (void)hipFuncSetAttribute((const void*)aae::conv_wino_phase_kernel<3, 2, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::wino_smem_bytes<1>());
     (void)hipFuncSetAttribute((const void*)aae::conv_wino_phase_kernel<3, 2, true, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::wino_smem_bytes<1>());
     (void)hipFuncSetAttribute((const void*)aae::conv_wino_phase_kernel<2, 2, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::wino_smem_bytes<1>());
+#endif
     (void)hipFuncSetAttribute((const void*)aae::conv_igemm_f32_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
     (void)hipFuncSetAttribute((const void*)aae::conv_igemm_f32_kernel<false, true, false, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
     (void)hipFuncSetAttribute((const void*)aae::conv_igemm_f32_kernel<false, true, false, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
@@ -297,7 +301,11 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
             for (const Layer& L : enc->layers) any = any || L.wino_geom >= 0;
             if (!any) return fail(AAE_ERR_UNSUPPORTED, "winograd: no layer is eligible (5 x 5 stride-2 'SAME' layers behind the first one with 32 | Cin, 64 | Cout and 16 | Ho, Wo or an 8 x 8 output)");
         }
-        enc->winograd = value ? 1 : 0;
+        if (value < 0 || value > 2) return fail(AAE_ERR_INVALID, "winograd %d: 0 = direct kernels, 1 = one launch per layer, 2 = one launch per polyphase component", value);
+#ifndef AAE_EXPERIMENTS
+        if (value == 2) return fail(AAE_ERR_UNSUPPORTED, "option 'winograd' = 2 (one launch per polyphase component: measured slower) is a kernel variant of the experiments build (-DAAE_EXPERIMENTS)");
+#endif
+        enc->winograd = value;
     } else if (!strcmp(name, "winograd_min_batch")) {
         enc->winograd_min_batch = value < 1 ? 1 : value;
     } else if (!strcmp(name, "precision")) {

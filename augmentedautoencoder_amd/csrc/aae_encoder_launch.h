@@ -531,6 +531,7 @@ static int launch_detect_chain(aae_encoder* enc, int B, const std::vector<WaveKP
 
 #endif  // AAE_EXPERIMENTS
 
+#ifdef AAE_EXPERIMENTS
 // A conv layer as four polyphase Winograd launches (conv_winograd_f32.h): the phases add up in the output buffer, the last one applies
 // bias / ReLU / BN.  The 3 x 3-tap phase goes first (it stores), the 2 x 2-tap one last.
 template <int GEOM>
@@ -541,33 +542,52 @@ static void launch_wino_phase(const aae::ConvWinoArgs& a, int eh, int ew, unsign
     else if (ew) AAE_LAUNCH((aae::conv_wino_phase_kernel<3, 2, true, GEOM>), dim3(grid), dim3(512), smem, stream, a);
     else AAE_LAUNCH((aae::conv_wino_phase_kernel<2, 2, false, GEOM>), dim3(grid), dim3(512), smem, stream, a);
 }
+#endif
 
 static int launch_winograd(aae_encoder* enc, const Layer& L, const float* x, int B, float* out, hipStream_t stream, Timer& tm, const char* name) {
-    (void)enc;
     aae::ConvWinoArgs a;
-    a.x = x; a.bias = L.bias; a.bn_scale = L.bn_scale; a.bn_shift = L.bn_shift; a.out = out;
+    a.x = x; a.U = nullptr; a.bias = L.bias; a.bn_scale = L.bn_scale; a.bn_shift = L.bn_shift; a.out = out;
     a.B = B; a.H = L.H; a.W = L.W; a.Cin = L.Cin; a.Cout = L.Cout; a.Ho = L.Ho; a.Wo = L.Wo; a.relu = L.relu;
+    a.eh = a.ew = 0; a.mode = 0;
     a.blocks_x = L.wino_geom == 0 ? L.Wo / 16 : 1;
     a.blocks_y = L.wino_geom == 0 ? L.Ho / 16 : 1;
     const unsigned grid = (unsigned)(L.Cout / 64) * (L.wino_geom == 0 ? (unsigned)(a.blocks_x * a.blocks_y * B) : (unsigned)ceil_div(B, 4));
-    static const int order[4][2] = {{1, 1}, {1, 0}, {0, 1}, {0, 0}};
-    for (int i = 0; i < 4; ++i) {
-        const int eh = order[i][0], ew = order[i][1];
-        a.eh = eh; a.ew = ew; a.U = L.wino[2 * eh + ew];
-        a.mode = i == 0 ? 0 : (i == 3 ? 2 : 1);
-        if (L.wino_geom == 0) launch_wino_phase<0>(a, eh, ew, grid, stream);
-        else launch_wino_phase<1>(a, eh, ew, grid, stream);
-        // (the record carries the flops the kernel EXECUTES -- products x channels -- so that its TFLOP/s figure is a statement about the
-        //  kernel; the direct form of the phase would multiply taps x 4 per tile where this multiplies `points`)
-        const int taps = (eh ? 3 : 2) * (ew ? 3 : 2), points = ((eh ? 3 : 2) + 1) * ((ew ? 3 : 2) + 1);
-        char label[128];
-        snprintf(label, sizeof(label), "%s:conv_wino_f32 phase %d%d (%d taps as %d products per 2x2 outputs) M=%d N=%d C=%d", name, eh, ew, taps, points,
-                 B * L.Ho * L.Wo, L.Cout, L.Cin);
-        note_kernel({label, 2.0 * (double)B * (L.Ho / 2) * (L.Wo / 2) * points * (double)L.Cin * (double)L.Cout});
-        AAE_HIP_TRY(hipGetLastError());
-        if (int rc = tm.mark()) return rc;
+    const double tiles = (double)B * (L.Ho / 2) * (L.Wo / 2);
+    char label[128];
+#ifdef AAE_EXPERIMENTS
+    if (enc->winograd == 2) {
+        // one launch per phase, the phases add up in the output buffer (A/B of the one-launch form: 2 % slower)
+        static const int order[4][2] = {{1, 1}, {1, 0}, {0, 1}, {0, 0}};
+        for (int i = 0; i < 4; ++i) {
+            const int eh = order[i][0], ew = order[i][1];
+            a.eh = eh; a.ew = ew; a.U = L.wino[2 * eh + ew];
+            a.mode = i == 0 ? 0 : (i == 3 ? 2 : 1);
+            if (L.wino_geom == 0) launch_wino_phase<0>(a, eh, ew, grid, stream);
+            else launch_wino_phase<1>(a, eh, ew, grid, stream);
+            const int taps = (eh ? 3 : 2) * (ew ? 3 : 2), points = ((eh ? 3 : 2) + 1) * ((ew ? 3 : 2) + 1);
+            snprintf(label, sizeof(label), "%s:conv_wino_f32 phase %d%d (%d taps as %d products per 2x2 outputs) M=%d N=%d C=%d", name, eh, ew, taps, points,
+                     B * L.Ho * L.Wo, L.Cout, L.Cin);
+            note_kernel({label, 2.0 * tiles * points * (double)L.Cin * (double)L.Cout});
+            AAE_HIP_TRY(hipGetLastError());
+            if (int rc = tm.mark()) return rc;
+        }
+        return AAE_OK;
     }
-    return AAE_OK;
+#else
+    (void)enc;
+#endif
+    // one launch for the layer: the four phases inside the block, output written once
+    aae::ConvWinoLayerArgs p;
+    p.c = a;
+    for (int i = 0; i < 4; ++i) p.U4[i] = L.wino[i];
+    if (L.wino_geom == 0) AAE_LAUNCH((aae::conv_wino_layer_kernel<0>), dim3(grid), dim3(512), aae::wino_layer_smem_bytes<0>(), stream, p);
+    else AAE_LAUNCH((aae::conv_wino_layer_kernel<1>), dim3(grid), dim3(512), aae::wino_layer_smem_bytes<1>(), stream, p);
+    // (the record carries the flops the kernel EXECUTES -- 49 products per 2 x 2 outputs and channel pair where the direct form
+    //  multiplies 100 -- so that its TFLOP/s figure is a statement about the kernel)
+    snprintf(label, sizeof(label), "%s:conv_wino_f32 layer (25 taps as 49 products per 2x2 outputs) M=%d N=%d C=%d", name, B * L.Ho * L.Wo, L.Cout, L.Cin);
+    note_kernel({label, 2.0 * tiles * 49.0 * (double)L.Cin * (double)L.Cout});
+    AAE_HIP_TRY(hipGetLastError());
+    return tm.mark();
 }
 
 static bool runs_winograd(const aae_encoder* enc, const Layer& L, int B) {

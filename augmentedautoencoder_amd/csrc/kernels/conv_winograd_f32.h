@@ -14,7 +14,9 @@
 // Measured error against float64 is SMALLER than the direct fp32 kernel's (fewer, better-conditioned additions per output: 3.7e-7 vs
 // 8.5e-7 of the output scale on conv3, tools/ubench/polyphase_winograd.hip); results differ from the direct kernels by that much.
 //
-// One launch per phase (the four phases add up in the output buffer: mode 0 stores, 1 adds, 2 adds and applies bias / ReLU / BN):
+// One launch per LAYER (conv_wino_layer_kernel: the four phases run one behind the other inside the block and add up in an LDS buffer; the
+// output is written once with bias / ReLU / BN).  The experiments build also has one launch per PHASE (the phases add up in the output
+// buffer: measured 2 % slower, tools/wino_ab.py).  Either way:
 //   block = 8 waves = 64 tiles x 64 output channels.  GEOM 0: an 8 x 8-tile (16 x 16-pixel) region of one image (conv2, conv3);
 //           GEOM 1: the 4 x 4 tiles of four images (conv4: 8 x 8 outputs).  Wave (mh, nh, ph): 32 tiles x 32 channels x HALF the points --
 //           the point rows of the split dimension A go to two waves (rows {0, 1} | the rest), so a wave keeps 8 (6, 3) accumulator tiles
@@ -88,47 +90,59 @@ __device__ __forceinline__ f32x4 wino_sub4(f32x4 a, f32x4 b) {
     return f32x4{lo.x, lo.y, hi.x, hi.y};
 }
 
-// TA / TB: taps along the split dimension A / the other dimension B (3 | 2).  SWAP: A = columns.
-template <int TA, int TB, bool SWAP, int GEOM>
-__global__ __launch_bounds__(512) void conv_wino_phase_kernel(ConvWinoArgs a) {
+// Block geometry shared by the phases of a launch: which images / window a block covers and where a tile of a wave lies.
+struct WinoBlock {
+    int nb, img0, wy0, wx0;
+};
+template <int GEOM>
+__device__ __forceinline__ WinoBlock wino_block(int block, int nbn, int blocks_x, int blocks_y) {
+    WinoBlock w;
+    w.nb = block % nbn;
+    int rest = block / nbn;
+    if (GEOM == 0) {
+        const int bx = rest % blocks_x;
+        rest /= blocks_x;
+        const int by = rest % blocks_y;
+        w.img0 = rest / blocks_y;
+        w.wy0 = 16 * by - 1;
+        w.wx0 = 16 * bx - 1;
+    } else {
+        w.img0 = 4 * rest;
+        w.wy0 = w.wx0 = -1;
+    }
+    return w;
+}
+// tile t (0 ... 31) of the wave with tile half mh: (image of the block, tile row, tile column)
+template <int GEOM>
+__device__ __forceinline__ void wino_tile(int mh, int t, int& ti, int& ty, int& tx) {
+    if (GEOM == 0) { ti = 0; ty = 4 * mh + (t >> 3); tx = t & 7; }
+    else { ti = 2 * mh + (t >> 4); ty = (t >> 2) & 3; tx = t & 3; }
+}
+
+// One polyphase component for one block: the K loop over all input channels and the two-wave output transform.  Leaves the block's
+// 64 tiles x 4 pixels x 64 channels in the exchange buffer `xch_all` ([wave pair mh + 2 nh][register r * 4 + pixel k][lane] floats,
+// pixel k = 2 iA + iB): stored when !ACCUMULATE, added to what is there otherwise.  Ends behind a block barrier.
+// TA / TB: taps along the split dimension A / the other dimension B (3 | 2).  SWAP: A = columns.  STAGE_CH: input channels per LDS stage.
+template <int TA, int TB, bool SWAP, int GEOM, int STAGE_CH, bool ACCUMULATE>
+__device__ __forceinline__ void wino_phase_body(const ConvWinoArgs& a, const float* U, int eh, int ew, const WinoBlock& wb, f32x4* lds, float* xch_all) {
     using G = WinoGeom<GEOM>;
     constexpr int PB = TB + 1;                                  // points (= patch positions) along B
-    constexpr int kPlane = wino_plane_units<GEOM>(), kStage = wino_stage_units<GEOM>();
+    constexpr int kQuads = STAGE_CH / 4, kGroups = STAGE_CH / 8;                    // channel quads / 8-channel groups per stage
+    constexpr int kPlane = wino_plane_units<GEOM>(), kStage = kQuads * kPlane;
     constexpr int kParity = G::kRows * G::kRowPitch;            // units between the two column-parity halves of an image
-    constexpr int kStageQuads = G::kImages * G::kRows * G::kCols * 8;
-    constexpr int kHalf = ((kStageQuads + 511) / 512 + 1) / 2;  // float4 per thread and half stage
+    constexpr int kStageQuads = G::kImages * G::kRows * G::kCols * kQuads;
+    constexpr int kParts = kGroups / 2;                         // the fill of the next stage happens in this many parts (load at an even group, store at the next)
+    constexpr int kPer = ((kStageQuads + 511) / 512 + kParts - 1) / kParts;         // float4 per thread and part
     constexpr int kOffA = TA == 2 ? 1 : 0, kOffB = TB == 2 ? 1 : 0;   // a 2-tap dimension starts one sample into the window
-    AAE_DYN_SMEM(smem_raw);
-    f32x4* lds = reinterpret_cast<f32x4*>(smem_raw);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int mh = wave & 1, nh = (wave >> 1) & 1, ph = wave >> 2, m = lane & 31, h = lane >> 5;
-    const int nbn = a.Cout / 64;
-    const int nb = blockIdx.x % nbn;
-    int rest = blockIdx.x / nbn;
-    // block -> image(s) and window origin in sub-image coordinates
-    int img0, wy0, wx0;
-    if (GEOM == 0) {
-        const int bx = rest % a.blocks_x;
-        rest /= a.blocks_x;
-        const int by = rest % a.blocks_y;
-        img0 = rest / a.blocks_y;
-        wy0 = 16 * by - 1;
-        wx0 = 16 * bx - 1;
-    } else {
-        img0 = 4 * rest;
-        wy0 = wx0 = -1;
-    }
-    // tile of index t (0 ... 31) of this wave: (image of the block, tile row, tile column)
-    auto tile_of = [&](int t, int& ti, int& ty, int& tx) {
-        if (GEOM == 0) { ti = 0; ty = 4 * mh + (t >> 3); tx = t & 7; }
-        else { ti = 2 * mh + (t >> 4); ty = (t >> 2) & 3; tx = t & 3; }
-    };
+    const int img0 = wb.img0, wy0 = wb.wy0, wx0 = wb.wx0;
     int li, lty, ltx;
-    tile_of(m, li, lty, ltx);
-    const int n32 = nb * 2 + nh, KG = a.Cin / 8, nst = a.Cin / 32, cq_per_pixel = a.Cin / 4;
+    wino_tile<GEOM>(mh, m, li, lty, ltx);
+    const int n32 = wb.nb * 2 + nh, KG = a.Cin / 8, nst = a.Cin / STAGE_CH, cq_per_pixel = a.Cin / 4;
     constexpr int NP = (TA + 1) * PB;
     const f32x4* src = reinterpret_cast<const f32x4*>(a.x);
-    const f32x4* up = reinterpret_cast<const f32x4*>(a.U) + (size_t)n32 * KG * NP * 64 + (size_t)ph * 2 * PB * 64 + h * 32 + m;
+    const f32x4* up = reinterpret_cast<const f32x4*>(U) + (size_t)n32 * KG * NP * 64 + (size_t)ph * 2 * PB * 64 + h * 32 + m;
     const bool two_rows = TA == 3 || ph == 0;                   // point rows of A this wave owns: 2, or 1 (the third row of F(2, 2))
 
     f32x16 acc[2 * PB];
@@ -137,31 +151,31 @@ __global__ __launch_bounds__(512) void conv_wino_phase_kernel(ConvWinoArgs a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
 
-    // ---- stage fill: two halves, so that few staging registers are live at a time (the buffer of the next stage is free for the whole
+    // ---- stage fill in parts, so that few staging registers are live at a time (the buffer of the next stage is free for the whole
     //      of the current one: the barrier behind the previous stage)
-    f32x4 stg[kHalf];
-    auto stage_load = [&](int st, int half) {
+    f32x4 stg[kPer];
+    auto stage_load = [&](int st, int part) {
 #pragma unroll
-        for (int i = 0; i < kHalf; ++i) {
-            const int idx = tid + 512 * (half * kHalf + i);
+        for (int i = 0; i < kPer; ++i) {
+            const int idx = tid + 512 * (part * kPer + i);
             f32x4 val = {0.f, 0.f, 0.f, 0.f};
             if (idx < kStageQuads) {
-                const int pixel = idx >> 3, cq = idx & 7;
+                const int pixel = idx / kQuads, cq = idx - pixel * kQuads;
                 const int wi = pixel / (G::kRows * G::kCols), rem = pixel - wi * (G::kRows * G::kCols);
                 const int wy = rem / G::kCols, wx = rem - wy * G::kCols;
                 const int u = wy0 + wy, v = wx0 + wx, b = img0 + wi;
                 if (u >= 0 && u < a.Ho && v >= 0 && v < a.Wo && b < a.B)
-                    val = src[(((size_t)b * a.H + 2 * u + a.eh) * a.W + 2 * v + a.ew) * cq_per_pixel + st * 8 + cq];
+                    val = src[(((size_t)b * a.H + 2 * u + eh) * a.W + 2 * v + ew) * cq_per_pixel + st * kQuads + cq];
             }
             stg[i] = val;
         }
     };
-    auto stage_store = [&](int buf, int half) {
+    auto stage_store = [&](int buf, int part) {
 #pragma unroll
-        for (int i = 0; i < kHalf; ++i) {
-            const int idx = tid + 512 * (half * kHalf + i);
+        for (int i = 0; i < kPer; ++i) {
+            const int idx = tid + 512 * (part * kPer + i);
             if (idx < kStageQuads) {
-                const int pixel = idx >> 3, cq = idx & 7;
+                const int pixel = idx / kQuads, cq = idx - pixel * kQuads;
                 const int wi = pixel / (G::kRows * G::kCols), rem = pixel - wi * (G::kRows * G::kCols);
                 const int wy = rem / G::kCols, wx = rem - wy * G::kCols;
                 lds[buf * kStage + cq * kPlane + wi * G::kImagePitch + (wx & 1) * kParity + wy * G::kRowPitch + (wx >> 1)] = stg[i];
@@ -186,17 +200,18 @@ __global__ __launch_bounds__(512) void conv_wino_phase_kernel(ConvWinoArgs a) {
 #pragma unroll
     for (int p = 0; p < 2 * PB; ++p)
         if (two_rows || p < PB) u[p] = up[p * 64];
-    stage_load(0, 0);
-    stage_store(0, 0);
-    stage_load(0, 1);
-    stage_store(0, 1);
+#pragma unroll
+    for (int part = 0; part < kParts; ++part) {
+        stage_load(0, part);
+        stage_store(0, part);
+    }
     __syncthreads();
     for (int st = 0; st < nst; ++st) {
         const int buf = st & 1;
         const bool more = st + 1 < nst;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int gi = st * 4 + g;
+        for (int g = 0; g < kGroups; ++g) {
+            const int gi = st * kGroups + g;
             if (more && (g & 1) == 0) stage_load(st + 1, g >> 1);
             const f32x4* plane = lds + buf * kStage + (2 * g + h) * kPlane + lane_base;
             f32x4 v[2 * PB];
@@ -232,7 +247,7 @@ __global__ __launch_bounds__(512) void conv_wino_phase_kernel(ConvWinoArgs a) {
             // two points at a time (their accumulators alternate); as soon as a pair is through, ITS weight registers take the next
             // group's fragments: the global loads of group t + 1 fly under the MFMAs of group t without a second set of registers
             const f32x4* un = up + (size_t)(gi + 1) * NP * 64;
-            const bool next = gi + 1 < 4 * nst;
+            const bool next = gi + 1 < kGroups * nst;
             if (two_rows) {
 #pragma unroll
                 for (int bb = 0; bb < PB; ++bb) {
@@ -261,9 +276,9 @@ __global__ __launch_bounds__(512) void conv_wino_phase_kernel(ConvWinoArgs a) {
 
     // ---- output transform.  Along A the rows of A^T m split over the two waves:
     //        ph 0: q0 = m0 + m1, q1 = m1        ph 1, F(2, 3): q0 = m2, q1 = -m2 - m3        ph 1, F(2, 2): q0 = 0, q1 = -m2
-    //      each wave applies A along B to its part; the upper half hands its four partial outputs per accumulator register over through
-    //      LDS (the stage buffers are free after the last barrier), the lower half adds, finishes and stores.
-    float* xch = reinterpret_cast<float*>(smem_raw) + (size_t)(wave & 3) * 64 * 64;
+    //      each wave applies A along B to its part and adds its four partial outputs per accumulator register into the exchange
+    //      buffer, the upper half first (it STORES when the buffer holds nothing yet), the lower half behind a barrier.
+    float* xch = xch_all + (size_t)(wave & 3) * 64 * 64;
     auto partial = [&](int r, float (&y)[4]) {
         float q0[PB], q1[PB];
 #pragma unroll
@@ -273,17 +288,23 @@ __global__ __launch_bounds__(512) void conv_wino_phase_kernel(ConvWinoArgs a) {
             else if (TA == 3) { q0[j] = mA; q1[j] = -mA - mB; }
             else { q0[j] = 0.f; q1[j] = -mA; }
         }
+        // (pixel k = 2 iA + iB of the exchange buffer is output (dy, dx) = (iA, iB), or (iB, iA) when A = columns: stored as 2 dy + dx)
+        float t[4];
         if (TB == 3) {
-            y[0] = q0[0] + q0[1] + q0[2];
-            y[1] = q0[1] - q0[2] - q0[3];
-            y[2] = q1[0] + q1[1] + q1[2];
-            y[3] = q1[1] - q1[2] - q1[3];
+            t[0] = q0[0] + q0[1] + q0[2];
+            t[1] = q0[1] - q0[2] - q0[3];
+            t[2] = q1[0] + q1[1] + q1[2];
+            t[3] = q1[1] - q1[2] - q1[3];
         } else {
-            y[0] = q0[0] + q0[1];
-            y[1] = q0[1] - q0[2];
-            y[2] = q1[0] + q1[1];
-            y[3] = q1[1] - q1[2];
+            t[0] = q0[0] + q0[1];
+            t[1] = q0[1] - q0[2];
+            t[2] = q1[0] + q1[1];
+            t[3] = q1[1] - q1[2];
         }
+        y[0] = t[0];
+        y[1] = SWAP ? t[2] : t[1];
+        y[2] = SWAP ? t[1] : t[2];
+        y[3] = t[3];
     };
     if (ph == 1) {
 #pragma unroll
@@ -291,7 +312,10 @@ __global__ __launch_bounds__(512) void conv_wino_phase_kernel(ConvWinoArgs a) {
             float y[4];
             partial(r, y);
 #pragma unroll
-            for (int k = 0; k < 4; ++k) xch[(r * 4 + k) * 64 + lane] = y[k];
+            for (int k = 0; k < 4; ++k) {
+                if (ACCUMULATE) xch[(r * 4 + k) * 64 + lane] += y[k];
+                else xch[(r * 4 + k) * 64 + lane] = y[k];
+            }
         }
     }
     __syncthreads();
@@ -305,10 +329,14 @@ __global__ __launch_bounds__(512) void conv_wino_phase_kernel(ConvWinoArgs a) {
         }
     }
     __syncthreads();
-    // ---- the block's 64 tiles x 4 pixels x 64 channels leave as float4 per thread (eight each, all loads of the accumulating modes in
-    //      flight together): value (tile t, pixel k = 2 iA + iB, channel c) sits at pair (t / 32, c / 32), register r = (t & 3) + 4 ((t & 31) / 8),
-    //      lane 32 ((t / 4) & 1) + c % 32 of the exchange buffer
-    const float* xall = reinterpret_cast<const float*>(smem_raw);
+}
+
+// The block's 64 tiles x 4 pixels x 64 channels leave the exchange buffer as float4 per thread (eight each, all loads of the accumulating
+// modes in flight together): value (tile t, pixel k = 2 dy + dx, channel c) sits at pair (t / 32, c / 32), register
+// r = (t & 3) + 4 ((t & 31) / 8), lane 32 ((t / 4) & 1) + c % 32.
+template <int GEOM>
+__device__ __forceinline__ void wino_store_block(const ConvWinoArgs& a, int mode, const WinoBlock& wb, const float* xall) {
+    const int tid = threadIdx.x;
     f32x4 val[8];
     float* optr[8];
 #pragma unroll
@@ -318,14 +346,12 @@ __global__ __launch_bounds__(512) void conv_wino_phase_kernel(ConvWinoArgs a) {
         const int r = (mt & 3) + 4 * (mt >> 3), hh = (mt >> 2) & 1;
         val[i] = *reinterpret_cast<const f32x4*>(xall + (size_t)(tmh + 2 * tnh) * 64 * 64 + (r * 4 + k) * 64 + 32 * hh + (cq & 7) * 4);
         int ti, ty, tx;
-        if (GEOM == 0) { ti = 0; ty = 4 * tmh + (mt >> 3); tx = mt & 7; }
-        else { ti = 2 * tmh + (mt >> 4); ty = (mt >> 2) & 3; tx = mt & 3; }
-        const int b = img0 + ti;
-        const int iA = k >> 1, iB = k & 1, dy = SWAP ? iB : iA, dx = SWAP ? iA : iB;
-        const int oy = (GEOM == 0 ? wy0 + 1 : 0) + 2 * ty + dy, ox = (GEOM == 0 ? wx0 + 1 : 0) + 2 * tx + dx;
-        optr[i] = b < a.B ? a.out + (((size_t)b * a.Ho + oy) * a.Wo + ox) * a.Cout + nb * 64 + cq * 4 : nullptr;
+        wino_tile<GEOM>(tmh, mt, ti, ty, tx);
+        const int b = wb.img0 + ti;
+        const int oy = (GEOM == 0 ? wb.wy0 + 1 : 0) + 2 * ty + (k >> 1), ox = (GEOM == 0 ? wb.wx0 + 1 : 0) + 2 * tx + (k & 1);
+        optr[i] = b < a.B ? a.out + (((size_t)b * a.Ho + oy) * a.Wo + ox) * a.Cout + wb.nb * 64 + cq * 4 : nullptr;
     }
-    if (a.mode != 0) {
+    if (mode == 1 || mode == 2) {
         f32x4 old[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i)
@@ -334,8 +360,8 @@ __global__ __launch_bounds__(512) void conv_wino_phase_kernel(ConvWinoArgs a) {
         for (int i = 0; i < 8; ++i)
             if (optr[i]) val[i] += old[i];
     }
-    if (a.mode == 2) {
-        const int n4 = nb * 64 + (tid & 15) * 4;                     // (the channel quad of a thread is the same in all eight rounds)
+    if (mode >= 2) {
+        const int n4 = wb.nb * 64 + (tid & 15) * 4;                  // (the channel quad of a thread is the same in all eight rounds)
         const f32x4 bs = *reinterpret_cast<const f32x4*>(a.bias + n4);
         f32x4 sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
         if (a.bn_scale) {
@@ -355,6 +381,44 @@ __global__ __launch_bounds__(512) void conv_wino_phase_kernel(ConvWinoArgs a) {
 #pragma unroll
     for (int i = 0; i < 8; ++i)
         if (optr[i]) *reinterpret_cast<f32x4*>(optr[i]) = val[i];
+}
+
+#ifdef AAE_EXPERIMENTS
+// ---- one launch per PHASE: 32-channel stages, the exchange buffer overlays the stage buffers; the phases add up in the output buffer
+//      (a.mode 0 stores, 1 adds, 2 adds and applies bias / ReLU / BN).  a.U / a.eh / a.ew select the phase.
+template <int TA, int TB, bool SWAP, int GEOM>
+__global__ __launch_bounds__(512) void conv_wino_phase_kernel(ConvWinoArgs a) {
+    AAE_DYN_SMEM(smem_raw);
+    const WinoBlock wb = wino_block<GEOM>(blockIdx.x, a.Cout / 64, a.blocks_x, a.blocks_y);
+    wino_phase_body<TA, TB, SWAP, GEOM, 32, false>(a, a.U, a.eh, a.ew, wb, reinterpret_cast<f32x4*>(smem_raw), reinterpret_cast<float*>(smem_raw));
+    wino_store_block<GEOM>(a, a.mode, wb, reinterpret_cast<const float*>(smem_raw));
+}
+#endif
+
+// ---- one launch per LAYER: the four phases one behind the other in the block (3 x 3, 3 x 2, 2 x 3, 2 x 2 taps), their outputs added
+//      up in an exchange buffer of its own (64 KB behind the stage buffers, which shrink to 16-channel stages to make room); the
+//      output is written once, with bias / ReLU / BN.  No read-modify-write of the output tensor, one prologue / epilogue per four phases.
+struct ConvWinoLayerArgs {
+    ConvWinoArgs c;          // (U, eh, ew, mode unused)
+    const float* U4[4];      // index 2 eh + ew
+};
+template <int GEOM>
+constexpr int wino_layer_stage_bytes() { return 2 * 4 * wino_plane_units<GEOM>() * 16; }
+template <int GEOM>
+constexpr int wino_layer_smem_bytes() { return wino_layer_stage_bytes<GEOM>() + 4 * 64 * 64 * 4; }
+
+template <int GEOM>
+__global__ __launch_bounds__(512) void conv_wino_layer_kernel(ConvWinoLayerArgs p) {
+    AAE_DYN_SMEM(smem_raw);
+    const ConvWinoArgs& a = p.c;
+    const WinoBlock wb = wino_block<GEOM>(blockIdx.x, a.Cout / 64, a.blocks_x, a.blocks_y);
+    f32x4* lds = reinterpret_cast<f32x4*>(smem_raw);
+    float* xch = reinterpret_cast<float*>(smem_raw + wino_layer_stage_bytes<GEOM>());
+    wino_phase_body<3, 3, false, GEOM, 16, false>(a, p.U4[3], 1, 1, wb, lds, xch);
+    wino_phase_body<3, 2, false, GEOM, 16, true>(a, p.U4[2], 1, 0, wb, lds, xch);
+    wino_phase_body<3, 2, true, GEOM, 16, true>(a, p.U4[1], 0, 1, wb, lds, xch);
+    wino_phase_body<2, 2, false, GEOM, 16, true>(a, p.U4[0], 0, 0, wb, lds, xch);
+    wino_store_block<GEOM>(a, 3, wb, xch);
 }
 
 }  // namespace aae

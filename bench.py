@@ -302,8 +302,8 @@ def main():
         # a polyphase-Winograd launch (csrc/kernels/conv_winograd_f32.h): its record counts the multiply-adds it EXECUTES (`points` products per
         # 2 x 2 outputs and channel pair), so that achieved / peak stays a statement about the kernel; the direct form of the same phase
         # multiplies 4 x taps per tile -- its flops / the same time is the "TF-equivalent" figure
-        wino = re.search(r'conv_wino_f32 phase (\d)(\d) \((\d+) taps as (\d+) products', dom['kernel'])
-        traffic_key = dom['kernel'].split(':')[0] + ('/wino%s%s' % (wino.group(1), wino.group(2)) if wino else '')
+        wino = re.search(r'conv_wino_f32 (layer|phase \d\d) \((\d+) taps as (\d+) products', dom['kernel'])
+        traffic_key = dom['kernel'].split(':')[0] + ('/wino' if wino else '')
         peak = PEAK_F32_TFLOPS if precision == 'f32' else PEAK_X3H_TFLOPS
         traffic, traffic_src, busy = None, None, {}
         try:      # HBM-side bytes per launch from the committed rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE)
@@ -323,9 +323,9 @@ def main():
                                             '; a committed measurement, not taken in this run (PMC collection needs the profiler)') if traffic is not None else None,
                          'flops_per_launch': dom_flops, 'avg_ms': dom['ms'],
                          'arithmetic': ('polyphase Winograd F(2x2): flops_per_launch = the multiply-adds the launch executes (%s products per 2x2 outputs where the '
-                                        'direct form of this phase multiplies %d)' % (wino.group(4), 4 * int(wino.group(3)))) if wino else 'direct',
-                         'direct_form_flops_per_launch': dom_flops * 4 * int(wino.group(3)) / int(wino.group(4)) if wino else None,
-                         'tf_equivalent_of_the_direct_form': round(achieved * 4 * int(wino.group(3)) / int(wino.group(4)), 2) if wino else None,
+                                        'direct form multiplies %d)' % (wino.group(3), 4 * int(wino.group(2)))) if wino else 'direct',
+                         'direct_form_flops_per_launch': dom_flops * 4 * int(wino.group(2)) / int(wino.group(3)) if wino else None,
+                         'tf_equivalent_of_the_direct_form': round(achieved * 4 * int(wino.group(2)) / int(wino.group(3)), 2) if wino else None,
                          'mfma_busy_frac': busy.get('mfma_busy_frac'), 'delivered_GHz_under_pmc': busy.get('delivered_GHz'),
                          'mfma_busy_source': busy.get('source'),
                          # (the split-precision mode is clock-limited: its fraction of the peak AT THE DELIVERED CLOCK, nominal 2.4 GHz)

@@ -11,13 +11,13 @@ from oracle import reference_cpu as ref
 from oracle import synth
 
 
-def _run(cfg, B, seed, options=None):
+def _run(cfg, B, seed, options=None, mode=1):
     w = synth.make_weights(seed=seed, shape=cfg.shape, num_filter=cfg.num_filter, strides=cfg.strides,
                            latent=cfg.latent_space_size, batch_norm=cfg.batch_norm, kernel_size=cfg.kernel_size)
     x = synth.make_crops(B, seed=seed + 1, shape=cfg.shape)
     enc = eb.EmuEncoder(w, cfg)
     enc.set_option('winograd_min_batch', 1)
-    enc.set_option('winograd', 1)
+    enc.set_option('winograd', mode)
     for k, v in (options or {}).items():
         enc.set_option(k, v)
     z = enc.forward(x)
@@ -33,30 +33,38 @@ def _run(cfg, B, seed, options=None):
     return labels, errs
 
 
-def test_one_region_per_image_one_stage():
-    # conv2: 32 x 32 x 32 -> 16 x 16 x 64: geometry 0, one block per image and phase, one 32-channel stage
-    labels, _ = _run(EncoderConfig((64, 64, 3), [32, 64], [2, 2], 5, 128), 2, 11)
+# mode 1: one launch per layer (the four phases inside the block, 16-channel stages, outputs added up in LDS); mode 2: one launch per phase
+# (32-channel stages, the phases add up in the output buffer)
+@pytest.mark.parametrize('mode', [1, 2])
+def test_one_region_per_image_one_stage(mode):
+    # conv2: 32 x 32 x 32 -> 16 x 16 x 64: geometry 0, one block per image, one 32-channel stage (two 16-channel ones)
+    labels, _ = _run(EncoderConfig((64, 64, 3), [32, 64], [2, 2], 5, 128), 2, 11, mode=mode)
     wino = [l for l in labels if 'conv_wino_f32' in l]
-    assert len(wino) == 4 and all(l.startswith('conv2') for l in wino)
-    assert [l.split('phase ')[1][:2] for l in wino] == ['11', '10', '01', '00']
+    assert all(l.startswith('conv2') for l in wino)
+    if mode == 1:
+        assert len(wino) == 1 and 'layer' in wino[0]
+    else:
+        assert [l.split('phase ')[1][:2] for l in wino] == ['11', '10', '01', '00']
 
 
-def test_several_regions_per_image_two_stages_two_column_blocks():
-    # conv2: 64 x 64 x 64 -> 32 x 32 x 128: 2 x 2 regions per image, two stages, two 64-column blocks
-    labels, _ = _run(EncoderConfig((128, 128, 3), [64, 128], [2, 2], 5, 64), 1, 23)
-    assert sum('conv_wino_f32' in l for l in labels) == 4
+@pytest.mark.parametrize('mode', [1, 2])
+def test_several_regions_per_image_two_stages_two_column_blocks(mode):
+    # conv2: 64 x 64 x 64 -> 32 x 32 x 128: 2 x 2 regions per image, two 32-channel stages, two 64-column blocks
+    labels, _ = _run(EncoderConfig((128, 128, 3), [64, 128], [2, 2], 5, 64), 1, 23, mode=mode)
+    assert sum('conv_wino_f32' in l for l in labels) == (1 if mode == 1 else 4)
 
 
-@pytest.mark.parametrize('B', [1, 5])
-def test_four_images_per_block_ragged_groups(B):
+@pytest.mark.parametrize('B,mode', [(1, 1), (5, 1), (5, 2)])
+def test_four_images_per_block_ragged_groups(B, mode):
     # conv2: 16 x 16 x 32 -> 8 x 8 x 64: geometry 1; B = 5: the second block holds one image and three empty slots
-    labels, _ = _run(EncoderConfig((32, 32, 3), [32, 64], [2, 2], 5, 128), B, 31 + B)
-    assert sum('conv_wino_f32' in l for l in labels) == 4
+    labels, _ = _run(EncoderConfig((32, 32, 3), [32, 64], [2, 2], 5, 128), B, 31 + B, mode=mode)
+    assert sum('conv_wino_f32' in l for l in labels) == (1 if mode == 1 else 4)
 
 
-def test_both_geometries_in_one_network_with_batch_norm():
-    labels, _ = _run(EncoderConfig((64, 64, 3), [32, 64, 64], [2, 2, 2], 5, 128, True), 3, 47)
-    assert sum('conv_wino_f32' in l for l in labels) == 8
+@pytest.mark.parametrize('mode', [1, 2])
+def test_both_geometries_in_one_network_with_batch_norm(mode):
+    labels, _ = _run(EncoderConfig((64, 64, 3), [32, 64, 64], [2, 2, 2], 5, 128, True), 3, 47, mode=mode)
+    assert sum('conv_wino_f32' in l for l in labels) == (2 if mode == 1 else 8)
     assert labels[0].startswith('conv1') and 'wino' not in labels[0]
 
 

@@ -23,7 +23,7 @@ def main():
     w = synth.make_weights(seed=2024)
     direct = EncoderEngine(cfg, w, max_batch=max(batches))
     wino = EncoderEngine(cfg, w, max_batch=max(batches))
-    wino.set_option('winograd', 1)
+    wino.set_option('winograd', int(os.environ.get('WINO_MODE', '1')))
     for B in batches:
         x = torch.from_numpy(synth.make_crops(B, seed=7)).cuda()
         out = {'what': 'winograd_vs_direct', 'B': B}
