@@ -591,7 +591,9 @@ static int launch_winograd(aae_encoder* enc, const Layer& L, const float* x, int
 }
 
 static bool runs_winograd(const aae_encoder* enc, const Layer& L, int B) {
-    return enc->winograd && L.wino_geom >= 0 && L.wino[0] && B >= enc->winograd_min_batch;
+    // (the kernel reads the input through a 32-bit buffer view whose upper half marks "outside the image": activations below 2 GiB)
+    const unsigned long long x_bytes = (unsigned long long)B * L.H * L.W * L.Cin * sizeof(float);
+    return enc->winograd && L.wino_geom >= 0 && L.wino[0] && B >= enc->winograd_min_batch && x_bytes < 0x7FFFFF00ull;
 }
 
 static int forward_impl(aae_encoder* enc, const void* x, int x_dtype, int B, float* z_out, void* workspace,

@@ -88,6 +88,11 @@ __device__ __forceinline__ buffer_rsrc make_buffer(const void* base, uint32_t by
 __device__ __forceinline__ f32x4 buffer_load4(buffer_rsrc r, uint32_t byte_off) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0));
 }
+// ... with a wave-uniform part of the offset in a scalar register (no vector add per load).  The range check covers the lane offset
+// only: an out-of-range lane offset returns zeros whatever the scalar part is.
+__device__ __forceinline__ f32x4 buffer_load4_s(buffer_rsrc r, uint32_t lane_off, uint32_t uniform_off) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)lane_off, (int)uniform_off, 0));
+}
 
 // LDS-DMA: buffer_load_dwordx4 ... lds.  Lane l's 16 bytes go straight from the buffer view to
 // LDS at lds_wave_base + 16*l (no VGPR staging, no ds_write); out-of-range lanes deposit zeros.

@@ -31,6 +31,7 @@
 //           group's finished points released.
 //   weights: packed [32-column block][8-channel group][point = a PB + b][K half][32 columns][4 channels] per phase (aae_encoder_plan.h).
 #pragma once
+#include <type_traits>
 
 namespace aae {
 
@@ -80,6 +81,22 @@ __device__ __forceinline__ f32x2 wino_pk_sub(f32x2 a, f32x2 b) {
 #else
 __host__ __device__ inline f32x2 wino_pk_add(f32x2 a, f32x2 b) { return a + b; }
 __host__ __device__ inline f32x2 wino_pk_sub(f32x2 a, f32x2 b) { return a - b; }
+#endif
+// a * s + b with one scalar s for all four lanes of the quad
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ f32x4 wino_fma4(float s, f32x4 a, f32x4 b) {
+    const f32x2 ss = {s, s};
+    f32x2 lo, hi;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(lo) : "v"(ss), "v"(a.lo), "v"(b.lo));
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(hi) : "v"(ss), "v"(a.hi), "v"(b.hi));
+    return f32x4{lo.x, lo.y, hi.x, hi.y};
+}
+#else
+__host__ __device__ inline f32x4 wino_fma4(float s, f32x4 a, f32x4 b) {
+    f32x4 r;
+    for (int e = 0; e < 4; ++e) r[e] = fmaf(s, a[e], b[e]);
+    return r;
+}
 #endif
 __device__ __forceinline__ f32x4 wino_add4(f32x4 a, f32x4 b) {
     const f32x2 lo = wino_pk_add(a.lo, b.lo), hi = wino_pk_add(a.hi, b.hi);
@@ -141,8 +158,12 @@ __device__ __forceinline__ void wino_phase_body(const ConvWinoArgs& a, const flo
     wino_tile<GEOM>(mh, m, li, lty, ltx);
     const int n32 = wb.nb * 2 + nh, KG = a.Cin / 8, nst = a.Cin / STAGE_CH, cq_per_pixel = a.Cin / 4;
     constexpr int NP = (TA + 1) * PB;
-    const f32x4* src = reinterpret_cast<const f32x4*>(a.x);
-    const f32x4* up = reinterpret_cast<const f32x4*>(U) + (size_t)n32 * KG * NP * 64 + (size_t)ph * 2 * PB * 64 + h * 32 + m;
+    // both operands through raw buffer views (scalar base + one 32-bit lane offset; out-of-range = zeros: the 'SAME' padding and the empty
+    // image slots of a ragged group need no branches).  The host keeps the activation below 2 GiB for that (0x80000000 marks "outside").
+    constexpr uint32_t kOutside = 0x80000000u;
+    const buffer_rsrc xrs = make_buffer(a.x, (uint32_t)((size_t)a.B * a.H * a.W * a.Cin * 4));
+    const buffer_rsrc urs = make_buffer(U, (uint32_t)((size_t)NP * a.Cin * a.Cout * 4));
+    const uint32_t ulane = (uint32_t)(((size_t)n32 * KG * NP + (size_t)ph * 2 * PB) * 64 + h * 32 + m) * 16u;
     const bool two_rows = TA == 3 || ph == 0;                   // point rows of A this wave owns: 2, or 1 (the third row of F(2, 2))
 
     f32x16 acc[2 * PB];
@@ -152,35 +173,33 @@ __device__ __forceinline__ void wino_phase_body(const ConvWinoArgs& a, const flo
         for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
 
     // ---- stage fill in parts, so that few staging registers are live at a time (the buffer of the next stage is free for the whole
-    //      of the current one: the barrier behind the previous stage)
+    //      of the current one: the barrier behind the previous stage).  A thread's source offsets and LDS slots are the same in every stage.
     f32x4 stg[kPer];
+    uint32_t goff[kParts * kPer];
+    int lslot[kParts * kPer];
+#pragma unroll
+    for (int i = 0; i < kParts * kPer; ++i) {
+        const int idx = tid + 512 * i;
+        goff[i] = kOutside;
+        lslot[i] = -1;
+        if (idx < kStageQuads) {
+            const int pixel = idx / kQuads, cq = idx - pixel * kQuads;
+            const int wi = pixel / (G::kRows * G::kCols), rem = pixel - wi * (G::kRows * G::kCols);
+            const int wy = rem / G::kCols, wx = rem - wy * G::kCols;
+            const int uu = wy0 + wy, vv = wx0 + wx, b = img0 + wi;
+            if (uu >= 0 && uu < a.Ho && vv >= 0 && vv < a.Wo && b < a.B)
+                goff[i] = (uint32_t)(((((size_t)b * a.H + 2 * uu + eh) * a.W + 2 * vv + ew) * cq_per_pixel + cq) * 16);
+            lslot[i] = cq * kPlane + wi * G::kImagePitch + (wx & 1) * kParity + wy * G::kRowPitch + (wx >> 1);
+        }
+    }
     auto stage_load = [&](int st, int part) {
 #pragma unroll
-        for (int i = 0; i < kPer; ++i) {
-            const int idx = tid + 512 * (part * kPer + i);
-            f32x4 val = {0.f, 0.f, 0.f, 0.f};
-            if (idx < kStageQuads) {
-                const int pixel = idx / kQuads, cq = idx - pixel * kQuads;
-                const int wi = pixel / (G::kRows * G::kCols), rem = pixel - wi * (G::kRows * G::kCols);
-                const int wy = rem / G::kCols, wx = rem - wy * G::kCols;
-                const int u = wy0 + wy, v = wx0 + wx, b = img0 + wi;
-                if (u >= 0 && u < a.Ho && v >= 0 && v < a.Wo && b < a.B)
-                    val = src[(((size_t)b * a.H + 2 * u + eh) * a.W + 2 * v + ew) * cq_per_pixel + st * kQuads + cq];
-            }
-            stg[i] = val;
-        }
+        for (int i = 0; i < kPer; ++i) stg[i] = buffer_load4_s(xrs, goff[part * kPer + i], (uint32_t)(st * kQuads * 16));
     };
     auto stage_store = [&](int buf, int part) {
 #pragma unroll
-        for (int i = 0; i < kPer; ++i) {
-            const int idx = tid + 512 * (part * kPer + i);
-            if (idx < kStageQuads) {
-                const int pixel = idx / kQuads, cq = idx - pixel * kQuads;
-                const int wi = pixel / (G::kRows * G::kCols), rem = pixel - wi * (G::kRows * G::kCols);
-                const int wy = rem / G::kCols, wx = rem - wy * G::kCols;
-                lds[buf * kStage + cq * kPlane + wi * G::kImagePitch + (wx & 1) * kParity + wy * G::kRowPitch + (wx >> 1)] = stg[i];
-            }
-        }
+        for (int i = 0; i < kPer; ++i)
+            if (lslot[part * kPer + i] >= 0) lds[buf * kStage + lslot[part * kPer + i]] = stg[i];
     };
     // ---- patch addressing.  A sample at window position (wy, wx) = (2 ty + pA, 2 tx + pB) (or with A and B exchanged when SWAP) lies at
     //      lane_base + fA(pA) + fB(pB).  The A positions this wave reads, in the order (y0, y1, y2) that makes both halves the same
@@ -199,80 +218,93 @@ __device__ __forceinline__ void wino_phase_body(const ConvWinoArgs& a, const flo
     f32x4 u[2 * PB];
 #pragma unroll
     for (int p = 0; p < 2 * PB; ++p)
-        if (two_rows || p < PB) u[p] = up[p * 64];
+        if (two_rows || p < PB) u[p] = buffer_load4(urs, ulane + p * 1024u);
 #pragma unroll
     for (int part = 0; part < kParts; ++part) {
         stage_load(0, part);
         stage_store(0, part);
     }
     __syncthreads();
-    for (int st = 0; st < nst; ++st) {
-        const int buf = st & 1;
-        const bool more = st + 1 < nst;
+
+    // ---- the K loop in UNITS of one point row (PB points = 4 PB MFMAs): the patch rows of unit t + 1 are read and transformed between
+    //      the MFMAs of unit t, into registers of their own, so that a wave feeds the matrix pipe by itself (two waves that run the same
+    //      instruction stream side by side stall at the same places: the partner does not fill the gaps).  Pinned with scheduling fences:
+    //      reads of t + 1 | MFMAs q = 0 | MFMAs q = 1, A-step of t + 1 | MFMAs q = 2, B-step of t + 1 | MFMAs q = 3, weight prefetch.
+    //      The first unit behind a stage barrier has nothing to hide behind (once per STAGE_CH channels).
+    auto read_unit = [&](const f32x4* plane, int i, f32x4 (&raw)[2 * PB]) {
 #pragma unroll
-        for (int g = 0; g < kGroups; ++g) {
-            const int gi = st * kGroups + g;
-            if (more && (g & 1) == 0) stage_load(st + 1, g >> 1);
-            const f32x4* plane = lds + buf * kStage + (2 * g + h) * kPlane + lane_base;
-            f32x4 v[2 * PB];
-            // rows of B^T d along A ...
-#pragma unroll
-            for (int s = 0; s < PB; ++s) {
-                const int ob = fB(s + kOffB);
-                const f32x4 y0 = plane[offA0 + ob], y2 = plane[offA2 + ob];
-                v[s] = wino_sub4(y0, y2);
-                if (TA == 3) {
-                    const f32x4 y1 = plane[offA1 + ob];
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[PB + s][e] = fmaf(sg, y1[e], y2[e]);
-                } else {
-                    v[PB + s] = y2;
-                }
-            }
-            // ... then along B
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                if (TB == 3) {
-                    const f32x4 e0 = v[PB * i], e1 = v[PB * i + 1], e2 = v[PB * i + 2], e3 = v[PB * i + 3];
-                    v[PB * i] = wino_sub4(e0, e2);
-                    v[PB * i + 1] = wino_add4(e1, e2);
-                    v[PB * i + 2] = wino_sub4(e2, e1);
-                    v[PB * i + 3] = wino_sub4(e1, e3);
-                } else {
-                    const f32x4 e0 = v[PB * i], e1 = v[PB * i + 1], e2 = v[PB * i + 2];
-                    v[PB * i] = wino_sub4(e0, e1);
-                    v[PB * i + 2] = wino_sub4(e1, e2);
-                }
-            }
-            // two points at a time (their accumulators alternate); as soon as a pair is through, ITS weight registers take the next
-            // group's fragments: the global loads of group t + 1 fly under the MFMAs of group t without a second set of registers
-            const f32x4* un = up + (size_t)(gi + 1) * NP * 64;
-            const bool next = gi + 1 < kGroups * nst;
-            if (two_rows) {
-#pragma unroll
-                for (int bb = 0; bb < PB; ++bb) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        acc[bb] = mfma_32x32x2(v[bb][q], u[bb][q], acc[bb]);
-                        acc[PB + bb] = mfma_32x32x2(v[PB + bb][q], u[PB + bb][q], acc[PB + bb]);
-                    }
-                    if (next) {
-                        u[bb] = un[bb * 64];
-                        u[PB + bb] = un[(PB + bb) * 64];
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int bb = 0; bb < PB; ++bb) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) acc[bb] = mfma_32x32x2(v[bb][q], u[bb][q], acc[bb]);
-                    if (next) u[bb] = un[bb * 64];
-                }
-            }
-            if (more && (g & 1) == 1) stage_store(buf ^ 1, g >> 1);
+        for (int s2 = 0; s2 < PB; ++s2) {
+            const int ob = fB(s2 + kOffB);
+            if (i == 0) raw[s2] = plane[offA0 + ob];
+            else if (TA == 3) raw[s2] = plane[offA1 + ob];
+            raw[PB + s2] = plane[offA2 + ob];
         }
-        __syncthreads();
-    }
+    };
+    auto step_a = [&](int i, const f32x4 (&raw)[2 * PB], f32x4 (&w)[PB]) {       // rows of B^T d along A
+#pragma unroll
+        for (int s2 = 0; s2 < PB; ++s2) {
+            if (i == 0) w[s2] = wino_sub4(raw[s2], raw[PB + s2]);
+            else if (TA == 3) w[s2] = wino_fma4(sg, raw[s2], raw[PB + s2]);
+            else w[s2] = raw[PB + s2];
+        }
+    };
+    auto step_b = [&](f32x4 (&w)[PB]) {                                           // ... then along B, in place
+        if (TB == 3) {
+            const f32x4 e0 = w[0], e1 = w[1], e2 = w[2], e3 = w[PB - 1];
+            w[0] = wino_sub4(e0, e2);
+            w[1] = wino_add4(e1, e2);
+            w[2] = wino_sub4(e2, e1);
+            w[PB - 1] = wino_sub4(e1, e3);
+        } else {
+            const f32x4 e0 = w[0], e1 = w[1], e2 = w[2];
+            w[0] = wino_sub4(e0, e1);
+            w[2] = wino_sub4(e1, e2);
+        }
+    };
+    auto run = [&](auto rows_tag) {
+        constexpr int ROWS = decltype(rows_tag)::value, NU = kGroups * ROWS;
+        f32x4 raw[2 * PB], v[PB], vn[PB];
+        for (int st = 0; st < nst; ++st) {
+            const int buf = st & 1;
+            const bool more = st + 1 < nst;
+            const f32x4* stage = lds + buf * kStage + h * kPlane + lane_base;
+            read_unit(stage, 0, raw);
+            step_a(0, raw, v);
+            step_b(v);
+#pragma unroll
+            for (int t = 0; t < NU; ++t) {
+                const int g = t / ROWS, i = t % ROWS, gi = st * kGroups + g;
+                if (more && i == 0 && (g & 1) == 0) stage_load(st + 1, g >> 1);
+                if (t + 1 < NU) read_unit(stage + 2 * ((t + 1) / ROWS) * kPlane, (t + 1) % ROWS, raw);
+                sched_fence();
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                    for (int j = 0; j < PB; ++j) acc[i * PB + j] = mfma_32x32x2(v[j][q], u[i * PB + j][q], acc[i * PB + j]);
+                    sched_fence();
+                    if (t + 1 < NU) {
+                        if (q == 1) step_a((t + 1) % ROWS, raw, vn);
+                        if (q == 2) step_b(vn);
+                    }
+                    sched_fence();
+                }
+                // this row's weight registers take the next group's fragments (they fly under the MFMAs of the units in between)
+                if (gi + 1 < kGroups * nst) {
+                    const uint32_t un = (uint32_t)(gi + 1) * (NP * 1024u) + i * PB * 1024u;        // (wave-uniform: a scalar register)
+#pragma unroll
+                    for (int j = 0; j < PB; ++j) u[i * PB + j] = buffer_load4_s(urs, ulane + j * 1024u, un);
+                }
+                if (more && i == ROWS - 1 && (g & 1) == 1) stage_store(buf ^ 1, g >> 1);
+                if (t + 1 < NU) {
+#pragma unroll
+                    for (int j = 0; j < PB; ++j) v[j] = vn[j];
+                }
+            }
+            __syncthreads();
+        }
+    };
+    if (TA == 3 || ph == 0) run(std::integral_constant<int, 2>());
+    else run(std::integral_constant<int, 1>());
 
     // ---- output transform.  Along A the rows of A^T m split over the two waves:
     //        ph 0: q0 = m0 + m1, q1 = m1        ph 1, F(2, 3): q0 = m2, q1 = -m2 - m3        ph 1, F(2, 2): q0 = 0, q1 = -m2

@@ -78,6 +78,12 @@ inline f32x4 buffer_load4(buffer_rsrc r, uint32_t byte_off) {
     return v;
 }
 
+inline f32x4 buffer_load4_s(buffer_rsrc r, uint32_t lane_off, uint32_t uniform_off) {
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if ((uint64_t)lane_off + 16 <= r.bytes) memcpy(&v, r.base + lane_off + uniform_off, 16);     // (the range check sees the lane offset only)
+    return v;
+}
+
 // buffer_load_dwordx4 ... lds model: lane l's 16 bytes land at wave_base + 16*l (zeros when
 // out of range).  The emulator completes it at issue; the landing order on hardware is
 // covered by wait_dma_and_lds() + barrier in the kernels and by the GPU parity tests.
