@@ -308,6 +308,8 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
         enc->winograd = value;
     } else if (!strcmp(name, "winograd_min_batch")) {
         enc->winograd_min_batch = value < 1 ? 1 : value;
+    } else if (!strcmp(name, "winograd_min_blocks")) {
+        enc->winograd_min_blocks = value < 0 ? 0 : value;
     } else if (!strcmp(name, "precision")) {
         if (value < 0 || value > 2) return fail(AAE_ERR_INVALID, "precision %d: 0 = fp32, 1 = f32x3h, 2 = f32x3h where it is faster", value);
         if (value != 0) {

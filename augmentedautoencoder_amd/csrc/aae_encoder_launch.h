@@ -591,9 +591,15 @@ static int launch_winograd(aae_encoder* enc, const Layer& L, const float* x, int
 }
 
 static bool runs_winograd(const aae_encoder* enc, const Layer& L, int B) {
+    if (!enc->winograd || L.wino_geom < 0 || !L.wino[0] || B < enc->winograd_min_batch) return false;
     // (the kernel reads the input through a 32-bit buffer view whose upper half marks "outside the image": activations below 2 GiB)
     const unsigned long long x_bytes = (unsigned long long)B * L.H * L.W * L.Cin * sizeof(float);
-    return enc->winograd && L.wino_geom >= 0 && L.wino[0] && B >= enc->winograd_min_batch && x_bytes < 0x7FFFFF00ull;
+    if (x_bytes >= 0x7FFFFF00ull) return false;
+    // measured on MI355X (tools/wino_ab.py): a layer gains from about three quarters of a round of blocks on (conv2 of the default net
+    // from B = 12, conv3 from 24, conv4 -- four images per block -- from 96); below that the wave-split-K kernels fill the chip better
+    const long long blocks = (long long)(L.Cout / 64) * (L.wino_geom == 0 ? (long long)(L.Ho / 16) * (L.Wo / 16) * B : (long long)ceil_div(B, 4));
+    const int min_blocks = enc->winograd_min_blocks > 0 ? enc->winograd_min_blocks : 3 * wavek_round_blocks(enc) / 4;
+    return blocks >= min_blocks;
 }
 
 static int forward_impl(aae_encoder* enc, const void* x, int x_dtype, int B, float* z_out, void* workspace,

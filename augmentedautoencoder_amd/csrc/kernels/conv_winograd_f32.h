@@ -35,6 +35,10 @@
 
 namespace aae {
 
+#ifndef WINO_PRIO
+#define WINO_PRIO 0
+#endif
+
 struct ConvWinoArgs {
     const float* x;          // [B][H][W][Cin]  (H = 2 Ho, W = 2 Wo)
     const float* U;          // packed transformed weights of this phase
@@ -279,8 +283,10 @@ __device__ __forceinline__ void wino_phase_body(const ConvWinoArgs& a, const flo
                 sched_fence();
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
+                    if (WINO_PRIO) wave_priority<1>();
 #pragma unroll
                     for (int j = 0; j < PB; ++j) acc[i * PB + j] = mfma_32x32x2(v[j][q], u[i * PB + j][q], acc[i * PB + j]);
+                    if (WINO_PRIO) wave_priority<0>();
                     sched_fence();
                     if (t + 1 < NU) {
                         if (q == 1) step_a((t + 1) % ROWS, raw, vn);

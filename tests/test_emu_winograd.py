@@ -17,6 +17,7 @@ def _run(cfg, B, seed, options=None, mode=1):
     x = synth.make_crops(B, seed=seed + 1, shape=cfg.shape)
     enc = eb.EmuEncoder(w, cfg)
     enc.set_option('winograd_min_batch', 1)
+    enc.set_option('winograd_min_blocks', 1)     # (the product rule: launches of at least three quarters of a round of blocks)
     enc.set_option('winograd', mode)
     for k, v in (options or {}).items():
         enc.set_option(k, v)

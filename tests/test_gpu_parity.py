@@ -917,8 +917,8 @@ def test_small_batch_wave_split_k_path_matches_fp64_oracle(default_model, B, cha
         assert all(':conv_wavek_f32_' in l for l in labels[1:4]), labels
         if B == 3:
             assert any('_g1t' in l for l in labels[1:4]), labels
-    else:                                                       # B >= 5: family and tile shape per layer by the planner's cost model
-        assert all((':conv_wavek_f32_' in l) or (':conv_igemm_f32' in l) or l.endswith(':splitk_reduce') for l in labels[1:-1]), labels
+    else:                                                       # B >= 5: family and tile shape per layer by the planner's cost model (conv2 from B = 12: the Winograd form)
+        assert all((':conv_wavek_f32_' in l) or (':conv_igemm_f32' in l) or (':conv_wino_f32' in l) or l.endswith(':splitk_reduce') for l in labels[1:-1]), labels
         # (the dense layer: the GEMV up to B = 8 -- the 8-row form of its block --, the wave-split-K tile beyond)
         assert labels[-1].startswith('dense:dense_gemv_f32_ticket' if B <= 8 else 'dense:conv_wavek_f32_'), labels
     z64, acts = ref.encoder_forward_torch(ref.input_to_float(crops), weights, STRIDES, False, 'float64', return_activations=True)
@@ -946,6 +946,14 @@ def test_planner_by_cost_model_batches_match_fp64_oracle(default_model, B):
     weights, enc, cb, E, _ = default_model
     eng = enc.engine
     crops = synth.make_crops(B, seed=2500 + B)
+    eng.set_option('winograd', 0)           # (this test is about the planner of the direct kernels; tests/test_gpu_winograd.py has the Winograd layers at these batches)
+    try:
+        _planner_by_cost_body(weights, eng, cb, E, B, crops)
+    finally:
+        eng.set_option('winograd', 1)
+
+
+def _planner_by_cost_body(weights, eng, cb, E, B, crops):
     z, recs = eng.encode_timed(crops)
     labels = [l.split(' ')[0] for l, _, _ in recs]
     z64, acts = ref.encoder_forward_torch(ref.input_to_float(crops), weights, STRIDES, False, 'float64', return_activations=True)

@@ -16,7 +16,7 @@ def _rel(a, b):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-12))
 
 
-@pytest.mark.parametrize('B', [64, 67, 130, 256])
+@pytest.mark.parametrize('B', [12, 24, 48, 64, 67, 96, 130, 256])
 def test_layers_and_latent_against_the_fp64_oracle_and_the_direct_kernels(B):
     from augmentedautoencoder_amd.engine import EncoderEngine
     from augmentedautoencoder_amd.weights import EncoderConfig
@@ -25,7 +25,7 @@ def test_layers_and_latent_against_the_fp64_oracle_and_the_direct_kernels(B):
     enc = EncoderEngine(EncoderConfig(), weights, max_batch=B)
     z, recs = enc.encode_timed(crops)
     labels = [l for l, _, _ in recs]
-    assert sum('conv_wino_f32 layer' in l for l in labels) == 3, labels      # conv2 .. conv4, one launch each
+    assert sum('conv_wino_f32 layer' in l for l in labels) == (3 if B >= 93 else 2 if B >= 24 else 1), labels      # conv2, from B = 24 conv3, from 93 conv4: one launch each
     acts_w = [enc.activation(i).cpu().numpy() for i in range(4)]
     z_w = z.cpu().numpy()
     enc.set_option('winograd', 0)
@@ -42,15 +42,19 @@ def test_layers_and_latent_against_the_fp64_oracle_and_the_direct_kernels(B):
     enc.close()
 
 
-def test_min_batch_switches_back_to_the_per_detection_kernels():
+def test_layers_take_the_winograd_form_from_three_quarters_of_a_round_of_blocks():
+    """blocks of a launch = 64-channel blocks x (16 x 16-pixel regions x B | groups of four 8 x 8 images): conv2 16 B, conv3 8 B, conv4 8 ceil(B / 4);
+    the rule (aae_encoder_launch.h: runs_winograd) takes a layer from 192 blocks on, never below winograd_min_batch = 8."""
     from augmentedautoencoder_amd.engine import EncoderEngine
     from augmentedautoencoder_amd.weights import EncoderConfig
-    enc = EncoderEngine(EncoderConfig(), synth.make_weights(seed=5), max_batch=64)
-    for B, want in ((4, False), (63, False), (64, True)):
+    enc = EncoderEngine(EncoderConfig(), synth.make_weights(seed=5), max_batch=96)
+    for B, want in ((4, []), (11, []), (12, ['conv2']), (23, ['conv2']), (24, ['conv2', 'conv3']), (92, ['conv2', 'conv3']), (93, ['conv2', 'conv3', 'conv4'])):
         labels = [l for l, _, _ in enc.encode_timed(synth.make_crops(B, seed=B))[1]]
-        assert any('wino' in l for l in labels) == want, (B, labels)
-    enc.set_option('winograd_min_batch', 16)
-    assert any('wino' in l for l, _, _ in enc.encode_timed(synth.make_crops(16, seed=1))[1])
+        assert [l.split(':')[0] for l in labels if 'wino' in l] == want, (B, labels)
+    enc.set_option('winograd_min_blocks', 64)
+    assert sum('wino' in l for l, _, _ in enc.encode_timed(synth.make_crops(32, seed=1))[1]) == 3
+    enc.set_option('winograd_min_batch', 33)
+    assert not any('wino' in l for l, _, _ in enc.encode_timed(synth.make_crops(32, seed=1))[1])
     enc.close()
 
 
@@ -62,6 +66,7 @@ def test_three_layer_net_with_batch_norm_and_both_block_geometries():
     B = 70
     crops = synth.make_crops(B, seed=10, shape=cfg.shape)
     enc = EncoderEngine(cfg, weights, max_batch=B)
+    enc.set_option('winograd_min_blocks', 1)                                  # (this small net's launches stay below the 192 blocks of the product rule)
     z, recs = enc.encode_timed(crops)
     assert sum('conv_wino_f32' in l for l, _, _ in recs) == 2                 # conv2: 16 x 16 outputs (regions), conv3: 8 x 8 (four images per block)
     z64, acts = ref.encoder_forward_torch(ref.input_to_float(crops), weights, cfg.strides, True, 'float64', return_activations=True)

@@ -22,8 +22,10 @@ def main():
     cfg = EncoderConfig()
     w = synth.make_weights(seed=2024)
     direct = EncoderEngine(cfg, w, max_batch=max(batches))
+    direct.set_option('winograd', 0)
     wino = EncoderEngine(cfg, w, max_batch=max(batches))
     wino.set_option('winograd', int(os.environ.get('WINO_MODE', '1')))
+    wino.set_option('winograd_min_batch', int(os.environ.get('WINO_MIN', '64')))
     for B in batches:
         x = torch.from_numpy(synth.make_crops(B, seed=7)).cuda()
         out = {'what': 'winograd_vs_direct', 'B': B}
