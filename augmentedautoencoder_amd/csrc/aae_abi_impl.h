@@ -116,8 +116,7 @@ int aae_encoder_create(const aae_encoder_desc* d, const void* const* hw, int n_w
     (void)hipFuncSetAttribute((const void*)aae::conv_igemm_f32_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
     (void)hipFuncSetAttribute((const void*)aae::conv_igemm_f32_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::kConvIgemmSmem);
 #endif
-    (void)hipFuncSetAttribute((const void*)aae::conv_wino_layer_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::wino_layer_smem_bytes<0>());
-    (void)hipFuncSetAttribute((const void*)aae::conv_wino_layer_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::wino_layer_smem_bytes<1>());
+    wino_set_attributes();
 #ifdef AAE_EXPERIMENTS
     (void)hipFuncSetAttribute((const void*)aae::conv_wino_phase_kernel<3, 3, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::wino_smem_bytes<0>());
     (void)hipFuncSetAttribute((const void*)aae::conv_wino_phase_kernel<3, 2, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::wino_smem_bytes<0>());
@@ -189,7 +188,7 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
         // tests).  Here their options accept the default value and nothing else.
         static const struct { const char* name; int only; } kExperimentOptions[] = {
             {"detect_chain", 0}, {"chain_timeline", 0}, {"wavek_timeline", 0}, {"wavek_ablate", 0}, {"wavek_waves", 4}, {"wavek_tiny_waves", 4},
-            {"wavek_depth", 2}, {"wavek_pingpong", 0}, {"gemv_ticket", 1}, {"wavek_spread", 3}, {"igemm_dma", 1}, {"igemm_breg", 1}, {"x3h_dma", 1}, {"x3h_wide_min_blocks", 0}};
+            {"wavek_depth", 2}, {"wavek_pingpong", 0}, {"gemv_ticket", 1}, {"wavek_spread", 3}, {"igemm_dma", 1}, {"igemm_breg", 1}, {"x3h_dma", 1}, {"x3h_wide_min_blocks", 0}, {"winograd_wide", 0}};
         for (const auto& o : kExperimentOptions)
             if (!strcmp(name, o.name)) {
                 if (value == o.only) return AAE_OK;
@@ -306,6 +305,8 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
         if (value == 2) return fail(AAE_ERR_UNSUPPORTED, "option 'winograd' = 2 (one launch per polyphase component: measured slower) is a kernel variant of the experiments build (-DAAE_EXPERIMENTS)");
 #endif
         enc->winograd = value;
+    } else if (!strcmp(name, "winograd_wide")) {
+        enc->winograd_wide = value ? 1 : 0;
     } else if (!strcmp(name, "winograd_min_batch")) {
         enc->winograd_min_batch = value < 1 ? 1 : value;
     } else if (!strcmp(name, "winograd_min_blocks")) {

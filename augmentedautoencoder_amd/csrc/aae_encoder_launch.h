@@ -573,15 +573,12 @@ static int launch_winograd(aae_encoder* enc, const Layer& L, const float* x, int
         }
         return AAE_OK;
     }
-#else
-    (void)enc;
 #endif
     // one launch for the layer: the four phases inside the block, output written once
     aae::ConvWinoLayerArgs p;
     p.c = a;
     for (int i = 0; i < 4; ++i) p.U4[i] = L.wino[i];
-    if (L.wino_geom == 0) AAE_LAUNCH((aae::conv_wino_layer_kernel<0>), dim3(grid), dim3(512), aae::wino_layer_smem_bytes<0>(), stream, p);
-    else AAE_LAUNCH((aae::conv_wino_layer_kernel<1>), dim3(grid), dim3(512), aae::wino_layer_smem_bytes<1>(), stream, p);
+    wino_layer_launch(L.wino_geom, enc->winograd_wide, grid, stream, p);
     // (the record carries the flops the kernel EXECUTES -- 49 products per 2 x 2 outputs and channel pair where the direct form
     //  multiplies 100 -- so that its TFLOP/s figure is a statement about the kernel)
     snprintf(label, sizeof(label), "%s:conv_wino_f32 layer (25 taps as 49 products per 2x2 outputs) M=%d N=%d C=%d", name, B * L.Ho * L.Wo, L.Cout, L.Cin);

@@ -26,6 +26,7 @@
 #include "kernels/conv_wavek_f32.h"
 #include "kernels/conv_igemm_x3h.h"
 #include "kernels/conv_winograd_f32.h"
+#include "aae_wino_launch.h"
 #include "kernels/conv_first_f32.h"
 #include "kernels/conv_direct_generic.h"
 #include "kernels/dense_gemv_f32.h"

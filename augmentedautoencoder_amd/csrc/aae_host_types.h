@@ -93,6 +93,7 @@ struct aae_encoder {
     int precision = 0;                     // 0: exact fp32 MFMA; 1: f32x3h split-precision igemm (explicit opt-in)
     int winograd = 1;                      // 1: conv layers behind the first one as polyphase Winograd F(2 x 2) on the fp32 matrix cores (2.04 x fewer multiplies,
                                            // results differ from the direct kernels by fp32 rounding: conv_winograd_f32.h) for batches >= winograd_min_batch
+    int winograd_wide = 0;                 // 1: blocks of 4 waves, each over both 32-channel halves (one wave per SIMD) instead of 8 waves (two per SIMD)
     int winograd_min_batch = 8;            // ... and layers whose launch has at least winograd_min_blocks blocks (64 tiles x 64 channels each): below that the
     int winograd_min_blocks = 0;           // chip is not filled and the direct kernels win (conv4 of the default net: B >= 96).  0 = three quarters of the CUs
     int first_target_blocks = 512;         // conv1 grid size aimed at (x N tiles); 2 blocks fit a CU

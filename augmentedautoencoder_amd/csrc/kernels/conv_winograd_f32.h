@@ -70,6 +70,19 @@ constexpr int wino_stage_units() { return 8 * wino_plane_units<GEOM>(); }
 template <int GEOM>
 constexpr int wino_smem_bytes() { return 2 * wino_stage_units<GEOM>() * 16; }
 
+// arguments of the one-launch-per-layer kernel (below) and its LDS budget: 16-channel stages + a 64 KB exchange buffer of its own
+struct ConvWinoLayerArgs {
+    ConvWinoArgs c;          // (U, eh, ew, mode unused)
+    const float* U4[4];      // index 2 eh + ew
+};
+template <int GEOM>
+constexpr int wino_layer_stage_bytes() { return 2 * 4 * wino_plane_units<GEOM>() * 16; }
+template <int GEOM>
+constexpr int wino_layer_smem_bytes() { return wino_layer_stage_bytes<GEOM>() + 4 * 64 * 64 * 4; }
+
+
+#ifndef AAE_WINO_DECLARATIONS_ONLY      // (the product library compiles the kernels below in a translation unit of their own: aae_wino.hip)
+
 // packed fp32 add / subtract: two values per instruction and lane (the transforms are vector work beside the MFMA stream)
 #if defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ f32x2 wino_pk_add(f32x2 a, f32x2 b) {
@@ -144,7 +157,9 @@ __device__ __forceinline__ void wino_tile(int mh, int t, int& ti, int& ty, int& 
 // 64 tiles x 4 pixels x 64 channels in the exchange buffer `xch_all` ([wave pair mh + 2 nh][register r * 4 + pixel k][lane] floats,
 // pixel k = 2 iA + iB): stored when !ACCUMULATE, added to what is there otherwise.  Ends behind a block barrier.
 // TA / TB: taps along the split dimension A / the other dimension B (3 | 2).  SWAP: A = columns.  STAGE_CH: input channels per LDS stage.
-template <int TA, int TB, bool SWAP, int GEOM, int STAGE_CH, bool ACCUMULATE>
+// WIDE: block = 4 waves (mh, ph), each over BOTH 32-channel halves (twice the MFMAs per patch read, transform and barrier; 256 accumulator
+// registers: one wave per SIMD).  Otherwise 8 waves (mh, nh, ph), one 32-channel half each, two waves per SIMD.
+template <int TA, int TB, bool SWAP, int GEOM, int STAGE_CH, bool ACCUMULATE, bool WIDE>
 __device__ __forceinline__ void wino_phase_body(const ConvWinoArgs& a, const float* U, int eh, int ew, const WinoBlock& wb, f32x4* lds, float* xch_all) {
     using G = WinoGeom<GEOM>;
     constexpr int PB = TB + 1;                                  // points (= patch positions) along B
@@ -153,10 +168,11 @@ __device__ __forceinline__ void wino_phase_body(const ConvWinoArgs& a, const flo
     constexpr int kParity = G::kRows * G::kRowPitch;            // units between the two column-parity halves of an image
     constexpr int kStageQuads = G::kImages * G::kRows * G::kCols * kQuads;
     constexpr int kParts = kGroups / 2;                         // the fill of the next stage happens in this many parts (load at an even group, store at the next)
-    constexpr int kPer = ((kStageQuads + 511) / 512 + kParts - 1) / kParts;         // float4 per thread and part
+    constexpr int NT = WIDE ? 256 : 512, NH = WIDE ? 2 : 1;                         // threads of the block, 32-channel halves per wave
+    constexpr int kPer = ((kStageQuads + NT - 1) / NT + kParts - 1) / kParts;       // float4 per thread and part
     constexpr int kOffA = TA == 2 ? 1 : 0, kOffB = TB == 2 ? 1 : 0;   // a 2-tap dimension starts one sample into the window
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int mh = wave & 1, nh = (wave >> 1) & 1, ph = wave >> 2, m = lane & 31, h = lane >> 5;
+    const int mh = wave & 1, nh = WIDE ? 0 : (wave >> 1) & 1, ph = WIDE ? wave >> 1 : wave >> 2, m = lane & 31, h = lane >> 5;
     const int img0 = wb.img0, wy0 = wb.wy0, wx0 = wb.wx0;
     int li, lty, ltx;
     wino_tile<GEOM>(mh, m, li, lty, ltx);
@@ -170,11 +186,13 @@ __device__ __forceinline__ void wino_phase_body(const ConvWinoArgs& a, const flo
     const uint32_t ulane = (uint32_t)(((size_t)n32 * KG * NP + (size_t)ph * 2 * PB) * 64 + h * 32 + m) * 16u;
     const bool two_rows = TA == 3 || ph == 0;                   // point rows of A this wave owns: 2, or 1 (the third row of F(2, 2))
 
-    f32x16 acc[2 * PB];
+    f32x16 acc[NH][2 * PB];
 #pragma unroll
-    for (int p = 0; p < 2 * PB; ++p)
+    for (int n2 = 0; n2 < NH; ++n2)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[p][r] = 0.f;
+        for (int p = 0; p < 2 * PB; ++p)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[n2][p][r] = 0.f;
 
     // ---- stage fill in parts, so that few staging registers are live at a time (the buffer of the next stage is free for the whole
     //      of the current one: the barrier behind the previous stage).  A thread's source offsets and LDS slots are the same in every stage.
@@ -183,7 +201,7 @@ __device__ __forceinline__ void wino_phase_body(const ConvWinoArgs& a, const flo
     int lslot[kParts * kPer];
 #pragma unroll
     for (int i = 0; i < kParts * kPer; ++i) {
-        const int idx = tid + 512 * i;
+        const int idx = tid + NT * i;
         goff[i] = kOutside;
         lslot[i] = -1;
         if (idx < kStageQuads) {
@@ -219,10 +237,13 @@ __device__ __forceinline__ void wino_phase_body(const ConvWinoArgs& a, const flo
     const int offA0 = fA(posA0), offA1 = fA(posA1), offA2 = fA(posA2);
     const float sg = ph == 0 ? 1.f : -1.f;
 
-    f32x4 u[2 * PB];
+    const uint32_t half_stride = (uint32_t)KG * NP * 1024u;      // the next 32-column block of the packed weights lies KG * NP KB on
+    f32x4 u[NH][2 * PB];
 #pragma unroll
-    for (int p = 0; p < 2 * PB; ++p)
-        if (two_rows || p < PB) u[p] = buffer_load4(urs, ulane + p * 1024u);
+    for (int n2 = 0; n2 < NH; ++n2)
+#pragma unroll
+        for (int p = 0; p < 2 * PB; ++p)
+            if (two_rows || p < PB) u[n2][p] = buffer_load4_s(urs, ulane + p * 1024u, n2 * half_stride);
 #pragma unroll
     for (int part = 0; part < kParts; ++part) {
         stage_load(0, part);
@@ -283,10 +304,10 @@ __device__ __forceinline__ void wino_phase_body(const ConvWinoArgs& a, const flo
                 sched_fence();
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    if (WINO_PRIO) wave_priority<1>();
 #pragma unroll
-                    for (int j = 0; j < PB; ++j) acc[i * PB + j] = mfma_32x32x2(v[j][q], u[i * PB + j][q], acc[i * PB + j]);
-                    if (WINO_PRIO) wave_priority<0>();
+                    for (int j = 0; j < PB; ++j)
+#pragma unroll
+                        for (int n2 = 0; n2 < NH; ++n2) acc[n2][i * PB + j] = mfma_32x32x2(v[j][q], u[n2][i * PB + j][q], acc[n2][i * PB + j]);
                     sched_fence();
                     if (t + 1 < NU) {
                         if (q == 1) step_a((t + 1) % ROWS, raw, vn);
@@ -298,7 +319,9 @@ __device__ __forceinline__ void wino_phase_body(const ConvWinoArgs& a, const flo
                 if (gi + 1 < kGroups * nst) {
                     const uint32_t un = (uint32_t)(gi + 1) * (NP * 1024u) + i * PB * 1024u;        // (wave-uniform: a scalar register)
 #pragma unroll
-                    for (int j = 0; j < PB; ++j) u[i * PB + j] = buffer_load4_s(urs, ulane + j * 1024u, un);
+                    for (int n2 = 0; n2 < NH; ++n2)
+#pragma unroll
+                        for (int j = 0; j < PB; ++j) u[n2][i * PB + j] = buffer_load4_s(urs, ulane + j * 1024u, un + n2 * half_stride);
                 }
                 if (more && i == ROWS - 1 && (g & 1) == 1) stage_store(buf ^ 1, g >> 1);
                 if (t + 1 < NU) {
@@ -316,12 +339,11 @@ __device__ __forceinline__ void wino_phase_body(const ConvWinoArgs& a, const flo
     //        ph 0: q0 = m0 + m1, q1 = m1        ph 1, F(2, 3): q0 = m2, q1 = -m2 - m3        ph 1, F(2, 2): q0 = 0, q1 = -m2
     //      each wave applies A along B to its part and adds its four partial outputs per accumulator register into the exchange
     //      buffer, the upper half first (it STORES when the buffer holds nothing yet), the lower half behind a barrier.
-    float* xch = xch_all + (size_t)(wave & 3) * 64 * 64;
-    auto partial = [&](int r, float (&y)[4]) {
+    auto partial = [&](int n2, int r, float (&y)[4]) {
         float q0[PB], q1[PB];
 #pragma unroll
         for (int j = 0; j < PB; ++j) {
-            const float mA = acc[j][r], mB = acc[PB + j][r];
+            const float mA = acc[n2][j][r], mB = acc[n2][PB + j][r];
             if (ph == 0) { q0[j] = mA + mB; q1[j] = mB; }
             else if (TA == 3) { q0[j] = mA; q1[j] = -mA - mB; }
             else { q0[j] = 0.f; q1[j] = -mA; }
@@ -346,24 +368,32 @@ __device__ __forceinline__ void wino_phase_body(const ConvWinoArgs& a, const flo
     };
     if (ph == 1) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float y[4];
-            partial(r, y);
+        for (int n2 = 0; n2 < NH; ++n2) {
+            float* xch = xch_all + (size_t)(mh + 2 * (nh + n2)) * 64 * 64;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                if (ACCUMULATE) xch[(r * 4 + k) * 64 + lane] += y[k];
-                else xch[(r * 4 + k) * 64 + lane] = y[k];
+            for (int r = 0; r < 16; ++r) {
+                float y[4];
+                partial(n2, r, y);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (ACCUMULATE) xch[(r * 4 + k) * 64 + lane] += y[k];
+                    else xch[(r * 4 + k) * 64 + lane] = y[k];
+                }
             }
         }
     }
     __syncthreads();
     if (ph == 0) {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            float y[4];
-            partial(r, y);
+        for (int n2 = 0; n2 < NH; ++n2) {
+            float* xch = xch_all + (size_t)(mh + 2 * (nh + n2)) * 64 * 64;
 #pragma unroll
-            for (int k = 0; k < 4; ++k) xch[(r * 4 + k) * 64 + lane] += y[k];
+            for (int r = 0; r < 16; ++r) {
+                float y[4];
+                partial(n2, r, y);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) xch[(r * 4 + k) * 64 + lane] += y[k];
+            }
         }
     }
     __syncthreads();
@@ -372,14 +402,15 @@ __device__ __forceinline__ void wino_phase_body(const ConvWinoArgs& a, const flo
 // The block's 64 tiles x 4 pixels x 64 channels leave the exchange buffer as float4 per thread (eight each, all loads of the accumulating
 // modes in flight together): value (tile t, pixel k = 2 dy + dx, channel c) sits at pair (t / 32, c / 32), register
 // r = (t & 3) + 4 ((t & 31) / 8), lane 32 ((t / 4) & 1) + c % 32.
-template <int GEOM>
+template <int GEOM, int NT>
 __device__ __forceinline__ void wino_store_block(const ConvWinoArgs& a, int mode, const WinoBlock& wb, const float* xall) {
     const int tid = threadIdx.x;
+    for (int round = 0; round < 512 / NT; ++round) {
     f32x4 val[8];
     float* optr[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const int idx = tid + 512 * i, cq = idx & 15, pix = idx >> 4, t = pix >> 2, k = pix & 3;
+        const int idx = tid + NT * (i + 8 * round), cq = idx & 15, pix = idx >> 4, t = pix >> 2, k = pix & 3;
         const int tmh = t >> 5, mt = t & 31, tnh = cq >> 3;
         const int r = (mt & 3) + 4 * (mt >> 3), hh = (mt >> 2) & 1;
         val[i] = *reinterpret_cast<const f32x4*>(xall + (size_t)(tmh + 2 * tnh) * 64 * 64 + (r * 4 + k) * 64 + 32 * hh + (cq & 7) * 4);
@@ -419,6 +450,7 @@ __device__ __forceinline__ void wino_store_block(const ConvWinoArgs& a, int mode
 #pragma unroll
     for (int i = 0; i < 8; ++i)
         if (optr[i]) *reinterpret_cast<f32x4*>(optr[i]) = val[i];
+    }
 }
 
 #ifdef AAE_EXPERIMENTS
@@ -428,35 +460,28 @@ template <int TA, int TB, bool SWAP, int GEOM>
 __global__ __launch_bounds__(512) void conv_wino_phase_kernel(ConvWinoArgs a) {
     AAE_DYN_SMEM(smem_raw);
     const WinoBlock wb = wino_block<GEOM>(blockIdx.x, a.Cout / 64, a.blocks_x, a.blocks_y);
-    wino_phase_body<TA, TB, SWAP, GEOM, 32, false>(a, a.U, a.eh, a.ew, wb, reinterpret_cast<f32x4*>(smem_raw), reinterpret_cast<float*>(smem_raw));
-    wino_store_block<GEOM>(a, a.mode, wb, reinterpret_cast<const float*>(smem_raw));
+    wino_phase_body<TA, TB, SWAP, GEOM, 32, false, false>(a, a.U, a.eh, a.ew, wb, reinterpret_cast<f32x4*>(smem_raw), reinterpret_cast<float*>(smem_raw));
+    wino_store_block<GEOM, 512>(a, a.mode, wb, reinterpret_cast<const float*>(smem_raw));
 }
 #endif
 
 // ---- one launch per LAYER: the four phases one behind the other in the block (3 x 3, 3 x 2, 2 x 3, 2 x 2 taps), their outputs added
 //      up in an exchange buffer of its own (64 KB behind the stage buffers, which shrink to 16-channel stages to make room); the
 //      output is written once, with bias / ReLU / BN.  No read-modify-write of the output tensor, one prologue / epilogue per four phases.
-struct ConvWinoLayerArgs {
-    ConvWinoArgs c;          // (U, eh, ew, mode unused)
-    const float* U4[4];      // index 2 eh + ew
-};
-template <int GEOM>
-constexpr int wino_layer_stage_bytes() { return 2 * 4 * wino_plane_units<GEOM>() * 16; }
-template <int GEOM>
-constexpr int wino_layer_smem_bytes() { return wino_layer_stage_bytes<GEOM>() + 4 * 64 * 64 * 4; }
-
-template <int GEOM>
-__global__ __launch_bounds__(512) void conv_wino_layer_kernel(ConvWinoLayerArgs p) {
+template <int GEOM, bool WIDE>
+__global__ __launch_bounds__(WIDE ? 256 : 512) void conv_wino_layer_kernel(ConvWinoLayerArgs p) {
     AAE_DYN_SMEM(smem_raw);
     const ConvWinoArgs& a = p.c;
     const WinoBlock wb = wino_block<GEOM>(blockIdx.x, a.Cout / 64, a.blocks_x, a.blocks_y);
     f32x4* lds = reinterpret_cast<f32x4*>(smem_raw);
     float* xch = reinterpret_cast<float*>(smem_raw + wino_layer_stage_bytes<GEOM>());
-    wino_phase_body<3, 3, false, GEOM, 16, false>(a, p.U4[3], 1, 1, wb, lds, xch);
-    wino_phase_body<3, 2, false, GEOM, 16, true>(a, p.U4[2], 1, 0, wb, lds, xch);
-    wino_phase_body<3, 2, true, GEOM, 16, true>(a, p.U4[1], 0, 1, wb, lds, xch);
-    wino_phase_body<2, 2, false, GEOM, 16, true>(a, p.U4[0], 0, 0, wb, lds, xch);
-    wino_store_block<GEOM>(a, 3, wb, xch);
+    wino_phase_body<3, 3, false, GEOM, 16, false, WIDE>(a, p.U4[3], 1, 1, wb, lds, xch);
+    wino_phase_body<3, 2, false, GEOM, 16, true, WIDE>(a, p.U4[2], 1, 0, wb, lds, xch);
+    wino_phase_body<3, 2, true, GEOM, 16, true, WIDE>(a, p.U4[1], 0, 1, wb, lds, xch);
+    wino_phase_body<2, 2, false, GEOM, 16, true, WIDE>(a, p.U4[0], 0, 0, wb, lds, xch);
+    wino_store_block<GEOM, WIDE ? 256 : 512>(a, 3, wb, xch);
 }
+
+#endif  // AAE_WINO_DECLARATIONS_ONLY
 
 }  // namespace aae

@@ -48,23 +48,24 @@ def test_one_region_per_image_one_stage(mode):
         assert [l.split('phase ')[1][:2] for l in wino] == ['11', '10', '01', '00']
 
 
-@pytest.mark.parametrize('mode', [1, 2])
-def test_several_regions_per_image_two_stages_two_column_blocks(mode):
+@pytest.mark.parametrize('mode,wide', [(1, 0), (1, 1), (2, 0)])
+def test_several_regions_per_image_two_stages_two_column_blocks(mode, wide):
     # conv2: 64 x 64 x 64 -> 32 x 32 x 128: 2 x 2 regions per image, two 32-channel stages, two 64-column blocks
-    labels, _ = _run(EncoderConfig((128, 128, 3), [64, 128], [2, 2], 5, 64), 1, 23, mode=mode)
+    labels, _ = _run(EncoderConfig((128, 128, 3), [64, 128], [2, 2], 5, 64), 1, 23, mode=mode, options={'winograd_wide': wide})
     assert sum('conv_wino_f32' in l for l in labels) == (1 if mode == 1 else 4)
 
 
-@pytest.mark.parametrize('B,mode', [(1, 1), (5, 1), (5, 2)])
-def test_four_images_per_block_ragged_groups(B, mode):
+@pytest.mark.parametrize('B,mode,wide', [(1, 1, 0), (5, 1, 0), (5, 1, 1), (5, 2, 0)])
+def test_four_images_per_block_ragged_groups(B, mode, wide):
     # conv2: 16 x 16 x 32 -> 8 x 8 x 64: geometry 1; B = 5: the second block holds one image and three empty slots
-    labels, _ = _run(EncoderConfig((32, 32, 3), [32, 64], [2, 2], 5, 128), B, 31 + B, mode=mode)
+    labels, _ = _run(EncoderConfig((32, 32, 3), [32, 64], [2, 2], 5, 128), B, 31 + B, mode=mode, options={'winograd_wide': wide})
     assert sum('conv_wino_f32' in l for l in labels) == (1 if mode == 1 else 4)
 
 
-@pytest.mark.parametrize('mode', [1, 2])
-def test_both_geometries_in_one_network_with_batch_norm(mode):
-    labels, _ = _run(EncoderConfig((64, 64, 3), [32, 64, 64], [2, 2, 2], 5, 128, True), 3, 47, mode=mode)
+@pytest.mark.parametrize('mode,wide', [(1, 0), (1, 1), (2, 0)])
+def test_both_geometries_in_one_network_with_batch_norm(mode, wide):
+    # wide = 1: blocks of four waves, each over both 32-channel halves of the block's 64 channels
+    labels, _ = _run(EncoderConfig((64, 64, 3), [32, 64, 64], [2, 2, 2], 5, 128, True), 3, 47, mode=mode, options={'winograd_wide': wide})
     assert sum('conv_wino_f32' in l for l in labels) == (2 if mode == 1 else 8)
     assert labels[0].startswith('conv1') and 'wino' not in labels[0]
 

@@ -15,10 +15,13 @@
 int main() {
     const int B = 256;
     struct Shape { const char* name; int H, Cin, Cout, geom; } shapes[3] = {{"conv2", 64, 128, 256, 0}, {"conv3", 32, 256, 512, 0}, {"conv4", 16, 512, 512, 1}};
-    CHECK(hipFuncSetAttribute((const void*)aae::conv_wino_layer_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::wino_layer_smem_bytes<0>()));
-    CHECK(hipFuncSetAttribute((const void*)aae::conv_wino_layer_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::wino_layer_smem_bytes<1>()));
+    CHECK(hipFuncSetAttribute((const void*)aae::conv_wino_layer_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::wino_layer_smem_bytes<0>()));
+    CHECK(hipFuncSetAttribute((const void*)aae::conv_wino_layer_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::wino_layer_smem_bytes<1>()));
+    CHECK(hipFuncSetAttribute((const void*)aae::conv_wino_layer_kernel<0, true>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::wino_layer_smem_bytes<0>()));
+    CHECK(hipFuncSetAttribute((const void*)aae::conv_wino_layer_kernel<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::wino_layer_smem_bytes<1>()));
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
+    for (int wide = 0; wide < 2; ++wide) {
     double total = 0;
     for (const Shape& s : shapes) {
         const int Ho = s.H / 2;
@@ -38,8 +41,13 @@ int main() {
         for (int i = 0; i < 4; ++i) p.U4[i] = du;          // (every phase reads a prefix of the 16-point array)
         const unsigned grid = (unsigned)(s.Cout / 64) * (s.geom == 0 ? (unsigned)(p.c.blocks_x * p.c.blocks_y * B) : (unsigned)(B / 4));
         auto launch = [&]() {
-            if (s.geom == 0) hipLaunchKernelGGL(aae::conv_wino_layer_kernel<0>, dim3(grid), dim3(512), aae::wino_layer_smem_bytes<0>(), 0, p);
-            else hipLaunchKernelGGL(aae::conv_wino_layer_kernel<1>, dim3(grid), dim3(512), aae::wino_layer_smem_bytes<1>(), 0, p);
+            if (wide) {
+                if (s.geom == 0) hipLaunchKernelGGL((aae::conv_wino_layer_kernel<0, true>), dim3(grid), dim3(256), aae::wino_layer_smem_bytes<0>(), 0, p);
+                else hipLaunchKernelGGL((aae::conv_wino_layer_kernel<1, true>), dim3(grid), dim3(256), aae::wino_layer_smem_bytes<1>(), 0, p);
+            } else {
+                if (s.geom == 0) hipLaunchKernelGGL((aae::conv_wino_layer_kernel<0, false>), dim3(grid), dim3(512), aae::wino_layer_smem_bytes<0>(), 0, p);
+                else hipLaunchKernelGGL((aae::conv_wino_layer_kernel<1, false>), dim3(grid), dim3(512), aae::wino_layer_smem_bytes<1>(), 0, p);
+            }
         };
         for (int w = 0; w < 3; ++w) launch();
         CHECK(hipDeviceSynchronize());
@@ -52,11 +60,12 @@ int main() {
         CHECK(hipEventElapsedTime(&ms, e0, e1));
         ms /= reps;
         const double executed = 2.0 * B * (Ho / 2) * (Ho / 2) * 49.0 * s.Cin * s.Cout;
-        printf("{\"layer\": \"%s\", \"ms\": %.4f, \"mfma_tflops\": %.1f, \"mfma_frac_of_157\": %.3f, \"tf_equivalent\": %.1f}\n", s.name, ms, executed / (ms * 1e-3) / 1e12,
+        printf("{\"wide\": %d, \"layer\": \"%s\", \"ms\": %.4f, \"mfma_tflops\": %.1f, \"mfma_frac_of_157\": %.3f, \"tf_equivalent\": %.1f}\n", wide, s.name, ms, executed / (ms * 1e-3) / 1e12,
                executed / (ms * 1e-3) / 1e12 / 157.3, executed * 100.0 / 49.0 / (ms * 1e-3) / 1e12);
         total += ms;
         CHECK(hipFree(dx)); CHECK(hipFree(du)); CHECK(hipFree(dout)); CHECK(hipFree(dbias));
     }
-    printf("{\"conv2_to_conv4_ms\": %.4f}\n", total);
+    printf("{\"wide\": %d, \"conv2_to_conv4_ms\": %.4f}\n", wide, total);
+    }
     return 0;
 }
