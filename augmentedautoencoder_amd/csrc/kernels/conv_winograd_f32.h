@@ -57,11 +57,13 @@ template <int GEOM>
 struct WinoGeom;
 template <>
 struct WinoGeom<0> {         // one image, 8 x 8 tiles: window 18 x 18
-    static constexpr int kImages = 1, kRows = 18, kCols = 18, kRowPitch = 12, kImagePitch = 2 * 18 * 12;
+    // (parity pitch 220 instead of 18 * 12 = 216 quads: the fill writes the two column parities of neighbouring pixels from neighbouring
+    //  lanes -- 880 dwords apart they fall into different halves of the 32 banks a ds_write_b128 group uses)
+    static constexpr int kImages = 1, kRows = 18, kCols = 18, kRowPitch = 12, kParityPitch = 220, kImagePitch = 2 * 220;
 };
 template <>
 struct WinoGeom<1> {         // four images, 4 x 4 tiles each: windows 10 x 10
-    static constexpr int kImages = 4, kRows = 10, kCols = 10, kRowPitch = 6, kImagePitch = 128;
+    static constexpr int kImages = 4, kRows = 10, kCols = 10, kRowPitch = 6, kParityPitch = 60, kImagePitch = 128;
 };
 template <int GEOM>
 constexpr int wino_plane_units() { return WinoGeom<GEOM>::kImages * WinoGeom<GEOM>::kImagePitch + 1; }
@@ -165,7 +167,7 @@ __device__ __forceinline__ void wino_phase_body(const ConvWinoArgs& a, const flo
     constexpr int PB = TB + 1;                                  // points (= patch positions) along B
     constexpr int kQuads = STAGE_CH / 4, kGroups = STAGE_CH / 8;                    // channel quads / 8-channel groups per stage
     constexpr int kPlane = wino_plane_units<GEOM>(), kStage = kQuads * kPlane;
-    constexpr int kParity = G::kRows * G::kRowPitch;            // units between the two column-parity halves of an image
+    constexpr int kParity = G::kParityPitch;                    // units between the two column-parity halves of an image
     constexpr int kStageQuads = G::kImages * G::kRows * G::kCols * kQuads;
     constexpr int kParts = kGroups / 2;                         // the fill of the next stage happens in this many parts (load at an even group, store at the next)
     constexpr int NT = WIDE ? 256 : 512, NH = WIDE ? 2 : 1;                         // threads of the block, 32-channel halves per wave

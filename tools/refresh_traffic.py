@@ -34,6 +34,20 @@ for name, layer in (('conv2', 1), ('conv3', 2), ('conv4', 3)):
         b = max(busy, key=lambda v: v.get('dispatches_seen', 0))
         t.setdefault('mfma', {})[name] = {'mfma_busy_frac': round(b['SQ_VALU_MFMA_BUSY_CYCLES'] / (b['GRBM_GUI_ACTIVE'] / 8.0 * 1024.0), 4),
                                           'delivered_GHz': round(b['GRBM_GUI_ACTIVE'] / 8.0 / b['avg_ns_under_pmc'], 3)}
+# the Winograd layer kernels (the default conv2 ... conv4 from three quarters of a round of blocks on): keys 'convN/wino'; the grid tells the
+# layers of the default net apart (geometry 0: conv2 = 4096 blocks, conv3 = 2048 at B = 256; geometry 1: conv4)
+for name, kern, grid in (('conv2/wino', 'conv_wino_layer_kernel<0, false>', 4096 * 512), ('conv3/wino', 'conv_wino_layer_kernel<0, false>', 2048 * 512),
+                         ('conv4/wino', 'conv_wino_layer_kernel<1, false>', None)):
+    rows = [v for k, v in main.items() if k.startswith(kern) and (grid is None or k.endswith('grid=%d' % grid))]
+    hb = [v for v in rows if 'hbm_side_bytes' in v]
+    if hb:
+        t['f32'][name] = int(round(max(hb, key=lambda v: v.get('dispatches_seen', 0))['hbm_side_bytes'], -5))
+        changed[name] = t['f32'][name]
+    busy = [v for v in rows if 'SQ_VALU_MFMA_BUSY_CYCLES' in v and v.get('GRBM_GUI_ACTIVE', 0) > 0]
+    if busy:
+        b = max(busy, key=lambda v: v.get('dispatches_seen', 0))
+        t.setdefault('mfma', {})[name] = {'mfma_busy_frac': round(b['SQ_VALU_MFMA_BUSY_CYCLES'] / (b['GRBM_GUI_ACTIVE'] / 8.0 * 1024.0), 4),
+                                          'delivered_GHz': round(b['GRBM_GUI_ACTIVE'] / 8.0 / b['avg_ns_under_pmc'], 3)}
 # the opt-in split-precision mode is power / clock limited: what clock did the chip deliver under its dominant kernel?
 for name, kern in (('conv2', 'conv_igemm_x3h_wide_kernel<1, 1>'), ('conv3', 'conv_igemm_x3h_wide_kernel<1, 2>'), ('conv4', 'conv_igemm_x3h_dma_kernel<1, 3, 2>')):
     rows = [v for k, v in main.items() if k.startswith(kern) and 'SQ_VALU_MFMA_BUSY_CYCLES' in v and v.get('GRBM_GUI_ACTIVE', 0) > 0]
