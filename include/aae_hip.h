@@ -101,7 +101,7 @@ void aae_encoder_destroy(aae_encoder* enc);
  *                        own plan: bit-identical to aae_encode_nn.
  * Everything else the call accepts -- the planner's constants, kernel-variant switches for A/B measurements -- is listed in
  * include/aae_hip_tuning.h.  In this (product) build every accepted value gives results that are bit-identical to the defaults
- * or differ by fp32 summation order only; variants that measured slower and the profiling aids live in the experiments build
+ * or differ by fp32 rounding / summation order only; variants that measured slower and the profiling aids live in the experiments build
  * (aae_has_experiments()) and are refused here with AAE_ERR_UNSUPPORTED. */
 int aae_encoder_set_option(aae_encoder* enc, const char* name, int value);
 

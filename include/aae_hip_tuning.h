@@ -1,6 +1,6 @@
 /* aae_hip_tuning.h -- the launch-planning knobs and A/B switches of libaae_hip.so.
  *
- * Nothing here is needed to USE the library: include/aae_hip.h documents the options a caller may want ("precision",
+ * Nothing here is needed to USE the library: include/aae_hip.h documents the options a caller may want ("winograd", "precision",
  * "x3h_act_shift", "compact_workspace", "dense_gemv", "multi_group_plan") and the scan modes AAE_SCAN_AUTO /
  * AAE_SCAN_AUTO_PACKED.  This header lists everything else aae_encoder_set_option() / aae_codebook_set_scan_mode() accept --
  * the constants the planner was tuned with and the switches the A/B measurements of CHANGELOG.md were taken with -- and
@@ -44,6 +44,11 @@
  *   "first_target_blocks" (512), "first_max_tiles_per_block" (16), "first_vec4" (1), "first_group_split_max_tiles" (128): conv1 grid shaping
  *   [experiments] "igemm_dma" (1), "igemm_breg" (1), "x3h_dma" (1): 0 = the register-staged operand paths (bit-identical, slower)
  *   [experiments] "x3h_wide_min_blocks" (0): > 0 = 256 x 128 f32x3h tiles (measured neutral)
+ * polyphase Winograd conv layers (conv_winograd_f32.h; "winograd" itself: include/aae_hip.h)
+ *   "winograd_min_batch" (8), "winograd_min_blocks" (0 = three quarters of the device's compute units): a layer takes the Winograd form
+ *                        when its launch has at least this many 64-tile x 64-channel blocks (below, the wave-split-K kernels fill the chip better)
+ *   [experiments] "winograd" = 2: one launch per polyphase component, the components adding up in the output buffer (2 % slower than the
+ *                        one-launch form); "winograd_wide" (0): blocks of 4 waves over both 32-channel halves, one wave per SIMD (13 % slower)
  * small and mid batches (wave-split-K implicit GEMM, conv_wavek_f32.h; the planner: aae_encoder_plan.h)
  *   "wavek" (1), "wavek_dense" (1), "wavek_max_tiles" (512), "wavek_tiny_max_tiles" (64), "wavek_narrow_max_tiles" (128): which layers
  *                        run it and the wave-tile thresholds of the per-detection batches (B = 1, 2, 4)
