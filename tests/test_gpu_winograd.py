@@ -118,3 +118,25 @@ def test_full_query_answers_match_the_fp64_oracle():
         assert idx[i] == cs64[i].argmax() or top2[i, 1] - top2[i, 0] < 2e-5 or cs64[i, idx[i]] >= top2[i, 1] - 2e-5, i
     enc.close()
     cb.close()
+
+
+def test_hip_graph_replay_and_chunked_batches_equal_the_eager_calls():
+    """The Winograd launches inside a captured HIP graph (one replay per query batch) and in a batch that the engine cuts into chunks of
+    different sizes (each chunk planned on its own: 256 crops with all three layers in the Winograd form, 44 with conv2 and conv3)."""
+    import torch
+    from augmentedautoencoder_amd.engine import CapturedNearestNeighbour, CodebookEngine, EncoderEngine
+    from augmentedautoencoder_amd.weights import EncoderConfig
+    enc = EncoderEngine(EncoderConfig(), synth.make_weights(seed=2024), max_batch=256)
+    cb = CodebookEngine(synth.make_codebook(92232, 128, seed=7))
+    cap = CapturedNearestNeighbour(enc, cb, 96)
+    assert cap.graph is not None
+    for seed in (1, 2):
+        x = synth.make_crops(96, seed=40 + seed)
+        i0, s0 = cb.nn(enc.encode(x), 1, 1)
+        i1, s1 = cap(x)
+        assert torch.equal(i0, i1) and torch.equal(s0, s1)
+    x = synth.make_crops(300, seed=77)
+    z = enc.encode(x)
+    assert torch.equal(z[:256], enc.encode(x[:256])) and torch.equal(z[256:], enc.encode(x[256:]))
+    enc.close()
+    cb.close()
