@@ -1,5 +1,6 @@
 // 5 x 5 stride-2 'SAME' convolution (conv2 ... conv4 of /root/reference/auto_pose/ae/encoder.py:41-52) with FEWER MULTIPLIES in fp32:
-// polyphase split + Winograd F(2 x 2, r x s), transforms fused on MFMA fragments.  Opt-in (encoder option "winograd"), large batches.
+// polyphase split + Winograd F(2 x 2, r x s), transforms fused on MFMA fragments.  The default for every eligible layer whose launch fills three quarters of the chip (encoder
+// option "winograd", aae_encoder_launch.h: runs_winograd); 0 = the direct implicit-GEMM kernels.
 //
 // The arithmetic.  out[y][x] = sum_{kh,kw} in[2y + kh - 1][2x + kw - 1] w[kh][kw] splits by the parity (eh, ew) of the input row / column
 // into four stride-1 convolutions over the sub-images X_e[u][v] = in[2u + eh][2v + ew]:
@@ -23,21 +24,17 @@
 //           = at most 128 registers, two waves share a SIMD and one's patch reads, transform and weight loads run under the other's
 //           MFMAs.  The two halves of the output transform meet through LDS once per block.  A = rows, or columns when SWAP (the
 //           2 x 3-tap phase: the 3-tap dimension is the one that splits evenly).
-//   K loop = stages of 32 input channels: the block's window of the sub-image (tiles + halo, zero outside the image = the 'SAME'
+//   K loop = stages of 16 input channels (32 in the one-launch-per-phase form): the block's window of the sub-image (tiles + halo, zero outside the image = the 'SAME'
 //           padding) goes global -> registers -> LDS, double buffered, laid out [channel quad][image][column parity][row][column / 2]
-//           with pitches that make the patch reads (ds_read_b128 by 32 tiles) and the fill conflict-free.  Per 8-channel group a lane
-//           reads the patch rows its points need as float4 (4 channels of its K half), transforms them with packed fp32 adds, and
-//           issues 4 MFMAs per point against weight fragments that were loaded one group ahead into the registers the previous
-//           group's finished points released.
+//           with pitches that make the patch reads (ds_read_b128 by 32 tiles) and the fill conflict-free.  The loop runs in units of
+//           one point row: a lane reads the patch rows the row needs as float4 (4 channels of its K half), transforms them with packed
+//           fp32 adds BETWEEN the MFMAs of the previous unit, and issues 4 MFMAs per point against weight fragments that were loaded
+//           one group ahead (raw buffer views, scalar offsets) into the registers the previous group's finished row released.
 //   weights: packed [32-column block][8-channel group][point = a PB + b][K half][32 columns][4 channels] per phase (aae_encoder_plan.h).
 #pragma once
 #include <type_traits>
 
 namespace aae {
-
-#ifndef WINO_PRIO
-#define WINO_PRIO 0
-#endif
 
 struct ConvWinoArgs {
     const float* x;          // [B][H][W][Cin]  (H = 2 Ho, W = 2 Wo)
