@@ -18,7 +18,7 @@ fi
 ls -la $OUT
 # the Winograd path: per-layer timing harness, the A/B against the direct kernels over batch sizes, the fused 3 x 3-phase micro-benchmark
 timeout -s KILL 100 tools/ubench/wino_layer_time.bin > $OUT/wino_layer_time.jsonl 2>&1; echo "wino_layer_time rc=$?"
-WINO_MIN=1 timeout -s KILL 300 python tools/wino_ab.py 8 12 16 24 32 48 64 93 96 128 192 256 > $OUT/winograd_vs_direct_forced_on.jsonl 2> $OUT/wino_ab.err; echo "wino_ab forced rc=$?"
-timeout -s KILL 300 python tools/wino_ab.py 8 12 16 24 32 48 64 93 96 128 192 256 > $OUT/winograd_vs_direct_product_rule.jsonl 2>> $OUT/wino_ab.err; echo "wino_ab rule rc=$?"
+WINO_MIN=1 WINO_MIN_BLOCKS=1 timeout -s KILL 300 python tools/wino_ab.py 8 12 16 24 32 48 64 93 96 128 192 256 > $OUT/winograd_vs_direct_every_layer_forced.jsonl 2> $OUT/wino_ab.err; echo "wino_ab forced rc=$?"
+timeout -s KILL 300 python tools/wino_ab.py 8 12 16 24 32 48 64 93 96 128 192 256 > $OUT/winograd_vs_direct_by_batch.jsonl 2>> $OUT/wino_ab.err; echo "wino_ab rule rc=$?"
 WF_ABLATE=1 timeout -s KILL 100 tools/ubench/polyphase_winograd.bin > $OUT/polyphase_winograd_ubench.jsonl 2>&1; echo "ubench rc=$?"
 ls -la $OUT

@@ -25,12 +25,15 @@ def main():
     direct.set_option('winograd', 0)
     wino = EncoderEngine(cfg, w, max_batch=max(batches))
     wino.set_option('winograd', int(os.environ.get('WINO_MODE', '1')))
-    wino.set_option('winograd_min_batch', int(os.environ.get('WINO_MIN', '64')))
+    if os.environ.get('WINO_MIN'):          # (default: the product rule -- a layer from three quarters of a round of blocks on, never below B = 8)
+        wino.set_option('winograd_min_batch', int(os.environ['WINO_MIN']))
+    if os.environ.get('WINO_MIN_BLOCKS'):
+        wino.set_option('winograd_min_blocks', int(os.environ['WINO_MIN_BLOCKS']))
     for B in batches:
         x = torch.from_numpy(synth.make_crops(B, seed=7)).cuda()
         out = {'what': 'winograd_vs_direct', 'B': B}
         for name, enc in (('direct', direct), ('winograd', wino)):
-            for _ in range(3):
+            for _ in range(5):
                 enc.encode(x)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
