@@ -309,6 +309,8 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
         enc->winograd_wide = value ? 1 : 0;
     } else if (!strcmp(name, "winograd_min_batch")) {
         enc->winograd_min_batch = value < 1 ? 1 : value;
+    } else if (!strcmp(name, "winograd_min_fill_pct")) {
+        enc->winograd_min_fill_pct = value < 1 ? 1 : (value > 100 ? 100 : value);
     } else if (!strcmp(name, "winograd_min_blocks")) {
         enc->winograd_min_blocks = value < 0 ? 0 : value;
     } else if (!strcmp(name, "precision")) {

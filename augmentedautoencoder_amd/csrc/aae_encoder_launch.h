@@ -592,11 +592,14 @@ static bool runs_winograd(const aae_encoder* enc, const Layer& L, int B) {
     // (the kernel reads the input through a 32-bit buffer view whose upper half marks "outside the image": activations below 2 GiB)
     const unsigned long long x_bytes = (unsigned long long)B * L.H * L.W * L.Cin * sizeof(float);
     if (x_bytes >= 0x7FFFFF00ull) return false;
-    // measured on MI355X (tools/wino_ab.py): a layer gains from about three quarters of a round of blocks on (conv2 of the default net
-    // from B = 12, conv3 from 24, conv4 -- four images per block -- from 96); below that the wave-split-K kernels fill the chip better
+    // A launch costs WHOLE rounds of blocks (one block per compute unit at a time: 121-131 KB of LDS), and a block-slot of the Winograd form
+    // costs 0.6-0.7 of what the direct kernels need for the same outputs (tools/wino_ab.py, profiles/r14/winograd_vs_direct_*.jsonl): a layer
+    // gains when its blocks fill at least winograd_min_fill_pct (68) per cent of the rounds they occupy -- default net: conv2 from B = 11,
+    // conv3 from 22, conv4 (four images per block) from 85, and e.g. not conv3 at B = 33 ... 43 (a second round for a few blocks)
     const long long blocks = (long long)(L.Cout / 64) * (L.wino_geom == 0 ? (long long)(L.Ho / 16) * (L.Wo / 16) * B : (long long)ceil_div(B, 4));
-    const int min_blocks = enc->winograd_min_blocks > 0 ? enc->winograd_min_blocks : 3 * wavek_round_blocks(enc) / 4;
-    return blocks >= min_blocks;
+    if (enc->winograd_min_blocks > 0) return blocks >= enc->winograd_min_blocks;
+    const long long cus = wavek_round_blocks(enc), rounds = (blocks + cus - 1) / cus;
+    return 100 * blocks >= (long long)enc->winograd_min_fill_pct * rounds * cus;
 }
 
 static int forward_impl(aae_encoder* enc, const void* x, int x_dtype, int B, float* z_out, void* workspace,

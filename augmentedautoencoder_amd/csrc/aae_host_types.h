@@ -94,8 +94,9 @@ struct aae_encoder {
     int winograd = 1;                      // 1: conv layers behind the first one as polyphase Winograd F(2 x 2) on the fp32 matrix cores (2.04 x fewer multiplies,
                                            // results differ from the direct kernels by fp32 rounding: conv_winograd_f32.h) for batches >= winograd_min_batch
     int winograd_wide = 0;                 // 1: blocks of 4 waves, each over both 32-channel halves (one wave per SIMD) instead of 8 waves (two per SIMD)
-    int winograd_min_batch = 8;            // ... and layers whose launch has at least winograd_min_blocks blocks (64 tiles x 64 channels each): below that the
-    int winograd_min_blocks = 0;           // chip is not filled and the direct kernels win (conv4 of the default net: B >= 96).  0 = three quarters of the CUs
+    int winograd_min_batch = 8;            // ... and layers whose blocks (64 tiles x 64 channels each) fill at least winograd_min_fill_pct per cent of the
+    int winograd_min_fill_pct = 68;        // rounds of blocks they occupy (runs_winograd); winograd_min_blocks > 0 replaces that rule by a plain
+    int winograd_min_blocks = 0;           // block count (tests, A/B)
     int first_target_blocks = 512;         // conv1 grid size aimed at (x N tiles); 2 blocks fit a CU
     int first_group_split_max_tiles = 128; // conv1: batches of at most this many 128-pixel tiles (B <= 4 of the default net) run one block per 32-pixel group
     int first_vec4 = 1;                    // conv1: stage uint8 rows as aligned dwords when W*C % 4 == 0

@@ -1,5 +1,5 @@
 // 5 x 5 stride-2 'SAME' convolution (conv2 ... conv4 of /root/reference/auto_pose/ae/encoder.py:41-52) with FEWER MULTIPLIES in fp32:
-// polyphase split + Winograd F(2 x 2, r x s), transforms fused on MFMA fragments.  The default for every eligible layer whose launch fills three quarters of the chip (encoder
+// polyphase split + Winograd F(2 x 2, r x s), transforms fused on MFMA fragments.  The default for every eligible layer whose blocks fill the rounds of blocks they occupy (encoder
 // option "winograd", aae_encoder_launch.h: runs_winograd); 0 = the direct implicit-GEMM kernels.
 //
 // The arithmetic.  out[y][x] = sum_{kh,kw} in[2y + kh - 1][2x + kw - 1] w[kh][kw] splits by the parity (eh, ew) of the input row / column

@@ -25,7 +25,7 @@ def test_layers_and_latent_against_the_fp64_oracle_and_the_direct_kernels(B):
     enc = EncoderEngine(EncoderConfig(), weights, max_batch=B)
     z, recs = enc.encode_timed(crops)
     labels = [l for l, _, _ in recs]
-    assert sum('conv_wino_f32 layer' in l for l in labels) == (3 if B >= 93 else 2 if B >= 24 else 1), labels      # conv2, from B = 24 conv3, from 93 conv4: one launch each
+    assert sum('conv_wino_f32 layer' in l for l in labels) == {12: 1, 24: 2, 48: 2, 64: 2, 67: 2, 96: 3, 130: 2, 256: 3}[B], labels      # (runs_winograd: by round fill)
     acts_w = [enc.activation(i).cpu().numpy() for i in range(4)]
     z_w = z.cpu().numpy()
     enc.set_option('winograd', 0)
@@ -42,13 +42,15 @@ def test_layers_and_latent_against_the_fp64_oracle_and_the_direct_kernels(B):
     enc.close()
 
 
-def test_layers_take_the_winograd_form_from_three_quarters_of_a_round_of_blocks():
+def test_layers_take_the_winograd_form_where_their_blocks_fill_the_rounds_they_occupy():
     """blocks of a launch = 64-channel blocks x (16 x 16-pixel regions x B | groups of four 8 x 8 images): conv2 16 B, conv3 8 B, conv4 8 ceil(B / 4);
-    the rule (aae_encoder_launch.h: runs_winograd) takes a layer from 192 blocks on, never below winograd_min_batch = 8."""
+    a launch costs whole rounds of 256 blocks: the rule (aae_encoder_launch.h: runs_winograd) takes a layer when its blocks fill >= 68 % of
+    their rounds, never below winograd_min_batch = 8."""
     from augmentedautoencoder_amd.engine import EncoderEngine
     from augmentedautoencoder_amd.weights import EncoderConfig
     enc = EncoderEngine(EncoderConfig(), synth.make_weights(seed=5), max_batch=96)
-    for B, want in ((4, []), (11, []), (12, ['conv2']), (23, ['conv2']), (24, ['conv2', 'conv3']), (92, ['conv2', 'conv3']), (93, ['conv2', 'conv3', 'conv4'])):
+    for B, want in ((4, []), (10, []), (11, ['conv2']), (17, []), (21, []), (22, ['conv2', 'conv3']), (40, ['conv2']), (84, ['conv2', 'conv3']),
+                    (85, ['conv2', 'conv3', 'conv4'])):
         labels = [l for l, _, _ in enc.encode_timed(synth.make_crops(B, seed=B))[1]]
         assert [l.split(':')[0] for l in labels if 'wino' in l] == want, (B, labels)
     enc.set_option('winograd_min_blocks', 64)
@@ -122,7 +124,7 @@ def test_full_query_answers_match_the_fp64_oracle():
 
 def test_hip_graph_replay_and_chunked_batches_equal_the_eager_calls():
     """The Winograd launches inside a captured HIP graph (one replay per query batch) and in a batch that the engine cuts into chunks of
-    different sizes (each chunk planned on its own: 256 crops with all three layers in the Winograd form, 44 with conv2 and conv3)."""
+    different sizes (each chunk planned on its own: 256 crops with all three layers in the Winograd form, 44 with conv2 only)."""
     import torch
     from augmentedautoencoder_amd.engine import CapturedNearestNeighbour, CodebookEngine, EncoderEngine
     from augmentedautoencoder_amd.weights import EncoderConfig
