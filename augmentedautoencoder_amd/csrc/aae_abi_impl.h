@@ -313,6 +313,9 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
         enc->winograd_min_fill_pct = value < 1 ? 1 : (value > 100 ? 100 : value);
     } else if (!strcmp(name, "winograd_min_blocks")) {
         enc->winograd_min_blocks = value < 0 ? 0 : value;
+    } else if (!strcmp(name, "winograd_xcd_cols")) {
+        if (value < -1 || value > 8) return fail(AAE_ERR_INVALID, "winograd_xcd_cols %d: -1 = per-layer default, 0 = plain block order, 1 ... 8 = column blocks of a region per XCD", value);
+        enc->winograd_xcd_cols = value;
     } else if (!strcmp(name, "precision")) {
         if (value < 0 || value > 2) return fail(AAE_ERR_INVALID, "precision %d: 0 = fp32, 1 = f32x3h, 2 = f32x3h where it is faster", value);
         if (value != 0) {

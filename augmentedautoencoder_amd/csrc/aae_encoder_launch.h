@@ -544,6 +544,16 @@ static void launch_wino_phase(const aae::ConvWinoArgs& a, int eh, int ew, unsign
 }
 #endif
 
+// 64-column blocks of a region per XCD (conv_winograd_f32.h: wino_block).  Option winograd_xcd_cols: -1 = the measured default per layer,
+// 0 = plain block order, S > 0 = S where the layer's column-block count allows it.
+static int wino_xcd_cols(const aae_encoder* enc, const Layer& L) {
+    const int nbn = L.Cout / 64;
+    int s = enc->winograd_xcd_cols;
+    if (s < 0) s = nbn >= 8 ? 4 : nbn;
+    while (s > 0 && !aae::wino_xcd_cols_valid(nbn, s)) s >>= 1;
+    return s;
+}
+
 static int launch_winograd(aae_encoder* enc, const Layer& L, const float* x, int B, float* out, hipStream_t stream, Timer& tm, const char* name) {
     aae::ConvWinoArgs a;
     a.x = x; a.U = nullptr; a.bias = L.bias; a.bn_scale = L.bn_scale; a.bn_shift = L.bn_shift; a.out = out;
@@ -551,7 +561,9 @@ static int launch_winograd(aae_encoder* enc, const Layer& L, const float* x, int
     a.eh = a.ew = 0; a.mode = 0;
     a.blocks_x = L.wino_geom == 0 ? L.Wo / 16 : 1;
     a.blocks_y = L.wino_geom == 0 ? L.Ho / 16 : 1;
-    const unsigned grid = (unsigned)(L.Cout / 64) * (L.wino_geom == 0 ? (unsigned)(a.blocks_x * a.blocks_y * B) : (unsigned)ceil_div(B, 4));
+    a.regions = L.wino_geom == 0 ? a.blocks_x * a.blocks_y * B : ceil_div(B, 4);
+    a.xcd_cols = wino_xcd_cols(enc, L);
+    const unsigned grid = aae::wino_grid_blocks(a.regions, L.Cout / 64, a.xcd_cols);
     const double tiles = (double)B * (L.Ho / 2) * (L.Wo / 2);
     char label[128];
 #ifdef AAE_EXPERIMENTS

@@ -80,3 +80,18 @@ def test_min_batch_and_ineligible_layers_keep_the_direct_kernels():
     with pytest.raises(Exception):
         enc.set_option('winograd', 1)
     enc.close()
+
+
+@pytest.mark.parametrize('xcd_cols', [-1, 0, 1, 2])
+def test_block_to_xcd_mappings_cover_every_region_and_column_block(xcd_cols):
+    # conv2: 64 x 64 x 64 -> 32 x 32 x 128 at B = 3: 12 regions x 2 column blocks.  xcd_cols = 1: 2 column groups x 4 region groups (the grid
+    # is padded to 8 * 1 * 3 = 24 blocks), 2 (= the default for two column blocks): 1 x 8 (8 * 2 * 2 = 32 blocks, eight of them leave at once)
+    labels, _ = _run(EncoderConfig((128, 128, 3), [64, 128], [2, 2], 5, 64), 3, 61, options={'winograd_xcd_cols': xcd_cols})
+    assert sum('conv_wino_f32' in l for l in labels) == 1
+
+
+@pytest.mark.parametrize('xcd_cols', [0, 1])
+def test_block_to_xcd_mapping_with_four_images_per_block(xcd_cols):
+    # conv2: 16 x 16 x 32 -> 8 x 8 x 64 at B = 21: 6 regions (the last one ragged) x 1 column block over 8 region groups
+    labels, _ = _run(EncoderConfig((32, 32, 3), [32, 64], [2, 2], 5, 128), 21, 67, options={'winograd_xcd_cols': xcd_cols})
+    assert sum('conv_wino_f32' in l for l in labels) == 1
