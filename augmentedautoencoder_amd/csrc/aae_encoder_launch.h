@@ -614,9 +614,12 @@ static bool runs_winograd(const aae_encoder* enc, const Layer& L, int B) {
     return 100 * blocks >= (long long)enc->winograd_min_fill_pct * rounds * cus;
 }
 
+// layer_begin / layer_end: run only the layers [layer_begin, layer_end) of the chain -- conv layers 0 ... nl - 1, the dense layer = nl; x is
+// then the INPUT of layer layer_begin (fp32 activation when layer_begin > 0) and the workspace the one of a whole forward (the grouped
+// mid-batch query runs conv1 and the dense layer per object around its one-launch-per-layer Winograd convolutions: aae_multi_impl.h).
 static int forward_impl(aae_encoder* enc, const void* x, int x_dtype, int B, float* z_out, void* workspace,
                         size_t ws_bytes, void* stream_v, Timer& tm, const ExtraTicketPrep* extra = nullptr, bool* extra_prepared = nullptr,
-                        bool* scan_done = nullptr) {
+                        bool* scan_done = nullptr, int layer_begin = 0, int layer_end = -1) {
     if (extra_prepared) *extra_prepared = false;
     if (scan_done) *scan_done = false;
     if (!enc || !x || !z_out) return fail(AAE_ERR_INVALID, "aae_encoder_forward: null argument");
@@ -639,6 +642,10 @@ static int forward_impl(aae_encoder* enc, const void* x, int x_dtype, int B, flo
     const void* cur = x;
     bool cur_u8 = (x_dtype == AAE_DTYPE_U8);
     t_x3h_last_slot = -1;
+    const bool ranged = layer_begin != 0 || layer_end >= 0;
+    if (layer_end < 0) layer_end = (int)enc->layers.size() + 1;
+    if (ranged && (layer_begin < 0 || layer_begin >= layer_end || layer_end > (int)enc->layers.size() + 1 || runs_split(enc, B) || (layer_begin > 0 && cur_u8)))
+        return fail(AAE_ERR_INVALID, "aae_encoder_forward: layer range [%d, %d) of a %zu-layer encoder", layer_begin, layer_end, enc->layers.size() + 1);
     if (runs_split(enc, B)) {
         // this forward's range flag: a ring slot, or -- while the stream is being captured into a graph -- a slot of its own
         hipStreamCaptureStatus capture = hipStreamCaptureStatusNone;
@@ -716,7 +723,7 @@ static int forward_impl(aae_encoder* enc, const void* x, int x_dtype, int B, flo
     // (nonce, 0) -- also when a captured graph replays the launch with the SAME nonce.  The first kernel resets them with the
     // other ticket words; where it cannot, a memset in front of the launch does.
 #ifdef AAE_EXPERIMENTS
-    const bool chain = chain_eligible(enc, B, plans, gemv_ticket);
+    const bool chain = !ranged && chain_eligible(enc, B, plans, gemv_ticket);
     unsigned long long* barrier_words = tickets + (kConvTicketBytes + kGemvTicketBytes) / 8;
     const unsigned barrier_nonce = chain ? next_nonce() : 0u;
     const bool barrier_listed = chain && add_prep(barrier_words, aae::kGridBarrierWords, barrier_nonce);
@@ -745,7 +752,7 @@ static int forward_impl(aae_encoder* enc, const void* x, int x_dtype, int B, flo
     }
 #endif
 
-    for (size_t li = 0; li < nl; ++li) {
+    for (size_t li = (size_t)layer_begin; li < nl && (int)li < layer_end; ++li) {
         const Layer& L = enc->layers[li];
         float* out = reinterpret_cast<float*>(base + ws.act_off[li]);
         char name[16];
@@ -763,6 +770,7 @@ static int forward_impl(aae_encoder* enc, const void* x, int x_dtype, int B, flo
         cur = out;
         cur_u8 = false;
     }
+    if (layer_end <= (int)nl) return AAE_OK;
     if (dense_gemv)
         return launch_dense_gemv(enc, D, static_cast<const float*>(cur), B, z_out, partial, gemv_ticket ? gemv_tickets : nullptr, gemv_nonce, stream, tm);
     if (plans[nl].use)

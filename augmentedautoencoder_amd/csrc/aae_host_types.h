@@ -97,6 +97,8 @@ struct aae_encoder {
     int winograd_min_batch = 8;            // ... and layers whose blocks (64 tiles x 64 channels each) fill at least winograd_min_fill_pct per cent of the
     int winograd_min_fill_pct = 68;        // rounds of blocks they occupy (runs_winograd); winograd_min_blocks > 0 replaces that rule by a plain
     int winograd_min_blocks = 0;           // block count (tests, A/B)
+    int multi_mid_group = 1;               // grouped multi-object query: objects with 5 or more detections each share ONE Winograd launch per conv layer where the GROUP's blocks fill
+                                           // the rounds they occupy (aae_multi_impl.h); 0 = such objects one after the other
     int winograd_xcd_cols = -1;            // column blocks of a region that share an XCD (aae_encoder_launch.h: wino_xcd_cols); -1 = per-layer default
     int first_target_blocks = 512;         // conv1 grid size aimed at (x N tiles); 2 blocks fit a CU
     int first_group_split_max_tiles = 128; // conv1: batches of at most this many 128-pixel tiles (B <= 4 of the default net) run one block per 32-pixel group

@@ -10,14 +10,23 @@
 // i.e. n <= 4 of the reference network at the default options.  Items of one group share the batch n and the network shape
 // (so that one kernel instantiation serves all of them); each keeps ITS launch plan -- tiles, K splits, tail cut -- and gets
 // its own slice of the workspace (activations, partials, ticket words), so the answers are the per-object calls' bit for bit.
-// Everything else (larger n, bf16 codebooks, split precision, other networks or options) is answered by the per-object
-// path inside the same call, one item after the other in a shared slice.
+// Mid batches (5 or more detections per object; the reference's one-AAE-per-class frame at B = 256 over 8 objects holds ~32 each,
+// SURVEY section 8d config 4): objects of one network shape whose conv layers all run as polyphase Winograd share ONE launch per conv layer
+// (conv_wino_layer_multi_kernel: the block -> object map is a prefix sum over the objects' window regions) where the GROUP's blocks
+// fill the rounds of blocks they occupy -- eight buckets of 32 crops fill the chip like one batch of 256, where each bucket alone leaves
+// conv4 (four images per block: 64 blocks) a quarter of a round.  conv1, the dense layer and the scan run per object around them.  Every
+// block runs exactly its object's single-launch block: each layer bit-identical to the object's own Winograd launch -- an object whose
+// own call would take the direct kernels for a layer (too few blocks alone) differs from that call by the two forms' fp32 rounding
+// (<= 2.3e-6 of the latent scale, conv_winograd_f32.h).
+// Everything else (bf16 codebooks, split precision, other networks or options) is answered by the per-object path inside the same call,
+// one item after the other in a shared slice.
 #pragma once
 
 namespace aae_host {
 
 struct MultiItemPlan {
     bool grouped = false;
+    bool mid = false;                          // member of a mid-batch group (one Winograd launch per conv layer across the objects)
     int n = 0, row0 = 0;                       // detections of the item, its first row in the concatenated inputs / outputs
     size_t enc_off = 0, enc_bytes = 0, cb_off = 0, cb_bytes = 0;     // grouped items: own workspace slices
     Workspace ws;
@@ -31,6 +40,7 @@ struct MultiItemPlan {
 struct MultiPlan {
     std::vector<MultiItemPlan> items;
     std::vector<std::vector<int>> groups;      // grouped items that share launches: equal signatures, at most kMultiMax members, item order
+    std::vector<std::vector<int>> mid_groups;  // mid-batch items that share their Winograd launches
     size_t seq_enc_off = 0, seq_enc_bytes = 0, seq_cb_off = 0, seq_cb_bytes = 0, total = 0;
     int rows = 0;
 };
@@ -165,6 +175,39 @@ static Workspace plan_workspace_grouped(const aae_encoder* enc, int n, const std
     return ws;
 }
 
+// Can (enc, n detections) join a mid-batch group?  Default options in exact fp32, every conv layer behind the first one prepared for Winograd.
+static bool multi_encoder_mid_groupable(const aae_encoder* enc, int n, std::vector<int>& sig) {
+    const size_t nl = enc->layers.size();
+    if (n < 5 || nl < 2 || enc->winograd != 1 || enc->winograd_wide || !enc->multi_mid_group || runs_split(enc, n)) return false;
+    for (size_t li = 1; li < nl; ++li) {
+        const Layer& L = enc->layers[li];
+        if (L.kind != KIND_IGEMM || L.wino_geom < 0 || !L.wino[0]) return false;
+        if ((unsigned long long)n * L.H * L.W * L.Cin * sizeof(float) >= 0x7FFFFF00ull) return false;
+    }
+    sig.clear();
+    sig.push_back(enc->winograd_min_fill_pct); sig.push_back(enc->winograd_min_blocks); sig.push_back(enc->winograd_xcd_cols); sig.push_back(wavek_round_blocks(enc));
+    const int32_t* d = reinterpret_cast<const int32_t*>(&enc->desc);
+    for (size_t i = 0; i < sizeof(aae_encoder_desc) / sizeof(int32_t); ++i) sig.push_back(d[i]);
+    return true;
+}
+static int wino_regions(const Layer& L, int n) { return L.wino_geom == 0 ? (L.Ho / 16) * (L.Wo / 16) * n : ceil_div(n, 4); }
+// ... and does the group fill the chip on every conv layer (the round-fill rule of runs_winograd, on the group's blocks)?
+static bool mid_group_fills(const aae_encoder* enc0, const std::vector<int>& counts) {
+    const long long cus = wavek_round_blocks(enc0);
+    for (size_t li = 1; li < enc0->layers.size(); ++li) {
+        const Layer& L = enc0->layers[li];
+        long long regions = 0;
+        for (int n : counts) regions += wino_regions(L, n);
+        const long long blocks = regions * (L.Cout / 64), rounds = (blocks + cus - 1) / cus;
+        if (enc0->winograd_min_blocks > 0) {                               // (tests, A/B: a plain block count instead of the fill rule, as in runs_winograd)
+            if (blocks < enc0->winograd_min_blocks) return false;
+            continue;
+        }
+        if (100 * blocks < (long long)enc0->winograd_min_fill_pct * rounds * cus) return false;
+    }
+    return true;
+}
+
 // Layout of one call: [shared slice of the per-object path: encoder part, codebook part][grouped item 0: encoder, codebook][item 1] ...
 static int plan_multi(const aae_multi_item* items, int n_items, bool scan_only, MultiPlan& mp) {
     if (!items || n_items < 1) return fail(AAE_ERR_INVALID, "multi-object query: no items");
@@ -192,6 +235,35 @@ static int plan_multi(const aae_multi_item* items, int n_items, bool scan_only, 
         if (p.grouped) {
             p.sp = plan_scan(p.eff, it.n, 1);
             p.cb_bytes = align_up(p.sp.total, 256);
+        } else if (!scan_only && multi_encoder_mid_groupable(it.enc, it.n, p.sig)) {
+            p.mid = true;                           // (a candidate: confirmed below once its group is known)
+        }
+    }
+    // mid-batch groups: equal signatures, at most kMultiMax members, at least two, and the group must fill the chip on every conv layer
+    mp.mid_groups.clear();
+    for (size_t i = 0; i < mp.items.size(); ++i) {
+        if (!mp.items[i].mid) continue;
+        bool placed = false;
+        for (auto& g : mp.mid_groups)
+            if ((int)g.size() < aae::kMultiMax && mp.items[(size_t)g[0]].sig == mp.items[i].sig) { g.push_back((int)i); placed = true; break; }
+        if (!placed) mp.mid_groups.push_back(std::vector<int>(1, (int)i));
+    }
+    for (size_t gi = 0; gi < mp.mid_groups.size();) {
+        const std::vector<int>& g = mp.mid_groups[gi];
+        std::vector<int> counts;
+        for (int i : g) counts.push_back(mp.items[(size_t)i].n);
+        if (g.size() >= 2 && mid_group_fills(items[g[0]].enc, counts)) { ++gi; continue; }
+        for (int i : g) mp.items[(size_t)i].mid = false;
+        mp.mid_groups.erase(mp.mid_groups.begin() + (long)gi);
+    }
+    for (int i = 0; i < n_items; ++i) {
+        const aae_multi_item& it = items[i];
+        MultiItemPlan& p = mp.items[(size_t)i];
+        if (p.grouped) continue;
+        if (p.mid) {
+            p.ws = plan_workspace(it.enc, it.n);
+            p.enc_bytes = align_up(p.ws.total, 256);
+            p.cb_bytes = align_up(plan_scan(it.cb, it.n, 1).total, 256);
         } else {
             if (!scan_only) mp.seq_enc_bytes = std::max(mp.seq_enc_bytes, align_up(plan_workspace(it.enc, it.n).total, 256));
             mp.seq_cb_bytes = std::max(mp.seq_cb_bytes, align_up(plan_scan(it.cb, it.n, 1).total, 256));
@@ -230,7 +302,7 @@ static int plan_multi(const aae_multi_item* items, int n_items, bool scan_only, 
     mp.seq_enc_off = off; off += mp.seq_enc_bytes;
     mp.seq_cb_off = off; off += mp.seq_cb_bytes;
     for (MultiItemPlan& p : mp.items)
-        if (p.grouped) {
+        if (p.grouped || p.mid) {
             p.enc_off = off; off += p.enc_bytes;
             p.cb_off = off; off += p.cb_bytes;
         }
@@ -441,6 +513,61 @@ static int launch_encoder_multi(const aae_multi_item* items, const MultiPlan& mp
     return AAE_OK;
 }
 
+// A mid-batch group: conv1 per object, ONE Winograd launch per conv layer across the objects, dense layer + scan per object.
+static int launch_mid_group(const aae_multi_item* items, const MultiPlan& mp, const std::vector<int>& members, const void* x, int x_dtype, float* z_out,
+                            int64_t* idx_out, float* score_out, unsigned char* base, void* stream_v) {
+    hipStream_t stream = static_cast<hipStream_t>(stream_v);
+    aae_encoder* enc0 = items[members[0]].enc;
+    const size_t nl = enc0->layers.size();
+    const int J = enc0->desc.latent_size;
+    const size_t crop_bytes = (size_t)enc0->desc.in_h * enc0->desc.in_w * enc0->desc.in_c * (x_dtype == AAE_DTYPE_U8 ? 1 : 4);
+    Timer tm;
+    for (int i : members) {
+        const MultiItemPlan& p = mp.items[(size_t)i];
+        if (int rc = forward_impl(items[i].enc, static_cast<const unsigned char*>(x) + (size_t)p.row0 * crop_bytes, x_dtype, p.n, z_out + (size_t)p.row0 * J,
+                                  base + p.enc_off, p.enc_bytes, stream_v, tm, nullptr, nullptr, nullptr, 0, 1)) return rc;
+    }
+    for (size_t li = 1; li < nl; ++li) {
+        const Layer& L0 = enc0->layers[li];
+        aae::ConvWinoMultiArgs m;
+        memset(&m, 0, sizeof(m));
+        aae::ConvWinoArgs& c = m.c;
+        c.H = L0.H; c.W = L0.W; c.Cin = L0.Cin; c.Cout = L0.Cout; c.Ho = L0.Ho; c.Wo = L0.Wo; c.relu = L0.relu;
+        c.blocks_x = L0.wino_geom == 0 ? L0.Wo / 16 : 1;
+        c.blocks_y = L0.wino_geom == 0 ? L0.Ho / 16 : 1;
+        int at = 0;
+        m.range.n = (int)members.size();
+        for (size_t k = 0; k < members.size(); ++k) {
+            const MultiItemPlan& p = mp.items[(size_t)members[k]];
+            const Layer& L = items[members[k]].enc->layers[li];
+            aae::ConvWinoObject& ob = m.obj[k];
+            ob.x = reinterpret_cast<const float*>(base + p.enc_off + p.ws.act_off[li - 1]);
+            ob.out = reinterpret_cast<float*>(base + p.enc_off + p.ws.act_off[li]);
+            for (int q = 0; q < 4; ++q) ob.U4[q] = L.wino[q];
+            ob.bias = L.bias; ob.bn_scale = L.bn_scale; ob.bn_shift = L.bn_shift; ob.B = p.n;
+            m.range.first[k] = at;
+            at += wino_regions(L, p.n);
+        }
+        m.range.first[members.size()] = at;
+        c.regions = at;
+        c.xcd_cols = wino_xcd_cols(enc0, L0);
+        wino_layer_multi_launch(L0.wino_geom, aae::wino_grid_blocks(at, L0.Cout / 64, c.xcd_cols), stream, m);
+        AAE_HIP_TRY(hipGetLastError());
+        ++t_multi_launches;
+    }
+    for (int i : members) {
+        const MultiItemPlan& p = mp.items[(size_t)i];
+        if (int rc = forward_impl(items[i].enc, base + p.enc_off + p.ws.act_off[nl - 1], AAE_DTYPE_F32, p.n, z_out + (size_t)p.row0 * J, base + p.enc_off, p.enc_bytes,
+                                  stream_v, tm, nullptr, nullptr, nullptr, (int)nl, (int)nl + 1)) return rc;
+    }
+    for (int i : members) {
+        const MultiItemPlan& p = mp.items[(size_t)i];
+        if (int rc = aae_codebook_nn(items[i].cb, z_out + (size_t)p.row0 * J, p.n, 1, items[i].col_stride, idx_out + p.row0, score_out + p.row0, base + p.cb_off,
+                                     p.cb_bytes, stream_v)) return rc;
+    }
+    return AAE_OK;
+}
+
 static int multi_impl(const aae_multi_item* items, int n_items, const void* x, int x_dtype, const float* z_in, float* z_out, int64_t* idx_out,
                       float* score_out, void* workspace, size_t ws_bytes, void* stream_v) {
     const bool scan_only = z_in != nullptr;
@@ -459,7 +586,7 @@ static int multi_impl(const aae_multi_item* items, int n_items, const void* x, i
     // ---- the items the grouped kernels do not cover: the per-object path, one after the other in the shared slice
     for (int i = 0; i < n_items; ++i) {
         const MultiItemPlan& p = mp.items[(size_t)i];
-        if (p.grouped) continue;
+        if (p.grouped || p.mid) continue;
         const aae_multi_item& it = items[i];
         int rc;
         if (scan_only)
@@ -473,6 +600,14 @@ static int multi_impl(const aae_multi_item* items, int n_items, const void* x, i
                                base + mp.seq_cb_off, mp.seq_cb_bytes, stream_v);
         }
         if (rc) return rc;
+    }
+    // ---- mid-batch groups: one Winograd launch per conv layer and group
+    for (const std::vector<int>& g : mp.mid_groups) {
+        for (int i : g) {
+            const aae_encoder_desc &a = items[i].enc->desc, &b = items[g[0]].enc->desc;
+            if (a.in_h != b.in_h || a.in_w != b.in_w || a.in_c != b.in_c) return fail(AAE_ERR_RUNTIME, "multi-object query: group members differ in crop shape");
+        }
+        if (int rc = launch_mid_group(items, mp, g, x, x_dtype, z_out, idx_out, score_out, base, stream_v)) return rc;
     }
     // ---- grouped items: one launch per layer and group
     if (!mp.groups.empty()) t_x3h_last_slot = -1;

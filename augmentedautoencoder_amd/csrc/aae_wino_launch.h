@@ -7,6 +7,7 @@ namespace aae_host {
 
 #ifdef AAE_WINO_DECLARATIONS_ONLY
 void wino_layer_launch(int geom, int wide, unsigned grid, hipStream_t stream, const aae::ConvWinoLayerArgs& p);
+void wino_layer_multi_launch(int geom, unsigned grid, hipStream_t stream, const aae::ConvWinoMultiArgs& p);
 void wino_set_attributes();
 #else
 #ifdef AAE_WINO_TU
@@ -26,7 +27,13 @@ AAE_WINO_LINKAGE void wino_layer_launch(int geom, int wide, unsigned grid, hipSt
     if (geom == 0) AAE_LAUNCH((aae::conv_wino_layer_kernel<0, false>), dim3(grid), dim3(512), aae::wino_layer_smem_bytes<0>(), stream, p);
     else AAE_LAUNCH((aae::conv_wino_layer_kernel<1, false>), dim3(grid), dim3(512), aae::wino_layer_smem_bytes<1>(), stream, p);
 }
+AAE_WINO_LINKAGE void wino_layer_multi_launch(int geom, unsigned grid, hipStream_t stream, const aae::ConvWinoMultiArgs& p) {
+    if (geom == 0) AAE_LAUNCH((aae::conv_wino_layer_multi_kernel<0>), dim3(grid), dim3(512), aae::wino_layer_smem_bytes<0>(), stream, p);
+    else AAE_LAUNCH((aae::conv_wino_layer_multi_kernel<1>), dim3(grid), dim3(512), aae::wino_layer_smem_bytes<1>(), stream, p);
+}
 AAE_WINO_LINKAGE void wino_set_attributes() {
+    (void)hipFuncSetAttribute((const void*)aae::conv_wino_layer_multi_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::wino_layer_smem_bytes<0>());
+    (void)hipFuncSetAttribute((const void*)aae::conv_wino_layer_multi_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::wino_layer_smem_bytes<1>());
     (void)hipFuncSetAttribute((const void*)aae::conv_wino_layer_kernel<0, false>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::wino_layer_smem_bytes<0>());
     (void)hipFuncSetAttribute((const void*)aae::conv_wino_layer_kernel<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::wino_layer_smem_bytes<1>());
 #ifdef AAE_EXPERIMENTS

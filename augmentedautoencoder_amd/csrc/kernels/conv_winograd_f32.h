@@ -34,6 +34,8 @@
 #pragma once
 #include <type_traits>
 
+#include "multi_launch.h"
+
 namespace aae {
 
 struct ConvWinoArgs {
@@ -96,6 +98,23 @@ struct ConvWinoLayerArgs {
     ConvWinoArgs c;          // (U, eh, ew, mode unused)
     const float* U4[4];      // index 2 eh + ew
 };
+// ... and of the same launch over SEVERAL objects (one network shape; each its own activations, Winograd-domain weights and epilogue
+// vectors): the grouped mid-batch query of aae_encode_nn_multi.  c holds the shared geometry, c.regions the regions of all objects; regions
+// [range.first[o], range.first[o + 1]) belong to object o.  Lives in the kernel-argument segment (multi_launch.h).
+struct ConvWinoObject {
+    const float* x;
+    float* out;
+    const float* U4[4];
+    const float* bias;
+    const float* bn_scale;
+    const float* bn_shift;
+    int B, pad_;
+};
+struct ConvWinoMultiArgs {
+    ConvWinoArgs c;
+    MultiRange range;
+    ConvWinoObject obj[kMultiMax];
+};
 template <int GEOM>
 constexpr int wino_layer_stage_bytes() { return 2 * 4 * wino_plane_units<GEOM>() * 16; }
 template <int GEOM>
@@ -149,29 +168,34 @@ __device__ __forceinline__ f32x4 wino_sub4(f32x4 a, f32x4 b) {
 // Which block takes which (region, column block): physical block p runs on XCD p % 8 (observed dispatch order; a wrong guess costs speed
 // only), and every XCD has an L2 of its own.  The nbn column blocks of a region read the SAME input window and different weights; the
 // regions of a column block read the same weights and different windows.  With xcd_cols = S the XCDs form nbn / S column groups x
-// 8 S / nbn region groups: an XCD runs S column blocks of every region of its group side by side (consecutive slots of the XCD), so
-// a window crosses the fabric nbn / S times and an XCD's L2 streams S / nbn of the weights.  S = 1 is the plain order p = region * nbn + nb
-// for nbn = 4 | 8 (every column block on its own XCD: the window is fetched nbn times -- 2.8 / 2.5 / 1.2 GB per launch for conv2 / conv3 /
-// conv4 at B = 256 against 0.8 / 0.4 / 0.2 GB of tensors, profiles/r14/pmc_summary.txt).
+// 8 S / nbn region groups: an XCD runs S column blocks of a region side by side (consecutive slots of the XCD), so a window crosses the
+// fabric nbn / S times and an XCD's L2 streams S / nbn of the weights.  A region group takes a CONTIGUOUS chunk of the region list, in
+// order: the 32 / S regions an XCD works on at a time are neighbours -- in a grouped launch (ConvWinoMultiArgs) regions of ONE object,
+// which share their weight fetches.  xcd_cols = 0: plain order p = region * nbn + nb (for nbn = 4 | 8 every column block on its own
+// XCD: the window is fetched nbn times -- 2.8 / 2.5 / 1.2 GB per launch for conv2 / conv3 / conv4 at B = 256 against 0.8 / 0.4 / 0.2 GB
+// of tensors, profiles/r14/pmc_summary.txt).
 struct WinoBlock {
-    int nb, img0, wy0, wx0;
+    int nb, region, img0, wy0, wx0;
     bool live;
 };
-template <int GEOM>
-__device__ __forceinline__ WinoBlock wino_block(int block, int nbn, int blocks_x, int blocks_y, int regions, int xcd_cols) {
-    WinoBlock w;
-    int rest;
+__device__ __forceinline__ void wino_block_index(int block, int nbn, int regions, int xcd_cols, WinoBlock& w) {
     if (xcd_cols > 0) {
-        const int col_groups = nbn / xcd_cols, region_groups = 8 / col_groups;
-        const int xcd = block & 7, within = block >> 3;
+        const int col_groups = nbn / xcd_cols, region_groups = 8 / col_groups, chunk = (regions + region_groups - 1) / region_groups;
+        const int xcd = block & 7, within = block >> 3, k = within / xcd_cols;
         w.nb = (xcd % col_groups) * xcd_cols + within % xcd_cols;
-        rest = (within / xcd_cols) * region_groups + xcd / col_groups;
+        w.region = (xcd / col_groups) * chunk + k;
+        w.live = k < chunk && w.region < regions;
     } else {
         w.nb = block % nbn;
-        rest = block / nbn;
+        w.region = block / nbn;
+        w.live = w.region < regions;
     }
-    w.live = rest < regions;
+}
+// region `local` of one object's launch: the images / window it covers
+template <int GEOM>
+__device__ __forceinline__ void wino_block_geometry(int local, int blocks_x, int blocks_y, WinoBlock& w) {
     if (GEOM == 0) {
+        int rest = local;
         const int bx = rest % blocks_x;
         rest /= blocks_x;
         const int by = rest % blocks_y;
@@ -179,9 +203,15 @@ __device__ __forceinline__ WinoBlock wino_block(int block, int nbn, int blocks_x
         w.wy0 = 16 * by - 1;
         w.wx0 = 16 * bx - 1;
     } else {
-        w.img0 = 4 * rest;
+        w.img0 = 4 * local;
         w.wy0 = w.wx0 = -1;
     }
+}
+template <int GEOM>
+__device__ __forceinline__ WinoBlock wino_block(int block, int nbn, int blocks_x, int blocks_y, int regions, int xcd_cols) {
+    WinoBlock w;
+    wino_block_index(block, nbn, regions, xcd_cols, w);
+    wino_block_geometry<GEOM>(w.region, blocks_x, blocks_y, w);
     return w;
 }
 // tile t (0 ... 31) of the wave with tile half mh: (image of the block, tile row, tile column)
@@ -593,11 +623,7 @@ __global__ __launch_bounds__(512) void conv_wino_phase_kernel(ConvWinoArgs a) {
 //      The phases are CHAINED: each fetches the next one's first stage and first weight fragments while its own K loop ends, so that only
 //      the first phase of a block waits for global memory with an empty matrix pipe.
 template <int GEOM, bool WIDE>
-__global__ __launch_bounds__(WIDE ? 256 : 512) void conv_wino_layer_kernel(ConvWinoLayerArgs p) {
-    AAE_DYN_SMEM(smem_raw);
-    const ConvWinoArgs& a = p.c;
-    const WinoBlock wb = wino_block<GEOM>(blockIdx.x, a.Cout / 64, a.blocks_x, a.blocks_y, a.regions, a.xcd_cols);
-    if (!wb.live) return;
+__device__ __forceinline__ void wino_layer_block(const ConvWinoArgs& a, const float* const (&U4)[4], const WinoBlock& wb, unsigned char* smem_raw) {
     f32x4* lds = reinterpret_cast<f32x4*>(smem_raw);
     float* xch = reinterpret_cast<float*>(smem_raw + wino_layer_stage_bytes<GEOM>());
     WinoFillPlan<GEOM, 16, WIDE ? 256 : 512> fill;
@@ -605,23 +631,49 @@ __global__ __launch_bounds__(WIDE ? 256 : 512) void conv_wino_layer_kernel(ConvW
     int buf0 = 0;
     f32x4 ua[8], ub[8];
     if (WIDE) {
-        wino_phase_body<3, 3, false, GEOM, 16, false, WIDE>(a, p.U4[3], 1, 1, wb, lds, xch, fill, buf0, ua, nullptr, 0, 0, ub);
-        wino_phase_body<3, 2, false, GEOM, 16, true, WIDE>(a, p.U4[2], 1, 0, wb, lds, xch, fill, buf0, ua, nullptr, 0, 0, ub);
-        wino_phase_body<3, 2, true, GEOM, 16, true, WIDE>(a, p.U4[1], 0, 1, wb, lds, xch, fill, buf0, ua, nullptr, 0, 0, ub);
-        wino_phase_body<2, 2, false, GEOM, 16, true, WIDE>(a, p.U4[0], 0, 0, wb, lds, xch, fill, buf0, ua, nullptr, 0, 0, ub);
+        wino_phase_body<3, 3, false, GEOM, 16, false, WIDE>(a, U4[3], 1, 1, wb, lds, xch, fill, buf0, ua, nullptr, 0, 0, ub);
+        wino_phase_body<3, 2, false, GEOM, 16, true, WIDE>(a, U4[2], 1, 0, wb, lds, xch, fill, buf0, ua, nullptr, 0, 0, ub);
+        wino_phase_body<3, 2, true, GEOM, 16, true, WIDE>(a, U4[1], 0, 1, wb, lds, xch, fill, buf0, ua, nullptr, 0, 0, ub);
+        wino_phase_body<2, 2, false, GEOM, 16, true, WIDE>(a, U4[0], 0, 0, wb, lds, xch, fill, buf0, ua, nullptr, 0, 0, ub);
     } else {
         constexpr bool W = WIDE;        // (false here: the chained form)
-        wino_phase_body<3, 3, false, GEOM, 16, false, W, W ? 0 : 2, 3, 2>(a, p.U4[3], 1, 1, wb, lds, xch, fill, buf0, ua, p.U4[2], 1, 0, ub);
-        wino_phase_body<3, 2, false, GEOM, 16, true, W, W ? 0 : 3, 3, 2>(a, p.U4[2], 1, 0, wb, lds, xch, fill, buf0, ub, p.U4[1], 0, 1, ua);
-        wino_phase_body<3, 2, true, GEOM, 16, true, W, W ? 0 : 3, 2, 2>(a, p.U4[1], 0, 1, wb, lds, xch, fill, buf0, ua, p.U4[0], 0, 0, ub);
-        wino_phase_body<2, 2, false, GEOM, 16, true, W, W ? 0 : 1>(a, p.U4[0], 0, 0, wb, lds, xch, fill, buf0, ub, nullptr, 0, 0, ua);
+        wino_phase_body<3, 3, false, GEOM, 16, false, W, W ? 0 : 2, 3, 2>(a, U4[3], 1, 1, wb, lds, xch, fill, buf0, ua, U4[2], 1, 0, ub);
+        wino_phase_body<3, 2, false, GEOM, 16, true, W, W ? 0 : 3, 3, 2>(a, U4[2], 1, 0, wb, lds, xch, fill, buf0, ub, U4[1], 0, 1, ua);
+        wino_phase_body<3, 2, true, GEOM, 16, true, W, W ? 0 : 3, 2, 2>(a, U4[1], 0, 1, wb, lds, xch, fill, buf0, ua, U4[0], 0, 0, ub);
+        wino_phase_body<2, 2, false, GEOM, 16, true, W, W ? 0 : 1>(a, U4[0], 0, 0, wb, lds, xch, fill, buf0, ub, nullptr, 0, 0, ua);
     }
     wino_store_block<GEOM, WIDE ? 256 : 512>(a, 3, wb, xch);
+}
+
+template <int GEOM, bool WIDE>
+__global__ __launch_bounds__(WIDE ? 256 : 512) void conv_wino_layer_kernel(ConvWinoLayerArgs p) {
+    AAE_DYN_SMEM(smem_raw);
+    const ConvWinoArgs& a = p.c;
+    const WinoBlock wb = wino_block<GEOM>(blockIdx.x, a.Cout / 64, a.blocks_x, a.blocks_y, a.regions, a.xcd_cols);
+    if (!wb.live) return;
+    wino_layer_block<GEOM, WIDE>(a, p.U4, wb, smem_raw);
 #ifdef AAE_WINO_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     AAE_WINO_STAMP(a, 16);
     if (threadIdx.x == 0) a.stamps[((size_t)blockIdx.x * 8) * kWinoStampSlots + 17] = (long long)(__builtin_amdgcn_s_getreg(20 | (0 << 6) | (3 << 11)) & 15);
 #endif
+}
+
+// ---- the same launch over several objects (ConvWinoMultiArgs): a block finds the object its region belongs to and runs exactly the
+//      single-object block on that object's tensors -- bit-identical to the object's own launch.
+template <int GEOM>
+__global__ __launch_bounds__(512) void conv_wino_layer_multi_kernel(ConvWinoMultiArgs p) {
+    AAE_DYN_SMEM(smem_raw);
+    WinoBlock wb;
+    wino_block_index(blockIdx.x, p.c.Cout / 64, p.c.regions, p.c.xcd_cols, wb);
+    if (!wb.live) return;
+    const int o = multi_find(p.range, wb.region);
+    wino_block_geometry<GEOM>(wb.region - p.range.first[o], p.c.blocks_x, p.c.blocks_y, wb);
+    ConvWinoArgs a = p.c;
+    const ConvWinoObject& ob = p.obj[o];
+    a.x = ob.x; a.out = ob.out; a.bias = ob.bias; a.bn_scale = ob.bn_scale; a.bn_shift = ob.bn_shift; a.B = ob.B;
+    const float* U4[4] = {ob.U4[0], ob.U4[1], ob.U4[2], ob.U4[3]};
+    wino_layer_block<GEOM, false>(a, U4, wb, smem_raw);
 }
 
 #endif  // AAE_WINO_DECLARATIONS_ONLY

@@ -55,7 +55,8 @@ def _group_shape(dist, group, world_size, rank, what):
 
 class ShardedPoseEngine(object):
     """local_infer(obj_id, crops_subset) -> (idx int64 [n] or [n,1], score float32 likewise); crops_subset is
-    ``crops[positions]`` (numpy array or torch tensor, whatever the caller passed in).
+    ``crops[positions]`` (numpy array or torch tensor, whatever the caller passed in).  local_infer_many (optional)
+    answers all of the rank's objects in one call instead.
 
     pack_pairs(idx, score, pos int32 tensor, packed) / unpack_pairs(gathered, owner int32 tensor, n, rows_per_rank,
     idx_out, score_out): optional one-launch writers of the gather payload and of its way back (the HIP path passes
@@ -65,13 +66,16 @@ class ShardedPoseEngine(object):
     other ranks, written once), the gather buffer and the outputs belong to the cached plan -- the (idx, score) tensors
     a call returns are overwritten by the next call with the same layout."""
 
-    def __init__(self, local_infer, world_size=None, rank=None, group=None, device=None, pack_pairs=None, unpack_pairs=None):
+    def __init__(self, local_infer, world_size=None, rank=None, group=None, device=None, pack_pairs=None, unpack_pairs=None, local_infer_many=None):
         import torch.distributed as dist
         self.dist = dist
         self.group = group
         self.distributed = dist.is_available() and dist.is_initialized()
         self.world_size, self.rank, self._gather = _group_shape(dist, group, world_size, rank, 'ShardedPoseEngine')
         self.local_infer = local_infer
+        # local_infer_many({obj_id: crops_subset}) -> {obj_id: (idx, score)}: ALL of this rank's objects in one call (the HIP path answers a
+        # rank's buckets with one launch per conv layer across its objects: engine.MultiObjectQuery); local_infer may then be None
+        self.local_infer_many = local_infer_many
         self.device = device
         self.pack_pairs = pack_pairs
         self.unpack_pairs = unpack_pairs
@@ -111,12 +115,14 @@ class ShardedPoseEngine(object):
         dev = self.device if self.device is not None else torch.device('cpu')
         buckets, pos_dev, owners, bufs = self.plan(class_ids)
         packed = bufs['packed']
-        for obj, pos in buckets.items():
+
+        def select(obj, pos):
             if isinstance(crops, dict):
-                sel = crops[obj]
-            else:
-                sel = crops[pos_dev[obj].to(crops.device).long()] if torch.is_tensor(crops) else crops[pos]
-            idx, score = self.local_infer(obj, sel)
+                return crops[obj]
+            return crops[pos_dev[obj].to(crops.device).long()] if torch.is_tensor(crops) else crops[pos]
+        answers = self.local_infer_many({obj: select(obj, pos) for obj, pos in buckets.items()}) if self.local_infer_many is not None and buckets else None
+        for obj, pos in buckets.items():
+            idx, score = answers[obj] if answers is not None else self.local_infer(obj, select(obj, pos))
             idx = torch.as_tensor(idx, dtype=torch.int64, device=dev).reshape(len(pos), -1).contiguous()
             score = torch.as_tensor(score, dtype=torch.float32, device=dev).reshape(len(pos), -1).contiguous()
             if self.pack_pairs is not None:

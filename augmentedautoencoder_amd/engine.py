@@ -582,9 +582,13 @@ class MultiObjectQuery(object):
     class in one process and runs one session.run per detected box, whatever its class
     (m3_interface/ae_pose_estimator.py:61-78,143-170; 30 classes for T-LESS, cfg_m3vision/m3_config_tless.cfg:10-39).
     items: [(EncoderEngine, CodebookEngine, n detections[, col_stride])] in the order the crops are concatenated.  Items
-    with n <= 4 at the default options are GROUPED -- one launch per layer across all of them (six launches per distinct n
-    instead of six per object); the rest take the per-object path inside the same call.  Bit-identical to one
-    EncoderEngine.encode_nn call per item.  The layout is fixed at construction (a detector's class mix changes per
+    with n <= 4 at the default options are GROUPED -- one launch per layer across all of them, objects with different
+    detection counts included (six launches for the frame instead of six per object); items with n >= 5 whose conv layers
+    run as Winograd share one launch per conv layer when together they fill the chip (eight buckets of ~32 crops: the
+    reference's one-AAE-per-class frame at B = 256); the rest take the per-object path inside the same call.  Against one
+    EncoderEngine.encode_nn call per item the answers differ by fp32 summation order only (a group brings its own launch
+    plan, as a batch of another size does: <= 2.3e-6 of the latent scale, indices equal wherever the top-2 gap exceeds
+    that); encoder option multi_group_plan = 0 (and multi_mid_group = 0) makes them bit-identical.  The layout is fixed at construction (a detector's class mix changes per
     frame: AePoseEstimator builds the item array per frame instead -- detect_nn_multi below); outputs are static device
     tensors, valid until the next call."""
 

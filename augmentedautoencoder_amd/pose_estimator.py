@@ -405,7 +405,9 @@ class AePoseEstimator(object):
         pinned staging buffer and one copy, every class (in chunks when it has many detections) is ONE C call -- aae_detect_nn:
         crop + resize, encoder, top-1 query -- whose indices are written straight into pinned host memory, with an event behind
         it; the float64 geometry of chunk k then runs on the host while the GPU is busy with chunk k + 1.  Nothing is
-        allocated per frame; bit-identical to _process_plain."""
+        allocated per frame.  Same answers as _process_plain: bit for bit with multi_call = False; with multi_call = True the classes of a
+        frame share launch plans (aae_encode_nn_multi), so latents differ by fp32 summation order (<= 2.3e-6 of their scale) and the
+        index only where the top-2 cosine gap is below that."""
         import torch
         stage = self.__dict__.setdefault('_stages', {}).get(device)
         if stage is None:

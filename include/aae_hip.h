@@ -247,9 +247,16 @@ int aae_detect_nn(aae_encoder* enc, aae_codebook* cb, const void* img, int H, in
  * [rows,H,W,C], z_out [rows,latent], idx_out [rows] int64, score_out [rows], rows = sum of n (aae_multi_rows).
  * Items with n <= 4 whose per-object call would run the per-detection chain (fp32, default options, fp32 codebook, stride 1
  * or a prepared upright copy) are GROUPED: conv1, every later conv layer, the dense GEMV and the codebook scan each run as ONE
- * launch over all grouped items of equal n -- every block the per-object launch's block on the per-object launch's arguments,
- * tickets per (object, tile) -- so a frame with C classes costs 6 launches per distinct n instead of 6 C.  All other items are
- * answered by aae_encode_nn inside the same call.  Answers are bit-identical to per-object aae_encode_nn calls either way.
+ * launch over all grouped items -- objects with different n included -- every block the per-object launch's block, tickets per
+ * (object, tile): a frame with C classes costs 6 launches instead of 6 C.  Items with n >= 5 whose conv layers all run as
+ * polyphase Winograd (default options) form MID-BATCH groups: one Winograd launch per conv layer across the objects where the
+ * group's blocks fill the chip (eight buckets of ~32 crops fill it like one batch of 256), conv1 / dense / scan per object.
+ * All other items are answered by aae_encode_nn inside the same call.
+ * Results against one aae_encode_nn call per item: with the defaults a group runs ONE launch plan chosen for the group
+ * ("multi_group_plan" = 1) resp. the Winograd form where the object alone would take the direct kernels, so latents differ by
+ * fp32 summation order / the two forms' rounding (<= 2.3e-6 of the latent scale; indices equal wherever the top-2 cosine gap
+ * exceeds that), as a batch of another size does; every answer is checked against the object's own fp64 oracle.  With encoder
+ * options "multi_group_plan" = 0 and "multi_mid_group" = 0 the call is bit-identical to the per-object calls.
  * All encoders must share the crop shape and the latent size.  The workspace (aae_multi_workspace_bytes; scan_only = 1 for
  * aae_codebook_nn_multi) holds a slice per grouped item: nothing in it outlives the call. */
 typedef struct aae_multi_item {

@@ -290,3 +290,59 @@ def test_argument_errors_are_reported_not_crashed():
     arr[0].n = 0
     assert L.aae_encode_nn_multi(arr, 1, x.ctypes.data, _lib.AAE_DTYPE_U8, z.ctypes.data, idx.ctypes.data, sc.ctypes.data, buf.ctypes.data, n, None) == -1
     _close([a, b])
+
+
+_WINO = {'winograd_min_batch': 1, 'winograd_min_blocks': 1}      # (every eligible layer as Winograd, alone and in a group: the emulated launches are tiny against the 256 compute units the fill rule counts with)
+
+
+@pytest.mark.parametrize('order', [0, 1, 2])
+def test_mid_batch_group_one_winograd_launch_per_conv_layer_across_objects(order):
+    """objects with 5 or more detections each: conv1, the dense layer and the scan per object, ONE Winograd launch per conv layer across
+    the objects (conv_wino_layer_multi_kernel) -- both block geometries (16 x 16-pixel regions of one image; four 8 x 8 images per block,
+    ragged groups), three objects with different detection counts; bit for bit the per-object calls, and right against the oracle."""
+    cfg = EncoderConfig((64, 64, 3), [32, 64, 64], [2, 2, 2], 5, 128, True)
+    counts = [5, 7, 6]
+    eb.set_block_order(order)
+    try:
+        objs = [_object(cfg, 500 + 7 * o, 36 * (9 + 2 * o) + 3 * o, _WINO) for o in range(3)]
+        items = [(e, c, n, 1) for (e, c, _), n in zip(objs, counts)]
+        x = synth.make_crops(sum(counts), seed=58, shape=cfg.shape)
+        z0, i0, s0 = _per_object(items, x)
+        z1, i1, s1, launches = eb.encode_nn_multi(items, x)
+        assert launches == 2                                             # (the grouped launches: conv2 and conv3 -- the rest is counted by the per-object path)
+        assert np.array_equal(z1, z0) and np.array_equal(i1, i0) and np.array_equal(s1, s0)
+        at = 0
+        for (e, c, w), n in zip(objs, counts):
+            z64 = ref.encoder_forward_np(ref.input_to_float(x[at:at + n]), w, cfg.strides, cfg.batch_norm)
+            assert np.abs(z1[at:at + n] - z64).max() / np.abs(z64).max() < 5e-6
+            cs = c.similarity(z1[at:at + n])
+            assert np.array_equal(i1[at:at + n], np.argmax(cs, axis=1))
+            at += n
+        # a frame that mixes a per-detection group (n <= 4), a mid-batch group and a loner that joins neither (its own options)
+        lone = _object(cfg, 600, 36 * 8, dict(_WINO, multi_mid_group=0))
+        small = [_object(cfg, 610 + o, 36 * 7 + o) for o in range(2)]
+        mixed = [(small[0][0], small[0][1], 2, 1)] + items[:2] + [(lone[0], lone[1], 5, 1), (small[1][0], small[1][1], 1, 1)]
+        xm = synth.make_crops(sum(it[2] for it in mixed), seed=59, shape=cfg.shape)
+        zp, ip, sp = _per_object(mixed, xm)
+        zm, im, sm, _ = eb.encode_nn_multi(mixed, xm)
+        assert np.array_equal(im, ip)
+        at = 0
+        for k, (e, c, n, _) in enumerate(mixed):
+            same = np.array_equal(zm[at:at + n], zp[at:at + n]) and np.array_equal(sm[at:at + n], sp[at:at + n])
+            assert same or k in (0, 4), k                                # (the two per-detection items share a group plan: summation order)
+            assert np.abs(zm[at:at + n] - zp[at:at + n]).max() / np.abs(zp).max() < 2e-6 and np.abs(sm[at:at + n] - sp[at:at + n]).max() < 1e-6
+            at += n
+        _close(objs + [lone] + small)
+    finally:
+        eb.set_block_order(0)
+
+
+def test_mid_batch_group_needs_two_members_that_fill_the_chip():
+    cfg = EncoderConfig((64, 64, 3), [32, 64, 64], [2, 2, 2], 5, 128, True)
+    objs = [_object(cfg, 700 + o, 36 * 8, {'winograd_min_batch': 1}) for o in range(2)]            # default fill rule: two tiny launches do not fill 256 compute units
+    items = [(e, c, 5, 1) for e, c, _ in objs]
+    x = synth.make_crops(10, seed=60, shape=cfg.shape)
+    z0, i0, s0 = _per_object(items, x)
+    z1, i1, s1, launches = eb.encode_nn_multi(items, x)
+    assert launches == 0 and np.array_equal(z1, z0) and np.array_equal(i1, i0)
+    _close(objs)

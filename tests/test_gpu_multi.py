@@ -239,3 +239,53 @@ def test_objects_that_share_one_workspace_alternate_on_the_ticketed_path(eight_o
     finally:
         E.unshare_workspaces(rebound)
     assert objs[0][0].ws is not objs[5][0].ws
+
+
+def test_mid_batch_group_eight_buckets_of_a_256_crop_batch(eight_objects):
+    """SURVEY section 8d config 4 on one GPU: 256 crops over 8 objects ({34, 26, 27, 32, 31, 32, 33, 41}): ONE Winograd launch per conv layer
+    across the objects (conv4's four-image blocks fill two rounds where one bucket alone fills a quarter), conv1 / dense / scan per object.
+    Against (a) each object's own call with every eligible layer forced to Winograd -- bit for bit --, (b) each object's default call
+    (conv3 / conv4 on the direct kernels at these sizes: fp32 rounding of the two forms), (c) each object's fp64 oracle."""
+    import torch
+    from augmentedautoencoder_amd.engine import MultiObjectQuery
+    weights, books, objs, dev = eight_objects
+    counts = [34, 26, 27, 32, 31, 32, 33, 41]
+    rows = sum(counts)
+    crops_host = synth.make_crops(rows, seed=4321)
+    x = torch.from_numpy(crops_host).to(dev)
+    zd, idd, sd = _per_object(objs, counts, x)                           # the default per-object calls
+    mq = MultiObjectQuery([(e, c, n) for (e, c), n in zip(objs, counts)])
+    z1, i1, s1 = mq(x)
+    torch.cuda.synchronize()
+    assert mq.launches == 3                                              # conv2, conv3, conv4: one launch each for all eight objects
+    z1, i1, s1 = z1.clone(), i1.clone(), s1.clone()
+    for e, _ in objs:
+        e.set_option('winograd_min_blocks', 1)
+    try:
+        zf, idf, sf = _per_object(objs, counts, x)                       # every layer as the object's OWN Winograd launch
+    finally:
+        for e, _ in objs:
+            e.set_option('winograd_min_blocks', 0)
+    assert torch.equal(z1, zf) and torch.equal(i1, idf) and torch.equal(s1, sf)
+    scale = float(zd.abs().max())
+    assert float((z1 - zd).abs().max()) / scale < 5e-6
+    at = 0
+    for o, n in enumerate(counts):
+        sub = slice(at, at + min(n, 6))                                  # (six crops per object against the fp64 oracle: seconds, not minutes)
+        z64 = ref.encoder_forward_torch(ref.input_to_float(crops_host[sub]), weights[o], STRIDES, False, 'float64')
+        cs64 = ref.cos_similarity(z64, books[o])
+        assert np.abs(z1[sub].cpu().numpy() - z64).max() / np.abs(z64).max() < 2e-5, o
+        assert np.abs(s1[sub].cpu().numpy() - cs64.max(axis=1)).max() <= COS_TOL, o
+        _check_indices(i1[sub].cpu().numpy(), cs64, where='mid-batch group, object %d (%d crops)' % (o, n))
+        at += n
+    # option multi_mid_group = 0: the buckets one after the other, bit-identical to the default per-object calls
+    for e, _ in objs:
+        e.set_option('multi_mid_group', 0)
+    try:
+        mq0 = MultiObjectQuery([(e, c, n) for (e, c), n in zip(objs, counts)])
+        z0, i0, s0 = mq0(x)
+        torch.cuda.synchronize()
+        assert mq0.launches == 0 and torch.equal(z0, zd) and torch.equal(i0, idd) and torch.equal(s0, sd)
+    finally:
+        for e, _ in objs:
+            e.set_option('multi_mid_group', 1)
