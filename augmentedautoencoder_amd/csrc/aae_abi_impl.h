@@ -78,16 +78,10 @@ int aae_encoder_create(const aae_encoder_desc* d, const void* const* hw, int n_w
             if (int rc = upload(enc, packed.data(), packed.size(), &L.wp)) return bail(rc);
             const std::vector<unsigned short> p16 = pack_weights_x3h(k, L.KS * L.KS, L.Cin, L.Cout, L.CoutPad, &L.w_shift);
             if (int rc = upload(enc, reinterpret_cast<const float*>(p16.data()), p16.size() / 2, reinterpret_cast<float**>(&L.wp16))) return bail(rc);
-            // the Winograd-domain weights of the four polyphase components (conv_winograd_f32.h; 49/25 of the layer's weight bytes)
-            const int geom = winograd_geometry(L);
-            if (geom >= 0) {
-                for (int eh = 0; eh < 2; ++eh)
-                    for (int ew = 0; ew < 2; ++ew) {
-                        const std::vector<float> U = pack_weights_winograd(k, L.KS, L.Cin, L.Cout, eh, ew, !eh && ew);
-                        if (int rc = upload(enc, U.data(), U.size(), &L.wino[2 * eh + ew])) return bail(rc);
-                    }
-                L.wino_geom = geom;
-            }
+            // eligible for the polyphase-Winograd form?  Its weights (49/25 of the layer's weight bytes: 83.5 MB for the default network) are
+            // prepared on first need -- ensure_winograd_weights, from the workspace-size queries -- so that a per-detection deployment
+            // (30 T-LESS classes at 1 ... 16 boxes each never run the form) keeps 59 MB per object
+            L.wino_geom = winograd_geometry(L);
         }
         enc->layers.push_back(L);
         H = L.Ho; W = L.Wo; C = L.Cout;
@@ -175,6 +169,8 @@ int aae_encoder_create(const aae_encoder_desc* d, const void* const* hw, int n_w
 void aae_encoder_destroy(aae_encoder* enc) {
     if (!enc) return;
     for (void* p : enc->allocations) (void)hipFree(p);
+    for (hipEvent_t e : enc->x3h_release_ev)
+        if (e) (void)hipEventDestroy(e);
     delete enc;
 }
 
@@ -333,6 +329,9 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
 
 size_t aae_encoder_workspace_bytes(const aae_encoder* enc, int B) {
     if (!enc || B < 1) return 0;
+    // (a caller sizes its workspace for a batch before it runs it: the one place outside the hot calls that knows a batch is coming --
+    //  batches that take the Winograd conv layers get their transformed weights here, once; a forward never allocates)
+    if (aae_host::wants_winograd_weights(enc, B) && aae_host::ensure_winograd_weights(const_cast<aae_encoder*>(enc)) != AAE_OK) return 0;
     return aae_host::plan_workspace(enc, B).total;
 }
 
@@ -423,6 +422,12 @@ int aae_encoder_x3h_release_slot(aae_encoder* enc, int slot, void* stream_v) {
     // (the next owner starts from a lowered flag; asynchronous on the caller's stream: a synchronous null-stream memset is
     //  invalid while any stream of the process is being captured)
     AAE_HIP_TRY(hipMemsetAsync(enc->x3h_sat + slot, 0, sizeof(int), static_cast<hipStream_t>(stream_v)));
+    // ... and the slot is handed out again only once that clear has executed (forward_impl asks the event): a capture on another stream that
+    // took it earlier could replay before the clear and lose a raised flag to it
+    const size_t k = (size_t)(slot - kX3hRing);
+    if (enc->x3h_release_ev.size() <= k) enc->x3h_release_ev.resize(k + 1, nullptr);
+    if (!enc->x3h_release_ev[k]) AAE_HIP_TRY(hipEventCreateWithFlags(&enc->x3h_release_ev[k], hipEventDisableTiming));
+    AAE_HIP_TRY(hipEventRecord(enc->x3h_release_ev[k], static_cast<hipStream_t>(stream_v)));
     enc->x3h_free.push_back(slot);
     return AAE_OK;
 }

@@ -599,8 +599,34 @@ static int launch_winograd(aae_encoder* enc, const Layer& L, const float* x, int
     return tm.mark();
 }
 
-static bool runs_winograd(const aae_encoder* enc, const Layer& L, int B) {
-    if (!enc->winograd || L.wino_geom < 0 || !L.wino[0] || B < enc->winograd_min_batch) return false;
+static bool winograd_rule(const aae_encoder* enc, const Layer& L, int B);
+static bool runs_winograd(const aae_encoder* enc, const Layer& L, int B) { return L.wino[0] && winograd_rule(enc, L, B); }
+// would any conv layer of a batch of B take the Winograd form, were its weights there?
+static bool wants_winograd_weights(const aae_encoder* enc, int B) {
+    for (const Layer& L : enc->layers)
+        if (L.kind == KIND_IGEMM && !L.wino[0] && winograd_rule(enc, L, B)) return true;
+    return false;
+}
+// the Winograd-domain weights of every eligible layer: packed from the device copy of the HWIO kernel and uploaded, once (NOT from a hot call:
+// it allocates and copies synchronously -- aae_encoder_workspace_bytes / aae_multi_workspace_bytes call it for batches that will use them)
+static int ensure_winograd_weights(aae_encoder* enc) {
+    std::lock_guard<std::mutex> lk(enc->wino_mu);
+    for (Layer& L : enc->layers) {
+        if (L.kind != KIND_IGEMM || L.wino_geom < 0 || L.wino[0] || !L.w_hwio) continue;
+        std::vector<float> k((size_t)L.K() * L.Cout);
+        AAE_HIP_TRY(hipMemcpy(k.data(), L.w_hwio, k.size() * sizeof(float), hipMemcpyDeviceToHost));
+        float* dev[4] = {nullptr, nullptr, nullptr, nullptr};
+        for (int eh = 0; eh < 2; ++eh)
+            for (int ew = 0; ew < 2; ++ew) {
+                const std::vector<float> U = pack_weights_winograd(k.data(), L.KS, L.Cin, L.Cout, eh, ew, !eh && ew);
+                if (int rc = upload(enc, U.data(), U.size(), &dev[2 * eh + ew])) return rc;
+            }
+        for (int q = 3; q >= 0; --q) L.wino[q] = dev[q];          // (component 0 last: runs_winograd asks for it)
+    }
+    return AAE_OK;
+}
+static bool winograd_rule(const aae_encoder* enc, const Layer& L, int B) {
+    if (!enc->winograd || L.wino_geom < 0 || B < enc->winograd_min_batch) return false;
     // (the kernel reads the input through a 32-bit buffer view whose upper half marks "outside the image": activations below 2 GiB)
     const unsigned long long x_bytes = (unsigned long long)B * L.H * L.W * L.Cin * sizeof(float);
     if (x_bytes >= 0x7FFFFF00ull) return false;
@@ -653,10 +679,15 @@ static int forward_impl(aae_encoder* enc, const void* x, int x_dtype, int B, flo
         int slot;
         if (capture != hipStreamCaptureStatusNone) {
             std::lock_guard<std::mutex> lk(enc->x3h_mu);
-            if (!enc->x3h_free.empty()) {
-                slot = enc->x3h_free.back();
-                enc->x3h_free.pop_back();
-            } else {
+            slot = -1;
+            for (size_t f = 0; f < enc->x3h_free.size(); ++f) {          // a released slot whose flag clear has executed (aae_encoder_x3h_release_slot)
+                const size_t k = (size_t)(enc->x3h_free[f] - kX3hRing);
+                if (k < enc->x3h_release_ev.size() && enc->x3h_release_ev[k] && hipEventQuery(enc->x3h_release_ev[k]) != hipSuccess) continue;
+                slot = enc->x3h_free[f];
+                enc->x3h_free.erase(enc->x3h_free.begin() + (long)f);
+                break;
+            }
+            if (slot < 0) {
                 if (enc->x3h_captured >= kX3hCaptured)         // (nothing is consumed by the failing call)
                     return fail(AAE_ERR_UNSUPPORTED, "more than %d f32x3h forwards live in HIP graphs on one encoder handle (aae_encoder_x3h_release_slot returns a destroyed graph's slot)", kX3hCaptured);
                 slot = kX3hRing + enc->x3h_captured++;

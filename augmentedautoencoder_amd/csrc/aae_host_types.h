@@ -83,7 +83,9 @@ struct aae_encoder {
     std::atomic<unsigned long long> x3h_seq{0};
     int x3h_captured = 0;                  // slots of the captured region handed out so far (under x3h_mu) ...
     std::vector<int> x3h_free;             // ... and the ones given back (aae_encoder_x3h_release_slot)
+    std::vector<hipEvent_t> x3h_release_ev; // per captured slot: recorded behind the flag clear of its release -- a slot is handed out again only once that clear has executed
     std::mutex x3h_mu;
+    std::mutex wino_mu;                    // guards the one-time preparation of the Winograd-domain weights (ensure_winograd_weights)
     std::vector<void*> allocations;
     std::vector<aae_host::KernelRecord> records;   // of the most recent completed forward (swapped in under rec_mu)
     std::mutex rec_mu;

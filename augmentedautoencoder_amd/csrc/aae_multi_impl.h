@@ -181,7 +181,7 @@ static bool multi_encoder_mid_groupable(const aae_encoder* enc, int n, std::vect
     if (n < 5 || nl < 2 || enc->winograd != 1 || enc->winograd_wide || !enc->multi_mid_group || runs_split(enc, n)) return false;
     for (size_t li = 1; li < nl; ++li) {
         const Layer& L = enc->layers[li];
-        if (L.kind != KIND_IGEMM || L.wino_geom < 0 || !L.wino[0]) return false;
+        if (L.kind != KIND_IGEMM || L.wino_geom < 0 || !L.wino[0]) return false;      // (the weights: prepared by aae_multi_workspace_bytes)
         if ((unsigned long long)n * L.H * L.W * L.Cin * sizeof(float) >= 0x7FFFFF00ull) return false;
     }
     sig.clear();
@@ -312,35 +312,29 @@ static int plan_multi(const aae_multi_item* items, int n_items, bool scan_only, 
 
 template <int KS, int C>
 static void launch_first_multi_t(const aae::ConvFirstMultiArgs& m, bool u8, bool vec4, dim3 grid, int smem, hipStream_t stream) {
-    if (u8 && vec4) {
-        (void)hipFuncSetAttribute((const void*)aae::conv_first_multi_kernel<KS, C, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        AAE_LAUNCH((aae::conv_first_multi_kernel<KS, C, true, true>), grid, dim3(256), smem, stream, m);
-    } else if (u8) {
-        (void)hipFuncSetAttribute((const void*)aae::conv_first_multi_kernel<KS, C, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        AAE_LAUNCH((aae::conv_first_multi_kernel<KS, C, true, false>), grid, dim3(256), smem, stream, m);
-    } else {
-        (void)hipFuncSetAttribute((const void*)aae::conv_first_multi_kernel<KS, C, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        AAE_LAUNCH((aae::conv_first_multi_kernel<KS, C, false, false>), grid, dim3(256), smem, stream, m);
-    }
+    // (the dynamic-LDS ceiling of every instantiation is raised ONCE per process, to the CU's 160 KB: not a runtime call per grouped frame)
+    static const bool once = ((void)hipFuncSetAttribute((const void*)aae::conv_first_multi_kernel<KS, C, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                              (void)hipFuncSetAttribute((const void*)aae::conv_first_multi_kernel<KS, C, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                              (void)hipFuncSetAttribute((const void*)aae::conv_first_multi_kernel<KS, C, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+    (void)once;
+    if (u8 && vec4) AAE_LAUNCH((aae::conv_first_multi_kernel<KS, C, true, true>), grid, dim3(256), smem, stream, m);
+    else if (u8) AAE_LAUNCH((aae::conv_first_multi_kernel<KS, C, true, false>), grid, dim3(256), smem, stream, m);
+    else AAE_LAUNCH((aae::conv_first_multi_kernel<KS, C, false, false>), grid, dim3(256), smem, stream, m);
 }
 
 template <int MT, int NT, bool SPREAD, int DEPTH = 2>
 static void launch_wavek_multi_t(const aae::ConvWaveKMultiArgs& m, int tag, int nblk, hipStream_t stream) {
     constexpr int smem = aae::conv_wavek_smem<MT, NT, 4>();
     // TAG only makes the symbol unique per encoder layer (separate rows in rocprofv3 --stats)
-    if (tag == 1) {
-        (void)hipFuncSetAttribute((const void*)aae::conv_wavek_multi_kernel<MT, NT, 4, DEPTH, 1, SPREAD>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        AAE_LAUNCH((aae::conv_wavek_multi_kernel<MT, NT, 4, DEPTH, 1, SPREAD>), dim3(nblk), dim3(256), smem, stream, m);
-    } else if (tag == 2) {
-        (void)hipFuncSetAttribute((const void*)aae::conv_wavek_multi_kernel<MT, NT, 4, DEPTH, 2, SPREAD>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        AAE_LAUNCH((aae::conv_wavek_multi_kernel<MT, NT, 4, DEPTH, 2, SPREAD>), dim3(nblk), dim3(256), smem, stream, m);
-    } else if (tag == 3) {
-        (void)hipFuncSetAttribute((const void*)aae::conv_wavek_multi_kernel<MT, NT, 4, DEPTH, 3, SPREAD>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        AAE_LAUNCH((aae::conv_wavek_multi_kernel<MT, NT, 4, DEPTH, 3, SPREAD>), dim3(nblk), dim3(256), smem, stream, m);
-    } else {
-        (void)hipFuncSetAttribute((const void*)aae::conv_wavek_multi_kernel<MT, NT, 4, DEPTH, 0, SPREAD>, hipFuncAttributeMaxDynamicSharedMemorySize, smem);
-        AAE_LAUNCH((aae::conv_wavek_multi_kernel<MT, NT, 4, DEPTH, 0, SPREAD>), dim3(nblk), dim3(256), smem, stream, m);
-    }
+    static const bool once = ((void)hipFuncSetAttribute((const void*)aae::conv_wavek_multi_kernel<MT, NT, 4, DEPTH, 0, SPREAD>, hipFuncAttributeMaxDynamicSharedMemorySize, smem),
+                              (void)hipFuncSetAttribute((const void*)aae::conv_wavek_multi_kernel<MT, NT, 4, DEPTH, 1, SPREAD>, hipFuncAttributeMaxDynamicSharedMemorySize, smem),
+                              (void)hipFuncSetAttribute((const void*)aae::conv_wavek_multi_kernel<MT, NT, 4, DEPTH, 2, SPREAD>, hipFuncAttributeMaxDynamicSharedMemorySize, smem),
+                              (void)hipFuncSetAttribute((const void*)aae::conv_wavek_multi_kernel<MT, NT, 4, DEPTH, 3, SPREAD>, hipFuncAttributeMaxDynamicSharedMemorySize, smem), true);
+    (void)once;
+    if (tag == 1) AAE_LAUNCH((aae::conv_wavek_multi_kernel<MT, NT, 4, DEPTH, 1, SPREAD>), dim3(nblk), dim3(256), smem, stream, m);
+    else if (tag == 2) AAE_LAUNCH((aae::conv_wavek_multi_kernel<MT, NT, 4, DEPTH, 2, SPREAD>), dim3(nblk), dim3(256), smem, stream, m);
+    else if (tag == 3) AAE_LAUNCH((aae::conv_wavek_multi_kernel<MT, NT, 4, DEPTH, 3, SPREAD>), dim3(nblk), dim3(256), smem, stream, m);
+    else AAE_LAUNCH((aae::conv_wavek_multi_kernel<MT, NT, 4, DEPTH, 0, SPREAD>), dim3(nblk), dim3(256), smem, stream, m);
 }
 
 // the scan of up to kMultiMax grouped items in one launch (z: the items' raw latent codes, rows in item order)
@@ -630,6 +624,11 @@ static int multi_impl(const aae_multi_item* items, int n_items, const void* x, i
 extern "C" {
 
 size_t aae_multi_workspace_bytes(const aae_multi_item* items, int n_items, int scan_only) {
+    // (the one place outside the hot calls that sees a frame's layout: objects that may join a mid-batch group get their Winograd weights here)
+    if (items && !scan_only)
+        for (int i = 0; i < n_items; ++i)
+            if (items[i].enc && items[i].n >= 5 && items[i].enc->winograd == 1 && items[i].enc->multi_mid_group &&
+                aae_host::ensure_winograd_weights(items[i].enc) != AAE_OK) return 0;
     aae_host::MultiPlan mp;
     if (aae_host::plan_multi(items, n_items, scan_only != 0, mp) != AAE_OK) return 0;
     return mp.total;

@@ -120,6 +120,7 @@ def share_workspaces(engines):
                     e._own_ws = e.ws
                 e.ws = pools[key]
                 pools[key].shared = True
+                pools[key].users = getattr(pools[key], 'users', 0) + 1
                 rebound.append(e)
         else:
             pools[key] = ws
@@ -127,12 +128,18 @@ def share_workspaces(engines):
 
 
 def unshare_workspaces(engines):
-    """undo share_workspaces for these engines: each gets the buffer it owned before"""
+    """undo share_workspaces for these engines: each gets the buffer it owned before; the pool owner's buffer stops being a
+    shared (one-stream) buffer once the last engine that borrowed it is gone"""
     for e in engines:
         own = getattr(e, '_own_ws', None)
         if own is not None:
+            pool = e.ws
             e.ws = own
             del e._own_ws
+            pool.users = max(0, getattr(pool, 'users', 1) - 1)
+            if pool.users == 0:                # only its owner is left: an ordinary single-engine buffer again (any stream may use it)
+                pool.shared = False
+                pool.stream = None
 
 
 class EncoderEngine(object):

@@ -86,9 +86,19 @@ def cpu_baseline(weights, E, crops, min_seconds=10.0, max_iters=60):
     d_n, t_n = run(lambda: nn(z64), 1.0, 50)
     one = sample[:1]
     encode(one)
-    d_1, t_1 = run(lambda: nn(encode(one)), 2.0, 400)
+    # B = 1 with the NN leg in torch too: one runtime, one thread pool -- what a single-runtime reference (TensorFlow) does per detection.
+    # (NumPy's BLAS pool behind torch's OpenMP pool costs 25+ ms of hand-over per call at B = 1: kept as ..._numpy_nn for the record)
+    E_t = torch.from_numpy(np.ascontiguousarray(E, dtype=np.float32))
+
+    def nn_torch(z):
+        zt = torch.from_numpy(np.ascontiguousarray(z, dtype=np.float32))
+        zn = zt / zt.norm(dim=1, keepdim=True).clamp_min(1e-12)
+        return torch.argmax(zn @ E_t.T, dim=1)
+    nn_torch(z64[:1])
+    d_1, t_1 = run(lambda: nn_torch(encode(one)), 2.0, 400)
     d_1e, t_1e = run(lambda: encode(one), 1.0, 400)
-    d_1n, t_1n = run(lambda: nn(z64[:1]), 0.7, 400)
+    d_1n, t_1n = run(lambda: nn_torch(z64[:1]), 0.7, 400)
+    d_1x, t_1x = run(lambda: nn(encode(one)), 1.0, 100)
     model = 'unknown'
     try:
         with open('/proc/cpuinfo') as f:
@@ -102,9 +112,10 @@ def cpu_baseline(weights, E, crops, min_seconds=10.0, max_iters=60):
                     'nn_only_crops_per_s': round(d_n * 64 / t_n, 1)},
             'B1': {'encode+nn_crops_per_s': round(d_1 / t_1, 2), 'encode+nn_ms': round(t_1 / d_1 * 1e3, 2),
                    'encode_only_ms': round(t_1e / d_1e * 1e3, 2), 'nn_only_ms': round(t_1n / d_1n * 1e3, 2),
-                   'note': "the reference's operating point: one session.run + np.argmax per detection.  encode+nn alternates between torch's OpenMP pool and "
-                           "NumPy's BLAS pool every call and pays for it (it costs more than the sum of its parts); a single-runtime reference (TensorFlow) "
-                           "would sit near encode_only_ms + nn_only_ms"},
+                   'encode+nn_ms_numpy_nn': round(t_1x / d_1x * 1e3, 2),
+                   'note': "the reference's operating point: one session.run + arg-max per detection, encoder AND codebook matmul in one runtime (torch-CPU, one "
+                           "thread pool).  ..._numpy_nn: the same with the matmul in NumPy -- alternating between torch's OpenMP pool and NumPy's BLAS pool every call "
+                           "costs more than the sum of the parts (an artefact of mixing runtimes, not of the reference)"},
             'host': {'cpu_model': model, 'logical_cpus': os.cpu_count(),
                      'note': 'threads = best point of a sweep (8..256) on this host; more threads are slower'}}
 
@@ -179,9 +190,10 @@ def main():
     ap.add_argument('--profile-steps', type=int, default=5, help='instrumented per-kernel timing passes after the timed region')
     ap.add_argument('--force-dist', action='store_true',
                     help='initialise the RCCL process group and take the multi-GPU code path (pair packing, all_gather, config4) even at world size 1')
-    ap.add_argument('--full-extras', action='store_true',
-                    help='also time config3 at the reference batch size 64 (kept out of the default run: those launches share the kernel '
-                         'symbols of the headline batch and would blur the rocprofv3 --stats averages of the same command)')
+    ap.add_argument('--full-extras', action='store_true', help='(kept for old command lines: config3 at batch 64 is part of the default run since round 6)')
+    ap.add_argument('--no-config3-b64', action='store_true',
+                    help='skip config3 at the reference batch size 64 (profiling runs: those launches share the kernel symbols of the headline batch '
+                         'and blur the per-symbol averages of rocprofv3 --stats)')
     ap.add_argument('--enc-opt', action='append', default=[], metavar='NAME=INT',
                     help='set an encoder option before measuring (kernel-variant A/B under a profiler); recorded in config')
     ap.add_argument('--no-extras', action='store_true', help='skip the secondary measurements (latency, scan, config3, config5, pcie, decoder)')
@@ -598,7 +610,7 @@ def main():
         del E5
         # ---- BASELINE config 3: ae_embed -- encode 92232 views (codebook.py:190-219), encoder only, inputs resident
         c3 = {}
-        for bs in ((64, 256) if args.full_extras else (256,)):
+        for bs in ((256,) if args.no_config3_b64 else (64, 256)):
             bs = min(bs, B)
             xb = x[:bs].contiguous()
             nb = -(-N_ROWS // bs)
@@ -610,8 +622,8 @@ def main():
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             c3['batch%d' % bs] = {'seconds': round(dt, 3), 'crops_per_s': round(nb * bs / dt, 1), 'batches': nb}
-        c3['note'] = ('92232 synthetic views in batches of 256, fp32, the float64 normalise on the host is not timed; the reference batch size 64 '
-                      '(train_template.cfg:61) is timed with --full-extras: 31.6 k crops/s = 2.92 s (profiles/r09)')
+        c3['note'] = ('92232 synthetic views, fp32, the float64 normalise on the host is not timed; batch64 = the reference batch size '
+                      '(train_template.cfg:61), batch256 = the headline batch')
         extras['config3'] = c3
         # ---- PCIe-inclusive: host uint8 batches, H2D of batch i+1 overlapped with compute of batch i
         host = [synth.make_crops(B, seed=100 + i) for i in range(4)]

@@ -425,6 +425,9 @@ inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 struct hipEvent_emu {};
 typedef hipEvent_emu* hipEvent_t;
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = new hipEvent_emu; return hipSuccess; }
+constexpr unsigned hipEventDisableTiming = 2;
+inline hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { *e = new hipEvent_emu; return hipSuccess; }
+inline hipError_t hipEventQuery(hipEvent_t) { return hipSuccess; }      // (launches run to completion inside the call)
 inline hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }
 inline hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }

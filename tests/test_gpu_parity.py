@@ -4,8 +4,9 @@ box with `pytest -m gpu`.
 
 Tolerances (BASELINE.json north_star): rotation index bit-exact, cosine within
 1e-5 (fp32).  Index equality is tie-aware: a differing index is accepted only
-where the fp64 oracle's top-2 gap is below GAP_TOL (structural near-ties exist
-in every codebook: rows 36k and 36k+35 are the same rotation)."""
+where the fp64 oracle's top-2 gap is below GAP_TOL = 2e-6 (SURVEY section 8c's figure;
+structural ties exist in every codebook -- rows 36k and 36k+35 are the same
+rotation, identical rows, gap 0)."""
 import numpy as np
 import pytest
 
@@ -21,8 +22,10 @@ EXPERIMENTS = experiments_loaded()
 OLD_FAMILY = ('wavek', 'wavek_dense', 'gemv_ticket') if EXPERIMENTS else ('wavek', 'wavek_dense', 'dense_gemv')     # options that send small batches to the 128 x 128 split-K igemm + reduce launches
 
 COS_TOL = 1e-5
-GAP_TOL = 2e-5          # 2 x COS_TOL: the hard bound -- a differing index above this gap fails
-STRICT_GAP_TOL = 2e-6   # SURVEY 8c's figure: flips between the two are counted and reported (parity_report.json)
+GAP_TOL = 2e-6          # SURVEY 8c's figure, the failing bound since round 6 (rounds 1-5: 2e-5 failing, 2e-6 reported -- 0 flips at any gap in five rounds):
+STRICT_GAP_TOL = GAP_TOL   # a differing index where the fp64 oracle's own top-2 gap is >= 2e-6 fails; every flip below it is counted in parity_report.json
+BF16_GAP_TOL = 1e-5     # bf16 codebooks: scores come from two-term bf16 queries on the bf16 matrix cores (error bound 3.8e-6, codebook_scan_bf16.h): index / top-k
+                        # differences are accepted below ~2.5 x that bound
 STRIDES = [2, 2, 2, 2]
 
 
@@ -43,22 +46,22 @@ def default_model():
     return weights, enc, cb, E, dataset
 
 
-def _check_indices(got, cs64, upright_stride=1, where=''):
+def _check_indices(got, cs64, upright_stride=1, where='', gap_tol=None):
     """Tie-aware index equality against the fp64 oracle's similarity.  A differing index FAILS when the oracle's own
-    top-2 gap is >= GAP_TOL (2e-5); differences below that are counted at both thresholds -- SURVEY 8c's 2e-6 and the
-    hard bound -- and land in gpurun_out/parity_report.json (tests/parity_report.py), with a warning when one sits
-    between the two."""
+    top-2 gap is >= GAP_TOL (2e-6); differences below that (identical rows: the structural duplicates 36k / 36k+35
+    and the planted ones) are counted and land in gpurun_out/parity_report.json (tests/parity_report.py)."""
+    gap_tol = GAP_TOL if gap_tol is None else gap_tol           # (bf16 codebooks: the two-term bf16 query carries a proven 3.8e-6 score bound -- BF16_GAP_TOL)
     cs = cs64[:, ::upright_stride]
     want = np.argmax(cs, axis=1) * upright_stride
     part = np.partition(cs, cs.shape[1] - 2, axis=1)
     gap = part[:, -1] - part[:, -2]
     got = np.asarray(got).reshape(-1)
     diff = np.flatnonzero(got != want)
-    bad = [(int(b), int(got[b]), int(want[b]), float(gap[b])) for b in diff if gap[b] >= GAP_TOL]
+    bad = [(int(b), int(got[b]), int(want[b]), float(gap[b])) for b in diff if gap[b] >= gap_tol]
     assert not bad, 'index mismatch outside near-ties (b, got, want, gap): %s' % bad[:5]
     # a flipped answer must itself be a (near-)maximum of the oracle's row
     for b in diff:
-        assert cs64[b, got[b]] >= cs64[b, want[b]] - GAP_TOL and got[b] % upright_stride == 0
+        assert cs64[b, got[b]] >= cs64[b, want[b]] - gap_tol and got[b] % upright_stride == 0
     loose = int(np.sum(gap[diff] >= STRICT_GAP_TOL))
     report.record('indices', where or report.current_test(), queries=int(len(want)), stride=int(upright_stride), flips=int(len(diff)),
                   flips_with_gap_above_2e6=loose, min_gap=float(gap.min()), median_gap=float(np.median(gap)))
@@ -68,9 +71,10 @@ def _check_indices(got, cs64, upright_stride=1, where=''):
     return int(len(diff))
 
 
-def _check_topk(got, cs64, k, where=''):
+def _check_topk(got, cs64, k, where='', gap_tol=None):
     """Tie-aware top-k equality: the oracle's canonical list (descending score, lowest row among equals) position by
     position, a different row accepted only where its fp64 score is within GAP_TOL of the wanted one."""
+    gap_tol = GAP_TOL if gap_tol is None else gap_tol
     got = np.asarray(got).reshape(len(cs64), k)
     want = ref.topk_canonical(cs64, k)
     swaps = 0
@@ -80,7 +84,7 @@ def _check_topk(got, cs64, k, where=''):
             if got[b, j] != want[b, j]:
                 swaps += 1
                 d = abs(float(cs64[b, got[b, j]]) - float(cs64[b, want[b, j]]))
-                assert d < GAP_TOL, 'top-%d position %d of query %d: got row %d, oracle row %d, fp64 scores differ by %.3e' % (k, j, b, got[b, j], want[b, j], d)
+                assert d < gap_tol, 'top-%d position %d of query %d: got row %d, oracle row %d, fp64 scores differ by %.3e' % (k, j, b, got[b, j], want[b, j], d)
     report.record('topk', where or report.current_test(), queries=int(len(cs64)), k=int(k), swapped_positions=int(swaps))
     return swaps
 
@@ -632,13 +636,13 @@ def test_config5_large_bf16_codebook_topk():
     cs64 = ref.cos_similarity(z[:Bo], Eb)
     cs = cb.similarity(z[:Bo]).cpu().numpy()
     assert np.abs(cs - cs64).max() <= COS_TOL
-    _check_indices(idx1[:Bo], cs64)
+    _check_indices(idx1[:Bo], cs64, gap_tol=BF16_GAP_TOL)
     assert np.abs(sc1[:Bo] - cs64.max(axis=1)).max() <= COS_TOL
     want = ref.topk_canonical(cs64, K)
     for b in range(Bo):                                        # tie-aware: equal sets unless fp64 gaps are tiny
         if not np.array_equal(idxk[b], want[b]):
             s = np.sort(cs64[b])[::-1][:K + 1]
-            assert np.min(-np.diff(s)) < GAP_TOL, (b, idxk[b], want[b])
+            assert np.min(-np.diff(s)) < BF16_GAP_TOL, (b, idxk[b], want[b])
     assert np.array_equal(idxk[:Bo], ref.topk_canonical(cs, K))   # exact w.r.t. the kernel's own scores
     up, _ = cb.nn(z[:Bo], 1, 36)
     assert np.array_equal(up[:, 0].cpu().numpy(), ref.nearest_indices_reference(cs, 1, upright=True, num_cyclo=36))

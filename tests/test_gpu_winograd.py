@@ -117,7 +117,7 @@ def test_full_query_answers_match_the_fp64_oracle():
     assert np.abs(score - cs64.max(axis=1)).max() <= 1e-5
     top2 = np.sort(cs64, axis=1)[:, -2:]
     for i in range(B):      # index equal to the oracle's except on the oracle's own near-ties (rows 36 k and 36 k + 35 are the same rotation)
-        assert idx[i] == cs64[i].argmax() or top2[i, 1] - top2[i, 0] < 2e-5 or cs64[i, idx[i]] >= top2[i, 1] - 2e-5, i
+        assert idx[i] == cs64[i].argmax() or top2[i, 1] - top2[i, 0] < 2e-6 or cs64[i, idx[i]] >= top2[i, 1] - 2e-6, i     # (SURVEY 8c's gap)
     enc.close()
     cb.close()
 

@@ -308,7 +308,7 @@ def test_process_on_gpu_full_size_two_objects():
         srt = np.sort(cs64[0])
         R, t = ref.auto_pose6d_geometry(idx, ds.viewsphere_for_embedding, bbs.astype(np.int32), bb, camK, K_train, 700.0)
         assert g.name == c
-        if srt[-1] - srt[-2] >= 2e-5:                       # away from near-ties the whole pose must agree
+        if srt[-1] - srt[-2] >= 2e-6:                       # away from near-ties (SURVEY 8c's gap) the whole pose must agree
             assert np.allclose(g.trafo[:3, :3], R.squeeze(), atol=1e-9) and np.allclose(g.trafo[:3, 3], t.squeeze(), atol=1e-6)
 
 

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Per-kernel averages of rocprofv3 --pmc counter_collection CSVs (one directory per pass, as
-tools/gpu_pmc.sh writes them) + the derived figures DESIGN.md quotes:
+tools/gpu_run.sh, steps pmc_bench / prof:..., writes them) + the derived figures DESIGN.md quotes:
   hbm_bytes  = 2 * FETCH_SIZE_KB * 1024 ... see below (gfx950 correction of MI355X_MICROARCH.md:
                FETCH_SIZE counts 64-B units reported in KB of 32 B -> x2; WRITE_SIZE as is)
   mfma_busy  = SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMD-cycles per CU-cycle basis) relative to GRBM_GUI_ACTIVE
@@ -24,7 +24,7 @@ def main():
     out_json = sys.argv[sys.argv.index('--json') + 1] if '--json' in sys.argv else None
     acc = defaultdict(lambda: defaultdict(list))        # kernel -> counter -> [per-dispatch values]
     dur = defaultdict(list)
-    for path in sorted(glob.glob(os.path.join(root, 'pmc*', '*counter_collection.csv'))):
+    for path in sorted(glob.glob(os.path.join(root, '*pmc[0-9]*', '**', '*counter_collection.csv'), recursive=True)):
         with open(path) as f:
             for row in csv.DictReader(f):
                 k = short(row['Kernel_Name'])

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""The HBM-bound and per-detection launches in ONE process, for rocprofv3 passes (tools/gpu_pmc_small.sh):
+"""The HBM-bound and per-detection launches in ONE process, for rocprofv3 passes (tools/gpu_run.sh prof:small:python,tools/prof_mix.py):
   * fused encode+nn (aae_encode_nn) at B = 1 and B = 4 -- the reference's per-detection operating point
     (m3_interface/ae_pose_estimator.py:143-170);
   * the stand-alone codebook query at B = 1, warm (one codebook) and cold (8 copies visited in turn, 378 MB);
