@@ -480,10 +480,14 @@ int aae_codebook_create(const void* E, int N, int J, int dtype, int src_is_devic
         if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && cus > 0) cb->cu_count = cus;
     }
     const size_t bytes = (size_t)N * J * (dtype == AAE_DTYPE_BF16 ? 2 : 4);
+    // the rows start on a 2 MB boundary: a B <= 4 query streams the whole codebook in ~10 us and every block touches its 64 KB at once -- the
+    // period moved by 10-20 % with where the allocation happened to land (profiles/r15/scan_identical_library_copies.jsonl)
+    constexpr size_t kCodebookAlign = 2u << 20;
     void* p = nullptr;
-    hipError_t e = hipMalloc(&p, bytes);
+    hipError_t e = hipMalloc(&p, bytes + kCodebookAlign);
     if (e != hipSuccess) { delete cb; return fail(AAE_ERR_RUNTIME, "hipMalloc(codebook): %s", hipGetErrorString(e)); }
-    cb->E = static_cast<float*>(p);
+    cb->E_alloc = p;
+    cb->E = reinterpret_cast<float*>(((uintptr_t)p + kCodebookAlign - 1) & ~(uintptr_t)(kCodebookAlign - 1));
     e = hipMemcpy(cb->E, E, bytes, src_is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice);
     if (e != hipSuccess) { aae_codebook_destroy(cb); return fail(AAE_ERR_RUNTIME, "hipMemcpy(codebook): %s", hipGetErrorString(e)); }
     *out = cb;
@@ -545,7 +549,8 @@ int aae_codebook_update(aae_codebook* cb, const void* E, int src_is_device, void
 void aae_codebook_destroy(aae_codebook* cb) {
     if (!cb) return;
     for (auto& c : cb->upright_copies) aae_codebook_destroy(c.second);
-    if (cb->E) (void)hipFree(cb->E);
+    if (cb->E_alloc) (void)hipFree(cb->E_alloc);
+    else if (cb->E) (void)hipFree(cb->E);
     delete cb;
 }
 

@@ -176,6 +176,7 @@ struct aae_encoder {
 
 struct aae_codebook {
     float* E = nullptr;    // device [N][J] (fp32 codebook), or the bf16 rows when dtype == AAE_DTYPE_BF16
+    void* E_alloc = nullptr;   // the allocation E lies in (E is aligned up to kCodebookAlign inside it)
     int dtype = AAE_DTYPE_F32;
     int N = 0, J = 0;
     int scan_mode = AAE_SCAN_AUTO;

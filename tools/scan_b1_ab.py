@@ -7,7 +7,10 @@ period drifted 10.5 -> 12.7 -> 14.3 us over the closing runs of rounds 4 / 5 wit
 Every library is loaded into THIS process (ctypes; torch owns the device memory), gets its own codebook handle over the same 92232 x 128
 fp32 rows and the same query, and is timed with ITS OWN aae_codebook_nn_timed (queries queued back to back from C between two HIP events:
 the kernel period, no per-call host cost) at B = 1, 2, 4 -- round-robin over the libraries, `rounds` times, so that clock / thermal drift
-of the box hits all of them alike.  One JSON line per (round, library); a summary line per library at the end (median / min / max)."""
+of the box hits all of them alike.  One JSON line per (round, library); a summary line per library at the end (median / min / max).
+--handles=H: H codebook handles per library, created interleaved across the libraries (WHERE a handle's 47 MB land moves the period by 10-20 %
+-- three byte-identical copies of one library gave 12.2 / 13.0 / 13.2 us, each stable: profiles/r15/scan_identical_library_copies.jsonl -- so
+builds are compared by their median over several placements)."""
 import ctypes
 import json
 import os
@@ -45,16 +48,17 @@ def main():
     idx = torch.empty(4, dtype=torch.int64, device=dev)
     score = torch.empty(4, dtype=torch.float32, device=dev)
     builds = []
-    for a in args:
-        tag, path = a.split('=', 1)
-        lib = load(path)
-        h = ctypes.c_void_p()
-        rc = lib.aae_codebook_create(E.ctypes.data, 92232, 128, 1, 0, ctypes.byref(h))    # (dtype 1 = AAE_DTYPE_F32, host source)
-        if rc:
-            raise RuntimeError('%s: aae_codebook_create rc=%d %s' % (tag, rc, lib.aae_last_error()))
-        nbytes = max(int(lib.aae_codebook_workspace_bytes(h, b, 1)) for b in (1, 2, 4))
-        ws = torch.zeros(nbytes + 256, dtype=torch.uint8, device=dev)
-        builds.append((tag, path, lib, h, ws, nbytes))
+    nh = int(opts.get('handles', 1))
+    libs = [(a.split('=', 1)[0], a.split('=', 1)[1], load(a.split('=', 1)[1])) for a in args]
+    for k in range(nh):
+        for tag, path, lib in libs:
+            h = ctypes.c_void_p()
+            rc = lib.aae_codebook_create(E.ctypes.data, 92232, 128, 1, 0, ctypes.byref(h))    # (dtype 1 = AAE_DTYPE_F32, host source)
+            if rc:
+                raise RuntimeError('%s: aae_codebook_create rc=%d %s' % (tag, rc, lib.aae_last_error()))
+            nbytes = max(int(lib.aae_codebook_workspace_bytes(h, b, 1)) for b in (1, 2, 4))
+            ws = torch.zeros(nbytes + 256, dtype=torch.uint8, device=dev)
+            builds.append((tag if nh == 1 else '%s#%d' % (tag, k), path, lib, h, ws, nbytes))
     stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
     samples = {tag: {1: [], 2: [], 4: []} for tag, *_ in builds}
 
@@ -84,6 +88,13 @@ def main():
             out['B%d_kernel_period_us' % B] = {'median': round(float(np.median(v)), 3), 'min': round(float(v.min()), 3), 'max': round(float(v.max()), 3)}
         out['B1_frac_of_8TBps'] = round(92232 * 128 * 4 / (float(np.median(samples[tag][1])) * 1e-6) / 8e12, 3)
         print(json.dumps(out), flush=True)
+    if nh > 1:
+        for tag, path, lib in libs:
+            out = {'what': 'scan_b1_ab_by_build', 'build': tag, 'library': path, 'handles': nh}
+            for B in (1, 2, 4):
+                med = np.asarray([np.median(samples['%s#%d' % (tag, k)][B]) for k in range(nh)])
+                out['B%d_kernel_period_us_over_handles' % B] = {'median': round(float(np.median(med)), 3), 'min': round(float(med.min()), 3), 'max': round(float(med.max()), 3)}
+            print(json.dumps(out), flush=True)
     for tag, path, lib, h, ws, nbytes in builds:
         lib.aae_codebook_destroy(h)
 
