@@ -614,7 +614,7 @@ static int nn_impl(aae_codebook* cb, const float* z, int B, int topk, int col_st
     ScanTicketOut fin;
     fin.idx_out = idx_out; fin.score_out = score_out; fin.idx_scale = idx_scale; fin.nonce = prepared_nonce;
     // (opt-in, AAE_SCAN_AUTO_FIN: the same for the query-resident scan of at most 32 queries -- one row of row blocks)
-    const bool resident_fin = topk == 1 && cb->scan_resident_fin && s.resident_ok && s.res_rh == 4 && col_stride == 1;
+    const bool resident_fin = topk == 1 && cb->scan_resident_fin && s.resident_ok && ceil_div(s.Bpad, 256 / s.res_rh) == 1 && col_stride == 1;
     const bool one_launch = topk == 1 && ((s.stream && cb->scan_ticket != 0) || resident_fin);
     if (int rc = run_scan(cb, z, B, col_stride, cs, s, base, stream, &partial_rows, one_launch ? &fin : nullptr, s.topk_fused ? topk : 1)) return rc;
     if (one_launch) return AAE_OK;

@@ -203,7 +203,7 @@ static int run_scan(aae_codebook* cb, const float* z, int B, int col_stride, flo
     const bool resident = s.resident_ok && cs_out == nullptr && col_stride == 1;
     if (partial_rows) *partial_rows = resident ? s.res_blocks : s.nblk;
     // arg-max on the query-resident kernel: the scan normalises the queries itself (no l2norm_pack launch in front)
-    const ScanTicketOut* rfin = (resident && topk == 1 && s.res_rh == 4) ? fin : nullptr;     // (nn_impl passes fin for these only when the mode asks)
+    const ScanTicketOut* rfin = (resident && topk == 1 && !s.stream) ? fin : nullptr;          // (nn_impl passes fin for these only when the mode asks and the grid is one column of row blocks)
     if (resident && topk == 1 && cb->scan_fused_norm && ((uintptr_t)z & 15) == 0) return launch_scan_resident(cb, nullptr, B, s, base, stream, 1, z, rfin);
     if (cb->dtype == AAE_DTYPE_BF16 && s.stream) {
         aae::ScanArgs a;

@@ -11,6 +11,7 @@
 
 #include "device_intrinsics.h"
 #include "kernels/tile_f32.h"
+#include "kernels/multi_launch.h"
 #include "kernels/codebook_scan_f32.h"
 #include "kernels/codebook_scan_bf16.h"
 #include "kernels/codebook_scan_resident.h"
@@ -42,17 +43,18 @@ static int run(const char* what, int N, int B, const void* E, const void* qp, fl
 #endif
     const int pw = aae::kPruneReplicas * a.Bpad * aae::kPruneGroups;
     CHECK(hipFuncSetAttribute((const void*)aae::scan_resident_kernel<true, K, RH>, hipFuncAttributeMaxDynamicSharedMemorySize, aae::scan_resident_smem<true, RH>()));
+    const int smem = aae::scan_resident_smem<true, RH>();
     hipEvent_t e0, e1;
     CHECK(hipEventCreate(&e0)); CHECK(hipEventCreate(&e1));
     const int reps = 50;
     for (int w = 0; w < 5; ++w) {
         if (prune) hipLaunchKernelGGL(reset_prune, dim3((pw + 255) / 256), dim3(256), 0, 0, prune, pw);
-        hipLaunchKernelGGL((aae::scan_resident_kernel<true, K, RH>), dim3(gx, chunks), dim3(aae::kScanResidentThreads), aae::scan_resident_smem<true, RH>(), 0, a);
+        hipLaunchKernelGGL((aae::scan_resident_kernel<true, K, RH>), dim3(gx, chunks), dim3(aae::kScanResidentThreads), smem, 0, a);
     }
     CHECK(hipEventRecord(e0, 0));
     for (int r = 0; r < reps; ++r) {
         if (prune) hipLaunchKernelGGL(reset_prune, dim3((pw + 255) / 256), dim3(256), 0, 0, prune, pw);
-        hipLaunchKernelGGL((aae::scan_resident_kernel<true, K, RH>), dim3(gx, chunks), dim3(aae::kScanResidentThreads), aae::scan_resident_smem<true, RH>(), 0, a);
+        hipLaunchKernelGGL((aae::scan_resident_kernel<true, K, RH>), dim3(gx, chunks), dim3(aae::kScanResidentThreads), smem, 0, a);
     }
     CHECK(hipEventRecord(e1, 0));
     CHECK(hipEventSynchronize(e1));

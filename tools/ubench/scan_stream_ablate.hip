@@ -9,6 +9,7 @@
 
 #include "device_intrinsics.h"
 #include "kernels/tile_f32.h"
+#include "kernels/multi_launch.h"
 #include "kernels/codebook_scan_f32.h"
 
 #define CHECK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e)); return 1; } } while (0)
