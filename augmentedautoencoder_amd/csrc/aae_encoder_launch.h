@@ -631,9 +631,10 @@ static bool winograd_rule(const aae_encoder* enc, const Layer& L, int B) {
     const unsigned long long x_bytes = (unsigned long long)B * L.H * L.W * L.Cin * sizeof(float);
     if (x_bytes >= 0x7FFFFF00ull) return false;
     // A launch costs WHOLE rounds of blocks (one block per compute unit at a time: 121-131 KB of LDS), and a block-slot of the Winograd form
-    // costs 0.6-0.7 of what the direct kernels need for the same outputs (tools/wino_ab.py, profiles/r14/winograd_vs_direct_*.jsonl): a layer
-    // gains when its blocks fill at least winograd_min_fill_pct (68) per cent of the rounds they occupy -- default net: conv2 from B = 11,
-    // conv3 from 22, conv4 (four images per block) from 85, and e.g. not conv3 at B = 33 ... 43 (a second round for a few blocks)
+    // costs 0.55-0.6 of what the direct kernels need for the same outputs (tools/wino_ab.py, profiles/r15/winograd_vs_direct_every_layer_forced.jsonl:
+    // direct / Winograd = 1.65-1.85 at full rounds, 1.0 where the blocks fill half of the rounds they occupy): a layer gains when its blocks
+    // fill at least winograd_min_fill_pct (56) per cent of their rounds -- default net: conv2 from B = 9, conv3 from 18, conv4 (four images
+    // per block) from 69, and e.g. not conv3 at B = 33 ... 35 or conv4 at B = 129 ... 140 (a new round for a few blocks)
     const long long blocks = (long long)(L.Cout / 64) * (L.wino_geom == 0 ? (long long)(L.Ho / 16) * (L.Wo / 16) * B : (long long)ceil_div(B, 4));
     if (enc->winograd_min_blocks > 0) return blocks >= enc->winograd_min_blocks;
     const long long cus = wavek_round_blocks(enc), rounds = (blocks + cus - 1) / cus;

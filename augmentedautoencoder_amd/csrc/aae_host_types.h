@@ -97,7 +97,7 @@ struct aae_encoder {
                                            // results differ from the direct kernels by fp32 rounding: conv_winograd_f32.h) for batches >= winograd_min_batch
     int winograd_wide = 0;                 // 1: blocks of 4 waves, each over both 32-channel halves (one wave per SIMD) instead of 8 waves (two per SIMD)
     int winograd_min_batch = 8;            // ... and layers whose blocks (64 tiles x 64 channels each) fill at least winograd_min_fill_pct per cent of the
-    int winograd_min_fill_pct = 68;        // rounds of blocks they occupy (runs_winograd); winograd_min_blocks > 0 replaces that rule by a plain
+    int winograd_min_fill_pct = 56;        // rounds of blocks they occupy (runs_winograd: break-even measured at 0.50-0.56, profiles/r15); winograd_min_blocks > 0 replaces that rule by a plain
     int winograd_min_blocks = 0;           // block count (tests, A/B)
     int multi_mid_group = 1;               // grouped multi-object query: objects with 5 or more detections each share ONE Winograd launch per conv layer where the GROUP's blocks fill
                                            // the rounds they occupy (aae_multi_impl.h); 0 = such objects one after the other

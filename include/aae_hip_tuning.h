@@ -45,8 +45,11 @@
  *   [experiments] "igemm_dma" (1), "igemm_breg" (1), "x3h_dma" (1): 0 = the register-staged operand paths (bit-identical, slower)
  *   [experiments] "x3h_wide_min_blocks" (0): > 0 = 256 x 128 f32x3h tiles (measured neutral)
  * polyphase Winograd conv layers (conv_winograd_f32.h; "winograd" itself: include/aae_hip.h)
- *   "winograd_min_batch" (8), "winograd_min_fill_pct" (68): a layer takes the Winograd form when its 64-tile x 64-channel blocks fill at least
+ *   "winograd_min_batch" (8), "winograd_min_fill_pct" (56): a layer takes the Winograd form when its 64-tile x 64-channel blocks fill at least
  *                        this share of the rounds of blocks (one per compute unit) they occupy; "winograd_min_blocks" (0): > 0 = a plain block count instead
+ *   "winograd_xcd_cols" (-1): 64-column blocks of a window region that share an XCD (-1 = per layer: all of them up to four; 0 = plain block order)
+ *   "multi_mid_group" (1): aae_encode_nn_multi -- objects with 5 or more detections share one Winograd launch per conv layer when together they fill
+ *                        the chip; 0 = such objects one after the other
  *   [experiments] "winograd" = 2: one launch per polyphase component, the components adding up in the output buffer (2 % slower than the
  *                        one-launch form); "winograd_wide" (0): blocks of 4 waves over both 32-channel halves, one wave per SIMD (13 % slower)
  * small and mid batches (wave-split-K implicit GEMM, conv_wavek_f32.h; the planner: aae_encoder_plan.h)

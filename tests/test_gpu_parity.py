@@ -921,7 +921,7 @@ def test_small_batch_wave_split_k_path_matches_fp64_oracle(default_model, B, cha
         assert all(':conv_wavek_f32_' in l for l in labels[1:4]), labels
         if B == 3:
             assert any('_g1t' in l for l in labels[1:4]), labels
-    else:                                                       # B >= 5: family and tile shape per layer by the planner's cost model (conv2 from B = 11: the Winograd form)
+    else:                                                       # B >= 5: family and tile shape per layer by the planner's cost model (conv2 from B = 9: the Winograd form)
         assert all((':conv_wavek_f32_' in l) or (':conv_igemm_f32' in l) or (':conv_wino_f32' in l) or l.endswith(':splitk_reduce') for l in labels[1:-1]), labels
         # (the dense layer: the GEMV up to B = 8 -- the 8-row form of its block --, the wave-split-K tile beyond)
         assert labels[-1].startswith('dense:dense_gemv_f32_ticket' if B <= 8 else 'dense:conv_wavek_f32_'), labels
