@@ -7,6 +7,7 @@
 #   bench_rocprof              the default bench command under rocprofv3 --kernel-trace --stats (kernel_stats CSV kept, big traces dropped)
 #   pmc_bench                  the six PMC passes (each its own run, --kernel-trace only, as the pool requires) of the headline step + pmc_summary
 #   prof:<name>:<cmd>          rocprofv3 stats + the six PMC passes of an arbitrary command (commas stand for spaces) -> <name>_trace/, <name>_pmc*/
+#   stats:<name>:<cmd>         rocprofv3 --kernel-trace --stats of an arbitrary command + per-symbol durations / gaps (tools/trace_gaps.py)
 #   run:<binary>:<args>        build/<binary> with comma-separated args                                   -> <binary>.jsonl
 #   py:<out>:<script>:<args>   python tools/<script> with comma-separated args                            -> <out>
 #   env:<NAME=VALUE>           export for the following steps
@@ -50,6 +51,11 @@ for step in "$@"; do
                   cut -c1-170 $(find $OUT/trace -name "*kernel_stats.csv" | head -1) | head -14 ;;
     pmc_bench)    prof bench python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --profile-steps 1 ;;
     prof:*)       name=$(echo $step | cut -d: -f2); cmd=$(echo $step | cut -d: -f3- | tr ',' ' '); prof $name $cmd ;;
+    stats:*)      name=$(echo $step | cut -d: -f2); cmd=$(echo $step | cut -d: -f3- | tr ',' ' ')
+                  ( cd /tmp; timeout -s KILL 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${name}_trace -o $name -- $cmd > $OUT/${name}_trace.log 2>&1 )
+                  python $ROOT/tools/trace_gaps.py $OUT/${name}_trace > $OUT/${name}_kernel_durations.txt 2>&1
+                  find $OUT/${name}_trace -name "*kernel_trace.csv" -size +8M -delete
+                  cut -c1-170 $(find $OUT/${name}_trace -name "*kernel_stats.csv" | head -1) | head -14 ;;
     run:*)        bin=$(echo $step | cut -d: -f2); args=$(echo $step | cut -d: -f3 | tr ',' ' ')
                   timeout -s KILL 300 ./build/$bin $args > $OUT/$bin.jsonl 2>&1; echo "$bin rc=$?" ;;
     py:*)         out=$(echo $step | cut -d: -f2); script=$(echo $step | cut -d: -f3); args=$(echo $step | cut -d: -f4- | tr ',' ' ')
