@@ -322,6 +322,18 @@ static void launch_first_multi_t(const aae::ConvFirstMultiArgs& m, bool u8, bool
     else AAE_LAUNCH((aae::conv_first_multi_kernel<KS, C, false, false>), grid, dim3(256), smem, stream, m);
 }
 
+// whole-tile form of the grouped conv1 (mid-batch groups): no ticket preparation blocks, grid.z = 1
+template <int KS, int C>
+static void launch_first_multi_tiles_t(const aae::ConvFirstMultiArgs& m, bool u8, bool vec4, dim3 grid, int smem, hipStream_t stream) {
+    static const bool once = ((void)hipFuncSetAttribute((const void*)aae::conv_first_multi_kernel<KS, C, true, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                              (void)hipFuncSetAttribute((const void*)aae::conv_first_multi_kernel<KS, C, true, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024),
+                              (void)hipFuncSetAttribute((const void*)aae::conv_first_multi_kernel<KS, C, false, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024), true);
+    (void)once;
+    if (u8 && vec4) AAE_LAUNCH((aae::conv_first_multi_kernel<KS, C, true, true, false>), grid, dim3(256), smem, stream, m);
+    else if (u8) AAE_LAUNCH((aae::conv_first_multi_kernel<KS, C, true, false, false>), grid, dim3(256), smem, stream, m);
+    else AAE_LAUNCH((aae::conv_first_multi_kernel<KS, C, false, false, false>), grid, dim3(256), smem, stream, m);
+}
+
 template <int MT, int NT, bool SPREAD, int DEPTH = 2>
 static void launch_wavek_multi_t(const aae::ConvWaveKMultiArgs& m, int tag, int nblk, hipStream_t stream) {
     constexpr int smem = aae::conv_wavek_smem<MT, NT, 4>();
@@ -507,7 +519,7 @@ static int launch_encoder_multi(const aae_multi_item* items, const MultiPlan& mp
     return AAE_OK;
 }
 
-// A mid-batch group: conv1 per object, ONE Winograd launch per conv layer across the objects, dense layer + scan per object.
+// A mid-batch group: conv1 and every Winograd conv layer as ONE launch across the objects, dense layer + scan per object.
 static int launch_mid_group(const aae_multi_item* items, const MultiPlan& mp, const std::vector<int>& members, const void* x, int x_dtype, float* z_out,
                             int64_t* idx_out, float* score_out, unsigned char* base, void* stream_v) {
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
@@ -516,11 +528,44 @@ static int launch_mid_group(const aae_multi_item* items, const MultiPlan& mp, co
     const int J = enc0->desc.latent_size;
     const size_t crop_bytes = (size_t)enc0->desc.in_h * enc0->desc.in_w * enc0->desc.in_c * (x_dtype == AAE_DTYPE_U8 ? 1 : 4);
     Timer tm;
-    for (int i : members) {
-        const MultiItemPlan& p = mp.items[(size_t)i];
-        if (int rc = forward_impl(items[i].enc, static_cast<const unsigned char*>(x) + (size_t)p.row0 * crop_bytes, x_dtype, p.n, z_out + (size_t)p.row0 * J,
-                                  base + p.enc_off, p.enc_bytes, stream_v, tm, nullptr, nullptr, nullptr, 0, 1)) return rc;
+    // ---- conv1: one launch across the objects where every member's first layer is the MFMA form with the same staging (whole 128-pixel tiles per block: every block
+    //      exactly the object's own launch's block); otherwise per object
+    bool conv1_grouped = true;
+    {
+        const bool u8 = x_dtype == AAE_DTYPE_U8;
+        aae::ConvFirstMultiArgs m;
+        memset(&m, 0, sizeof(m));
+        m.range.n = (int)members.size();
+        int at = 0, vec4 = -1;
+        for (size_t k = 0; k < members.size() && conv1_grouped; ++k) {
+            const aae_multi_item& it = items[members[k]];
+            const MultiItemPlan& p = mp.items[(size_t)members[k]];
+            const Layer& L = it.enc->layers[0];
+            if (L.kind != KIND_FIRST_MFMA || !(L.Cin == 3 || L.Cin == 1) || L.KS != 5 || L.first_smem != enc0->layers[0].first_smem || L.Cout != enc0->layers[0].Cout) { conv1_grouped = false; break; }
+            const void* xk = static_cast<const unsigned char*>(x) + (size_t)p.row0 * crop_bytes;
+            const int runs = first_core_args(it.enc, L, xk, u8, p.n, reinterpret_cast<float*>(base + p.enc_off + p.ws.act_off[0]), false, m.item[k]);
+            if (m.item[k].total_tiles <= it.enc->first_group_split_max_tiles) conv1_grouped = false;       // (its own launch would take the group-split form: keep the bits)
+            if (vec4 < 0) vec4 = m.item[k].vec4;
+            if (m.item[k].vec4 != vec4) conv1_grouped = false;
+            m.range.first[k] = at;
+            at += runs;
+        }
+        if (conv1_grouped) {
+            m.range.first[members.size()] = at;
+            const Layer& L0 = enc0->layers[0];
+            const dim3 grid((unsigned)at, ceil_div(L0.Cout, 128), 1);
+            if (L0.Cin == 3) launch_first_multi_tiles_t<5, 3>(m, u8, vec4 != 0, grid, L0.first_smem, stream);
+            else launch_first_multi_tiles_t<5, 1>(m, u8, vec4 != 0, grid, L0.first_smem, stream);
+            AAE_HIP_TRY(hipGetLastError());
+            ++t_multi_launches;
+        }
     }
+    if (!conv1_grouped)
+        for (int i : members) {
+            const MultiItemPlan& p = mp.items[(size_t)i];
+            if (int rc = forward_impl(items[i].enc, static_cast<const unsigned char*>(x) + (size_t)p.row0 * crop_bytes, x_dtype, p.n, z_out + (size_t)p.row0 * J,
+                                      base + p.enc_off, p.enc_bytes, stream_v, tm, nullptr, nullptr, nullptr, 0, 1)) return rc;
+        }
     for (size_t li = 1; li < nl; ++li) {
         const Layer& L0 = enc0->layers[li];
         aae::ConvWinoMultiArgs m;

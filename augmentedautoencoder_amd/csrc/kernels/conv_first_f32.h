@@ -354,7 +354,9 @@ struct ConvFirstMultiArgs {
     MultiTicketPrep prep[kMultiMax];       // (n == 0: nothing to prepare for that object)
     unsigned nonce;                        // one per call: every ticketed launch of the call has its own words
 };
-template <int KS, int C, bool IN_U8, bool VEC4>
+// GROUP_SPLIT = true: the per-detection form (one block per 32-pixel group); false: whole 128-pixel tiles per block, runs of tiles per block
+// -- the mid-batch groups (objects with five or more detections each, aae_multi_impl.h: launch_mid_group)
+template <int KS, int C, bool IN_U8, bool VEC4, bool GROUP_SPLIT = true>
 __global__ __launch_bounds__(256) void conv_first_multi_kernel(const ConvFirstMultiArgs m) {
     const int total = m.range.first[m.range.n];
     if ((int)blockIdx.x >= total) {                                   // the preparation blocks: one per object
@@ -363,7 +365,7 @@ __global__ __launch_bounds__(256) void conv_first_multi_kernel(const ConvFirstMu
         return;
     }
     const int o = multi_find(m.range, (int)blockIdx.x);
-    conv_first_block<KS, C, IN_U8, false, VEC4, true>(m.item[o], (int)blockIdx.x - m.range.first[o], (int)blockIdx.y, (int)blockIdx.z);
+    conv_first_block<KS, C, IN_U8, false, VEC4, GROUP_SPLIT>(m.item[o], (int)blockIdx.x - m.range.first[o], (int)blockIdx.y, (int)blockIdx.z);
 }
 
 }  // namespace aae

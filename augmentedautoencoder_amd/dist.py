@@ -73,7 +73,7 @@ class ShardedPoseEngine(object):
         self.distributed = dist.is_available() and dist.is_initialized()
         self.world_size, self.rank, self._gather = _group_shape(dist, group, world_size, rank, 'ShardedPoseEngine')
         self.local_infer = local_infer
-        # local_infer_many({obj_id: crops_subset}) -> {obj_id: (idx, score)}: ALL of this rank's objects in one call (the HIP path answers a
+        # local_infer_many({obj_id: crops_subset}) -> {obj_id: (idx, score)} or (idx_all, score_all, [obj ids in concatenation order]): ALL of this rank's objects in one call (the HIP path answers a
         # rank's buckets with one launch per conv layer across its objects: engine.MultiObjectQuery); local_infer may then be None
         self.local_infer_many = local_infer_many
         self.device = device
@@ -121,6 +121,22 @@ class ShardedPoseEngine(object):
                 return crops[obj]
             return crops[pos_dev[obj].to(crops.device).long()] if torch.is_tensor(crops) else crops[pos]
         answers = self.local_infer_many({obj: select(obj, pos) for obj, pos in buckets.items()}) if self.local_infer_many is not None and buckets else None
+        if isinstance(answers, tuple):
+            # (idx_all, score_all, [obj ids in concatenation order]): the rank's answers as ONE array -- one pack launch instead of one per object
+            idx_all, score_all, order = answers
+            key = tuple(order)
+            if bufs.get('pos_cat_key') != key:
+                bufs['pos_cat'] = torch.cat([pos_dev[o] for o in order]) if order else torch.empty(0, dtype=torch.int32, device=dev)
+                bufs['pos_cat_key'] = key
+            idx_all = torch.as_tensor(idx_all, dtype=torch.int64, device=dev).reshape(len(bufs['pos_cat']), -1).contiguous()
+            score_all = torch.as_tensor(score_all, dtype=torch.float32, device=dev).reshape(len(bufs['pos_cat']), -1).contiguous()
+            if self.pack_pairs is not None:
+                self.pack_pairs(idx_all, score_all, bufs['pos_cat'], packed)
+            else:
+                p = bufs['pos_cat'].long()
+                packed[p, 0] = idx_all[:, 0]
+                packed[p, 1] = score_all[:, 0].contiguous().view(torch.int32).to(torch.int64)
+            buckets = {}
         for obj, pos in buckets.items():
             idx, score = answers[obj] if answers is not None else self.local_infer(obj, select(obj, pos))
             idx = torch.as_tensor(idx, dtype=torch.int64, device=dev).reshape(len(pos), -1).contiguous()

@@ -411,7 +411,7 @@ def main():
 
         def local_infer_many(_buckets):
             _, idx_all, score_all = mq4(x4)
-            return {o: (idx_all[starts[k]:starts[k + 1]], score_all[starts[k]:starts[k + 1]]) for k, o in enumerate(order)}
+            return idx_all, score_all, order              # (one array for the rank: one pack launch)
         spe = ShardedPoseEngine(local_infer, world_size=None if use_dist else 1, rank=None if use_dist else 0, device=dev,
                                 pack_pairs=pack_pairs, unpack_pairs=unpack_pairs, local_infer_many=local_infer_many if mq4 is not None else None)
         for _ in range(max(args.warmup, 3)):
@@ -435,8 +435,8 @@ def main():
                              'objects': N_OBJ, 'objects_per_gpu': len(mine),
                              'bucket_sizes': np.bincount(labels, minlength=N_OBJ).tolist(), 'scaling': 'strong (global batch and object count fixed)',
                              'answers_complete': bool((idx4 >= 0).all().item()),
-                             'launches_per_step_besides_encode_nn': 'pack_pairs per object, %sunpack_pairs (buffers owned by the cached plan)' % ('all_gather, ' if use_dist else ''),
-                             'query': ('aae_encode_nn_multi: one C call for the rank\'s %d buckets, %d grouped launches (one Winograd launch per conv layer across the objects; conv1, '
+                             'launches_per_step_besides_encode_nn': 'one pack_pairs per rank, %sunpack_pairs (buffers owned by the cached plan)' % ('all_gather, ' if use_dist else ''),
+                             'query': ('aae_encode_nn_multi: one C call for the rank\'s %d buckets, %d grouped launches (one launch per conv layer across the objects: conv1 + the Winograd layers; '
                                        'dense layer and scan per object)' % (len(order), mq4.launches or 0)) if mq4 is not None else 'aae_encode_nn per object'}
     if not use_dist and not args.no_extras and args.precision == 'f32':
         from augmentedautoencoder_amd.engine import CapturedNearestNeighbour, DecoderEngine, StreamingNearestNeighbour

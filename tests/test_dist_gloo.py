@@ -88,6 +88,27 @@ def _worker(rank, world, port, out_dir):
     idx5, score5 = eng3.infer(mine, class_ids)
     assert (idx5.data_ptr(), score5.data_ptr(), eng3._plan[3]['packed'].data_ptr(), eng3._plan[3]['gathered'].data_ptr()) == ptrs
     assert torch.equal(idx5, idx) and torch.equal(score5, score)
+    # all of the rank's objects in ONE call (the HIP path: engine.MultiObjectQuery, one launch per conv layer across the objects), answers per object ...
+    many_calls = []
+
+    def infer_many(buckets):
+        many_calls.append(sorted(buckets))
+        return {o: base(o, zs) for o, zs in buckets.items()}
+    eng4 = ShardedPoseEngine(None, pack_pairs=pack, unpack_pairs=unpack, local_infer_many=infer_many)
+    idx6, score6 = eng4.infer(mine, class_ids)
+    assert torch.equal(idx6, idx) and torch.equal(score6, score) and many_calls == [sorted(mine)]
+    # ... or as one concatenated array with its object order: one pack per rank
+    del writes[:]
+
+    def infer_concat(buckets):
+        order = sorted(buckets, reverse=True)
+        parts = [base(o, buckets[o]) for o in order]
+        return np.concatenate([p[0] for p in parts]), np.concatenate([p[1] for p in parts]), order
+    eng5 = ShardedPoseEngine(None, pack_pairs=pack, unpack_pairs=unpack, local_infer_many=infer_concat)
+    idx7, score7 = eng5.infer(mine, class_ids)
+    assert torch.equal(idx7, idx) and torch.equal(score7, score) and len(writes) == (1 if mine else 0)
+    idx8, _ = eng5.infer(z, class_ids)                        # (whole batch handed over: the engine selects the rank's rows itself)
+    assert torch.equal(idx8, idx)
     # an explicit single-rank engine inside this 2-rank job is a LOCAL engine: it never enters the collective (the
     # other rank does not call it here -- a gather would hang or fail on the size mismatch)
     if rank == 0:

@@ -292,7 +292,7 @@ def test_argument_errors_are_reported_not_crashed():
     _close([a, b])
 
 
-_WINO = {'winograd_min_batch': 1, 'winograd_min_blocks': 1}      # (every eligible layer as Winograd, alone and in a group: the emulated launches are tiny against the 256 compute units the fill rule counts with)
+_WINO = {'winograd_min_batch': 1, 'winograd_min_blocks': 1, 'first_group_split_max_tiles': 0}      # (every eligible layer as Winograd, alone and in a group: the emulated launches are tiny against the 256 compute units the fill rule counts with; conv1 in its whole-tile form, as at the batch sizes that group on the GPU)
 
 
 @pytest.mark.parametrize('order', [0, 1, 2])
@@ -309,7 +309,7 @@ def test_mid_batch_group_one_winograd_launch_per_conv_layer_across_objects(order
         x = synth.make_crops(sum(counts), seed=58, shape=cfg.shape)
         z0, i0, s0 = _per_object(items, x)
         z1, i1, s1, launches = eb.encode_nn_multi(items, x)
-        assert launches == 2                                             # (the grouped launches: conv2 and conv3 -- the rest is counted by the per-object path)
+        assert launches == 3                                             # (the grouped launches: conv1 in its whole-tile form, conv2 and conv3 -- the rest is counted by the per-object path)
         assert np.array_equal(z1, z0) and np.array_equal(i1, i0) and np.array_equal(s1, s0)
         at = 0
         for (e, c, w), n in zip(objs, counts):

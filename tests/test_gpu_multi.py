@@ -242,8 +242,8 @@ def test_objects_that_share_one_workspace_alternate_on_the_ticketed_path(eight_o
 
 
 def test_mid_batch_group_eight_buckets_of_a_256_crop_batch(eight_objects):
-    """SURVEY section 8d config 4 on one GPU: 256 crops over 8 objects ({34, 26, 27, 32, 31, 32, 33, 41}): ONE Winograd launch per conv layer
-    across the objects (conv4's four-image blocks fill two rounds where one bucket alone fills a quarter), conv1 / dense / scan per object.
+    """SURVEY section 8d config 4 on one GPU: 256 crops over 8 objects ({34, 26, 27, 32, 31, 32, 33, 41}): ONE launch per conv layer
+    across the objects (conv1 in its whole-tile form, conv2 ... conv4 as Winograd: conv4's four-image blocks fill the chip where one bucket alone fills a quarter), dense / scan per object.
     Against (a) each object's own call with every eligible layer forced to Winograd -- bit for bit --, (b) each object's default call
     (conv3 / conv4 on the direct kernels at these sizes: fp32 rounding of the two forms), (c) each object's fp64 oracle."""
     import torch
@@ -257,7 +257,7 @@ def test_mid_batch_group_eight_buckets_of_a_256_crop_batch(eight_objects):
     mq = MultiObjectQuery([(e, c, n) for (e, c), n in zip(objs, counts)])
     z1, i1, s1 = mq(x)
     torch.cuda.synchronize()
-    assert mq.launches == 3                                              # conv2, conv3, conv4: one launch each for all eight objects
+    assert mq.launches == 4                                              # conv1, conv2, conv3, conv4: one launch each for all eight objects
     z1, i1, s1 = z1.clone(), i1.clone(), s1.clone()
     for e, _ in objs:
         e.set_option('winograd_min_blocks', 1)
