@@ -519,7 +519,7 @@ static int launch_encoder_multi(const aae_multi_item* items, const MultiPlan& mp
     return AAE_OK;
 }
 
-// A mid-batch group: conv1 and every Winograd conv layer as ONE launch across the objects, dense layer + scan per object.
+// A mid-batch group: conv1, every Winograd conv layer and the dense layer as ONE launch each across the objects, the scan per object.
 static int launch_mid_group(const aae_multi_item* items, const MultiPlan& mp, const std::vector<int>& members, const void* x, int x_dtype, float* z_out,
                             int64_t* idx_out, float* score_out, unsigned char* base, void* stream_v) {
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
@@ -594,11 +594,56 @@ static int launch_mid_group(const aae_multi_item* items, const MultiPlan& mp, co
         AAE_HIP_TRY(hipGetLastError());
         ++t_multi_launches;
     }
-    for (int i : members) {
-        const MultiItemPlan& p = mp.items[(size_t)i];
-        if (int rc = forward_impl(items[i].enc, base + p.enc_off + p.ws.act_off[nl - 1], AAE_DTYPE_F32, p.n, z_out + (size_t)p.row0 * J, base + p.enc_off, p.enc_bytes,
-                                  stream_v, tm, nullptr, nullptr, nullptr, (int)nl, (int)nl + 1)) return rc;
+    // ---- dense layer: one wave-split-K launch across the objects where every member's own plan is the same instantiated wave tile (each object its own plan, tickets and
+    //      partial buffer: bit-identical to its own launch); otherwise per object
+    bool dense_grouped = true;
+    {
+        aae::ConvWaveKMultiArgs m;
+        memset(&m, 0, sizeof(m));
+        m.range.n = (int)members.size();
+        const unsigned nonce = next_nonce();
+        int at = 0, key0 = -1;
+        for (size_t k = 0; k < members.size() && dense_grouped; ++k) {
+            const aae_multi_item& it = items[members[k]];
+            const MultiItemPlan& p = mp.items[(size_t)members[k]];
+            const Layer& D = it.enc->dense;
+            const bool gemv = D.kind == KIND_IGEMM && p.n <= gemv_max_batch(it.enc) && it.enc->dense_gemv && D.K() % aae::kGemvChunk == 0;
+            if (D.kind != KIND_IGEMM || gemv || !it.enc->wavek_dense) { dense_grouped = false; break; }
+            const WaveKPlan w = plan_wavek(it.enc, D, p.n, false);
+            const int key = wavek_shape_key(w);
+            if (!w.use || w.waves != 4 || w.depth != 2 || w.tail_tiles > 0 || w.partial_bytes > p.ws.partial_bytes ||
+                !((key == 1142 && (it.enc->wavek_spread & 2)) || key == 142 || (key == 242 && (it.enc->wavek_spread & 1)))) { dense_grouped = false; break; }
+            if (key0 < 0) key0 = key;
+            if (key != key0) { dense_grouped = false; break; }
+            unsigned long long* tickets = reinterpret_cast<unsigned long long*>(base + p.enc_off + p.ws.ticket_off) + nl * kLayerTicketWords;
+            m.item[k] = wavek_args(it.enc, D, w, reinterpret_cast<const float*>(base + p.enc_off + p.ws.act_off[nl - 1]), p.n, z_out + (size_t)p.row0 * J,
+                                   reinterpret_cast<float*>(base + p.enc_off + p.ws.partial_off), tickets, nonce, 0);
+            m.item[k].timeline = nullptr;
+            m.nblk[k] = w.blocks();
+            m.range.first[k] = at;
+            at += (w.blocks() + 7) / 8 * 8;
+        }
+        if (dense_grouped) {
+            m.range.first[members.size()] = at;
+            m.xcd_affine = 0;
+            switch (key0) {
+                case 1142: launch_wavek_multi_t<1, 1, true>(m, 0, at, stream); break;
+                case 142: launch_wavek_multi_t<2, 1, false>(m, 0, at, stream); break;
+                case 242: launch_wavek_multi_t<2, 2, true>(m, 0, at, stream); break;
+                default: dense_grouped = false;
+            }
+            if (dense_grouped) {
+                AAE_HIP_TRY(hipGetLastError());
+                ++t_multi_launches;
+            }
+        }
     }
+    if (!dense_grouped)
+        for (int i : members) {
+            const MultiItemPlan& p = mp.items[(size_t)i];
+            if (int rc = forward_impl(items[i].enc, base + p.enc_off + p.ws.act_off[nl - 1], AAE_DTYPE_F32, p.n, z_out + (size_t)p.row0 * J, base + p.enc_off, p.enc_bytes,
+                                      stream_v, tm, nullptr, nullptr, nullptr, (int)nl, (int)nl + 1)) return rc;
+        }
     for (int i : members) {
         const MultiItemPlan& p = mp.items[(size_t)i];
         if (int rc = aae_codebook_nn(items[i].cb, z_out + (size_t)p.row0 * J, p.n, 1, items[i].col_stride, idx_out + p.row0, score_out + p.row0, base + p.cb_off,

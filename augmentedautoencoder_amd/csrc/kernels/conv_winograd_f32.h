@@ -21,15 +21,16 @@
 //   block = 8 waves = 64 tiles x 64 output channels.  GEOM 0: an 8 x 8-tile (16 x 16-pixel) region of one image (conv2, conv3);
 //           GEOM 1: the 4 x 4 tiles of four images (conv4: 8 x 8 outputs).  Wave (mh, nh, ph): 32 tiles x 32 channels x HALF the points --
 //           the point rows of the split dimension A go to two waves (rows {0, 1} | the rest), so a wave keeps 8 (6, 3) accumulator tiles
-//           = at most 128 registers, two waves share a SIMD and one's patch reads, transform and weight loads run under the other's
-//           MFMAs.  The two halves of the output transform meet through LDS once per block.  A = rows, or columns when SWAP (the
+//           = at most 128 registers, two waves share a SIMD and one's cluster (patch reads, transform, loads) runs under the other's
+//           MFMA burst.  The two halves of the output transform meet through LDS once per phase.  A = rows, or columns when SWAP (the
 //           2 x 3-tap phase: the 3-tap dimension is the one that splits evenly).
 //   K loop = stages of 16 input channels (32 in the one-launch-per-phase form): the block's window of the sub-image (tiles + halo, zero outside the image = the 'SAME'
 //           padding) goes global -> registers -> LDS, double buffered, laid out [channel quad][image][column parity][row][column / 2]
-//           with pitches that make the patch reads (ds_read_b128 by 32 tiles) and the fill conflict-free.  The loop runs in units of
-//           one point row: a lane reads the patch rows the row needs as float4 (4 channels of its K half), transforms them with packed
-//           fp32 adds BETWEEN the MFMAs of the previous unit, and issues 4 MFMAs per point against weight fragments that were loaded
-//           one group ahead (raw buffer views, scalar offsets) into the registers the previous group's finished row released.
+//           with pitches that make the patch reads (ds_read_b128 by 32 tiles) conflict-free.  The loop runs in units of one point row,
+//           each ONE cluster + ONE burst (wino_phase_body: the price list of what an instruction costs next to fp32 MFMAs): a lane transforms
+//           the patch rows it read before the previous burst with packed fp32 adds, loads the weight fragments of the unit after next (raw
+//           buffer views, scalar offsets) into the register slot the previous burst released, reads the next unit's patch rows as float4
+//           (4 channels of its K half), and then issues the unit's 4 MFMAs per point back to back.
 //   weights: packed [32-column block][8-channel group][point = a PB + b][K half][32 columns][4 channels] per phase (aae_encoder_plan.h).
 #pragma once
 #include <type_traits>

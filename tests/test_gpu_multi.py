@@ -257,7 +257,7 @@ def test_mid_batch_group_eight_buckets_of_a_256_crop_batch(eight_objects):
     mq = MultiObjectQuery([(e, c, n) for (e, c), n in zip(objs, counts)])
     z1, i1, s1 = mq(x)
     torch.cuda.synchronize()
-    assert mq.launches == 4                                              # conv1, conv2, conv3, conv4: one launch each for all eight objects
+    assert mq.launches == 5                                              # conv1, conv2, conv3, conv4, dense: one launch each for all eight objects
     z1, i1, s1 = z1.clone(), i1.clone(), s1.clone()
     for e, _ in objs:
         e.set_option('winograd_min_blocks', 1)
