@@ -311,6 +311,8 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
         enc->winograd_min_blocks = value < 0 ? 0 : value;
     } else if (!strcmp(name, "multi_mid_group")) {
         enc->multi_mid_group = value ? 1 : 0;
+    } else if (!strcmp(name, "multi_mid_ragged")) {
+        enc->multi_mid_ragged = value ? 1 : 0;
     } else if (!strcmp(name, "winograd_xcd_cols")) {
         if (value < -1 || value > 8) return fail(AAE_ERR_INVALID, "winograd_xcd_cols %d: -1 = per-layer default, 0 = plain block order, 1 ... 8 = column blocks of a region per XCD", value);
         enc->winograd_xcd_cols = value;

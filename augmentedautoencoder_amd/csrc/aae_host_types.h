@@ -101,6 +101,8 @@ struct aae_encoder {
     int winograd_min_blocks = 0;           // block count (tests, A/B)
     int multi_mid_group = 1;               // grouped multi-object query: objects with 5 or more detections each share ONE Winograd launch per conv layer where the GROUP's blocks fill
                                            // the rounds they occupy (aae_multi_impl.h); 0 = such objects one after the other
+    int multi_mid_ragged = 1;              // ... and a layer of four-image blocks (8 x 8 outputs) hands the objects' LAST 1-3 images to one grouped wave-split-K launch when the ragged
+                                           // blocks would open one more round of blocks (config 4: 67 groups = 536 blocks = 3 rounds -> 61 groups + 12 images); 0 = ragged blocks
     int winograd_xcd_cols = -1;            // column blocks of a region that share an XCD (aae_encoder_launch.h: wino_xcd_cols); -1 = per-layer default
     int first_target_blocks = 512;         // conv1 grid size aimed at (x N tiles); 2 blocks fit a CU
     int first_group_split_max_tiles = 128; // conv1: batches of at most this many 128-pixel tiles (B <= 4 of the default net) run one block per 32-pixel group

@@ -31,6 +31,8 @@ struct MultiItemPlan {
     size_t enc_off = 0, enc_bytes = 0, cb_off = 0, cb_bytes = 0;     // grouped items: own workspace slices
     Workspace ws;
     std::vector<WaveKPlan> plans;              // per conv layer (grouped items)
+    std::vector<WaveKPlan> rem_plans;          // mid items, per conv layer: the wave-split-K plan of the last n mod 4 images where the group hands them over (use = false: none)
+    size_t rem_partial_off = 0, rem_partial_bytes = 0;      // ... and their partial sums (behind the item's own workspace)
     ScanPlan sp;
     const aae_codebook* eff = nullptr;         // the codebook the scan runs over (the compacted upright copy when col_stride > 1)
     int idx_scale = 1;
@@ -41,6 +43,7 @@ struct MultiPlan {
     std::vector<MultiItemPlan> items;
     std::vector<std::vector<int>> groups;      // grouped items that share launches: equal signatures, at most kMultiMax members, item order
     std::vector<std::vector<int>> mid_groups;  // mid-batch items that share their Winograd launches
+    std::vector<std::vector<char>> mid_rem;    // [mid group][conv layer]: the incomplete four-image blocks leave the Winograd launch (multi_mid_ragged)
     size_t seq_enc_off = 0, seq_enc_bytes = 0, seq_cb_off = 0, seq_cb_bytes = 0, total = 0;
     int rows = 0;
 };
@@ -186,18 +189,34 @@ static bool multi_encoder_mid_groupable(const aae_encoder* enc, int n, std::vect
     }
     sig.clear();
     sig.push_back(enc->winograd_min_fill_pct); sig.push_back(enc->winograd_min_blocks); sig.push_back(enc->winograd_xcd_cols); sig.push_back(wavek_round_blocks(enc));
+    sig.push_back(enc->multi_mid_ragged); sig.push_back(enc->wavek); sig.push_back(enc->wavek_spread); sig.push_back(enc->multi_force_shape); sig.push_back(enc->multi_force_g);
     const int32_t* d = reinterpret_cast<const int32_t*>(&enc->desc);
     for (size_t i = 0; i < sizeof(aae_encoder_desc) / sizeof(int32_t); ++i) sig.push_back(d[i]);
     return true;
 }
 static int wino_regions(const Layer& L, int n) { return L.wino_geom == 0 ? (L.Ho / 16) * (L.Wo / 16) * n : ceil_div(n, 4); }
 // ... and does the group fill the chip on every conv layer (the round-fill rule of runs_winograd, on the group's blocks)?
+// A layer of four-image blocks: do the objects' incomplete blocks (n mod 4 images) open one more round of blocks than the complete ones need?  Then they are worth a launch
+// of their own on the direct kernel (plan_mid_ragged) and the Winograd launch holds the complete blocks only.
+static bool mid_ragged_opens_a_round(const aae_encoder* enc0, const Layer& L, const std::vector<int>& counts, long long* complete_regions) {
+    if (L.wino_geom != 1 || !enc0->multi_mid_ragged || !enc0->wavek) return false;
+    long long with = 0, without = 0;
+    for (int n : counts) { with += ceil_div(n, 4); without += n / 4; }
+    const long long cus = wavek_round_blocks(enc0);
+    const int nbn = L.Cout / 64, xc = wino_xcd_cols(enc0, L);
+    const long long rounds_with = ((long long)aae::wino_grid_blocks((int)with, nbn, xc) + cus - 1) / cus;
+    const long long rounds_without = ((long long)aae::wino_grid_blocks((int)without, nbn, xc) + cus - 1) / cus;
+    if (complete_regions) *complete_regions = without;
+    return with > without && without >= 1 && rounds_without < rounds_with;
+}
 static bool mid_group_fills(const aae_encoder* enc0, const std::vector<int>& counts) {
     const long long cus = wavek_round_blocks(enc0);
     for (size_t li = 1; li < enc0->layers.size(); ++li) {
         const Layer& L = enc0->layers[li];
         long long regions = 0;
         for (int n : counts) regions += wino_regions(L, n);
+        long long complete = 0;
+        if (mid_ragged_opens_a_round(enc0, L, counts, &complete)) regions = complete;      // (then the rule looks at the complete blocks: the others leave the launch)
         const long long blocks = regions * (L.Cout / 64), rounds = (blocks + cus - 1) / cus;
         if (enc0->winograd_min_blocks > 0) {                               // (tests, A/B: a plain block count instead of the fill rule, as in runs_winograd)
             if (blocks < enc0->winograd_min_blocks) return false;
@@ -206,6 +225,47 @@ static bool mid_group_fills(const aae_encoder* enc0, const std::vector<int>& cou
         if (100 * blocks < (long long)enc0->winograd_min_fill_pct * rounds * cus) return false;
     }
     return true;
+}
+
+// Layers of four-image blocks (8 x 8 outputs) in a mid-batch group: an object with n mod 4 != 0 ends in a block with empty image slots.  Where those blocks
+// open one more ROUND of blocks than the complete ones need (config 4: {34, 26, 27, 32, 31, 32, 33, 41} -> 67 groups x 8 column blocks = 536 = three rounds for 24
+// blocks; the 61 complete groups = 488 fit two), the last n mod 4 images of every object go to ONE grouped wave-split-K launch (the per-detection chain's kernel,
+// a plan for the group: plan_wavek_group) behind the Winograd launch: 1.28 -> ~0.95 ms for conv4 of that frame.
+static bool wavek_multi_instantiated(const aae_encoder* enc, const WaveKPlan& w) {
+    const int key = wavek_shape_key(w);
+    return w.use && w.waves == 4 && w.depth == 2 && ((key == 1142 && (enc->wavek_spread & 2)) || key == 142 || (key == 242 && (enc->wavek_spread & 1)));
+}
+static void plan_mid_ragged(const aae_multi_item* items, MultiPlan& mp) {
+    mp.mid_rem.assign(mp.mid_groups.size(), std::vector<char>());
+    for (size_t gi = 0; gi < mp.mid_groups.size(); ++gi) {
+        const std::vector<int>& g = mp.mid_groups[gi];
+        const aae_encoder* enc0 = items[g[0]].enc;
+        const size_t nl = enc0->layers.size();
+        mp.mid_rem[gi].assign(nl, 0);
+        for (int i : g) mp.items[(size_t)i].rem_plans.assign(nl, WaveKPlan());
+        for (size_t li = 1; li < nl; ++li) {
+            const Layer& L = enc0->layers[li];
+            std::vector<long long> rows;
+            std::vector<int> who, counts;
+            for (int i : g) {
+                const int n = mp.items[(size_t)i].n;
+                counts.push_back(n);
+                if (n % 4) { rows.push_back((long long)(n % 4) * L.Ho * L.Wo); who.push_back(i); }
+            }
+            if (!mid_ragged_opens_a_round(enc0, L, counts, nullptr)) continue;
+            const std::vector<WaveKPlan> gp = plan_wavek_group(enc0, L, rows);
+            if (gp.size() != who.size() || !wavek_multi_instantiated(enc0, gp[0])) continue;
+            bool ok = true;
+            for (const WaveKPlan& w : gp) ok = ok && wavek_shape_key(w) == wavek_shape_key(gp[0]) && w.num_mt * w.num_nt <= kLayerTicketWords;
+            if (!ok) continue;
+            mp.mid_rem[gi][li] = 1;
+            for (size_t k = 0; k < who.size(); ++k) {
+                MultiItemPlan& p = mp.items[(size_t)who[k]];
+                p.rem_plans[li] = gp[k];
+                p.rem_partial_bytes = std::max(p.rem_partial_bytes, gp[k].partial_bytes);
+            }
+        }
+    }
 }
 
 // Layout of one call: [shared slice of the per-object path: encoder part, codebook part][grouped item 0: encoder, codebook][item 1] ...
@@ -256,13 +316,15 @@ static int plan_multi(const aae_multi_item* items, int n_items, bool scan_only, 
         for (int i : g) mp.items[(size_t)i].mid = false;
         mp.mid_groups.erase(mp.mid_groups.begin() + (long)gi);
     }
+    plan_mid_ragged(items, mp);
     for (int i = 0; i < n_items; ++i) {
         const aae_multi_item& it = items[i];
         MultiItemPlan& p = mp.items[(size_t)i];
         if (p.grouped) continue;
         if (p.mid) {
             p.ws = plan_workspace(it.enc, it.n);
-            p.enc_bytes = align_up(p.ws.total, 256);
+            p.rem_partial_off = align_up(p.ws.total, 256);
+            p.enc_bytes = p.rem_partial_off + align_up(p.rem_partial_bytes, 256);
             p.cb_bytes = align_up(plan_scan(it.cb, it.n, 1).total, 256);
         } else {
             if (!scan_only) mp.seq_enc_bytes = std::max(mp.seq_enc_bytes, align_up(plan_workspace(it.enc, it.n).total, 256));
@@ -520,8 +582,8 @@ static int launch_encoder_multi(const aae_multi_item* items, const MultiPlan& mp
 }
 
 // A mid-batch group: conv1, every Winograd conv layer and the dense layer as ONE launch each across the objects, the scan per object.
-static int launch_mid_group(const aae_multi_item* items, const MultiPlan& mp, const std::vector<int>& members, const void* x, int x_dtype, float* z_out,
-                            int64_t* idx_out, float* score_out, unsigned char* base, void* stream_v) {
+static int launch_mid_group(const aae_multi_item* items, const MultiPlan& mp, const std::vector<int>& members, const std::vector<char>& rem_layers, const void* x, int x_dtype,
+                            float* z_out, int64_t* idx_out, float* score_out, unsigned char* base, void* stream_v) {
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
     aae_encoder* enc0 = items[members[0]].enc;
     const size_t nl = enc0->layers.size();
@@ -576,6 +638,7 @@ static int launch_mid_group(const aae_multi_item* items, const MultiPlan& mp, co
         c.blocks_y = L0.wino_geom == 0 ? L0.Ho / 16 : 1;
         int at = 0;
         m.range.n = (int)members.size();
+        const bool split = li < rem_layers.size() && rem_layers[li];
         for (size_t k = 0; k < members.size(); ++k) {
             const MultiItemPlan& p = mp.items[(size_t)members[k]];
             const Layer& L = items[members[k]].enc->layers[li];
@@ -583,9 +646,10 @@ static int launch_mid_group(const aae_multi_item* items, const MultiPlan& mp, co
             ob.x = reinterpret_cast<const float*>(base + p.enc_off + p.ws.act_off[li - 1]);
             ob.out = reinterpret_cast<float*>(base + p.enc_off + p.ws.act_off[li]);
             for (int q = 0; q < 4; ++q) ob.U4[q] = L.wino[q];
-            ob.bias = L.bias; ob.bn_scale = L.bn_scale; ob.bn_shift = L.bn_shift; ob.B = p.n;
+            ob.bias = L.bias; ob.bn_scale = L.bn_scale; ob.bn_shift = L.bn_shift;
+            ob.B = split ? p.n / 4 * 4 : p.n;                                  // (split: the complete four-image blocks only)
             m.range.first[k] = at;
-            at += wino_regions(L, p.n);
+            at += wino_regions(L, ob.B);
         }
         m.range.first[members.size()] = at;
         c.regions = at;
@@ -593,6 +657,44 @@ static int launch_mid_group(const aae_multi_item* items, const MultiPlan& mp, co
         wino_layer_multi_launch(L0.wino_geom, aae::wino_grid_blocks(at, L0.Cout / 64, c.xcd_cols), stream, m);
         AAE_HIP_TRY(hipGetLastError());
         ++t_multi_launches;
+        if (split) {
+            // the objects' last n mod 4 images: one grouped wave-split-K launch (plan_mid_ragged), every object its own tiles, tickets and partial sums
+            aae::ConvWaveKMultiArgs r;
+            memset(&r, 0, sizeof(r));
+            const unsigned nonce = next_nonce();
+            int rat = 0, nk = 0;
+            const WaveKPlan* w0 = nullptr;
+            for (size_t k = 0; k < members.size(); ++k) {
+                const aae_multi_item& it = items[members[k]];
+                const MultiItemPlan& p = mp.items[(size_t)members[k]];
+                const Layer& L = it.enc->layers[li];
+                const WaveKPlan& w = p.rem_plans[li];
+                const int full = p.n / 4 * 4, rem = p.n - full;
+                if (!rem || !w.use) continue;
+                if (!w0) w0 = &w;
+                unsigned long long* tickets = reinterpret_cast<unsigned long long*>(base + p.enc_off + p.ws.ticket_off) + li * kLayerTicketWords;
+                r.item[nk] = wavek_args(it.enc, L, w, reinterpret_cast<const float*>(base + p.enc_off + p.ws.act_off[li - 1]) + (size_t)full * L.H * L.W * L.Cin, rem * L.Ho * L.Wo,
+                                        reinterpret_cast<float*>(base + p.enc_off + p.ws.act_off[li]) + (size_t)full * L.Ho * L.Wo * L.Cout,
+                                        reinterpret_cast<float*>(base + p.enc_off + p.rem_partial_off), tickets, nonce, (int)li);
+                r.item[nk].timeline = nullptr;
+                r.nblk[nk] = w.blocks();
+                r.range.first[nk] = rat;
+                rat += (w.blocks() + 7) / 8 * 8;
+                ++nk;
+            }
+            r.range.n = nk;
+            r.range.first[nk] = rat;
+            r.xcd_affine = 0;
+            const int tag = li <= 3 ? (int)li : 0;
+            switch (w0 ? wavek_shape_key(*w0) : 0) {
+                case 1142: launch_wavek_multi_t<1, 1, true>(r, tag, rat, stream); break;
+                case 142: launch_wavek_multi_t<2, 1, false>(r, tag, rat, stream); break;
+                case 242: launch_wavek_multi_t<2, 2, true>(r, tag, rat, stream); break;
+                default: return fail(AAE_ERR_RUNTIME, "multi-object query: no grouped wave-split-K instantiation for the incomplete blocks of conv%zu", li + 1);
+            }
+            AAE_HIP_TRY(hipGetLastError());
+            ++t_multi_launches;
+        }
     }
     // ---- dense layer: one wave-split-K launch across the objects where every member's own plan is the same instantiated wave tile (each object its own plan, tickets and
     //      partial buffer: bit-identical to its own launch); otherwise per object
@@ -686,12 +788,14 @@ static int multi_impl(const aae_multi_item* items, int n_items, const void* x, i
         if (rc) return rc;
     }
     // ---- mid-batch groups: one Winograd launch per conv layer and group
-    for (const std::vector<int>& g : mp.mid_groups) {
+    for (size_t gi = 0; gi < mp.mid_groups.size(); ++gi) {
+        const std::vector<int>& g = mp.mid_groups[gi];
         for (int i : g) {
             const aae_encoder_desc &a = items[i].enc->desc, &b = items[g[0]].enc->desc;
             if (a.in_h != b.in_h || a.in_w != b.in_w || a.in_c != b.in_c) return fail(AAE_ERR_RUNTIME, "multi-object query: group members differ in crop shape");
         }
-        if (int rc = launch_mid_group(items, mp, g, x, x_dtype, z_out, idx_out, score_out, base, stream_v)) return rc;
+        static const std::vector<char> none;
+        if (int rc = launch_mid_group(items, mp, g, gi < mp.mid_rem.size() ? mp.mid_rem[gi] : none, x, x_dtype, z_out, idx_out, score_out, base, stream_v)) return rc;
     }
     // ---- grouped items: one launch per layer and group
     if (!mp.groups.empty()) t_x3h_last_slot = -1;

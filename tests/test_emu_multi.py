@@ -337,6 +337,67 @@ def test_mid_batch_group_one_winograd_launch_per_conv_layer_across_objects(order
         eb.set_block_order(0)
 
 
+@pytest.mark.parametrize('order', [0, 2])
+def test_mid_batch_group_hands_incomplete_four_image_blocks_to_one_wave_split_k_launch(order):
+    """conv3 of this net packs four 8 x 8 images per block: counts {5, 7, 6} = 6 blocks, 3 of them incomplete.  On a "chip" of 4 compute units the
+    incomplete ones open a second round: the objects' last 1 / 3 / 2 images go to ONE grouped wave-split-K launch (plan_mid_ragged) -- the same
+    answers up to fp32 summation order on those images, bit for bit on the others; option multi_mid_ragged = 0 keeps every image in the Winograd launch."""
+    cfg = EncoderConfig((64, 64, 3), [32, 64, 64], [2, 2, 2], 5, 128, True)
+    counts = [5, 7, 6]
+    opts = dict(_WINO, wavek_target_blocks=4, winograd_xcd_cols=0)
+    eb.set_block_order(order)
+    try:
+        objs = [_object(cfg, 800 + 7 * o, 36 * (9 + 2 * o) + 3 * o, opts) for o in range(3)]
+        items = [(e, c, n, 1) for (e, c, _), n in zip(objs, counts)]
+        x = synth.make_crops(sum(counts), seed=61, shape=cfg.shape)
+        z0, i0, s0 = _per_object(items, x)
+        z1, i1, s1, launches = eb.encode_nn_multi(items, x)
+        assert launches == 4                                             # conv1, conv2, conv3's complete blocks, conv3's last images
+        at = 0
+        for (e, c, w), n in zip(objs, counts):
+            full = n // 4 * 4
+            assert np.array_equal(z1[at:at + full], z0[at:at + full])
+            assert not np.array_equal(z1[at + full:at + n], z0[at + full:at + n])          # (another kernel computed them ...)
+            assert np.abs(z1[at:at + n] - z0[at:at + n]).max() / np.abs(z0).max() < 2e-6   # (... to the same numbers)
+            z64 = ref.encoder_forward_np(ref.input_to_float(x[at:at + n]), w, cfg.strides, cfg.batch_norm)
+            assert np.abs(z1[at:at + n] - z64).max() / np.abs(z64).max() < 5e-6
+            assert np.array_equal(i1[at:at + n], np.argmax(c.similarity(z1[at:at + n]), axis=1))
+            at += n
+        for e, _, _ in objs:
+            e.set_option('multi_mid_ragged', 0)
+        z2, i2, s2, launches = eb.encode_nn_multi(items, x)
+        assert launches == 3 and np.array_equal(z2, z0) and np.array_equal(i2, i0) and np.array_equal(s2, s0)
+        _close(objs)
+    finally:
+        eb.set_block_order(0)
+
+
+def test_mid_batch_fill_rule_counts_the_complete_blocks_when_the_incomplete_ones_leave():
+    """Two objects with 25 + 24 crops on a "chip" of 12 compute units, conv2 with four 8 x 8 images per block: 13 blocks would occupy two rounds at 54 % (below the 56 % of
+    the fill rule: no group); handing the one incomplete block's image to the wave-split-K launch leaves 12 blocks = one full round: the group forms."""
+    cfg = EncoderConfig((32, 32, 3), [32, 64], [2, 2], 5, 128)
+    counts = [25, 24]
+    opts = {'winograd_min_batch': 1, 'first_group_split_max_tiles': 0, 'wavek_target_blocks': 12, 'winograd_xcd_cols': 0}
+    objs = [_object(cfg, 900 + o, 36 * 8 + o, opts) for o in range(2)]
+    items = [(e, c, n, 1) for (e, c, _), n in zip(objs, counts)]
+    x = synth.make_crops(sum(counts), seed=62, shape=cfg.shape)
+    z0, i0, s0 = _per_object(items, x)
+    z1, i1, s1, launches = eb.encode_nn_multi(items, x)
+    assert launches == 4                                                 # conv1, conv2's twelve complete blocks, the 25th crop of object 0, the dense layer
+    assert np.abs(z1 - z0).max() / np.abs(z0).max() < 5e-6
+    at = 0
+    for (e, c, w), n in zip(objs, counts):
+        z64 = ref.encoder_forward_np(ref.input_to_float(x[at:at + n]), w, cfg.strides, cfg.batch_norm)
+        assert np.abs(z1[at:at + n] - z64).max() / np.abs(z64).max() < 5e-6
+        assert np.array_equal(i1[at:at + n], np.argmax(c.similarity(z1[at:at + n]), axis=1))
+        at += n
+    for e, _, _ in objs:
+        e.set_option('multi_mid_ragged', 0)
+    z2, i2, s2, launches = eb.encode_nn_multi(items, x)
+    assert launches == 0 and np.array_equal(z2, z0) and np.array_equal(i2, i0)          # (13 blocks in two rounds: below the rule, one object after the other)
+    _close(objs)
+
+
 def test_mid_batch_group_needs_two_members_that_fill_the_chip():
     cfg = EncoderConfig((64, 64, 3), [32, 64, 64], [2, 2, 2], 5, 128, True)
     objs = [_object(cfg, 700 + o, 36 * 8, {'winograd_min_batch': 1}) for o in range(2)]            # default fill rule: two tiny launches do not fill 256 compute units

@@ -243,8 +243,8 @@ def test_objects_that_share_one_workspace_alternate_on_the_ticketed_path(eight_o
 
 def test_mid_batch_group_eight_buckets_of_a_256_crop_batch(eight_objects):
     """SURVEY section 8d config 4 on one GPU: 256 crops over 8 objects ({34, 26, 27, 32, 31, 32, 33, 41}): ONE launch per conv layer
-    across the objects (conv1 in its whole-tile form, conv2 ... conv4 as Winograd: conv4's four-image blocks fill the chip where one bucket alone fills a quarter), dense / scan per object.
-    Against (a) each object's own call with every eligible layer forced to Winograd -- bit for bit --, (b) each object's default call
+    across the objects (conv1 in its whole-tile form, conv2 ... conv4 as Winograd: conv4's four-image blocks fill the chip where one bucket alone fills a quarter; the dense layer), scan per object.
+    Against (a) each object's own call with every eligible layer forced to Winograd -- bit for bit except the images conv4 hands to the wave-split-K kernel --, (b) each object's default call
     (conv3 / conv4 on the direct kernels at these sizes: fp32 rounding of the two forms), (c) each object's fp64 oracle."""
     import torch
     from augmentedautoencoder_amd.engine import MultiObjectQuery
@@ -257,7 +257,9 @@ def test_mid_batch_group_eight_buckets_of_a_256_crop_batch(eight_objects):
     mq = MultiObjectQuery([(e, c, n) for (e, c), n in zip(objs, counts)])
     z1, i1, s1 = mq(x)
     torch.cuda.synchronize()
-    assert mq.launches == 5                                              # conv1, conv2, conv3, conv4, dense: one launch each for all eight objects
+    # conv1, conv2, conv3, conv4, dense: one launch each for all eight objects + conv4's incomplete four-image blocks (the last n mod 4 images of six objects: 67 blocks x 8
+    # column blocks would open a third round of blocks) as one grouped wave-split-K launch
+    assert mq.launches == 6
     z1, i1, s1 = z1.clone(), i1.clone(), s1.clone()
     for e, _ in objs:
         e.set_option('winograd_min_blocks', 1)
@@ -266,8 +268,24 @@ def test_mid_batch_group_eight_buckets_of_a_256_crop_batch(eight_objects):
     finally:
         for e, _ in objs:
             e.set_option('winograd_min_blocks', 0)
-    assert torch.equal(z1, zf) and torch.equal(i1, idf) and torch.equal(s1, sf)
     scale = float(zd.abs().max())
+    at = 0
+    for n in counts:                                                     # bit for bit where the same kernel computed, fp32 rounding of the two forms on the handed-over images
+        full = n // 4 * 4
+        assert torch.equal(z1[at:at + full], zf[at:at + full]) and torch.equal(i1[at:at + full], idf[at:at + full]) and torch.equal(s1[at:at + full], sf[at:at + full])
+        if n > full:
+            assert float((z1[at + full:at + n] - zf[at + full:at + n]).abs().max()) / scale < 5e-6
+        at += n
+    for e, _ in objs:
+        e.set_option('multi_mid_ragged', 0)
+    try:
+        mqr = MultiObjectQuery([(e, c, n) for (e, c), n in zip(objs, counts)])
+        zr, ir, sr = mqr(x)
+        torch.cuda.synchronize()
+        assert mqr.launches == 5 and torch.equal(zr, zf) and torch.equal(ir, idf) and torch.equal(sr, sf)       # every image in the Winograd launches: the objects' own bits
+    finally:
+        for e, _ in objs:
+            e.set_option('multi_mid_ragged', 1)
     assert float((z1 - zd).abs().max()) / scale < 5e-6
     at = 0
     for o, n in enumerate(counts):
