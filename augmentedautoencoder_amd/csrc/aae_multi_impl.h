@@ -195,7 +195,6 @@ static bool multi_encoder_mid_groupable(const aae_encoder* enc, int n, std::vect
     return true;
 }
 static int wino_regions(const Layer& L, int n) { return L.wino_geom == 0 ? (L.Ho / 16) * (L.Wo / 16) * n : ceil_div(n, 4); }
-// ... and does the group fill the chip on every conv layer (the round-fill rule of runs_winograd, on the group's blocks)?
 // A layer of four-image blocks: do the objects' incomplete blocks (n mod 4 images) open one more round of blocks than the complete ones need?  Then they are worth a launch
 // of their own on the direct kernel (plan_mid_ragged) and the Winograd launch holds the complete blocks only.
 static bool mid_ragged_opens_a_round(const aae_encoder* enc0, const Layer& L, const std::vector<int>& counts, long long* complete_regions) {
@@ -209,6 +208,7 @@ static bool mid_ragged_opens_a_round(const aae_encoder* enc0, const Layer& L, co
     if (complete_regions) *complete_regions = without;
     return with > without && without >= 1 && rounds_without < rounds_with;
 }
+// ... and does the group fill the chip on every conv layer (the round-fill rule of runs_winograd, on the group's blocks)?
 static bool mid_group_fills(const aae_encoder* enc0, const std::vector<int>& counts) {
     const long long cus = wavek_round_blocks(enc0);
     for (size_t li = 1; li < enc0->layers.size(); ++li) {
