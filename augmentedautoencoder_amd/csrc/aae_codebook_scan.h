@@ -161,8 +161,8 @@ static void launch_scan_resident_k(const aae::ScanResidentArgs& a, dim3 grid, hi
 }
 
 // topk == 1: block partials (pval, pidx) for argmax_reduce_kernel; topk 2..8: candidate lists for topk_merge_kernel
-static int launch_scan_resident(const aae_codebook* cb, const void* qp, int B, const ScanPlan& s, unsigned char* base, hipStream_t stream,
-                                int topk = 1, const float* raw_z = nullptr, const ScanTicketOut* fin = nullptr) {
+static aae::ScanResidentArgs scan_resident_args(const aae_codebook* cb, const void* qp, int B, const ScanPlan& s, unsigned char* base, int topk, const float* raw_z,
+                                                const ScanTicketOut* fin, dim3* grid_out) {
     aae::ScanResidentArgs a;
     a.E = cb->E; a.e_bytes = (unsigned)((size_t)cb->N * cb->J * (cb->dtype == AAE_DTYPE_BF16 ? 2 : 4));
     a.qp = qp;
@@ -181,6 +181,13 @@ static int launch_scan_resident(const aae_codebook* cb, const void* qp, int B, c
         a.cand_i = reinterpret_cast<int*>(base + s.cand_off + align_up((size_t)B * s.cand_chunks * topk * sizeof(float), 256));
         if (cb->topk_prune) a.prune = reinterpret_cast<int*>(base + s.prune_off);      // (reset by the normalise kernel in front)
     }
+    *grid_out = grid;
+    return a;
+}
+static int launch_scan_resident(const aae_codebook* cb, const void* qp, int B, const ScanPlan& s, unsigned char* base, hipStream_t stream,
+                                int topk = 1, const float* raw_z = nullptr, const ScanTicketOut* fin = nullptr) {
+    dim3 grid;
+    const aae::ScanResidentArgs a = scan_resident_args(cb, qp, B, s, base, topk, raw_z, fin, &grid);
     const bool bf16 = cb->dtype == AAE_DTYPE_BF16;
     if (s.res_rh == 4) {                           // (arg-max only: plan_scan)
         if (bf16 && a.z) launch_scan_resident_t<true, 0, 4, true>(a, grid, stream);

@@ -411,6 +411,84 @@ static void launch_wavek_multi_t(const aae::ConvWaveKMultiArgs& m, int tag, int 
     else AAE_LAUNCH((aae::conv_wavek_multi_kernel<MT, NT, 4, DEPTH, 0, SPREAD>), dim3(nblk), dim3(256), smem, stream, m);
 }
 
+template <int RH>
+static void launch_scan_resident_multi_t(const aae::ScanResidentMultiArgs& m, int nblk, hipStream_t stream) {
+    constexpr int smem = aae::scan_resident_smem<false, RH>();
+    static const bool once = ((void)hipFuncSetAttribute((const void*)aae::scan_resident_multi_kernel<RH>, hipFuncAttributeMaxDynamicSharedMemorySize, smem), true);
+    (void)once;
+    AAE_LAUNCH((aae::scan_resident_multi_kernel<RH>), dim3(nblk), dim3(aae::kScanResidentThreads), smem, stream, m);
+}
+
+// The codebook scans of a mid-batch group: objects whose query takes the query-resident arg-max form on an fp32 codebook (the block normalises its own queries) share ONE
+// launch per row-part count (plan_scan: res_rh by the query count) and ONE arg-max reduce launch -- every block the object's own launch's block, partials and answers in
+// the object's own workspace slice: bit-identical.  Returns the members it did not cover in `rest`.
+static int launch_mid_scans(const aae_multi_item* items, const MultiPlan& mp, const std::vector<int>& members, const float* z, int J, int64_t* idx_out, float* score_out,
+                            unsigned char* base, hipStream_t stream, std::vector<int>& rest) {
+    struct Member { int i; const aae_codebook* cb; ScanPlan s; int idx_scale; };
+    std::vector<Member> ok;
+    rest.clear();
+    for (int i : members) {
+        const aae_multi_item& it = items[i];
+        const MultiItemPlan& p = mp.items[(size_t)i];
+        const aae_codebook* cb = it.cb;
+        int idx_scale = 1, col_stride = it.col_stride;
+        if (col_stride > 1 && cb->upright && cb->upright_stride == col_stride) { idx_scale = col_stride; cb = cb->upright; col_stride = 1; }
+        const ScanPlan s = plan_scan(cb, p.n, 1, col_stride > 1);
+        const bool fits = it.enc->multi_mid_scan && col_stride == 1 && cb->dtype == AAE_DTYPE_F32 && s.resident_ok && !s.stream && cb->scan_fused_norm && !cb->scan_resident_fin &&
+                          cb->scan_mode == AAE_SCAN_AUTO && (((uintptr_t)(z + (size_t)p.row0 * J)) & 15) == 0 && s.total <= p.cb_bytes;
+        if (fits) ok.push_back({i, cb, s, idx_scale});
+        else rest.push_back(i);
+    }
+    if (ok.size() < 2) {
+        for (const Member& mbr : ok) rest.push_back(mbr.i);
+        return AAE_OK;
+    }
+    for (int rh : {1, 2, 4}) {
+        aae::ScanResidentMultiArgs m;
+        memset(&m, 0, sizeof(m));
+        int at = 0, nk = 0;
+        for (const Member& mbr : ok) {
+            if (mbr.s.res_rh != rh) continue;
+            const MultiItemPlan& p = mp.items[(size_t)mbr.i];
+            dim3 grid;
+            m.item[nk] = scan_resident_args(mbr.cb, nullptr, p.n, mbr.s, base + p.cb_off, 1, z + (size_t)p.row0 * J, nullptr, &grid);
+            m.row_blocks[nk] = (int)grid.x;
+            m.range.first[nk] = at;
+            at += (int)(grid.x * grid.y);
+            ++nk;
+        }
+        if (!nk) continue;
+        m.range.n = nk;
+        m.range.first[nk] = at;
+        if (rh == 1) launch_scan_resident_multi_t<1>(m, at, stream);
+        else if (rh == 2) launch_scan_resident_multi_t<2>(m, at, stream);
+        else launch_scan_resident_multi_t<4>(m, at, stream);
+        AAE_HIP_TRY(hipGetLastError());
+        ++t_multi_launches;
+    }
+    aae::ArgmaxReduceMultiArgs r;
+    memset(&r, 0, sizeof(r));
+    int at = 0, nk = 0;
+    for (const Member& mbr : ok) {
+        const MultiItemPlan& p = mp.items[(size_t)mbr.i];
+        aae::ArgmaxReduceArgs& a = r.item[nk];
+        a.pval = reinterpret_cast<float*>(base + p.cb_off + mbr.s.pval_off);
+        a.pidx = reinterpret_cast<int*>(base + p.cb_off + mbr.s.pidx_off);
+        a.idx_out = reinterpret_cast<long long*>(idx_out + p.row0);
+        a.score_out = score_out + p.row0;
+        a.nblk = mbr.s.res_blocks; a.B = p.n; a.Bstride = mbr.s.Bstride; a.idx_scale = mbr.idx_scale;
+        r.range.first[nk] = at;
+        at += p.n;
+        ++nk;
+    }
+    r.range.n = nk;
+    r.range.first[nk] = at;
+    AAE_LAUNCH((aae::argmax_reduce_multi_kernel), dim3(at), dim3(256), 64, stream, r);
+    AAE_HIP_TRY(hipGetLastError());
+    ++t_multi_launches;
+    return AAE_OK;
+}
+
 // the scan of up to kMultiMax grouped items in one launch (z: the items' raw latent codes, rows in item order)
 static int launch_scan_multi(const MultiPlan& mp, const std::vector<int>& members, const float* z, int J, int64_t* idx_out, float* score_out,
                              unsigned char* base, unsigned nonce, hipStream_t stream) {
@@ -746,7 +824,9 @@ static int launch_mid_group(const aae_multi_item* items, const MultiPlan& mp, co
             if (int rc = forward_impl(items[i].enc, base + p.enc_off + p.ws.act_off[nl - 1], AAE_DTYPE_F32, p.n, z_out + (size_t)p.row0 * J, base + p.enc_off, p.enc_bytes,
                                       stream_v, tm, nullptr, nullptr, nullptr, (int)nl, (int)nl + 1)) return rc;
         }
-    for (int i : members) {
+    std::vector<int> rest;
+    if (int rc = launch_mid_scans(items, mp, members, z_out, J, idx_out, score_out, base, stream, rest)) return rc;
+    for (int i : rest) {
         const MultiItemPlan& p = mp.items[(size_t)i];
         if (int rc = aae_codebook_nn(items[i].cb, z_out + (size_t)p.row0 * J, p.n, 1, items[i].col_stride, idx_out + p.row0, score_out + p.row0, base + p.cb_off,
                                      p.cb_bytes, stream_v)) return rc;

@@ -640,11 +640,11 @@ struct ArgmaxReduceArgs {
     int idx_scale;        // row ids are multiplied by this (upright search on the compacted every-k-th-row copy)
 };
 
-__global__ __launch_bounds__(256) void argmax_reduce_kernel(const ArgmaxReduceArgs p) {
+__device__ __forceinline__ void argmax_reduce_block(const ArgmaxReduceArgs& p, const int query) {
     AAE_DYN_SMEM(smem_raw);
     float* red_v = reinterpret_cast<float*>(smem_raw);      // [4]
     int* red_i = reinterpret_cast<int*>(red_v + 4);         // [4]
-    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int b = query, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     float bv = kNegInf;
     int bi = 0x7fffffff;
     for (int k0 = tid; k0 < p.nblk; k0 += 4 * 256) {        // 4 independent loads in flight per thread
@@ -676,6 +676,18 @@ __global__ __launch_bounds__(256) void argmax_reduce_kernel(const ArgmaxReduceAr
         p.idx_out[b] = (long long)bi * p.idx_scale;
         p.score_out[b] = bv;
     }
+}
+
+__global__ __launch_bounds__(256) void argmax_reduce_kernel(const ArgmaxReduceArgs p) { argmax_reduce_block(p, (int)blockIdx.x); }
+
+// ... for several codebooks in one launch (behind scan_resident_multi_kernel): block range.first[o] + q answers query q of object o
+struct ArgmaxReduceMultiArgs {
+    MultiRange range;
+    ArgmaxReduceArgs item[kMultiMax];
+};
+__global__ __launch_bounds__(256) void argmax_reduce_multi_kernel(const ArgmaxReduceMultiArgs m) {
+    const int o = multi_find(m.range, (int)blockIdx.x);
+    argmax_reduce_block(m.item[o], (int)blockIdx.x - m.range.first[o]);
 }
 
 // --------------------------------------------------------------------- top-k

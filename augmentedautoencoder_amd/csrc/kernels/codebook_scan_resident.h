@@ -177,8 +177,10 @@ __device__ __forceinline__ void scan_resident_normalise(const f32x4 (&zs)[16], f
     }
 }
 
-template <bool BF16, int K = 0, int RH = 2, bool NORM = false>
-__global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(const ScanResidentArgs p) {
+// One block of the scan: row block `bx` of `gx`, query chunk `by` (the single-codebook kernel passes its block / grid indices; the grouped kernel below the
+// position inside the object's own grid).
+template <bool BF16, int K, int RH, bool NORM>
+__device__ __forceinline__ void scan_resident_block(const ScanResidentArgs& p, const unsigned bx, const unsigned by, const unsigned gx) {
     constexpr int kTileRows = scan_resident_tile_rows<BF16, RH>();
     constexpr int kMi = kTileRows / (32 * RH);     // 32-row accumulator tiles per wave
     constexpr int kSlots = BF16 ? 16 : 32;         // 16-byte pieces per codebook row
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(con
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int rh = wave % RH, qg = wave / RH;
-    const int q0 = blockIdx.y * QB + qg * 32;
+    const int q0 = by * QB + qg * 32;
     const bool active = q0 < p.Bpad && q0 < p.B;   // wave-uniform (a query group of padding only has nothing to do)
     const int query = q0 + i;
 
@@ -223,7 +225,7 @@ __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(con
     }
 
     const int ntiles = (p.N + kTileRows - 1) / kTileRows;
-    const int tile0 = blockIdx.x * p.tiles_per_block;
+    const int tile0 = bx * p.tiles_per_block;
     const int tile1 = min(tile0 + p.tiles_per_block, ntiles);
 
     // staging by LDS-DMA: the codebook goes global -> LDS without passing through registers.  A tile is 2048 16-byte
@@ -255,7 +257,7 @@ __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(con
     auto publish = [&](float best) {               // top-k: raise this block's word of the lane's query, in every replica
 #pragma unroll
         for (int rep = 0; rep < kPruneReplicas; ++rep)
-            shared_word_max(p.prune + ((long long)rep * p.Bpad + query) * kPruneGroups + (blockIdx.x & (kPruneGroups - 1)), score_key(best));
+            shared_word_max(p.prune + ((long long)rep * p.Bpad + query) * kPruneGroups + (bx & (kPruneGroups - 1)), score_key(best));
     };
     constexpr int KL = K > 0 ? K : 1;
     float tv[KL];
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(con
                 float m16 = acc[mi][0];
 #pragma unroll
                 for (int r = 1; r < 16; ++r) m16 = fmaxf(m16, acc[mi][r]);
-                if (mi == 0 && t == tile0 && p.prune != nullptr && blockIdx.x < 4 * kPruneGroups && !(kAblate & 64)) {
+                if (mi == 0 && t == tile0 && p.prune != nullptr && bx < 4 * kPruneGroups && !(kAblate & 64)) {
                     // the first word of the bound: the best of this wave's first 32 rows, from four blocks per word -- in place
                     // long before the end of step 0, where every block reads the words for the first time
                     const float best = fmaxf(m16, shfl_xor(m16, 32));
@@ -382,7 +384,7 @@ __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(con
         // in-launch finish: block 0 gives the ticket words this launch's nonce now, with its first tiles in flight -- the arrivals come
         // microseconds later and then all take the one-atomic path (round 4 measured the finish WITHOUT this: every arrival of a
         // stand-alone query met a foreign word and queued behind the install, 20.7 against 16.1 us)
-        if (p.tickets != nullptr && blockIdx.x == 0) ticket_prepare_slot(p.tickets, p.nonce, gridDim.x);
+        if (p.tickets != nullptr && bx == 0) ticket_prepare_slot(p.tickets, p.nonce, gx);
     }
     if constexpr (NORM) {
         if (active) scan_resident_normalise<BF16>(zraw, bq);
@@ -409,13 +411,13 @@ __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(con
         block_barrier();                                       // image of tile t complete
         [[maybe_unused]] const int step = t - tile0;
 #ifdef AAE_SCAN_COUNT
-        if (tid == 0 && blockIdx.x == 100 && step < 16) reinterpret_cast<long long*>(p.dbg + 64)[step] = (long long)wall_ticks();
+        if (tid == 0 && bx == 100 && step < 16) reinterpret_cast<long long*>(p.dbg + 64)[step] = (long long)wall_ticks();
 #endif
         [[maybe_unused]] u32x4 pw[kPruneGroups / 4];
-        [[maybe_unused]] const bool reader = prune && tid < QB && blockIdx.y * QB + tid < p.Bpad && !(kAblate & 128);
+        [[maybe_unused]] const bool reader = prune && tid < QB && by * QB + tid < p.Bpad && !(kAblate & 128);
         [[maybe_unused]] auto load_words = [&]() {
             const buffer_rsrc pb = make_buffer(p.prune, (unsigned)(kPruneReplicas * p.Bpad) * kPruneGroups * 4u);
-            const int rq = (int)(blockIdx.x & (kPruneReplicas - 1)) * p.Bpad + blockIdx.y * QB + tid;      // this block's replica
+            const int rq = (int)(bx & (kPruneReplicas - 1)) * p.Bpad + by * QB + tid;      // this block's replica
 #pragma unroll
             for (int w4 = 0; w4 < kPruneGroups / 4; ++w4)      // (whole-vector casts: a bit_cast of one element indexed by a loop
                 pw[w4] = __builtin_bit_cast(u32x4, coherent_load4(pb, (unsigned)(rq * kPruneGroups + w4 * 4) * 4u));   // variable picked element 0 under clang -O2)
@@ -446,7 +448,7 @@ __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(con
             }
             if (active) {                                  // (published AFTER this block's own re-read: its loads do not queue behind its atomics)
                 if (prune && step < 32 && ((kPublishSteps >> step) & 1) && !(kAblate & 64) &&
-                    ((blockIdx.x >> 6) & 3) == (step == 1 ? 1u : step == 2 ? 2u : step == 4 ? 3u : 0u)) {     // a quarter of the blocks per step
+                    ((bx >> 6) & 3) == (step == 1 ? 1u : step == 2 ? 2u : step == 4 ? 3u : 0u)) {     // a quarter of the blocks per step
                     // one lane per query and wave, only what can move the bound (a score at or below it cannot become one of
                     // the K largest words), and a quarter of the blocks per step: a burst of device-scope atomics on a few thousand
                     // words right in front of the re-read of the same lines stalls it (every block publishing after step 1 made
@@ -464,7 +466,7 @@ __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(con
     }
 
 #ifdef AAE_SCAN_COUNT
-    if (tid == 0 && blockIdx.x == 100) reinterpret_cast<long long*>(p.dbg + 64)[tile1 - tile0 < 16 ? tile1 - tile0 : 15] = (long long)wall_ticks();
+    if (tid == 0 && bx == 100) reinterpret_cast<long long*>(p.dbg + 64)[tile1 - tile0 < 16 ? tile1 - tile0 : 15] = (long long)wall_ticks();
 #endif
     if constexpr (K > 0) {
         // ---- the sorted lists of a query (row part rh, lane half h) meet in LDS (the tile images are free) and
@@ -480,12 +482,12 @@ __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(con
             for (int j = 0; j < K; ++j) { lv[at + j] = tv[j]; li[at + j] = ti[j]; }
         }
         __syncthreads();
-        const int qo = blockIdx.y * QB + tid;
+        const int qo = by * QB + tid;
         if (tid < QB && qo < p.B) {
             int head[NL];
 #pragma unroll
             for (int l = 0; l < NL; ++l) head[l] = 0;
-            const long long obase = ((long long)qo * gridDim.x + blockIdx.x) * p.k;
+            const long long obase = ((long long)qo * gx + bx) * p.k;
             for (int j = 0; j < p.k; ++j) {
                 float wv = kNegInf;
                 int wi = 0x7fffffff, wl = 0;
@@ -504,7 +506,7 @@ __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(con
         }
 #ifdef AAE_SCAN_COUNT
         __syncthreads();
-        if (tid == 0 && blockIdx.x == 100) { reinterpret_cast<long long*>(p.dbg + 64)[13] = (long long)wall_ticks(); }
+        if (tid == 0 && bx == 100) { reinterpret_cast<long long*>(p.dbg + 64)[13] = (long long)wall_ticks(); }
 #endif
         return;
     }
@@ -523,7 +525,7 @@ __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(con
             // and merges them with the tie rule of argmax_reduce_kernel (higher score, then lower row: a total order, so the grouping
             // of the merge does not matter).
             constexpr int Q4 = QB / 4;                         // pieces per partial row
-            const int nblk = (int)gridDim.x;
+            const int nblk = (int)gx;
             const buffer_rsrc vbuf = make_buffer(p.pval, (unsigned)nblk * (unsigned)p.Bstride * 4u);
             const buffer_rsrc ibuf = make_buffer(p.pidx, (unsigned)nblk * (unsigned)p.Bstride * 4u);
             if (tid < Q4) {
@@ -542,11 +544,11 @@ __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(con
                     pi[e] = real ? (uint32_t)ix : 0x7fffffffu;
                 }
                 const bool in_row = 4 * tid < p.Bstride;
-                coherent_store4(vbuf, in_row ? (unsigned)(blockIdx.x * p.Bstride + 4 * tid) * 4u : kOobOffset, pv);
-                coherent_store4(ibuf, in_row ? (unsigned)(blockIdx.x * p.Bstride + 4 * tid) * 4u : kOobOffset, __builtin_bit_cast(f32x4, pi));
+                coherent_store4(vbuf, in_row ? (unsigned)(bx * p.Bstride + 4 * tid) * 4u : kOobOffset, pv);
+                coherent_store4(ibuf, in_row ? (unsigned)(bx * p.Bstride + 4 * tid) * 4u : kOobOffset, __builtin_bit_cast(f32x4, pi));
             }
             int* flag = red_i + 2 * 256 - 4;                   // (the tail of the reduction area: red_i holds RH * QB = 256 entries)
-            if (!block_ticket_arrive(p.tickets, p.nonce, (unsigned)nblk, blockIdx.x, flag)) return;
+            if (!block_ticket_arrive(p.tickets, p.nonce, (unsigned)nblk, bx, flag)) return;
             constexpr int PARTS = kScanResidentThreads / Q4;   // 32 (QB = 64) ... 8 (QB = 256)
             constexpr int KP = 8;                              // partial rows per thread and round: 256 row blocks in one round at QB = 64
             const int q4 = tid % Q4, part = tid / Q4;
@@ -594,7 +596,7 @@ __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(con
             return;
         }
     }
-    const int qout = blockIdx.y * QB + tid;
+    const int qout = by * QB + tid;
     if (tid < QB && qout < p.B) {
         float v = red_v[tid];
         int ix = red_i[tid];
@@ -604,9 +606,28 @@ __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(con
                 v = red_v[part * QB + tid];
                 ix = red_i[part * QB + tid];
             }
-        p.pval[(long long)blockIdx.x * p.Bstride + qout] = v;
-        p.pidx[(long long)blockIdx.x * p.Bstride + qout] = ix;
+        p.pval[(long long)bx * p.Bstride + qout] = v;
+        p.pidx[(long long)bx * p.Bstride + qout] = ix;
     }
+}
+
+template <bool BF16, int K = 0, int RH = 2, bool NORM = false>
+__global__ __launch_bounds__(kScanResidentThreads) void scan_resident_kernel(const ScanResidentArgs p) {
+    scan_resident_block<BF16, K, RH, NORM>(p, blockIdx.x, blockIdx.y, gridDim.x);
+}
+
+// ---- several codebooks in one launch (the arg-max form with the block normalising its own queries): object o owns blocks range.first[o] ... of the 1-D grid, laid out
+//      as its own (row blocks x query chunks) grid; every block is exactly the single-codebook launch's block -- bit-identical partials.
+struct ScanResidentMultiArgs {
+    MultiRange range;
+    int row_blocks[kMultiMax];             // gridDim.x of object o's own launch
+    ScanResidentArgs item[kMultiMax];
+};
+template <int RH>
+__global__ __launch_bounds__(kScanResidentThreads) void scan_resident_multi_kernel(const ScanResidentMultiArgs m) {
+    const int o = multi_find(m.range, (int)blockIdx.x);
+    const unsigned local = blockIdx.x - (unsigned)m.range.first[o], gx = (unsigned)m.row_blocks[o];
+    scan_resident_block<false, 0, RH, true>(m.item[o], local % gx, local / gx, gx);
 }
 
 }  // namespace aae

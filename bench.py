@@ -437,7 +437,7 @@ def main():
                              'answers_complete': bool((idx4 >= 0).all().item()),
                              'launches_per_step_besides_encode_nn': 'one pack_pairs per rank, %sunpack_pairs (buffers owned by the cached plan)' % ('all_gather, ' if use_dist else ''),
                              'query': ('aae_encode_nn_multi: one C call for the rank\'s %d buckets, %d grouped launches (one launch per layer across the objects: conv1, the Winograd conv layers, the dense layer, + one for the incomplete four-image blocks of conv4; '
-                                       'the scan per object)' % (len(order), mq4.launches or 0)) if mq4 is not None else 'aae_encode_nn per object'}
+                                       'the codebook scans as one launch per row-part count + one reduce launch)' % (len(order), mq4.launches or 0)) if mq4 is not None else 'aae_encode_nn per object'}
     if not use_dist and not args.no_extras and args.precision == 'f32':
         from augmentedautoencoder_amd.engine import CapturedNearestNeighbour, DecoderEngine, StreamingNearestNeighbour
         from augmentedautoencoder_amd.weights import DecoderConfig

@@ -251,7 +251,7 @@ int aae_detect_nn(aae_encoder* enc, aae_codebook* cb, const void* img, int H, in
  * (object, tile): a frame with C classes costs 6 launches instead of 6 C.  Items with n >= 5 whose conv layers all run as
  * polyphase Winograd (default options) form MID-BATCH groups: one Winograd launch per conv layer across the objects where the
  * group's blocks fill the chip (eight buckets of ~32 crops fill it like one batch of 256), conv1 and the dense layer likewise,
- * the scan per object; where the incomplete four-image blocks of an 8 x 8-output layer would open one more round of blocks, the
+ * the codebook scans in one launch per row-part count + one reduce launch; where the incomplete four-image blocks of an 8 x 8-output layer would open one more round of blocks, the
  * last n mod 4 images of every object are computed by one grouped launch of the direct kernel ("multi_mid_ragged").
  * All other items are answered by aae_encode_nn inside the same call.
  * Results against one aae_encode_nn call per item: with the defaults a group runs ONE launch plan chosen for the group

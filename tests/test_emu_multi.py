@@ -309,7 +309,7 @@ def test_mid_batch_group_one_winograd_launch_per_conv_layer_across_objects(order
         x = synth.make_crops(sum(counts), seed=58, shape=cfg.shape)
         z0, i0, s0 = _per_object(items, x)
         z1, i1, s1, launches = eb.encode_nn_multi(items, x)
-        assert launches == 3                                             # (the grouped launches: conv1 in its whole-tile form, conv2 and conv3 -- the rest is counted by the per-object path)
+        assert launches == 5                                             # (the grouped launches: conv1 in its whole-tile form, conv2, conv3, the three scans as one launch + one reduce launch; the dense GEMV per object)
         assert np.array_equal(z1, z0) and np.array_equal(i1, i0) and np.array_equal(s1, s0)
         at = 0
         for (e, c, w), n in zip(objs, counts):
@@ -352,7 +352,7 @@ def test_mid_batch_group_hands_incomplete_four_image_blocks_to_one_wave_split_k_
         x = synth.make_crops(sum(counts), seed=61, shape=cfg.shape)
         z0, i0, s0 = _per_object(items, x)
         z1, i1, s1, launches = eb.encode_nn_multi(items, x)
-        assert launches == 4                                             # conv1, conv2, conv3's complete blocks, conv3's last images
+        assert launches == 6                                             # conv1, conv2, conv3's complete blocks, conv3's last images, scans, reduce
         at = 0
         for (e, c, w), n in zip(objs, counts):
             full = n // 4 * 4
@@ -366,7 +366,11 @@ def test_mid_batch_group_hands_incomplete_four_image_blocks_to_one_wave_split_k_
         for e, _, _ in objs:
             e.set_option('multi_mid_ragged', 0)
         z2, i2, s2, launches = eb.encode_nn_multi(items, x)
-        assert launches == 3 and np.array_equal(z2, z0) and np.array_equal(i2, i0) and np.array_equal(s2, s0)
+        assert launches == 5 and np.array_equal(z2, z0) and np.array_equal(i2, i0) and np.array_equal(s2, s0)
+        for e, _, _ in objs:
+            e.set_option('multi_mid_scan', 0)
+        z3, i3, s3, launches = eb.encode_nn_multi(items, x)                # (the scans per object again: the same answers from two launches fewer in the count)
+        assert launches == 3 and np.array_equal(z3, z0) and np.array_equal(i3, i0) and np.array_equal(s3, s0)
         _close(objs)
     finally:
         eb.set_block_order(0)
@@ -383,7 +387,7 @@ def test_mid_batch_fill_rule_counts_the_complete_blocks_when_the_incomplete_ones
     x = synth.make_crops(sum(counts), seed=62, shape=cfg.shape)
     z0, i0, s0 = _per_object(items, x)
     z1, i1, s1, launches = eb.encode_nn_multi(items, x)
-    assert launches == 4                                                 # conv1, conv2's twelve complete blocks, the 25th crop of object 0, the dense layer
+    assert launches == 6                                                 # conv1, conv2's twelve complete blocks, the 25th crop of object 0, the dense layer, scans, reduce
     assert np.abs(z1 - z0).max() / np.abs(z0).max() < 5e-6
     at = 0
     for (e, c, w), n in zip(objs, counts):
