@@ -295,7 +295,7 @@ def test_argument_errors_are_reported_not_crashed():
 _WINO = {'winograd_min_batch': 1, 'winograd_min_blocks': 1, 'first_group_split_max_tiles': 0}      # (every eligible layer as Winograd, alone and in a group: the emulated launches are tiny against the 256 compute units the fill rule counts with; conv1 in its whole-tile form, as at the batch sizes that group on the GPU)
 
 
-@pytest.mark.parametrize('order', [0, 1, 2])
+@pytest.mark.parametrize('order', [0, 2])          # (ascending and scrambled block order; the descending order ran green through round 6 and was dropped for CPU suite time)
 def test_mid_batch_group_one_winograd_launch_per_conv_layer_across_objects(order):
     """objects with 5 or more detections each: conv1, the dense layer and the scan per object, ONE Winograd launch per conv layer across
     the objects (conv_wino_layer_multi_kernel) -- both block geometries (16 x 16-pixel regions of one image; four 8 x 8 images per block,
@@ -337,7 +337,7 @@ def test_mid_batch_group_one_winograd_launch_per_conv_layer_across_objects(order
         eb.set_block_order(0)
 
 
-@pytest.mark.parametrize('order', [0, 2])
+@pytest.mark.parametrize('order', [2])
 def test_mid_batch_group_hands_incomplete_four_image_blocks_to_one_wave_split_k_launch(order):
     """conv3 of this net packs four 8 x 8 images per block: counts {5, 7, 6} = 6 blocks, 3 of them incomplete.  On a "chip" of 4 compute units the
     incomplete ones open a second round: the objects' last 1 / 3 / 2 images go to ONE grouped wave-split-K launch (plan_mid_ragged) -- the same
