@@ -179,12 +179,13 @@ static Workspace plan_workspace_grouped(const aae_encoder* enc, int n, const std
 }
 
 // Can (enc, n detections) join a mid-batch group?  Default options in exact fp32, every conv layer behind the first one prepared for Winograd.
-static bool multi_encoder_mid_groupable(const aae_encoder* enc, int n, std::vector<int>& sig) {
+// (weights_pending: asked before the Winograd-domain weights exist -- aae_multi_workspace_bytes builds them only for objects whose group would form)
+static bool multi_encoder_mid_groupable(const aae_encoder* enc, int n, std::vector<int>& sig, bool weights_pending = false) {
     const size_t nl = enc->layers.size();
     if (n < 5 || nl < 2 || enc->winograd != 1 || enc->winograd_wide || !enc->multi_mid_group || runs_split(enc, n)) return false;
     for (size_t li = 1; li < nl; ++li) {
         const Layer& L = enc->layers[li];
-        if (L.kind != KIND_IGEMM || L.wino_geom < 0 || !L.wino[0]) return false;      // (the weights: prepared by aae_multi_workspace_bytes)
+        if (L.kind != KIND_IGEMM || L.wino_geom < 0 || (!L.wino[0] && !weights_pending)) return false;      // (the weights: prepared by aae_multi_workspace_bytes)
         if ((unsigned long long)n * L.H * L.W * L.Cin * sizeof(float) >= 0x7FFFFF00ull) return false;
     }
     sig.clear();
@@ -899,10 +900,24 @@ extern "C" {
 
 size_t aae_multi_workspace_bytes(const aae_multi_item* items, int n_items, int scan_only) {
     // (the one place outside the hot calls that sees a frame's layout: objects that may join a mid-batch group get their Winograd weights here)
-    if (items && !scan_only)
+    // Winograd-domain weights (+83.5 MB for the reference network) only for the objects of a group that WOULD form (an estimator with thirty classes of a few boxes each never builds them).
+    if (items && !scan_only) {
+        for (int i = 0; i < n_items; ++i)          // (an object whose OWN forward at this count takes the Winograd form: as aae_encoder_workspace_bytes does)
+            if (items[i].enc && items[i].n >= 1 && aae_host::wants_winograd_weights(items[i].enc, items[i].n) && aae_host::ensure_winograd_weights(items[i].enc) != AAE_OK) return 0;
+        std::vector<std::vector<int>> sigs((size_t)n_items);
+        std::vector<char> cand((size_t)n_items, 0), seen((size_t)n_items, 0);
         for (int i = 0; i < n_items; ++i)
-            if (items[i].enc && items[i].n >= 5 && items[i].enc->winograd == 1 && items[i].enc->multi_mid_group &&
-                aae_host::ensure_winograd_weights(items[i].enc) != AAE_OK) return 0;
+            cand[(size_t)i] = items[i].enc && items[i].cb && items[i].n >= 5 && aae_host::multi_encoder_mid_groupable(items[i].enc, items[i].n, sigs[(size_t)i], true);
+        for (int i = 0; i < n_items; ++i) {
+            if (!cand[(size_t)i] || seen[(size_t)i]) continue;
+            std::vector<int> members, counts;
+            for (int k = i; k < n_items && (int)members.size() < aae::kMultiMax; ++k)
+                if (cand[(size_t)k] && !seen[(size_t)k] && sigs[(size_t)k] == sigs[(size_t)i]) { members.push_back(k); counts.push_back(items[k].n); seen[(size_t)k] = 1; }
+            if (members.size() >= 2 && aae_host::mid_group_fills(items[members[0]].enc, counts))
+                for (int k : members)
+                    if (aae_host::ensure_winograd_weights(items[k].enc) != AAE_OK) return 0;
+        }
+    }
     aae_host::MultiPlan mp;
     if (aae_host::plan_multi(items, n_items, scan_only != 0, mp) != AAE_OK) return 0;
     return mp.total;

@@ -623,6 +623,7 @@ struct ScanResidentMultiArgs {
     int row_blocks[kMultiMax];             // gridDim.x of object o's own launch
     ScanResidentArgs item[kMultiMax];
 };
+static_assert(sizeof(ScanResidentMultiArgs) <= 4096, "kernel arguments: 4 KB");
 template <int RH>
 __global__ __launch_bounds__(kScanResidentThreads) void scan_resident_multi_kernel(const ScanResidentMultiArgs m) {
     const int o = multi_find(m.range, (int)blockIdx.x);
