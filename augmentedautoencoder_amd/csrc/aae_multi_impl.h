@@ -660,7 +660,7 @@ static int launch_encoder_multi(const aae_multi_item* items, const MultiPlan& mp
     return AAE_OK;
 }
 
-// A mid-batch group: conv1, every Winograd conv layer and the dense layer as ONE launch each across the objects, the scan per object.
+// A mid-batch group: conv1, every Winograd conv layer and the dense layer as ONE launch each across the objects, the scans in shared launches (launch_mid_scans).
 static int launch_mid_group(const aae_multi_item* items, const MultiPlan& mp, const std::vector<int>& members, const std::vector<char>& rem_layers, const void* x, int x_dtype,
                             float* z_out, int64_t* idx_out, float* score_out, unsigned char* base, void* stream_v) {
     hipStream_t stream = static_cast<hipStream_t>(stream_v);

@@ -297,7 +297,7 @@ _WINO = {'winograd_min_batch': 1, 'winograd_min_blocks': 1, 'first_group_split_m
 
 @pytest.mark.parametrize('order', [0, 2])          # (ascending and scrambled block order; the descending order ran green through round 6 and was dropped for CPU suite time)
 def test_mid_batch_group_one_winograd_launch_per_conv_layer_across_objects(order):
-    """objects with 5 or more detections each: conv1, the dense layer and the scan per object, ONE Winograd launch per conv layer across
+    """objects with 5 or more detections each: ONE launch per layer across the objects -- conv1, the dense layer where the members' plans agree, the scans, ONE Winograd launch per conv layer across
     the objects (conv_wino_layer_multi_kernel) -- both block geometries (16 x 16-pixel regions of one image; four 8 x 8 images per block,
     ragged groups), three objects with different detection counts; bit for bit the per-object calls, and right against the oracle."""
     cfg = EncoderConfig((64, 64, 3), [32, 64, 64], [2, 2, 2], 5, 128, True)

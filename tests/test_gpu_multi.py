@@ -243,7 +243,7 @@ def test_objects_that_share_one_workspace_alternate_on_the_ticketed_path(eight_o
 
 def test_mid_batch_group_eight_buckets_of_a_256_crop_batch(eight_objects):
     """SURVEY section 8d config 4 on one GPU: 256 crops over 8 objects ({34, 26, 27, 32, 31, 32, 33, 41}): ONE launch per conv layer
-    across the objects (conv1 in its whole-tile form, conv2 ... conv4 as Winograd: conv4's four-image blocks fill the chip where one bucket alone fills a quarter; the dense layer), scan per object.
+    across the objects (conv1 in its whole-tile form, conv2 ... conv4 as Winograd: conv4's four-image blocks fill the chip where one bucket alone fills a quarter; the dense layer), the scans in shared launches.
     Against (a) each object's own call with every eligible layer forced to Winograd -- bit for bit except the images conv4 hands to the wave-split-K kernel --, (b) each object's default call
     (conv3 / conv4 on the direct kernels at these sizes: fp32 rounding of the two forms), (c) each object's fp64 oracle."""
     import torch
