@@ -43,6 +43,7 @@ struct MultiPlan {
     std::vector<MultiItemPlan> items;
     std::vector<std::vector<int>> groups;      // grouped items that share launches: equal signatures, at most kMultiMax members, item order
     std::vector<std::vector<int>> mid_groups;  // mid-batch items that share their Winograd launches
+    std::vector<std::vector<char>> group_wino; // [group][conv layer]: the layer runs as one Winograd launch across the group's objects (multi_group_winograd)
     std::vector<std::vector<char>> mid_rem;    // [mid group][conv layer]: the incomplete four-image blocks leave the Winograd launch (multi_mid_ragged)
     size_t seq_enc_off = 0, seq_enc_bytes = 0, seq_cb_off = 0, seq_cb_bytes = 0, total = 0;
     int rows = 0;
@@ -79,6 +80,7 @@ static bool multi_encoder_groupable(const aae_encoder* enc, int n, std::vector<W
                                                    // per-object call's summation order); group plans: objects with 1 ... 4 detections share their launches
     sig.push_back(enc->multi_group_plan);      // ... and the options the group's plan is made from
     sig.push_back(enc->wavek_spread); sig.push_back(enc->wavek_g_boost); sig.push_back(wavek_round_blocks(enc)); sig.push_back(enc->wavek_eff64x32_pct);
+    sig.push_back(enc->multi_group_winograd); sig.push_back(enc->winograd); sig.push_back(enc->winograd_min_fill_pct); sig.push_back(enc->winograd_min_blocks); sig.push_back(enc->winograd_xcd_cols);
     sig.push_back(enc->compact_workspace); sig.push_back(enc->first_vec4); sig.push_back(enc->multi_force_shape); sig.push_back(enc->multi_force_g); sig.push_back(enc->multi_xcd_affine); sig.push_back(enc->multi_force_depth);
     const int32_t* d = reinterpret_cast<const int32_t*>(&enc->desc);
     for (size_t i = 0; i < sizeof(aae_encoder_desc) / sizeof(int32_t); ++i) sig.push_back(d[i]);      // (bn_eps as its bit pattern)
@@ -270,7 +272,7 @@ static void plan_mid_ragged(const aae_multi_item* items, MultiPlan& mp) {
 }
 
 // Layout of one call: [shared slice of the per-object path: encoder part, codebook part][grouped item 0: encoder, codebook][item 1] ...
-static int plan_multi(const aae_multi_item* items, int n_items, bool scan_only, MultiPlan& mp) {
+static int plan_multi(const aae_multi_item* items, int n_items, bool scan_only, MultiPlan& mp, bool weights_pending = false) {
     if (!items || n_items < 1) return fail(AAE_ERR_INVALID, "multi-object query: no items");
     mp.items.assign((size_t)n_items, MultiItemPlan());
     int row = 0;
@@ -358,6 +360,33 @@ static int plan_multi(const aae_multi_item* items, int n_items, bool scan_only, 
                 MultiItemPlan& p = mp.items[(size_t)i];
                 p.ws = plan_workspace_grouped(items[i].enc, p.n, p.plans);
                 p.enc_bytes = align_up(p.ws.total, 256);
+            }
+        }
+    // per-detection groups: conv layers whose blocks -- over ALL objects of the group -- pass the fill rule run as one Winograd launch (a frame of 8 classes x 4 boxes: conv2 512 blocks,
+    // conv3 256; 8 x 1: conv2 128 = half a round: stays on the wave-split-K kernel)
+    mp.group_wino.assign(mp.groups.size(), std::vector<char>());
+    if (!scan_only)
+        for (size_t gi = 0; gi < mp.groups.size(); ++gi) {
+            const std::vector<int>& g = mp.groups[gi];
+            const aae_encoder* enc0 = items[g[0]].enc;
+            const size_t nl = enc0->layers.size();
+            mp.group_wino[gi].assign(nl, 0);
+            if (g.size() < 2 || !enc0->multi_group_plan || !enc0->multi_group_winograd || enc0->winograd != 1 || enc0->winograd_wide) continue;
+            const long long cus = wavek_round_blocks(enc0);
+            for (size_t li = 1; li < nl; ++li) {
+                const Layer& L0 = enc0->layers[li];
+                if (L0.kind != KIND_IGEMM || L0.wino_geom < 0) continue;
+                long long regions = 0;
+                bool ready = true;
+                for (int i : g) {
+                    const Layer& L = items[i].enc->layers[li];
+                    ready = ready && L.wino_geom == L0.wino_geom && (L.wino[0] || weights_pending);
+                    regions += wino_regions(L, mp.items[(size_t)i].n);
+                }
+                if (!ready) continue;
+                const long long blocks = aae::wino_grid_blocks((int)regions, L0.Cout / 64, wino_xcd_cols(enc0, L0)), rounds = (blocks + cus - 1) / cus;
+                const bool fills = enc0->winograd_min_blocks > 0 ? blocks >= enc0->winograd_min_blocks : 100 * blocks >= (long long)enc0->winograd_min_fill_pct * rounds * cus;
+                if (fills) mp.group_wino[gi][li] = 1;
             }
         }
     mp.rows = row;
@@ -527,7 +556,7 @@ static int launch_scan_multi(const MultiPlan& mp, const std::vector<int>& member
 }
 
 // conv1 ... dense of up to kMultiMax grouped items (equal signatures): one launch per layer
-static int launch_encoder_multi(const aae_multi_item* items, const MultiPlan& mp, const std::vector<int>& members, const void* x, int x_dtype,
+static int launch_encoder_multi(const aae_multi_item* items, const MultiPlan& mp, const std::vector<int>& members, const std::vector<char>& wino_layers, const void* x, int x_dtype,
                                 float* z_out, unsigned char* base, unsigned nonce, hipStream_t stream) {
     const aae_encoder* enc0 = items[members[0]].enc;
     const size_t nl = enc0->layers.size();
@@ -563,7 +592,7 @@ static int launch_encoder_multi(const aae_multi_item* items, const MultiPlan& mp
                     if (tp.n < aae::kMultiPrepRanges) { tp.words[tp.n] = words; tp.count[tp.n] = count; ++tp.n; }
                 };
                 for (size_t li = 1; li < nl; ++li)
-                    if (p.plans[li].gsplits > 1 || p.plans[li].tail_tiles > 0)
+                    if ((p.plans[li].gsplits > 1 || p.plans[li].tail_tiles > 0) && !(li < wino_layers.size() && wino_layers[li]))
                         add(tickets_of(k) + li * kLayerTicketWords, p.plans[li].tail_tiles > 0 ? p.plans[li].tail_tiles : p.plans[li].num_mt * p.plans[li].num_nt);
                 add(tickets_of(k) + kConvTicketBytes / 8, (it.enc->dense.CoutPad / 128) * aae::kTicketSlotWords);
                 add(reinterpret_cast<unsigned long long*>(base + p.cb_off + p.sp.ticket_off), aae::kTicketSlotWords);
@@ -577,8 +606,37 @@ static int launch_encoder_multi(const aae_multi_item* items, const MultiPlan& mp
         AAE_HIP_TRY(hipGetLastError());
         ++t_multi_launches;
     }
-    // ---- conv2 ...: the wave-split-K kernel, every object with its own plan
+    // ---- conv2 ...: the wave-split-K kernel, every object with its own plan -- or, where the group's blocks fill the chip, the Winograd layer kernel across the objects
     for (size_t li = 1; li < nl; ++li) {
+        if (li < wino_layers.size() && wino_layers[li]) {
+            const Layer& L0 = enc0->layers[li];
+            aae::ConvWinoMultiArgs wm;
+            memset(&wm, 0, sizeof(wm));
+            aae::ConvWinoArgs& c = wm.c;
+            c.H = L0.H; c.W = L0.W; c.Cin = L0.Cin; c.Cout = L0.Cout; c.Ho = L0.Ho; c.Wo = L0.Wo; c.relu = L0.relu;
+            c.blocks_x = L0.wino_geom == 0 ? L0.Wo / 16 : 1;
+            c.blocks_y = L0.wino_geom == 0 ? L0.Ho / 16 : 1;
+            int wat = 0;
+            wm.range.n = (int)members.size();
+            for (size_t k = 0; k < members.size(); ++k) {
+                const MultiItemPlan& p = mp.items[(size_t)members[k]];
+                const Layer& L = items[members[k]].enc->layers[li];
+                aae::ConvWinoObject& ob = wm.obj[k];
+                ob.x = reinterpret_cast<const float*>(enc_base(k) + p.ws.act_off[li - 1]);
+                ob.out = reinterpret_cast<float*>(enc_base(k) + p.ws.act_off[li]);
+                for (int q = 0; q < 4; ++q) ob.U4[q] = L.wino[q];
+                ob.bias = L.bias; ob.bn_scale = L.bn_scale; ob.bn_shift = L.bn_shift; ob.B = p.n;
+                wm.range.first[k] = wat;
+                wat += wino_regions(L, p.n);
+            }
+            wm.range.first[members.size()] = wat;
+            c.regions = wat;
+            c.xcd_cols = wino_xcd_cols(enc0, L0);
+            wino_layer_multi_launch(L0.wino_geom, aae::wino_grid_blocks(wat, L0.Cout / 64, c.xcd_cols), stream, wm);
+            AAE_HIP_TRY(hipGetLastError());
+            ++t_multi_launches;
+            continue;
+        }
         aae::ConvWaveKMultiArgs m;
         memset(&m, 0, sizeof(m));
         m.range.n = (int)members.size();
@@ -880,14 +938,16 @@ static int multi_impl(const aae_multi_item* items, int n_items, const void* x, i
     }
     // ---- grouped items: one launch per layer and group
     if (!mp.groups.empty()) t_x3h_last_slot = -1;
-    for (const std::vector<int>& g : mp.groups) {
+    for (size_t gidx = 0; gidx < mp.groups.size(); ++gidx) {
+        const std::vector<int>& g = mp.groups[gidx];
         const unsigned nonce = next_nonce();           // one per group and call: every ticketed launch has its own words
         if (!scan_only) {
             for (int i : g) {
                 const aae_encoder_desc &a = items[i].enc->desc, &b = items[g[0]].enc->desc;
                 if (a.in_h != b.in_h || a.in_w != b.in_w || a.in_c != b.in_c) return fail(AAE_ERR_RUNTIME, "multi-object query: group members differ in crop shape");
             }
-            if (int rc = launch_encoder_multi(items, mp, g, x, x_dtype, z_out, base, nonce, stream)) return rc;
+            static const std::vector<char> no_wino;
+            if (int rc = launch_encoder_multi(items, mp, g, gidx < mp.group_wino.size() ? mp.group_wino[gidx] : no_wino, x, x_dtype, z_out, base, nonce, stream)) return rc;
         }
         if (int rc = launch_scan_multi(mp, g, z, J, idx_out, score_out, base, nonce, stream)) return rc;
     }
@@ -904,6 +964,17 @@ size_t aae_multi_workspace_bytes(const aae_multi_item* items, int n_items, int s
     if (items && !scan_only) {
         for (int i = 0; i < n_items; ++i)          // (an object whose OWN forward at this count takes the Winograd form: as aae_encoder_workspace_bytes does)
             if (items[i].enc && items[i].n >= 1 && aae_host::wants_winograd_weights(items[i].enc, items[i].n) && aae_host::ensure_winograd_weights(items[i].enc) != AAE_OK) return 0;
+        {   // per-detection groups with a layer in the Winograd form (multi_group_winograd): a dry plan tells which
+            aae_host::MultiPlan dry;
+            if (aae_host::plan_multi(items, n_items, false, dry, true) != AAE_OK) return 0;
+            for (size_t gi = 0; gi < dry.groups.size(); ++gi) {
+                bool any = false;
+                for (char c : dry.group_wino[gi]) any = any || c;
+                if (any)
+                    for (int k : dry.groups[gi])
+                        if (aae_host::ensure_winograd_weights(items[k].enc) != AAE_OK) return 0;
+            }
+        }
         std::vector<std::vector<int>> sigs((size_t)n_items);
         std::vector<char> cand((size_t)n_items, 0), seen((size_t)n_items, 0);
         for (int i = 0; i < n_items; ++i)

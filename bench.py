@@ -483,7 +483,9 @@ def main():
         lm = {'objects': N_OBJ, 'weights_plus_codebooks_MB': round(N_OBJ * (cfg.param_bytes() + cb_bytes) / 1e6, 1),
               'note': 'sequential = one six-launch aae_encode_nn chain per object; grouped = aae_encode_nn_multi: one launch per layer across the objects (problem table in the '
                       'kernel arguments, tickets per (object, tile), one scan launch over all codebooks), the launch plan chosen for the group (option multi_group_plan; 0 = '
-                      'per-object plans, bit-identical to the sequential calls).  Cold by construction: 853 MB of weights + codebooks against a 256 MB Infinity Cache'}
+                      'per-object plans, bit-identical to the sequential calls); a conv layer whose blocks fill the chip over all objects of the frame runs as ONE polyphase-Winograd launch '
+                      '(option multi_group_winograd: conv2 from 9 detections per frame, conv3 from 18 -- mfma_floor_us is the DIRECT form\'s floor, which such frames can undercut).  '
+                      'Cold by construction: 853 MB of weights + codebooks against a 256 MB Infinity Cache'}
         for d in (1, 4):
             def frame_seq():
                 for (e, c_b), xi in zip(all8, xs):

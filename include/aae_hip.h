@@ -248,7 +248,8 @@ int aae_detect_nn(aae_encoder* enc, aae_codebook* cb, const void* img, int H, in
  * Items with n <= 4 whose per-object call would run the per-detection chain (fp32, default options, fp32 codebook, stride 1
  * or a prepared upright copy) are GROUPED: conv1, every later conv layer, the dense GEMV and the codebook scan each run as ONE
  * launch over all grouped items -- objects with different n included -- every block the per-object launch's block, tickets per
- * (object, tile): a frame with C classes costs 6 launches instead of 6 C.  Items with n >= 5 whose conv layers all run as
+ * (object, tile): a frame with C classes costs 6 launches instead of 6 C; a conv layer whose blocks fill the chip over ALL grouped
+ * objects (conv2 from ~9 boxes per frame) runs as one polyphase-Winograd launch instead ("multi_group_winograd").  Items with n >= 5 whose conv layers all run as
  * polyphase Winograd (default options) form MID-BATCH groups: one Winograd launch per conv layer across the objects where the
  * group's blocks fill the chip (eight buckets of ~32 crops fill it like one batch of 256), conv1 and the dense layer likewise,
  * the codebook scans in one launch per row-part count + one reduce launch; where the incomplete four-image blocks of an 8 x 8-output layer would open one more round of blocks, the

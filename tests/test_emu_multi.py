@@ -295,6 +295,39 @@ def test_argument_errors_are_reported_not_crashed():
 _WINO = {'winograd_min_batch': 1, 'winograd_min_blocks': 1, 'first_group_split_max_tiles': 0}      # (every eligible layer as Winograd, alone and in a group: the emulated launches are tiny against the 256 compute units the fill rule counts with; conv1 in its whole-tile form, as at the batch sizes that group on the GPU)
 
 
+@pytest.mark.parametrize('order', [0, 2])
+def test_per_detection_group_runs_conv_layers_as_one_winograd_launch_where_the_group_fills_the_chip(order):
+    """three objects with 1, 2 and 4 detections (a frame of a detector): with the block-count rule forced low the group's conv2 (16 x 16-pixel regions) and conv3 (four 8 x 8 images per
+    block: every object one ragged block) run as ONE Winograd launch each across the objects (multi_group_winograd) between the grouped conv1 and the GEMV / scan launches.  The conv
+    layers are the objects' own Winograd launches bit for bit; latents against the per-object calls within the group plan's summation order, and right against the oracle."""
+    cfg = EncoderConfig((64, 64, 3), [32, 64, 64], [2, 2, 2], 5, 128, True)
+    counts = [1, 2, 4]
+    opts = {'winograd_min_batch': 1, 'winograd_min_blocks': 1}
+    eb.set_block_order(order)
+    try:
+        objs = [_object(cfg, 950 + 7 * o, 36 * (8 + o) + o, opts) for o in range(3)]
+        items = [(e, c, n, 1) for (e, c, _), n in zip(objs, counts)]
+        x = synth.make_crops(sum(counts), seed=63, shape=cfg.shape)
+        z0, i0, s0 = _per_object(items, x)                               # (every object's own call: Winograd conv layers too under these options)
+        z1, i1, s1, launches = eb.encode_nn_multi(items, x)
+        assert launches == 5                                             # conv1, conv2 (Winograd), conv3 (Winograd), GEMV, scan
+        assert np.abs(z1 - z0).max() / np.abs(z0).max() < 2e-6 and np.array_equal(i1, i0)
+        at = 0
+        for (e, c, w), n in zip(objs, counts):
+            z64 = ref.encoder_forward_np(ref.input_to_float(x[at:at + n]), w, cfg.strides, cfg.batch_norm)
+            assert np.abs(z1[at:at + n] - z64).max() / np.abs(z64).max() < 5e-6
+            assert np.array_equal(i1[at:at + n], np.argmax(c.similarity(z1[at:at + n]), axis=1))
+            at += n
+        for e, _, _ in objs:
+            e.set_option('multi_group_winograd', 0)                      # the wave-split-K kernel for every conv layer again
+        z2, i2, s2, launches = eb.encode_nn_multi(items, x)
+        assert launches == 5 and np.abs(z2 - z0).max() / np.abs(z0).max() < 5e-6 and np.array_equal(i2, i0)
+        assert not np.array_equal(z2, z1)                                # (another kernel computed the conv layers)
+        _close(objs)
+    finally:
+        eb.set_block_order(0)
+
+
 @pytest.mark.parametrize('order', [0, 2])          # (ascending and scrambled block order; the descending order ran green through round 6 and was dropped for CPU suite time)
 def test_mid_batch_group_one_winograd_launch_per_conv_layer_across_objects(order):
     """objects with 5 or more detections each: ONE launch per layer across the objects -- conv1, the dense layer where the members' plans agree, the scans, ONE Winograd launch per conv layer across
