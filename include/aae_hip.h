@@ -248,17 +248,18 @@ int aae_detect_nn(aae_encoder* enc, aae_codebook* cb, const void* img, int H, in
  * Items with n <= 4 whose per-object call would run the per-detection chain (fp32, default options, fp32 codebook, stride 1
  * or a prepared upright copy) are GROUPED: conv1, every later conv layer, the dense GEMV and the codebook scan each run as ONE
  * launch over all grouped items -- objects with different n included -- every block the per-object launch's block, tickets per
- * (object, tile): a frame with C classes costs 6 launches instead of 6 C; a conv layer whose blocks fill the chip over ALL grouped
- * objects (conv2 from ~9 boxes per frame) runs as one polyphase-Winograd launch instead ("multi_group_winograd").  Items with n >= 5 whose conv layers all run as
- * polyphase Winograd (default options) form MID-BATCH groups: one Winograd launch per conv layer across the objects where the
- * group's blocks fill the chip (eight buckets of ~32 crops fill it like one batch of 256), conv1 and the dense layer likewise,
- * the codebook scans in one launch per row-part count + one reduce launch; where the incomplete four-image blocks of an 8 x 8-output layer would open one more round of blocks, the
- * last n mod 4 images of every object are computed by one grouped launch of the direct kernel ("multi_mid_ragged").
+ * (object, tile): a frame with C classes costs 6 launches instead of 6 C; a conv layer whose blocks fill the chip over ALL
+ * grouped objects (conv2 from ~9 boxes per frame) runs as one polyphase-Winograd launch instead ("multi_group_winograd").
+ * Items with n >= 5 whose conv layers all run as polyphase Winograd (default options) form MID-BATCH groups: one Winograd
+ * launch per conv layer across the objects where the group's blocks fill the chip (eight buckets of ~32 crops fill it like one
+ * batch of 256), conv1 and the dense layer likewise, the codebook scans in one launch per row-part count + one reduce launch;
+ * where the incomplete four-image blocks of an 8 x 8-output layer would open one more round of blocks, the last n mod 4 images
+ * of every object are computed by one grouped launch of the direct kernel ("multi_mid_ragged").
  * All other items are answered by aae_encode_nn inside the same call.
  * Results against one aae_encode_nn call per item: with the defaults a group runs ONE launch plan chosen for the group
  * ("multi_group_plan" = 1) resp. the Winograd form where the object alone would take the direct kernels, so latents differ by
- * fp32 summation order / the two forms' rounding (<= 2.3e-6 of the latent scale; indices equal wherever the top-2 cosine gap
- * exceeds that), as a batch of another size does; every answer is checked against the object's own fp64 oracle.  With encoder
+ * fp32 summation order / the two forms' rounding (tests bound it at 5e-6 of the latent scale, measured <= 2.3e-6; indices equal
+ * wherever the top-2 cosine gap exceeds that), as a batch of another size does; every answer is checked against the object's own fp64 oracle.  With encoder
  * options "multi_group_plan" = 0 and "multi_mid_group" = 0 the call is bit-identical to the per-object calls.
  * All encoders must share the crop shape and the latent size.  The workspace (aae_multi_workspace_bytes; scan_only = 1 for
  * aae_codebook_nn_multi) holds a slice per grouped item: nothing in it outlives the call. */
