@@ -376,14 +376,18 @@ static int plan_multi(const aae_multi_item* items, int n_items, bool scan_only, 
             for (size_t li = 1; li < nl; ++li) {
                 const Layer& L0 = enc0->layers[li];
                 if (L0.kind != KIND_IGEMM || L0.wino_geom < 0) continue;
-                long long regions = 0;
+                long long regions = 0, images = 0;
                 bool ready = true;
                 for (int i : g) {
                     const Layer& L = items[i].enc->layers[li];
                     ready = ready && L.wino_geom == L0.wino_geom && (L.wino[0] || weights_pending);
                     regions += wino_regions(L, mp.items[(size_t)i].n);
+                    images += mp.items[(size_t)i].n;
                 }
                 if (!ready) continue;
+                // (four-image blocks: an object with one box fills a quarter of its block -- the block count says nothing about the work then; with at most 16 objects
+                //  per group such a layer never reaches the rule today, the guard keeps it that way)
+                if (L0.wino_geom == 1 && enc0->winograd_min_blocks == 0 && 4 * images < 3 * 4 * regions) continue;
                 const long long blocks = aae::wino_grid_blocks((int)regions, L0.Cout / 64, wino_xcd_cols(enc0, L0)), rounds = (blocks + cus - 1) / cus;
                 const bool fills = enc0->winograd_min_blocks > 0 ? blocks >= enc0->winograd_min_blocks : 100 * blocks >= (long long)enc0->winograd_min_fill_pct * rounds * cus;
                 if (fills) mp.group_wino[gi][li] = 1;
