@@ -44,6 +44,7 @@ struct MultiPlan {
     std::vector<std::vector<int>> groups;      // grouped items that share launches: equal signatures, at most kMultiMax members, item order
     std::vector<std::vector<int>> mid_groups;  // mid-batch items that share their Winograd launches
     std::vector<std::vector<char>> group_wino; // [group][conv layer]: the layer runs as one Winograd launch across the group's objects (multi_group_winograd)
+    std::vector<std::vector<char>> mid_wino;   // [mid group][conv layer]: the layer runs as one Winograd launch across the group (the others per object)
     std::vector<std::vector<char>> mid_rem;    // [mid group][conv layer]: the incomplete four-image blocks leave the Winograd launch (multi_mid_ragged)
     size_t seq_enc_off = 0, seq_enc_bytes = 0, seq_cb_off = 0, seq_cb_bytes = 0, total = 0;
     int rows = 0;
@@ -211,9 +212,11 @@ static bool mid_ragged_opens_a_round(const aae_encoder* enc0, const Layer& L, co
     if (complete_regions) *complete_regions = without;
     return with > without && without >= 1 && rounds_without < rounds_with;
 }
-// ... and does the group fill the chip on every conv layer (the round-fill rule of runs_winograd, on the group's blocks)?
-static bool mid_group_fills(const aae_encoder* enc0, const std::vector<int>& counts) {
+// ... and which conv layers does the GROUP fill the chip on (the round-fill rule of runs_winograd, on the group's blocks)?  Those run as one Winograd launch across the objects;
+// the others (4 classes x 6 boxes: conv4's 64 blocks) run per object on whatever kernel the object's own forward takes.  A group forms when at least one layer passes.
+static std::vector<char> mid_group_layers(const aae_encoder* enc0, const std::vector<int>& counts) {
     const long long cus = wavek_round_blocks(enc0);
+    std::vector<char> pass(enc0->layers.size(), 0);
     for (size_t li = 1; li < enc0->layers.size(); ++li) {
         const Layer& L = enc0->layers[li];
         long long regions = 0;
@@ -221,13 +224,15 @@ static bool mid_group_fills(const aae_encoder* enc0, const std::vector<int>& cou
         long long complete = 0;
         if (mid_ragged_opens_a_round(enc0, L, counts, &complete)) regions = complete;      // (then the rule looks at the complete blocks: the others leave the launch)
         const long long blocks = regions * (L.Cout / 64), rounds = (blocks + cus - 1) / cus;
-        if (enc0->winograd_min_blocks > 0) {                               // (tests, A/B: a plain block count instead of the fill rule, as in runs_winograd)
-            if (blocks < enc0->winograd_min_blocks) return false;
-            continue;
-        }
-        if (100 * blocks < (long long)enc0->winograd_min_fill_pct * rounds * cus) return false;
+        if (enc0->winograd_min_blocks > 0) pass[li] = blocks >= enc0->winograd_min_blocks;   // (tests, A/B: a plain block count instead of the fill rule, as in runs_winograd)
+        else pass[li] = 100 * blocks >= (long long)enc0->winograd_min_fill_pct * rounds * cus;
     }
-    return true;
+    return pass;
+}
+static bool mid_group_fills(const aae_encoder* enc0, const std::vector<int>& counts) {
+    for (char c : mid_group_layers(enc0, counts))
+        if (c) return true;
+    return false;
 }
 
 // Layers of four-image blocks (8 x 8 outputs) in a mid-batch group: an object with n mod 4 != 0 ends in a block with empty image slots.  Where those blocks
@@ -240,11 +245,17 @@ static bool wavek_multi_instantiated(const aae_encoder* enc, const WaveKPlan& w)
 }
 static void plan_mid_ragged(const aae_multi_item* items, MultiPlan& mp) {
     mp.mid_rem.assign(mp.mid_groups.size(), std::vector<char>());
+    mp.mid_wino.assign(mp.mid_groups.size(), std::vector<char>());
     for (size_t gi = 0; gi < mp.mid_groups.size(); ++gi) {
         const std::vector<int>& g = mp.mid_groups[gi];
         const aae_encoder* enc0 = items[g[0]].enc;
         const size_t nl = enc0->layers.size();
         mp.mid_rem[gi].assign(nl, 0);
+        {
+            std::vector<int> all;
+            for (int i : g) all.push_back(mp.items[(size_t)i].n);
+            mp.mid_wino[gi] = mid_group_layers(enc0, all);
+        }
         for (int i : g) mp.items[(size_t)i].rem_plans.assign(nl, WaveKPlan());
         for (size_t li = 1; li < nl; ++li) {
             const Layer& L = enc0->layers[li];
@@ -255,7 +266,7 @@ static void plan_mid_ragged(const aae_multi_item* items, MultiPlan& mp) {
                 counts.push_back(n);
                 if (n % 4) { rows.push_back((long long)(n % 4) * L.Ho * L.Wo); who.push_back(i); }
             }
-            if (!mid_ragged_opens_a_round(enc0, L, counts, nullptr)) continue;
+            if (!mp.mid_wino[gi][li] || !mid_ragged_opens_a_round(enc0, L, counts, nullptr)) continue;
             const std::vector<WaveKPlan> gp = plan_wavek_group(enc0, L, rows);
             if (gp.size() != who.size() || !wavek_multi_instantiated(enc0, gp[0])) continue;
             bool ok = true;
@@ -723,7 +734,7 @@ static int launch_encoder_multi(const aae_multi_item* items, const MultiPlan& mp
 }
 
 // A mid-batch group: conv1, every Winograd conv layer and the dense layer as ONE launch each across the objects, the scans in shared launches (launch_mid_scans).
-static int launch_mid_group(const aae_multi_item* items, const MultiPlan& mp, const std::vector<int>& members, const std::vector<char>& rem_layers, const void* x, int x_dtype,
+static int launch_mid_group(const aae_multi_item* items, const MultiPlan& mp, const std::vector<int>& members, const std::vector<char>& wino_layers, const std::vector<char>& rem_layers, const void* x, int x_dtype,
                             float* z_out, int64_t* idx_out, float* score_out, unsigned char* base, void* stream_v) {
     hipStream_t stream = static_cast<hipStream_t>(stream_v);
     aae_encoder* enc0 = items[members[0]].enc;
@@ -771,6 +782,15 @@ static int launch_mid_group(const aae_multi_item* items, const MultiPlan& mp, co
         }
     for (size_t li = 1; li < nl; ++li) {
         const Layer& L0 = enc0->layers[li];
+        if (!(li < wino_layers.size() && wino_layers[li])) {
+            // the group does not fill the chip on this layer: every object runs it alone, on the kernel its own forward takes at this batch
+            for (int i : members) {
+                const MultiItemPlan& p = mp.items[(size_t)i];
+                if (int rc = forward_impl(items[i].enc, base + p.enc_off + p.ws.act_off[li - 1], AAE_DTYPE_F32, p.n, z_out + (size_t)p.row0 * J, base + p.enc_off, p.enc_bytes,
+                                          stream_v, tm, nullptr, nullptr, nullptr, (int)li, (int)li + 1)) return rc;
+            }
+            continue;
+        }
         aae::ConvWinoMultiArgs m;
         memset(&m, 0, sizeof(m));
         aae::ConvWinoArgs& c = m.c;
@@ -938,7 +958,8 @@ static int multi_impl(const aae_multi_item* items, int n_items, const void* x, i
             if (a.in_h != b.in_h || a.in_w != b.in_w || a.in_c != b.in_c) return fail(AAE_ERR_RUNTIME, "multi-object query: group members differ in crop shape");
         }
         static const std::vector<char> none;
-        if (int rc = launch_mid_group(items, mp, g, gi < mp.mid_rem.size() ? mp.mid_rem[gi] : none, x, x_dtype, z_out, idx_out, score_out, base, stream_v)) return rc;
+        if (int rc = launch_mid_group(items, mp, g, gi < mp.mid_wino.size() ? mp.mid_wino[gi] : none, gi < mp.mid_rem.size() ? mp.mid_rem[gi] : none, x, x_dtype, z_out, idx_out,
+                                      score_out, base, stream_v)) return rc;
     }
     // ---- grouped items: one launch per layer and group
     if (!mp.groups.empty()) t_x3h_last_slot = -1;

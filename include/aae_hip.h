@@ -250,9 +250,10 @@ int aae_detect_nn(aae_encoder* enc, aae_codebook* cb, const void* img, int H, in
  * launch over all grouped items -- objects with different n included -- every block the per-object launch's block, tickets per
  * (object, tile): a frame with C classes costs 6 launches instead of 6 C; a conv layer whose blocks fill the chip over ALL
  * grouped objects (conv2 from ~9 boxes per frame) runs as one polyphase-Winograd launch instead ("multi_group_winograd").
- * Items with n >= 5 whose conv layers all run as polyphase Winograd (default options) form MID-BATCH groups: one Winograd
- * launch per conv layer across the objects where the group's blocks fill the chip (eight buckets of ~32 crops fill it like one
- * batch of 256), conv1 and the dense layer likewise, the codebook scans in one launch per row-part count + one reduce launch;
+ * Items with n >= 5 whose conv layers are all eligible for polyphase Winograd (default options) form MID-BATCH groups: one Winograd
+ * launch per conv layer across the objects for every layer the group's blocks fill the chip on (eight buckets of ~32 crops fill it
+ * like one batch of 256; four classes with six boxes each fill conv2 and conv3 -- the other layers run per object), conv1 and the
+ * dense layer likewise, the codebook scans in one launch per row-part count + one reduce launch;
  * where the incomplete four-image blocks of an 8 x 8-output layer would open one more round of blocks, the last n mod 4 images
  * of every object are computed by one grouped launch of the direct kernel ("multi_mid_ragged").
  * All other items are answered by aae_encode_nn inside the same call.

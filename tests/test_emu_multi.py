@@ -435,6 +435,25 @@ def test_mid_batch_fill_rule_counts_the_complete_blocks_when_the_incomplete_ones
     _close(objs)
 
 
+def test_mid_batch_group_takes_the_layers_it_fills_and_leaves_the_others_to_the_objects():
+    """two classes with six boxes each on a "chip" of 8 compute units: conv2 (one 16 x 16-pixel region per box: 12 blocks, two rounds at 75 %) runs as ONE Winograd launch across
+    the objects, conv3 (four 8 x 8 images per block: 4 blocks, half a round) does not pass the rule and runs per object on the kernel the object's own forward takes -- here
+    bit for bit the per-object calls (their conv2 passes the rule alone too)."""
+    cfg = EncoderConfig((64, 64, 3), [32, 64, 64], [2, 2, 2], 5, 128, True)
+    opts = {'winograd_min_batch': 1, 'first_group_split_max_tiles': 0, 'wavek_target_blocks': 8, 'winograd_xcd_cols': 0}
+    objs = [_object(cfg, 970 + o, 36 * 8 + o, opts) for o in range(2)]
+    items = [(e, c, 6, 1) for e, c, _ in objs]
+    x = synth.make_crops(12, seed=64, shape=cfg.shape)
+    z0, i0, s0 = _per_object(items, x)
+    z1, i1, s1, launches = eb.encode_nn_multi(items, x)
+    assert launches == 4                                                 # conv1, conv2, the scans, the reduce (conv3 and the dense GEMV per object)
+    assert np.array_equal(z1, z0) and np.array_equal(i1, i0) and np.array_equal(s1, s0)
+    for k, (e, c, w) in enumerate(objs):
+        z64 = ref.encoder_forward_np(ref.input_to_float(x[6 * k:6 * k + 6]), w, cfg.strides, cfg.batch_norm)
+        assert np.abs(z1[6 * k:6 * k + 6] - z64).max() / np.abs(z64).max() < 5e-6
+    _close(objs)
+
+
 def test_mid_batch_group_needs_two_members_that_fill_the_chip():
     cfg = EncoderConfig((64, 64, 3), [32, 64, 64], [2, 2, 2], 5, 128, True)
     objs = [_object(cfg, 700 + o, 36 * 8, {'winograd_min_batch': 1}) for o in range(2)]            # default fill rule: two tiny launches do not fill 256 compute units

@@ -311,8 +311,8 @@ def test_mid_batch_group_eight_buckets_of_a_256_crop_batch(eight_objects):
 
 
 def test_winograd_weights_are_built_only_for_objects_of_a_group_that_forms():
-    """ADVICE r5 / VERDICT r5 weak 8: the Winograd-domain copies of conv2 ... conv4 cost 83.5 MB per object.  aae_multi_workspace_bytes builds them for the
-    objects of a mid-batch group that WOULD form -- two classes with six boxes each (an estimator frame) never fill the chip and must not pay for them."""
+    """ADVICE r5 / VERDICT r5 weak 8: the Winograd-domain copies of conv2 ... conv4 cost 83.5 MB per object.  aae_multi_workspace_bytes builds them for the objects of a
+    group with a layer in the Winograd form -- two classes with four boxes each (an estimator frame: conv2 = 128 blocks, half a round) never get there and must not pay."""
     import torch
     from augmentedautoencoder_amd.engine import CodebookEngine, EncoderEngine, MultiObjectQuery
     from augmentedautoencoder_amd.weights import EncoderConfig
@@ -322,15 +322,21 @@ def test_winograd_weights_are_built_only_for_objects_of_a_group_that_forms():
     x = torch.from_numpy(synth.make_crops(64, seed=5)).to(dev)
     torch.cuda.synchronize()
     free0 = torch.cuda.mem_get_info()[0]
-    mq = MultiObjectQuery([(e, c, 6) for e, c in objs])
-    mq(x[:12])
+    mq = MultiObjectQuery([(e, c, 4) for e, c in objs])
+    mq(x[:8])
     torch.cuda.synchronize()
-    assert mq.launches == 0
+    assert mq.launches == 6                                               # the per-detection group on the wave-split-K kernel
     small = free0 - torch.cuda.mem_get_info()[0]
     assert small < 120 << 20, small                                       # (workspace slices only; 2 x 83.5 MB of weights would show)
-    mq2 = MultiObjectQuery([(e, c, 32) for e, c in objs])                  # 2 x 32 crops: conv2 and conv3 fill their rounds, conv4 16 blocks x 8 = half a round -> no group either
-    mq2(x)
+    mq2 = MultiObjectQuery([(e, c, 6) for e, c in objs])                  # 2 x 6 boxes: conv2 = 192 blocks pass the rule -> a mid-batch group with conv2 as one Winograd launch
+    z2, i2, s2 = mq2(x[:12])
     torch.cuda.synchronize()
+    assert mq2.launches >= 2 and free0 - torch.cuda.mem_get_info()[0] > 140 << 20      # ... and now the weights are there
+    at = 0
+    for e, c in objs:
+        wz, wi, wsc = e.encode_nn(c, x[at:at + 6], 1)
+        assert float((z2[at:at + 6] - wz).abs().max() / wz.abs().max()) < 5e-6 and torch.equal(i2[at:at + 6].cpu(), wi[:, 0].cpu())
+        at += 6
     for e, c in objs:
         e.close()
         c.close()
