@@ -37,3 +37,17 @@ for r in range(6):
         assert float((z[at:at+n]-wz).abs().max()/wz.abs().max()) < 1e-5, (r, n)
         at += n
 print('rotated layouts OK')
+# a frame the group fills on conv2 / conv3 only (4 classes x 6 boxes): conv4 per object between grouped launches
+mq3 = MultiObjectQuery([(e, c, 6) for e, c in objs[:4]])
+x3 = x[:24]
+z0, i0, s0 = [t.clone() for t in mq3(x3)]
+bad = 0
+for it in range(300):
+    if it % 4 == 0:
+        with torch.cuda.stream(side):
+            for _ in range(10): a.copy_(b)
+    z, i, s = mq3(x3)
+    if not (torch.equal(z, z0) and torch.equal(i, i0) and torch.equal(s, s0)): bad += 1
+torch.cuda.synchronize()
+print('soak: 300 frames of 4 classes x 6 boxes (per-layer choice), mismatching frames:', bad, 'launches', mq3.launches)
+
