@@ -515,6 +515,19 @@ def main():
             lm['8x{1,1,2,4,1,3,1,2}'] = {'detections': sum(counts), 'sequential_us': round(seq_m, 1), 'grouped_us': round(grp_m, 1), 'grouped_over_sequential': round(grp_m / seq_m, 3),
                                          'launches_grouped': mqm.launches, 'launches_sequential': 6 * N_OBJ,
                                          'mfma_floor_us': round(sum(counts) * cfg.flops_per_crop() / (PEAK_F32_TFLOPS * 1e6), 1)}
+            # a bin-picking frame: four classes with six boxes each -- between the per-detection chain and a chip-filling batch.  The mid-batch group takes the layers the frame
+            # fills (conv2, conv3) as one Winograd launch across the classes, the others per class (round 6)
+            x6 = [torch.from_numpy(synth.make_crops(6, seed=600 + i)).to(dev) for i in range(4)]
+
+            def six_seq():
+                for (e, c_b), xi in zip(all8[:4], x6):
+                    e.encode_nn(c_b, xi, 1)
+            mq6 = MultiQuery([(e, c_b, 6) for e, c_b in all8[:4]], device=dev)
+            xcat6 = torch.cat(x6).contiguous()
+            seq_6 = time_us(six_seq, 40, warm=4)
+            grp_6 = time_us(lambda: mq6(xcat6), 40, warm=4)
+            lm['4x6'] = {'detections': 24, 'sequential_us': round(seq_6, 1), 'grouped_us': round(grp_6, 1), 'grouped_over_sequential': round(grp_6 / seq_6, 3),
+                         'launches_grouped': mq6.launches, 'mfma_floor_us': round(24 * cfg.flops_per_crop() / (PEAK_F32_TFLOPS * 1e6), 1)}
             # the codebook stage alone over the eight codebooks (378 MB > the 256 MB Infinity Cache: every call streams from HBM):
             # ONE launch (aae_codebook_nn_multi) against eight aae_codebook_nn calls
             z8 = torch.randn(N_OBJ, 128, device=dev)
