@@ -311,6 +311,8 @@ int aae_encoder_set_option(aae_encoder* enc, const char* name, int value) {
         enc->winograd_min_blocks = value < 0 ? 0 : value;
     } else if (!strcmp(name, "multi_mid_group")) {
         enc->multi_mid_group = value ? 1 : 0;
+    } else if (!strcmp(name, "multi_split_items")) {
+        enc->multi_split_items = value ? 1 : 0;
     } else if (!strcmp(name, "multi_group_winograd")) {
         enc->multi_group_winograd = value ? 1 : 0;
     } else if (!strcmp(name, "multi_mid_scan")) {

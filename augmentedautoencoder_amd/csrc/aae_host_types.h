@@ -101,6 +101,8 @@ struct aae_encoder {
     int winograd_min_blocks = 0;           // block count (tests, A/B)
     int multi_mid_group = 1;               // grouped multi-object query: objects with 5 or more detections each share ONE Winograd launch per conv layer where the GROUP's blocks fill
                                            // the rounds they occupy (aae_multi_impl.h); 0 = such objects one after the other
+    int multi_split_items = 1;             // aae_encode_nn_multi: a class with 5 ... 8 boxes (up to 12 when it is the frame's only class beyond 4) is answered as items of <= 4 boxes inside the
+                                           // per-detection group of the frame (measured 3-19 % faster than a mid-batch group / its own call, profiles/r15/split_items_ab.jsonl); needs multi_group_plan = 1
     int multi_group_winograd = 1;          // per-detection groups (n <= 4 per object): a conv layer runs as ONE Winograd launch across the objects where the group's blocks pass the fill rule
                                            // (conv2 from ~9 detections in a frame, conv3 from ~18); needs multi_group_plan = 1 (the answers carry the Winograd form's rounding)
     int multi_mid_scan = 1;                // ... and the objects' codebook scans (query-resident arg-max form, fp32) run as one launch per row-part count + one reduce launch; 0 = per object

@@ -917,9 +917,58 @@ static int launch_mid_group(const aae_multi_item* items, const MultiPlan& mp, co
     return AAE_OK;
 }
 
-static int multi_impl(const aae_multi_item* items, int n_items, const void* x, int x_dtype, const float* z_in, float* z_out, int64_t* idx_out,
+// A class with a handful of boxes beyond four is cheapest INSIDE the frame's per-detection group: as consecutive items of at most four boxes that share the class's handles (rows stay in
+// order).  Measured against the mid-batch group / the class's own call (tools/split_items_ab.py, profiles/r15/split_items_ab.jsonl): 4 x 5 boxes -12 %, 4 x 8 -13 %, 8 x 6 -4 %,
+// 8 classes x {9,1,1,1,1,1,1,1} -23 %; from 10 boxes per class on the whole class wins (4 x 10 +9 %, 8 x 16 +20 % when split).  Rule: split when EVERY class of the frame beyond four boxes has
+// 5 ... 8 (up to 12 when it is the only one); never past kMultiMax items in all, never without the group plan (multi_group_plan = 0 promises the per-object bits).
+static bool expand_items(const aae_multi_item* items, int n_items, bool scan_only, std::vector<aae_multi_item>& out) {
+    if (scan_only || !items || n_items < 1) return false;
+    int beyond4 = 0, total = 0;
+    for (int i = 0; i < n_items; ++i) {
+        if (!items[i].enc || !items[i].cb || items[i].n < 1) return false;
+        if (items[i].n > 4) ++beyond4;
+    }
+    if (!beyond4) return false;
+    std::vector<int> parts((size_t)n_items, 1);
+    bool any = false;
+    for (int i = 0; i < n_items; ++i) {
+        const aae_multi_item& it = items[i];
+        const aae_encoder* e = it.enc;
+        std::vector<WaveKPlan> plans;
+        std::vector<int> sig;
+        const int limit = beyond4 == 1 ? 12 : 8;
+        const aae_codebook* eff = nullptr;
+        int idx_scale = 1;
+        if (it.n > 4 && it.n <= limit && e->multi_split_items && e->multi_group_plan && multi_encoder_groupable(e, 4, plans, sig) &&
+            multi_scan_groupable(it.cb, 4, it.col_stride, &eff, &idx_scale)) {
+            parts[(size_t)i] = ceil_div(it.n, 4);
+            any = true;
+        } else if (it.n > 4) {
+            return false;          // (a larger class stays whole -- then the small ones are worth more as its partners in a mid-batch group: {5, 9, 14} split only in part +19 %)
+        }
+        total += parts[(size_t)i];
+    }
+    if (!any || total > aae::kMultiMax) return false;
+    out.clear();
+    for (int i = 0; i < n_items; ++i) {
+        int left = items[i].n;
+        for (int k = 0; k < parts[(size_t)i]; ++k) {
+            aae_multi_item sub = items[i];
+            sub.n = parts[(size_t)i] == 1 ? left : std::min(4, left);
+            left -= sub.n;
+            out.push_back(sub);
+        }
+    }
+    return true;
+}
+
+static int multi_impl(const aae_multi_item* items_in, int n_items_in, const void* x, int x_dtype, const float* z_in, float* z_out, int64_t* idx_out,
                       float* score_out, void* workspace, size_t ws_bytes, void* stream_v) {
     const bool scan_only = z_in != nullptr;
+    std::vector<aae_multi_item> expanded;
+    const bool split = expand_items(items_in, n_items_in, scan_only, expanded);
+    const aae_multi_item* items = split ? expanded.data() : items_in;
+    const int n_items = split ? (int)expanded.size() : n_items_in;
     t_multi_launches = 0;
     MultiPlan mp;
     if (int rc = plan_multi(items, n_items, scan_only, mp)) return rc;
@@ -983,7 +1032,11 @@ static int multi_impl(const aae_multi_item* items, int n_items, const void* x, i
 
 extern "C" {
 
-size_t aae_multi_workspace_bytes(const aae_multi_item* items, int n_items, int scan_only) {
+size_t aae_multi_workspace_bytes(const aae_multi_item* items_in, int n_items_in, int scan_only) {
+    std::vector<aae_multi_item> expanded;
+    const bool split = aae_host::expand_items(items_in, n_items_in, scan_only != 0, expanded);
+    const aae_multi_item* items = split ? expanded.data() : items_in;
+    const int n_items = split ? (int)expanded.size() : n_items_in;
     // (the one place outside the hot calls that sees a frame's layout: objects that may join a mid-batch group get their Winograd weights here)
     // Winograd-domain weights (+83.5 MB for the reference network) only for the objects of a group that WOULD form (an estimator with thirty classes of a few boxes each never builds them).
     if (items && !scan_only) {

@@ -256,7 +256,8 @@ int aae_detect_nn(aae_encoder* enc, aae_codebook* cb, const void* img, int H, in
  * dense layer likewise, the codebook scans in one launch per row-part count + one reduce launch;
  * where the incomplete four-image blocks of an 8 x 8-output layer would open one more round of blocks, the last n mod 4 images
  * of every object are computed by one grouped launch of the direct kernel ("multi_mid_ragged").
- * All other items are answered by aae_encode_nn inside the same call.
+ * A class with a few boxes beyond four (5 ... 8; up to 12 for a frame's only such class) is answered as items of <= 4 boxes inside the
+ * per-detection group ("multi_split_items").  All other items are answered by aae_encode_nn inside the same call.
  * Results against one aae_encode_nn call per item: with the defaults a group runs ONE launch plan chosen for the group
  * ("multi_group_plan" = 1) resp. the Winograd form where the object alone would take the direct kernels, so latents differ by
  * fp32 summation order / the two forms' rounding (tests bound it at 5e-6 of the latent scale, measured <= 2.3e-6; indices equal

@@ -48,6 +48,8 @@
  *   "winograd_min_batch" (8), "winograd_min_fill_pct" (56): a layer takes the Winograd form when its 64-tile x 64-channel blocks fill at least
  *                        this share of the rounds of blocks (one per compute unit) they occupy; "winograd_min_blocks" (0): > 0 = a plain block count instead
  *   "winograd_xcd_cols" (-1): 64-column blocks of a window region that share an XCD (-1 = per layer: all of them up to four; 0 = plain block order)
+ *   "multi_split_items" (1): aae_encode_nn_multi -- a class with 5 ... 8 boxes in the frame (up to 12 when no other class has more than 4) joins the per-detection group as items of
+ *                        at most 4 boxes; 0 = such a class is a mid-batch candidate / its own call.  Needs "multi_group_plan" = 1
  *   "multi_group_winograd" (1): aae_encode_nn_multi -- in a group of objects with 1 ... 4 detections each a conv layer runs as one Winograd launch across the objects where the
  *                        group's blocks fill the chip (conv2 from ~9 detections per frame, conv3 from ~18); needs "multi_group_plan" = 1
  *   "multi_mid_scan" (1): ... and the codebook scans of the group's objects share their launches (bit-identical answers); 0 = one scan + one reduce launch per object

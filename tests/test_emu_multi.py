@@ -454,9 +454,35 @@ def test_mid_batch_group_takes_the_layers_it_fills_and_leaves_the_others_to_the_
     _close(objs)
 
 
+def test_a_class_with_a_few_boxes_beyond_four_joins_the_per_detection_group_as_items_of_four():
+    """a frame with 6 boxes of one class and 2 of another: the library answers the first class as two items (4 + 2 boxes, the same handles) inside the frame's per-detection
+    group -- six launches for the frame; answers within the group plan's summation order of the per-class calls and right against the oracle.  multi_split_items = 0: the
+    6-box class takes its own call."""
+    cfg = EncoderConfig((16, 16, 3), [32, 64, 64, 32], [2, 2, 2, 1], 5, 128, True)
+    objs = [_object(cfg, 980 + o, 36 * 9 + o) for o in range(2)]
+    counts = [6, 2]
+    items = [(e, c, n, 1) for (e, c, _), n in zip(objs, counts)]
+    x = synth.make_crops(8, seed=65, shape=cfg.shape)
+    z0, i0, s0 = _per_object(items, x)
+    z1, i1, s1, launches = eb.encode_nn_multi(items, x)
+    assert launches == 6                                                 # conv1, three conv layers, GEMV, scan: one group of three items
+    assert np.abs(z1 - z0).max() / np.abs(z0).max() < 5e-6 and np.array_equal(i1, i0) and np.abs(s1 - s0).max() < 1e-6
+    at = 0
+    for (e, c, w), n in zip(objs, counts):
+        z64 = ref.encoder_forward_np(ref.input_to_float(x[at:at + n]), w, cfg.strides, cfg.batch_norm)
+        assert np.abs(z1[at:at + n] - z64).max() / np.abs(z64).max() < 5e-6
+        assert np.array_equal(i1[at:at + n], np.argmax(c.similarity(z1[at:at + n]), axis=1))
+        at += n
+    for e, _, _ in objs:
+        e.set_option('multi_split_items', 0)
+    z2, i2, s2, launches = eb.encode_nn_multi(items, x)
+    assert np.array_equal(z2[:6], z0[:6]) and np.array_equal(i2, i0)     # the 6-box class: its own call, bit for bit
+    _close(objs)
+
+
 def test_mid_batch_group_needs_two_members_that_fill_the_chip():
     cfg = EncoderConfig((64, 64, 3), [32, 64, 64], [2, 2, 2], 5, 128, True)
-    objs = [_object(cfg, 700 + o, 36 * 8, {'winograd_min_batch': 1}) for o in range(2)]            # default fill rule: two tiny launches do not fill 256 compute units
+    objs = [_object(cfg, 700 + o, 36 * 8, {'winograd_min_batch': 1, 'multi_split_items': 0}) for o in range(2)]            # default fill rule: two tiny launches do not fill 256 compute units
     items = [(e, c, 5, 1) for e, c, _ in objs]
     x = synth.make_crops(10, seed=60, shape=cfg.shape)
     z0, i0, s0 = _per_object(items, x)
