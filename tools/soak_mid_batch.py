@@ -37,7 +37,8 @@ for r in range(6):
         assert float((z[at:at+n]-wz).abs().max()/wz.abs().max()) < 1e-5, (r, n)
         at += n
 print('rotated layouts OK')
-# a frame the group fills on conv2 / conv3 only (4 classes x 6 boxes): conv4 per object between grouped launches
+# 4 classes x 6 boxes: with the defaults answered as items of <= 4 boxes inside the per-detection group (multi_split_items); a second pass with that option off takes the
+# mid-batch group with its per-layer choice (conv2 / conv3 grouped, conv4 per object)
 mq3 = MultiObjectQuery([(e, c, 6) for e, c in objs[:4]])
 x3 = x[:24]
 z0, i0, s0 = [t.clone() for t in mq3(x3)]
@@ -49,5 +50,14 @@ for it in range(300):
     z, i, s = mq3(x3)
     if not (torch.equal(z, z0) and torch.equal(i, i0) and torch.equal(s, s0)): bad += 1
 torch.cuda.synchronize()
-print('soak: 300 frames of 4 classes x 6 boxes (per-layer choice), mismatching frames:', bad, 'launches', mq3.launches)
+print('soak: 300 frames of 4 classes x 6 boxes (split into items of four), mismatching frames:', bad, 'launches', mq3.launches)
+for e, _ in objs: e.set_option('multi_split_items', 0)
+mq4 = MultiObjectQuery([(e, c, 6) for e, c in objs[:4]])
+z0, i0, s0 = [t.clone() for t in mq4(x3)]
+bad = 0
+for it in range(300):
+    z, i, s = mq4(x3)
+    if not (torch.equal(z, z0) and torch.equal(i, i0) and torch.equal(s, s0)): bad += 1
+torch.cuda.synchronize()
+print('soak: 300 frames of 4 classes x 6 boxes (mid-batch group, per-layer choice), mismatching frames:', bad, 'launches', mq4.launches)
 
